@@ -1,0 +1,138 @@
+/* kicp.h -- C-ABI of the MI355X-native kinematic-ICP registration hot path (libkicp_amd.so).
+ *
+ * Drop-in boundary #2 of SURVEY.md section 8(b): everything the reference's
+ *   kinematic_icp::KinematicRegistration      (cpp/kinematic_icp/registration/Registration.hpp:32-50)
+ *   kiss_icp::VoxelHashMap (kiss-icp v1.2.0)  (used at registration/Registration.cpp:63,74,152,157,
+ *                                              pipeline/KinematicICP.hpp:79,88,92 and KinematicICP.cpp:79)
+ * need from a backend, as plain C: opaque handles, pointers and sizes, no C++/torch types.
+ *
+ * Conventions
+ *   points : contiguous AoS float64 xyz (the memory layout of std::vector<Eigen::Vector3d>, so
+ *            `frame.data()->data()` can be passed without a copy).
+ *   poses  : double[7] = [qx, qy, qz, qw, tx, ty, tz] (Sophus::SE3d parameter order).
+ *   return : 0 = OK;  >0 = warning, result still follows the reference convention (e.g. NaN pose on
+ *            zero correspondences, Registration.cpp:56-58,119-125);  <0 = backend error, outputs untouched.
+ *   threads: one handle is used by one host thread at a time (the reference is called from a single ROS
+ *            executor thread; SURVEY.md section 8b "Threading").
+ * There is NO CPU fallback: if no gfx950 device / HIP runtime is usable, *_create fails with KICP_ERR_HIP.
+ */
+#ifndef KICP_H_
+#define KICP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KICP_VERSION 100
+#define KICP_MAX_LOG_PASSES 32
+
+enum {
+    KICP_OK = 0,
+    KICP_WARN_NO_CORRESPONDENCES = 1, /* N_corr == 0 in some pass -> NaN pose, as the reference produces */
+    KICP_ERR_HIP = -1,                /* HIP runtime / device failure (message in kicp_last_error) */
+    KICP_ERR_ARG = -2,                /* bad argument */
+    KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 255, > 2^24-2 voxels) */
+    KICP_ERR_COMM = -4                /* RCCL failure */
+};
+
+typedef struct kicp_map kicp_map; /* twin of kiss_icp::VoxelHashMap: host-authoritative voxel map + HBM mirror */
+typedef struct kicp_reg kicp_reg; /* twin of kinematic_icp::KinematicRegistration + device workspace/stream */
+
+/* Constructor arguments / public fields of KinematicRegistration (Registration.hpp:33-37,45-49). */
+typedef struct kicp_reg_config {
+    int32_t max_num_iterations;
+    double convergence_criterion;
+    int32_t max_num_threads; /* kept for API parity; the HIP path ignores it */
+    int32_t use_adaptive_odometry_regularization;
+    double fixed_regularization;
+} kicp_reg_config;
+
+/* Per-call diagnostics (SURVEY.md section 5 "Metrics"): what the reference computes internally but never exposes. */
+typedef struct kicp_stats {
+    int32_t iterations; /* ComputePerturbation evaluations executed (Registration.cpp:179-187) */
+    int32_t converged;  /* 1 if ||dx|| < convergence_criterion ended the loop (Registration.cpp:184) */
+    int32_t empty_map;  /* 1 if the early-out of Registration.cpp:157 fired */
+    int32_t reserved;
+    double beta;                            /* regularisation used (Registration.cpp:171-177) */
+    double n_corr[KICP_MAX_LOG_PASSES];     /* correspondences per pass */
+    double sums[KICP_MAX_LOG_PASSES][6];    /* raw JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2 per pass */
+    double dx[KICP_MAX_LOG_PASSES][2];      /* solved (displacement, yaw) per pass */
+    double gpu_ms;                          /* device time of the call, HIP events on the handle's stream */
+} kicp_stats;
+
+const char *kicp_last_error(void); /* thread-local, valid until the next failing call on this thread */
+int kicp_version(void);
+int kicp_device_count(void); /* number of visible HIP devices, <0 on runtime failure */
+
+/* ---- kiss_icp::VoxelHashMap (kiss-icp v1.2.0 core/VoxelHashMap.hpp) ------------------ */
+/* VoxelHashMap(voxel_size, max_distance, max_points_per_voxel)   -- pipeline/KinematicICP.hpp:79 */
+int kicp_map_create(double voxel_size, double max_distance, unsigned int max_points_per_voxel, kicp_map **out);
+void kicp_map_destroy(kicp_map *map);
+int kicp_map_clear(kicp_map *map);                                           /* Clear()  -- KinematicICP.hpp:88 */
+int kicp_map_empty(const kicp_map *map);                                     /* Empty()  -- Registration.cpp:157 */
+int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n);         /* AddPoints(points) */
+int kicp_map_remove_far(kicp_map *map, const double origin[3]);              /* RemovePointsFarFromLocation(origin) */
+int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]); /* Update(points, origin) */
+int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose_qt[7]);  /* Update(points, pose) -- KinematicICP.cpp:79 */
+size_t kicp_map_num_points(const kicp_map *map);
+size_t kicp_map_num_voxels(const kicp_map *map);
+/* Pointcloud() -- KinematicICP.hpp:92.  Writes min(cap_points, total) points, returns total. */
+size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points);
+/* GetClosestNeighbor(query) for n queries -- Registration.cpp:74.  Host arrays in/out; runs the DEVICE
+ * search (the same 27-voxel 1-NN code path the fused registration kernel uses) on `device`.
+ * No candidate -> nn = (0,0,0), dist = DBL_MAX, exactly like the reference. */
+int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist);
+/* Make the HBM mirror on `device` current (a no-op when nothing changed since the last upload).
+ * kicp_register* call it implicitly; exposed so map upload can be kept out of a timed region. */
+int kicp_map_sync(kicp_map *map, int device);
+
+/* ---- kinematic_icp::KinematicRegistration (registration/Registration.hpp:32-50) ------------------------- */
+int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out);
+void kicp_reg_destroy(kicp_reg *reg);
+int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
+int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
+/* Backend tuning knobs (not part of the reference API): "pass_kernel" (0 gather, 1 lds-staged), "block",
+ * "sort" (0 off, 1 Morton-sort queries once per scan), "loop" (0 enqueue-all, 1 host-stepped), ... */
+int kicp_reg_set_option(kicp_reg *reg, const char *name, double value);
+double kicp_reg_get_option(const kicp_reg *reg, const char *name);
+
+/* ComputeRobotMotion(frame, voxel_map, last_robot_pose, relative_wheel_odometry, max_correspondence_distance)
+ * -- Registration.hpp:39-43 / Registration.cpp:151-190.  `frame_xyz` is a HOST pointer (uploaded inside). */
+int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
+                  const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats);
+/* Same, but the frame is already in HBM: `d_frame_xyz` is a DEVICE pointer on the handle's device
+ * (e.g. the output of an on-device pre-step, or a torch tensor's data_ptr()). */
+int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
+                         const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
+                         kicp_stats *stats);
+/* One fused association+accumulation pass at a fixed pose (DataAssociation + the reduction of
+ * ComputePerturbation + the sum of ComputeOdometryRegularization; Registration.cpp:62-81,102-118,51-55).
+ * out_sums = {JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2, N_corr}, un-normalised.  Host frame pointer. */
+int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                   double max_correspondence_distance, double out_sums[7]);
+
+/* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */
+int kicp_device_malloc(int device, size_t bytes, void **out_dptr);
+int kicp_device_free(int device, void *dptr);
+int kicp_device_upload(int device, void *dst_dptr, const void *src_host, size_t bytes);
+int kicp_device_synchronize(int device);
+
+/* ---- multi-GPU: scan points sharded across ranks, map replicated, one 7-double all-reduce per iteration
+ *      (SURVEY.md section 8e).  Every rank calls kicp_register* with ITS shard and gets the identical pose. ---- */
+#define KICP_COMM_ID_BYTES 128
+int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]); /* rank 0 creates, the caller broadcasts the bytes */
+int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]); /* RCCL comm on reg's device */
+int kicp_reg_comm_destroy(kicp_reg *reg);
+/* Alternative to the built-in RCCL communicator: the caller supplies the sum-all-reduce (e.g. torch.distributed).
+ * Called once per ICP iteration with a device buffer of `count` doubles to be reduced IN PLACE, ordered on
+ * `stream` (a hipStream_t).  Pass NULL to remove. */
+typedef int (*kicp_allreduce_fn)(void *user, double *d_buf, int count, void *stream);
+int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KICP_H_ */

@@ -1,0 +1,297 @@
+"""kinematic_icp_amd -- MI355X-native backend of the kinematic-ICP registration hot path.
+
+Python mirror of the reference's operator interface for this path, bound with ctypes to the C-ABI of
+include/kicp.h (libkicp_amd.so, hand-written HIP for gfx950):
+
+    kinematic_icp::KinematicRegistration   /root/reference/cpp/kinematic_icp/registration/Registration.hpp:32-50
+    kiss_icp::VoxelHashMap (v1.2.0)        call sites Registration.cpp:63,74,157; KinematicICP.hpp:79,88,92; KinematicICP.cpp:79
+
+Names, argument order and argument meaning follow the reference.  Poses are 7-vectors
+[qx, qy, qz, qw, tx, ty, tz] (Sophus::SE3d parameter order); point clouds are (N, 3) float64 arrays.
+
+There is NO CPU fallback: importing works anywhere, but creating a KinematicRegistration (or running any
+device operation) without the built extension or without a visible gfx950 device raises KicpError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkicp_amd.so")
+MAX_LOG_PASSES = 32
+COMM_ID_BYTES = 128
+
+KICP_OK = 0
+KICP_WARN_NO_CORRESPONDENCES = 1
+KICP_ERR_HIP, KICP_ERR_ARG, KICP_ERR_CAPACITY, KICP_ERR_COMM = -1, -2, -3, -4
+
+
+class KicpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("kicp error %d: %s" % (code, message))
+        self.code = code
+
+
+class RegConfig(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("convergence_criterion", C.c_double), ("max_num_threads", C.c_int32),
+                ("use_adaptive_odometry_regularization", C.c_int32), ("fixed_regularization", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("empty_map", C.c_int32), ("reserved", C.c_int32),
+                ("beta", C.c_double), ("n_corr", C.c_double * MAX_LOG_PASSES), ("sums", (C.c_double * 6) * MAX_LOG_PASSES),
+                ("dx", (C.c_double * 2) * MAX_LOG_PASSES), ("gpu_ms", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+# every symbol include/kicp.h declares: (restype, argtypes)
+_SIGNATURES = {
+    "kicp_last_error": (C.c_char_p, []),
+    "kicp_version": (C.c_int, []),
+    "kicp_device_count": (C.c_int, []),
+    "kicp_map_create": (C.c_int, [C.c_double, C.c_double, C.c_uint, C.POINTER(C.c_void_p)]),
+    "kicp_map_destroy": (None, [C.c_void_p]),
+    "kicp_map_clear": (C.c_int, [C.c_void_p]),
+    "kicp_map_empty": (C.c_int, [C.c_void_p]),
+    "kicp_map_add_points": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
+    "kicp_map_remove_far": (C.c_int, [C.c_void_p, _dp]),
+    "kicp_map_update_origin": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
+    "kicp_map_update_pose": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
+    "kicp_map_num_points": (C.c_size_t, [C.c_void_p]),
+    "kicp_map_num_voxels": (C.c_size_t, [C.c_void_p]),
+    "kicp_map_pointcloud": (C.c_size_t, [C.c_void_p, _dp, C.c_size_t]),
+    "kicp_map_closest": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, _dp, _dp]),
+    "kicp_map_sync": (C.c_int, [C.c_void_p, C.c_int]),
+    "kicp_reg_create": (C.c_int, [C.POINTER(RegConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "kicp_reg_destroy": (None, [C.c_void_p]),
+    "kicp_reg_get_config": (C.c_int, [C.c_void_p, C.POINTER(RegConfig)]),
+    "kicp_reg_set_config": (C.c_int, [C.c_void_p, C.POINTER(RegConfig)]),
+    "kicp_reg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "kicp_reg_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
+    "kicp_register": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
+    "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
+    "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
+    "kicp_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "kicp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "kicp_device_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "kicp_device_synchronize": (C.c_int, [C.c_int]),
+    "kicp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "kicp_reg_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "kicp_reg_comm_destroy": (C.c_int, [C.c_void_p]),
+    "kicp_reg_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+}
+
+
+def lib():
+    """Load libkicp_amd.so (once).  Fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KicpError(KICP_ERR_HIP, "HIP extension %s not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                          "or `make -C kinematic_icp_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise KicpError(rc, lib().kicp_last_error().decode(errors="replace"))
+    return rc
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def device_count():
+    return lib().kicp_device_count()
+
+
+class VoxelHashMap:
+    """kiss_icp::VoxelHashMap: host-authoritative voxel map with an HBM mirror."""
+
+    def __init__(self, voxel_size, max_distance, max_points_per_voxel):
+        self.voxel_size_, self.max_distance_, self.max_points_per_voxel_ = voxel_size, max_distance, max_points_per_voxel
+        h = C.c_void_p()
+        _check(lib().kicp_map_create(voxel_size, max_distance, max_points_per_voxel, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.kicp_map_destroy(self._h)
+            self._h = None
+
+    def Clear(self):
+        _check(lib().kicp_map_clear(self._h))
+
+    def Empty(self):
+        return bool(lib().kicp_map_empty(self._h))
+
+    def AddPoints(self, points):
+        a, p = _d(points)
+        _check(lib().kicp_map_add_points(self._h, p, a.size // 3))
+
+    def RemovePointsFarFromLocation(self, origin):
+        _, p = _d(origin)
+        _check(lib().kicp_map_remove_far(self._h, p))
+
+    def Update(self, points, pose_or_origin):
+        a, p = _d(points)
+        b, q = _d(pose_or_origin)
+        if b.size == 7:
+            _check(lib().kicp_map_update_pose(self._h, p, a.size // 3, q))
+        elif b.size == 3:
+            _check(lib().kicp_map_update_origin(self._h, p, a.size // 3, q))
+        else:
+            raise ValueError("Update expects a 7-vector pose or a 3-vector origin")
+
+    def num_points(self):
+        return lib().kicp_map_num_points(self._h)
+
+    def num_voxels(self):
+        return lib().kicp_map_num_voxels(self._h)
+
+    def Pointcloud(self):
+        n = self.num_points()
+        out = np.empty((n, 3), dtype=np.float64)
+        lib().kicp_map_pointcloud(self._h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def GetClosestNeighbor(self, queries, device=0):
+        """Batch form of GetClosestNeighbor: (N,3) queries -> ((N,3) neighbours, (N,) distances)."""
+        a, p = _d(queries)
+        n = a.size // 3
+        nn = np.empty((n, 3), dtype=np.float64)
+        d = np.empty(n, dtype=np.float64)
+        _check(lib().kicp_map_closest(self._h, device, p, n, nn.ctypes.data_as(_dp), d.ctypes.data_as(_dp)))
+        return nn, d
+
+    def sync(self, device=0):
+        _check(lib().kicp_map_sync(self._h, device))
+
+
+class DeviceFrame:
+    """A scan resident in HBM (what an on-device pre-step would hand to the registration)."""
+
+    def __init__(self, points, device=0):
+        a, _ = _d(points)
+        self.n, self.device = a.size // 3, device
+        self.ptr = C.c_void_p()
+        _check(lib().kicp_device_malloc(device, max(a.nbytes, 8), C.byref(self.ptr)))
+        if a.nbytes:
+            _check(lib().kicp_device_upload(device, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.kicp_device_free(self.device, self.ptr)
+            self.ptr = None
+
+
+class KinematicRegistration:
+    """kinematic_icp::KinematicRegistration (registration/Registration.hpp:32-50) on one MI355X."""
+
+    def __init__(self, max_num_iteration=10, convergence_criterion=1e-3, max_num_threads=1,
+                 use_adaptive_odometry_regularization=True, fixed_regularization=0.0, device=0):
+        cfg = RegConfig(max_num_iteration, convergence_criterion, max_num_threads, int(use_adaptive_odometry_regularization),
+                        fixed_regularization)
+        h = C.c_void_p()
+        _check(lib().kicp_reg_create(C.byref(cfg), device, C.byref(h)))
+        self._h, self.device = h, device
+        self.last_stats, self.last_status = None, 0
+        self._cb = None
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.kicp_reg_destroy(self._h)
+            self._h = None
+
+    # the reference exposes its five parameters as public mutable fields (Registration.hpp:45-49)
+    def _cfg(self):
+        c = RegConfig()
+        _check(lib().kicp_reg_get_config(self._h, C.byref(c)))
+        return c
+
+    def _set(self, **kw):
+        c = self._cfg()
+        for k, v in kw.items():
+            setattr(c, k, v)
+        _check(lib().kicp_reg_set_config(self._h, C.byref(c)))
+
+    max_num_iterations_ = property(lambda s: s._cfg().max_num_iterations, lambda s, v: s._set(max_num_iterations=int(v)))
+    convergence_criterion_ = property(lambda s: s._cfg().convergence_criterion, lambda s, v: s._set(convergence_criterion=float(v)))
+    max_num_threads_ = property(lambda s: s._cfg().max_num_threads, lambda s, v: s._set(max_num_threads=int(v)))
+    use_adaptive_odometry_regularization_ = property(lambda s: bool(s._cfg().use_adaptive_odometry_regularization),
+                                                     lambda s, v: s._set(use_adaptive_odometry_regularization=int(bool(v))))
+    fixed_regularization_ = property(lambda s: s._cfg().fixed_regularization, lambda s, v: s._set(fixed_regularization=float(v)))
+
+    def set_option(self, name, value):
+        _check(lib().kicp_reg_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        return lib().kicp_reg_get_option(self._h, name.encode())
+
+    def ComputeRobotMotion(self, frame, voxel_map, last_robot_pose, relative_wheel_odometry, max_correspondence_distance):
+        """frame: (N,3) float64 host array, or a DeviceFrame already resident in HBM."""
+        _, lp = _d(last_robot_pose)
+        _, ro = _d(relative_wheel_odometry)
+        out = np.zeros(7, dtype=np.float64)
+        st = Stats()
+        if isinstance(frame, DeviceFrame):
+            rc = lib().kicp_register_device(self._h, voxel_map._h, frame.ptr, frame.n, lp, ro, max_correspondence_distance,
+                                            out.ctypes.data_as(_dp), C.byref(st))
+        else:
+            a, p = _d(frame)
+            rc = lib().kicp_register(self._h, voxel_map._h, p, a.size // 3, lp, ro, max_correspondence_distance,
+                                     out.ctypes.data_as(_dp), C.byref(st))
+        self.last_status, self.last_stats = _check(rc), st
+        return out
+
+    def pass_sums(self, frame, voxel_map, pose, max_correspondence_distance):
+        """One fused association+accumulation pass at a fixed pose -> [JTJ00,JTJ01,JTJ11,JTr0,JTr1,ssq,N]."""
+        a, p = _d(frame)
+        _, q = _d(pose)
+        out = np.zeros(7, dtype=np.float64)
+        _check(lib().kicp_pass_sums(self._h, voxel_map._h, p, a.size // 3, q, max_correspondence_distance, out.ctypes.data_as(_dp)))
+        return out
+
+    # ---- multi-GPU ----
+    def comm_init(self, nranks, rank, unique_id):
+        _check(lib().kicp_reg_comm_init(self._h, nranks, rank, unique_id))
+
+    def comm_destroy(self):
+        _check(lib().kicp_reg_comm_destroy(self._h))
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> None: sum-all-reduce `count` doubles in place on `stream`."""
+        if fn is None:
+            self._cb = None
+            _check(lib().kicp_reg_set_allreduce(self._h, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def tramp(user, buf, count, stream):
+            try:
+                fn(buf or 0, count, stream or 0)
+                return 0
+            except Exception:  # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(tramp)
+        _check(lib().kicp_reg_set_allreduce(self._h, self._cb, None))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().kicp_comm_unique_id(buf))
+    return buf.raw

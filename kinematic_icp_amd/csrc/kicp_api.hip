@@ -1,0 +1,541 @@
+// kicp_api.hip -- implementation of include/kicp.h: handles, HBM mirror of the voxel map, the registration loop
+// (kernel enqueue / early exit / read-back), and the optional RCCL all-reduce.  gfx950 only; no CPU fallback.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kicp.h"
+#include "kicp_host_map.hpp"
+#include "kicp_kernels.hpp"
+
+namespace {
+using namespace kicp;
+
+thread_local std::string g_error;
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(KICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                          std::to_string(__LINE__) + ")");                                    \
+    } while (0)
+
+Pose pose_from(const double p[7]) { return Pose{p[0], p[1], p[2], p[3], p[4], p[5], p[6]}; }
+void pose_to(const Pose &T, double p[7]) { p[0] = T.qx, p[1] = T.qy, p[2] = T.qz, p[3] = T.qw, p[4] = T.tx, p[5] = T.ty, p[6] = T.tz; }
+
+// ---- RCCL, bound lazily so that single-GPU users never load it ------------------------------------------------
+struct CommApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string &err) {
+        if (handle) return true;
+        // prefer an RCCL that is already in the process (e.g. the one torch.distributed loaded)
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names)
+            if ((handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!handle)
+            for (const char *nm : names)
+                if ((handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!handle) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+            err = "librccl lacks an expected symbol";
+            return false;
+        }
+        return true;
+    }
+};
+CommApi g_comm;
+
+struct DeviceMirror {
+    int device = -1;
+    Slot *d_table = nullptr;
+    double *d_pool = nullptr;
+    size_t table_slots = 0, pool_doubles = 0;  // allocated sizes
+    uint64_t synced_epoch = ~0ull;
+    MapView view{};
+};
+}  // namespace
+
+struct kicp_map {
+    HostMap host;
+    DeviceMirror mirror;
+    kicp_map(double vs, double md, uint32_t cap) : host(vs, md, cap) {}
+};
+
+struct kicp_reg {
+    kicp_reg_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    IcpState *d_state = nullptr;
+    IcpState *h_state = nullptr;  // pinned
+    double *d_partials = nullptr;
+    size_t partial_blocks = 0;
+    double *d_frame = nullptr;  // staging for host frames
+    size_t frame_cap = 0;
+    // options
+    int pass_kernel = 1;  // 0 gather, 1 lds
+    int block = 128;
+    int loop_mode = 0;    // 0 enqueue every iteration up front, 1 host-stepped (sync per iteration)
+    int timing = 0;       // record HIP events around the call -> stats.gpu_ms
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    kicp_allreduce_fn allreduce_fn = nullptr;
+    void *allreduce_user = nullptr;
+};
+
+namespace {
+
+int set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return KICP_OK;
+}
+
+int map_sync(kicp_map *map, int device, hipStream_t stream) {
+    DeviceMirror &mr = map->mirror;
+    const HostMap &h = map->host;
+    if (mr.device == device && mr.synced_epoch == h.epoch()) return KICP_OK;
+    if (int rc = set_device(device)) return rc;
+    if (mr.device != device && mr.device >= 0) {  // mirror lives on another GPU: drop it
+        hipSetDevice(mr.device);
+        if (mr.d_table) hipFree(mr.d_table);
+        if (mr.d_pool) hipFree(mr.d_pool);
+        mr = DeviceMirror{};
+        hipSetDevice(device);
+    }
+    mr.device = device;
+    const size_t slots = h.table().size();
+    const size_t pool_doubles = h.buckets_in_use_hi() * static_cast<size_t>(h.cap()) * 3;
+    if (slots > mr.table_slots) {
+        if (mr.d_table) HIP_TRY(hipFree(mr.d_table));
+        mr.d_table = nullptr;
+        HIP_TRY(hipMalloc(&mr.d_table, slots * sizeof(Slot)));
+        mr.table_slots = slots;
+    }
+    if (pool_doubles > mr.pool_doubles) {
+        if (mr.d_pool) HIP_TRY(hipFree(mr.d_pool));
+        mr.d_pool = nullptr;
+        const size_t want = pool_doubles + pool_doubles / 4 + 1024;
+        HIP_TRY(hipMalloc(&mr.d_pool, want * sizeof(double)));
+        mr.pool_doubles = want;
+    }
+    HIP_TRY(hipMemcpyAsync(mr.d_table, h.table().data(), slots * sizeof(Slot), hipMemcpyHostToDevice, stream));
+    if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool, h.pool().data(), pool_doubles * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, h.cap(), h.voxel_size()};
+    mr.synced_epoch = h.epoch();
+    return KICP_OK;
+}
+
+template <int BLOCK>
+void launch_pass_block(int kernel, const PassParams &p, uint32_t grid, hipStream_t s) {
+    if (kernel == 0)
+        hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_pass_lds<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
+}
+void launch_pass(const kicp_reg *r, const PassParams &p, uint32_t grid) {
+    switch (r->block) {
+        case 64: launch_pass_block<64>(r->pass_kernel, p, grid, r->stream); break;
+        case 256: launch_pass_block<256>(r->pass_kernel, p, grid, r->stream); break;
+        default: launch_pass_block<128>(r->pass_kernel, p, grid, r->stream); break;
+    }
+}
+int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
+
+int ensure_partials(kicp_reg *r, size_t blocks) {
+    if (blocks <= r->partial_blocks) return KICP_OK;
+    if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
+    r->d_partials = nullptr;
+    const size_t want = blocks + blocks / 2 + 64;
+    HIP_TRY(hipMalloc(&r->d_partials, want * kNumSums * sizeof(double)));
+    r->partial_blocks = want;
+    return KICP_OK;
+}
+int ensure_frame(kicp_reg *r, size_t n) {
+    if (n <= r->frame_cap) return KICP_OK;
+    if (r->d_frame) HIP_TRY(hipFree(r->d_frame));
+    r->d_frame = nullptr;
+    const size_t want = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc(&r->d_frame, want * 3 * sizeof(double)));
+    r->frame_cap = want;
+    return KICP_OK;
+}
+
+// enqueue the collective between the partial reduction and the solve (multi-GPU only)
+int enqueue_allreduce(kicp_reg *r) {
+    double *buf = r->d_state->reduced;
+    if (r->allreduce_fn) {
+        if (r->allreduce_fn(r->allreduce_user, buf, kNumSums, static_cast<void *>(r->stream)) != 0)
+            return fail(KICP_ERR_COMM, "user all-reduce callback failed");
+        return KICP_OK;
+    }
+    const ncclResult_t rc = g_comm.AllReduce(buf, buf, kNumSums, ncclFloat64, ncclSum, r->comm, r->stream);
+    if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclAllReduce: ") + g_comm.GetErrorString(rc));
+    return KICP_OK;
+}
+
+int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
+                     const double rel_odom_qt[7], double tau, double out_pose_qt[7], kicp_stats *stats) {
+    if (!r || !map || !last_pose_qt || !rel_odom_qt || !out_pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    // current_estimate = last_robot_pose * relative_wheel_odometry   (Registration.cpp:156)
+    const Pose T0 = pose_mul(pose_from(last_pose_qt), pose_from(rel_odom_qt));
+    if (map->host.Empty()) {  // Registration.cpp:157
+        pose_to(T0, out_pose_qt);
+        if (stats) stats->empty_map = 1;
+        return KICP_OK;
+    }
+    if (n > 0xFFFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (int rc = set_device(r->device)) return rc;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    const int block = normalized_block(r->block);
+    const uint32_t grid = static_cast<uint32_t>((n + block - 1) / block);
+    if (int rc = ensure_partials(r, grid ? grid : 1)) return rc;
+    const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
+    const int max_it = r->cfg.max_num_iterations;
+
+    PassParams pp{};
+    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.partials = r->d_partials, pp.pose0 = T0;
+    FinalizeParams fp{};
+    fp.st = r->d_state, fp.partials = r->d_partials, fp.nblocks = grid, fp.pose0 = T0, fp.max_iterations = max_it;
+    fp.convergence_criterion = r->cfg.convergence_criterion, fp.adaptive = r->cfg.use_adaptive_odometry_regularization;
+    fp.fixed_regularization = r->cfg.fixed_regularization;
+
+    if (r->timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
+    if (max_it <= 0) {  // the reference's loop body never runs: the prediction is returned (Registration.cpp:179,189)
+        pose_to(T0, out_pose_qt);
+        return KICP_OK;
+    }
+    IcpState *hs = r->h_state;
+    for (int it = 0; it < max_it; ++it) {
+        pp.pass = it, fp.pass = it;
+        if (grid) launch_pass(r, pp, grid);
+        if (!multi) {
+            fp.stage = 0;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
+        } else {
+            fp.stage = 1;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
+            if (int rc = enqueue_allreduce(r)) return rc;
+            fp.stage = 2;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
+        }
+        if (r->loop_mode == 1) {  // host-stepped: look at the stop flag after every iteration
+            HIP_TRY(hipMemcpyAsync(&hs->done, &r->d_state->done, sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            if (hs->done) break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+    HIP_TRY(hipMemcpyAsync(hs, r->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    pose_to(hs->T, out_pose_qt);
+    if (stats) {
+        stats->iterations = hs->iter, stats->converged = hs->converged, stats->beta = hs->beta;
+        const int k = hs->iter < KICP_MAX_LOG_PASSES ? hs->iter : KICP_MAX_LOG_PASSES;
+        for (int i = 0; i < k; ++i) {
+            stats->n_corr[i] = hs->log_ncorr[i];
+            for (int j = 0; j < 6; ++j) stats->sums[i][j] = hs->log_sums[i][j];
+            stats->dx[i][0] = hs->log_dx[i][0], stats->dx[i][1] = hs->log_dx[i][1];
+        }
+        if (r->timing) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+            stats->gpu_ms = ms;
+        }
+    }
+    return hs->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char *kicp_last_error(void) { return g_error.c_str(); }
+int kicp_version(void) { return KICP_VERSION; }
+int kicp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+// ---- map ------------------------------------------------------------------------------------------------------------
+int kicp_map_create(double voxel_size, double max_distance, unsigned int max_points_per_voxel, kicp_map **out) {
+    if (!out || !(voxel_size > 0.0) || max_points_per_voxel == 0) return fail(KICP_ERR_ARG, "bad map parameters");
+    if (max_points_per_voxel > kMaxPointsPerVoxel) return fail(KICP_ERR_CAPACITY, "max_points_per_voxel > 255");
+    *out = new kicp_map(voxel_size, max_distance, max_points_per_voxel);
+    return KICP_OK;
+}
+void kicp_map_destroy(kicp_map *map) {
+    if (!map) return;
+    if (map->mirror.device >= 0) {
+        hipSetDevice(map->mirror.device);
+        if (map->mirror.d_table) hipFree(map->mirror.d_table);
+        if (map->mirror.d_pool) hipFree(map->mirror.d_pool);
+    }
+    delete map;
+}
+int kicp_map_clear(kicp_map *map) {
+    if (!map) return fail(KICP_ERR_ARG, "null map");
+    map->host.Clear();
+    return KICP_OK;
+}
+int kicp_map_empty(const kicp_map *map) { return (!map || map->host.Empty()) ? 1 : 0; }
+int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n) {
+    if (!map || (!xyz && n)) return fail(KICP_ERR_ARG, "null argument");
+    return map->host.AddPoints(xyz, n) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
+}
+int kicp_map_remove_far(kicp_map *map, const double origin[3]) {
+    if (!map || !origin) return fail(KICP_ERR_ARG, "null argument");
+    map->host.RemovePointsFarFromLocation(origin);
+    return KICP_OK;
+}
+int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]) {
+    if (!map || (!xyz && n) || !origin) return fail(KICP_ERR_ARG, "null argument");
+    return map->host.Update(xyz, n, origin) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
+}
+int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose_qt[7]) {
+    if (!map || (!xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    return map->host.Update(xyz, n, pose_from(pose_qt)) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
+}
+size_t kicp_map_num_points(const kicp_map *map) { return map ? map->host.num_points() : 0; }
+size_t kicp_map_num_voxels(const kicp_map *map) { return map ? map->host.num_voxels() : 0; }
+size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points) {
+    if (!map) return 0;
+    return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
+}
+int kicp_map_sync(kicp_map *map, int device) {
+    if (!map) return fail(KICP_ERR_ARG, "null map");
+    if (int rc = set_device(device)) return rc;
+    return map_sync(map, device, nullptr);
+}
+int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist) {
+    if (!map || (!queries_xyz && n) || !out_nn_xyz || !out_dist) return fail(KICP_ERR_ARG, "null argument");
+    if (n == 0) return KICP_OK;
+    if (map->host.Empty()) {
+        for (size_t i = 0; i < n; ++i) out_nn_xyz[3 * i] = out_nn_xyz[3 * i + 1] = out_nn_xyz[3 * i + 2] = 0.0, out_dist[i] = DBL_MAX;
+        return KICP_OK;
+    }
+    if (int rc = kicp_map_sync(map, device)) return rc;
+    double *d_q = nullptr, *d_nn = nullptr, *d_d = nullptr;
+    HIP_TRY(hipMalloc(&d_q, n * 24));
+    HIP_TRY(hipMalloc(&d_nn, n * 24));
+    HIP_TRY(hipMalloc(&d_d, n * 8));
+    HIP_TRY(hipMemcpy(d_q, queries_xyz, n * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_closest, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, nullptr, d_q, static_cast<uint32_t>(n),
+                       map->mirror.view, d_nn, d_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_nn_xyz, d_nn, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_dist, d_d, n * 8, hipMemcpyDeviceToHost));
+    hipFree(d_q), hipFree(d_nn), hipFree(d_d);
+    return KICP_OK;
+}
+
+// ---- registration ---------------------------------------------------------------------------------------------------
+int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
+    if (!config || !out) return fail(KICP_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KICP_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(KICP_ERR_ARG, "device index out of range");
+    if (int rc = set_device(device)) return rc;
+    kicp_reg *r = new kicp_reg;
+    r->cfg = *config, r->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+    if (e == hipSuccess) e = hipMalloc(&r->d_state, sizeof(IcpState));
+    if (e == hipSuccess) e = hipMemset(r->d_state, 0, sizeof(IcpState));
+    if (e == hipSuccess) e = hipHostMalloc(&r->h_state, sizeof(IcpState), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        kicp_reg_destroy(r);
+        return fail(KICP_ERR_HIP, std::string("kicp_reg_create: ") + hipGetErrorString(e));
+    }
+    if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env);
+    if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
+    if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
+    *out = r;
+    return KICP_OK;
+}
+void kicp_reg_destroy(kicp_reg *reg) {
+    if (!reg) return;
+    hipSetDevice(reg->device);
+    if (reg->comm) g_comm.CommDestroy(reg->comm);
+    if (reg->stream) hipStreamSynchronize(reg->stream);
+    if (reg->d_state) hipFree(reg->d_state);
+    if (reg->h_state) hipHostFree(reg->h_state);
+    if (reg->d_partials) hipFree(reg->d_partials);
+    if (reg->d_frame) hipFree(reg->d_frame);
+    if (reg->ev0) hipEventDestroy(reg->ev0);
+    if (reg->ev1) hipEventDestroy(reg->ev1);
+    if (reg->stream) hipStreamDestroy(reg->stream);
+    delete reg;
+}
+int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out) {
+    if (!reg || !out) return fail(KICP_ERR_ARG, "null argument");
+    *out = reg->cfg;
+    return KICP_OK;
+}
+int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config) {
+    if (!reg || !config) return fail(KICP_ERR_ARG, "null argument");
+    reg->cfg = *config;
+    return KICP_OK;
+}
+int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
+    if (!reg || !name) return fail(KICP_ERR_ARG, "null argument");
+    const std::string k(name);
+    if (k == "pass_kernel") reg->pass_kernel = static_cast<int>(value);
+    else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
+    else if (k == "loop") reg->loop_mode = static_cast<int>(value);
+    else if (k == "timing") reg->timing = static_cast<int>(value);
+    else return fail(KICP_ERR_ARG, "unknown option " + k);
+    return KICP_OK;
+}
+double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
+    if (!reg || !name) return -1.0;
+    const std::string k(name);
+    if (k == "pass_kernel") return reg->pass_kernel;
+    if (k == "block") return reg->block;
+    if (k == "loop") return reg->loop_mode;
+    if (k == "timing") return reg->timing;
+    return -1.0;
+}
+
+int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
+                         const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
+                         kicp_stats *stats) {
+    if (!d_frame_xyz && n) return fail(KICP_ERR_ARG, "null frame");
+    return run_registration(reg, map, d_frame_xyz, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
+                  const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
+    if (!reg || !map || (!frame_xyz && n)) return fail(KICP_ERR_ARG, "null argument");
+    if (!map->host.Empty() && n) {
+        if (int rc = set_device(reg->device)) return rc;
+        if (int rc = ensure_frame(reg, n)) return rc;
+        HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
+    }
+    return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                   double max_correspondence_distance, double out_sums[7]) {
+    if (!reg || !map || (!frame_xyz && n) || !pose_qt || !out_sums) return fail(KICP_ERR_ARG, "null argument");
+    for (int i = 0; i < 7; ++i) out_sums[i] = 0.0;
+    if (map->host.Empty() || n == 0) return KICP_OK;
+    if (int rc = set_device(reg->device)) return rc;
+    if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
+    if (int rc = ensure_frame(reg, n)) return rc;
+    const int block = normalized_block(reg->block);
+    const uint32_t grid = static_cast<uint32_t>((n + block - 1) / block);
+    if (int rc = ensure_partials(reg, grid)) return rc;
+    HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
+    PassParams pp{};
+    pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
+    pp.st = reg->d_state, pp.partials = reg->d_partials, pp.pose0 = pose_from(pose_qt), pp.pass = 0;
+    launch_pass(reg, pp, grid);
+    FinalizeParams fp{};
+    fp.st = reg->d_state, fp.partials = reg->d_partials, fp.nblocks = grid, fp.pass = 0, fp.stage = 1;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, reg->stream, fp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(reg->h_state->reduced, reg->d_state->reduced, sizeof(double) * kNumSums, hipMemcpyDeviceToHost, reg->stream));
+    HIP_TRY(hipStreamSynchronize(reg->stream));
+    for (int i = 0; i < 7; ++i) out_sums[i] = reg->h_state->reduced[i];
+    return KICP_OK;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------------------
+int kicp_device_malloc(int device, size_t bytes, void **out_dptr) {
+    if (!out_dptr) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipMalloc(out_dptr, bytes ? bytes : 1));
+    return KICP_OK;
+}
+int kicp_device_free(int device, void *dptr) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipFree(dptr));
+    return KICP_OK;
+}
+int kicp_device_upload(int device, void *dst_dptr, const void *src_host, size_t bytes) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipMemcpy(dst_dptr, src_host, bytes, hipMemcpyHostToDevice));
+    return KICP_OK;
+}
+int kicp_device_synchronize(int device) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return KICP_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------------------
+int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]) {
+    static_assert(KICP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id) return fail(KICP_ERR_ARG, "null argument");
+    std::string err;
+    if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);
+    ncclUniqueId uid;
+    const ncclResult_t rc = g_comm.GetUniqueId(&uid);
+    if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclGetUniqueId: ") + g_comm.GetErrorString(rc));
+    std::memcpy(id, uid.internal, KICP_COMM_ID_BYTES);
+    return KICP_OK;
+}
+int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]) {
+    if (!reg || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad communicator arguments");
+    std::string err;
+    if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);
+    if (int rc = set_device(reg->device)) return rc;
+    if (reg->comm) g_comm.CommDestroy(reg->comm), reg->comm = nullptr;
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, KICP_COMM_ID_BYTES);
+    const ncclResult_t rc = g_comm.CommInitRank(&reg->comm, nranks, uid, rank);
+    if (rc != ncclSuccess) {
+        reg->comm = nullptr;
+        return fail(KICP_ERR_COMM, std::string("ncclCommInitRank: ") + g_comm.GetErrorString(rc));
+    }
+    reg->nranks = nranks, reg->rank = rank;
+    return KICP_OK;
+}
+int kicp_reg_comm_destroy(kicp_reg *reg) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    if (reg->comm) {
+        hipSetDevice(reg->device);
+        hipStreamSynchronize(reg->stream);
+        g_comm.CommDestroy(reg->comm);
+        reg->comm = nullptr;
+    }
+    reg->nranks = 1, reg->rank = 0;
+    return KICP_OK;
+}
+int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    reg->allreduce_fn = fn, reg->allreduce_user = user;
+    return KICP_OK;
+}
+
+}  // extern "C"

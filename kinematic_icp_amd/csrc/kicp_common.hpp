@@ -1,0 +1,59 @@
+// kicp_common.hpp -- layouts and small helpers shared by the host map and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#define KICP_HD __host__ __device__ __forceinline__
+
+namespace kicp {
+
+// One slot of the open-addressing voxel table, 16 B = one global_load_dwordx4.
+//   key : the reference's Voxel = Eigen::Vector3i (kiss-icp v1.2.0 core/VoxelUtils.hpp)
+//   val : (bucket_index << 8) | point_count ; kEmptyVal marks a free slot.
+struct alignas(16) Slot {
+    int32_t x, y, z;
+    uint32_t val;
+};
+constexpr uint32_t kEmptyVal = 0xFFFFFFFFu;
+constexpr uint32_t kMaxBuckets = (1u << 24) - 2;
+constexpr uint32_t kMaxPointsPerVoxel = 255;
+
+// Table hash.  The reference's std::hash<Voxel> (three-prime XOR, App. A.1) followed by a murmur3
+// finaliser so that a power-of-two mask sees well mixed low bits.  The hash only decides slot positions;
+// it can never change a query result.
+KICP_HD uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
+    uint32_t h = (static_cast<uint32_t>(x) * 73856093u) ^ (static_cast<uint32_t>(y) * 19349669u) ^
+                 (static_cast<uint32_t>(z) * 83492791u);
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// Device view of a voxel map mirror (all pointers in HBM).
+struct MapView {
+    const Slot *table;    // capacity = mask + 1 (power of two), linear probing, no tombstones
+    uint32_t mask;
+    const double *pool;   // bucket b holds <= cap points at pool + b * cap * 3 (AoS xyz, insertion order)
+    uint32_t cap;         // max_points_per_voxel
+    double voxel_size;
+};
+
+// The reference's neighbour visiting order (kiss-icp v1.2.0 core/VoxelHashMap.cpp `voxel_shifts`; App. A.3),
+// packed 2 bits per axis (value+1) so it lives in three 64-bit immediates instead of a constant-memory table.
+//   shift s: dx = ((kShiftX >> 2s) & 3) - 1, ...
+constexpr int kShiftTable[27][3] = {{0, 0, 0},   {1, 0, 0},   {-1, 0, 0},  {0, 1, 0},   {0, -1, 0},  {0, 0, 1},   {0, 0, -1},
+                                    {1, 1, 0},   {1, -1, 0},  {-1, 1, 0},  {-1, -1, 0}, {1, 0, 1},   {1, 0, -1},  {-1, 0, 1},
+                                    {-1, 0, -1}, {0, 1, 1},   {0, 1, -1},  {0, -1, 1},  {0, -1, -1}, {1, 1, 1},   {1, 1, -1},
+                                    {1, -1, 1},  {1, -1, -1}, {-1, 1, 1},  {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+constexpr uint64_t pack_axis(int axis) {
+    uint64_t v = 0;
+    for (int s = 0; s < 27; ++s) v |= static_cast<uint64_t>(kShiftTable[s][axis] + 1) << (2 * s);
+    return v;
+}
+constexpr uint64_t kShiftX = pack_axis(0), kShiftY = pack_axis(1), kShiftZ = pack_axis(2);
+KICP_HD int shift_component(uint64_t packed, int s) { return static_cast<int>((packed >> (2 * s)) & 3u) - 1; }
+
+}  // namespace kicp

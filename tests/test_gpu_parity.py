@@ -1,0 +1,114 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances: the north star asks for poses within 1e-4 m / 1e-4 rad.  The HIP path computes in fp64 in the
+reference's operation order, so we assert far tighter: 1e-9 on poses, 1e-10 relative on the per-pass sums
+(only the summation order differs)."""
+import numpy as np
+import pytest
+
+import kinematic_icp_amd as K
+from kinematic_icp_amd import synthetic as syn
+from oracle import okicp
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-9
+SUM_RTOL = 1e-10
+VARIANTS = [(0, 64), (0, 128), (0, 256), (1, 64), (1, 128), (1, 256)]
+
+
+@pytest.fixture(scope="module")
+def case1():
+    cfg, scene, scans, rng = syn.make_case("cfg1", n_scans=3)
+    gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
+    omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    omap.AddPoints(gmap.Pointcloud())
+    return cfg, scans, gmap, omap
+
+
+def _reg(kernel, block, **kw):
+    reg = K.KinematicRegistration(**kw)
+    reg.set_option("pass_kernel", kernel)
+    reg.set_option("block", block)
+    return reg
+
+
+def test_device_present():
+    assert K.device_count() >= 1
+
+
+def test_closest_neighbor_matches_oracle(case1):
+    cfg, scans, gmap, omap = case1
+    rng = np.random.default_rng(7)
+    q = np.concatenate([scans[0]["frame"][:4000] + rng.normal(0, 0.3, (4000, 3)), rng.uniform(-200, 200, (500, 3))])
+    nn_g, d_g = gmap.GetClosestNeighbor(q)
+    nn_o, d_o = omap.GetClosestNeighbor(q)
+    assert np.array_equal(d_g, d_o)  # bit-exact: same fp64 operations
+    assert np.array_equal(nn_g, nn_o)
+    assert (d_o == np.finfo(np.float64).max).any()  # some queries have no candidate
+
+
+@pytest.mark.parametrize("kernel,block", VARIANTS)
+def test_pass_sums_match_oracle(case1, kernel, block):
+    cfg, scans, gmap, omap = case1
+    reg = _reg(kernel, block)
+    for s in scans:
+        guess = syn.pose_mul(s["last_pose"], s["rel_odom"])
+        for tau in (cfg.first_frame_tau(), 0.2):
+            g = reg.pass_sums(s["frame"], gmap, guess, tau)
+            o, _ = okicp.icp_pass(omap, s["frame"], guess, tau)
+            assert g[6] == o[6]  # identical accept/reject decisions
+            np.testing.assert_allclose(g, o, rtol=SUM_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("kernel,block", VARIANTS)
+@pytest.mark.parametrize("loop", [0, 1])
+def test_registration_matches_oracle(case1, kernel, block, loop):
+    cfg, scans, gmap, omap = case1
+    reg = _reg(kernel, block)
+    reg.set_option("loop", loop)
+    oreg = okicp.KinematicRegistration()
+    for s in scans:
+        # make the initial guess bad enough to need several iterations
+        rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.2, 0.0, np.deg2rad(1.5)))
+        pose = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, cfg.first_frame_tau())
+        ref = oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, cfg.first_frame_tau())
+        assert reg.last_stats.iterations == oreg.last_stats.iterations
+        assert reg.last_stats.converged == oreg.last_stats.converged
+        np.testing.assert_allclose(pose, ref, rtol=0, atol=POSE_TOL)
+        k = reg.last_stats.iterations
+        np.testing.assert_allclose(np.array(reg.last_stats.n_corr[:k]), np.array(oreg.last_stats.n_corr[:k]))
+
+
+def test_empty_map_returns_prediction(case1):
+    cfg, scans, gmap, omap = case1
+    s = scans[0]
+    reg = K.KinematicRegistration()
+    empty = K.VoxelHashMap(1.0, 100.0, 20)
+    pose = reg.ComputeRobotMotion(s["frame"], empty, s["last_pose"], s["rel_odom"], 1.0)
+    ref = okicp.KinematicRegistration().ComputeRobotMotion(s["frame"], okicp.VoxelHashMap(1.0, 100.0, 20), s["last_pose"], s["rel_odom"], 1.0)
+    np.testing.assert_allclose(pose, ref, rtol=0, atol=1e-15)
+    assert reg.last_stats.empty_map == 1
+
+
+def test_zero_correspondences_gives_nan_like_reference(case1):
+    cfg, scans, gmap, omap = case1
+    s = scans[0]
+    reg = K.KinematicRegistration()
+    far = s["frame"] + np.array([0.0, 0.0, 500.0])
+    pose = reg.ComputeRobotMotion(far, gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+    assert np.isnan(pose).any()
+    oreg = okicp.KinematicRegistration()
+    ref = oreg.ComputeRobotMotion(far, omap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    assert np.isnan(ref).any()
+
+
+def test_device_frame_equals_host_frame(case1):
+    cfg, scans, gmap, omap = case1
+    s = scans[1]
+    reg = K.KinematicRegistration()
+    a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    b = reg.ComputeRobotMotion(K.DeviceFrame(s["frame"]), gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    assert np.array_equal(a, b)  # deterministic: fixed-order reductions
