@@ -60,7 +60,8 @@ typedef struct kicp_stats {
     double n_corr[KICP_MAX_LOG_PASSES];     /* correspondences per pass */
     double sums[KICP_MAX_LOG_PASSES][6];    /* raw JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2 per pass */
     double dx[KICP_MAX_LOG_PASSES][2];      /* solved (displacement, yaw) per pass */
-    double gpu_ms;                          /* device time of the call, HIP events on the handle's stream */
+    double gpu_ms;                          /* device time of the call, HIP events on the handle's stream ("timing" >= 1) */
+    double pass_ms[KICP_MAX_LOG_PASSES];    /* device time of each fused pass kernel, HIP events around the launch ("timing" == 2) */
 } kicp_stats;
 
 const char *kicp_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -94,8 +95,13 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out);
 void kicp_reg_destroy(kicp_reg *reg);
 int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
 int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
-/* Backend tuning knobs (not part of the reference API): "pass_kernel" (0 gather, 1 lds-staged), "block",
- * "sort" (0 off, 1 Morton-sort queries once per scan), "loop" (0 enqueue-all, 1 host-stepped), ... */
+/* Backend tuning knobs (not part of the reference API):
+ *   "pass_kernel"  2 (default) queries binned by 2x2x2-voxel cell + LDS-staged neighbourhoods; 1 LDS staging over the
+ *                  queries in their given order; 0 thread-per-query gather
+ *   "block"        workgroup size of variants 0/1 (64|128|256);  "waves_per_cu" persistent grid of variant 2
+ *   "loop"         1 (default) stepped: one iteration queued ahead, host polls the stop flag; 0 all iterations queued
+ *   "wait"         0 (default) poll the host-mapped result record; 1 hipStreamSynchronize
+ *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[] */
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value);
 double kicp_reg_get_option(const kicp_reg *reg, const char *name);
 
@@ -120,16 +126,20 @@ int kicp_device_free(int device, void *dptr);
 int kicp_device_upload(int device, void *dst_dptr, const void *src_host, size_t bytes);
 int kicp_device_synchronize(int device);
 
-/* ---- multi-GPU: scan points sharded across ranks, map replicated, one 7-double all-reduce per iteration
- *      (SURVEY.md section 8e).  Every rank calls kicp_register* with ITS shard and gets the identical pose. ---- */
+/* ---- multi-GPU: scan points sharded across ranks, map replicated, one tiny all-reduce per ICP iteration
+ *      (SURVEY.md section 8e).  Every rank calls kicp_register* with ITS shard and gets the identical pose.
+ *      The payload is KICP_REDUCE_WORDS int64 values: the seven sums (JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2,
+ *      N_corr) are accumulated exactly as 3 x 40-bit fixed-point limbs each, so an integer sum-all-reduce makes the
+ *      result independent of the number of ranks, bit for bit. ---- */
+#define KICP_REDUCE_WORDS 24
 #define KICP_COMM_ID_BYTES 128
 int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]); /* rank 0 creates, the caller broadcasts the bytes */
 int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]); /* RCCL comm on reg's device */
 int kicp_reg_comm_destroy(kicp_reg *reg);
 /* Alternative to the built-in RCCL communicator: the caller supplies the sum-all-reduce (e.g. torch.distributed).
- * Called once per ICP iteration with a device buffer of `count` doubles to be reduced IN PLACE, ordered on
- * `stream` (a hipStream_t).  Pass NULL to remove. */
-typedef int (*kicp_allreduce_fn)(void *user, double *d_buf, int count, void *stream);
+ * Called once per ICP iteration with a device buffer of `count` int64 values to be sum-reduced IN PLACE, ordered
+ * on `stream` (a hipStream_t).  Return 0 on success.  Pass NULL to remove. */
+typedef int (*kicp_allreduce_fn)(void *user, long long *d_buf, int count, void *stream);
 int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user);
 
 #ifdef __cplusplus

@@ -41,7 +41,7 @@ class RegConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("empty_map", C.c_int32), ("reserved", C.c_int32),
                 ("beta", C.c_double), ("n_corr", C.c_double * MAX_LOG_PASSES), ("sums", (C.c_double * 6) * MAX_LOG_PASSES),
-                ("dx", (C.c_double * 2) * MAX_LOG_PASSES), ("gpu_ms", C.c_double)]
+                ("dx", (C.c_double * 2) * MAX_LOG_PASSES), ("gpu_ms", C.c_double), ("pass_ms", C.c_double * MAX_LOG_PASSES)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)

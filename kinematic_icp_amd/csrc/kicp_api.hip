@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,22 +85,40 @@ struct kicp_map {
     kicp_map(double vs, double md, uint32_t cap) : host(vs, md, cap) {}
 };
 
+struct BinBuffers {
+    unsigned long long *cell_keys = nullptr;
+    uint32_t *cell_count = nullptr, *cell_start = nullptr, *cell_list = nullptr, *counters = nullptr;
+    uint2 *qinfo = nullptr, *items = nullptr;
+    double *sorted_src = nullptr;
+    uint32_t mask = 0;
+    size_t cap_n = 0;
+};
+
 struct kicp_reg {
     kicp_reg_config cfg{};
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evp[2 * KICP_MAX_LOG_PASSES] = {};  // per-pass events ("timing" == 2), created on first use
     IcpState *d_state = nullptr;
-    IcpState *h_state = nullptr;  // pinned
-    double *d_partials = nullptr;
+    HostRecord *rec = nullptr;    // host-mapped pinned result record (host view)
+    HostRecord *d_rec = nullptr;  // same memory, device view
+    unsigned long long call_id = 0;
+    unsigned long long *d_partials = nullptr;  // limb rows of the reduction tree
+    unsigned int *d_tickets = nullptr;
     size_t partial_blocks = 0;
     double *d_frame = nullptr;  // staging for host frames
     size_t frame_cap = 0;
+    BinBuffers bin;
     // options
-    int pass_kernel = 1;  // 0 gather, 1 lds
-    int block = 128;
-    int loop_mode = 0;    // 0 enqueue every iteration up front, 1 host-stepped (sync per iteration)
+    int pass_kernel = 0;  // 0 gather, 1 lds (given order), 2 binned by cell
+    int block = 128;      // workgroup size of variants 0/1
+    int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
+    int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
+    int waves_per_cu = 12; // persistent grid of variants 1/2
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
+    int dbg = 0;
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -151,27 +170,45 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
 }
 
 template <int BLOCK>
-void launch_pass_block(int kernel, const PassParams &p, uint32_t grid, hipStream_t s) {
-    if (kernel == 0)
-        hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
-    else
-        hipLaunchKernelGGL(k_pass_lds<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
-}
-void launch_pass(const kicp_reg *r, const PassParams &p, uint32_t grid) {
-    switch (r->block) {
-        case 64: launch_pass_block<64>(r->pass_kernel, p, grid, r->stream); break;
-        case 256: launch_pass_block<256>(r->pass_kernel, p, grid, r->stream); break;
-        default: launch_pass_block<128>(r->pass_kernel, p, grid, r->stream); break;
-    }
+void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
 }
 int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
+uint32_t pass_grid(const kicp_reg *r, size_t n) {
+    if (r->pass_kernel != 0) {  // persistent one-wave workgroups
+        const size_t max_groups = (n + 63) / 64 + (r->pass_kernel == 2 ? n / 8 : 0);  // more workgroups than groups would only idle
+        const size_t want = static_cast<size_t>(r->num_cus) * r->waves_per_cu;
+        return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
+    }
+    const int block = normalized_block(r->block);
+    return static_cast<uint32_t>(std::max<size_t>(1, (n + block - 1) / block));
+}
+void launch_pass(const kicp_reg *r, const PassParams &p) {
+    const uint32_t grid = pass_grid(r, p.n);
+    if (r->pass_kernel == 2) {
+        hipLaunchKernelGGL(k_pass_binned, dim3(grid), dim3(64), 0, r->stream, p);
+        return;
+    }
+    if (r->pass_kernel == 1) {
+        hipLaunchKernelGGL(k_pass_lds, dim3(grid), dim3(64), 0, r->stream, p);
+        return;
+    }
+    switch (normalized_block(r->block)) {
+        case 64: launch_gather<64>(p, grid, r->stream); break;
+        case 256: launch_gather<256>(p, grid, r->stream); break;
+        default: launch_gather<128>(p, grid, r->stream); break;
+    }
+}
 
 int ensure_partials(kicp_reg *r, size_t blocks) {
     if (blocks <= r->partial_blocks) return KICP_OK;
     if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
-    r->d_partials = nullptr;
-    const size_t want = blocks + blocks / 2 + 64;
-    HIP_TRY(hipMalloc(&r->d_partials, want * kNumSums * sizeof(double)));
+    if (r->d_tickets) HIP_TRY(hipFree(r->d_tickets));
+    r->d_partials = nullptr, r->d_tickets = nullptr;
+    const size_t want = blocks + blocks / 2 + 64, groups = want / kGroup + 2;
+    HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
     r->partial_blocks = want;
     return KICP_OK;
 }
@@ -184,18 +221,83 @@ int ensure_frame(kicp_reg *r, size_t n) {
     r->frame_cap = want;
     return KICP_OK;
 }
+void free_bin(BinBuffers &b) {
+    hipFree(b.cell_keys), hipFree(b.cell_count), hipFree(b.cell_start), hipFree(b.cell_list), hipFree(b.counters);
+    hipFree(b.qinfo), hipFree(b.items), hipFree(b.sorted_src);
+    b = BinBuffers{};
+}
+int ensure_bin(kicp_reg *r, size_t n) {
+    BinBuffers &b = r->bin;
+    if (n <= b.cap_n) return KICP_OK;
+    free_bin(b);
+    const size_t cap = n + n / 4 + 1024;
+    size_t slots = 1024;
+    while (slots < 2 * cap) slots <<= 1;  // load factor <= 0.5 even if every query had its own cell
+    HIP_TRY(hipMalloc(&b.cell_keys, slots * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&b.cell_count, slots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.cell_start, slots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.cell_list, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.counters, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.qinfo, cap * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&b.items, (cap / kRunLen + cap + 2) * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&b.sorted_src, cap * 3 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(b.cell_keys, 0xFF, slots * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(b.cell_count, 0, slots * sizeof(uint32_t), r->stream));
+    HIP_TRY(hipMemsetAsync(b.counters, 0, 16 * sizeof(uint32_t), r->stream));
+    b.mask = static_cast<uint32_t>(slots - 1), b.cap_n = cap;
+    return KICP_OK;
+}
+// counting sort of the scan by cell at the predicted pose: three launches, once per scan
+void launch_binning(kicp_reg *r, const double *d_frame, size_t n, const Pose &T0, double voxel_size) {
+    BinBuffers &b = r->bin;
+    BinParams bp{};
+    bp.src = d_frame, bp.n = static_cast<uint32_t>(n), bp.pose0 = T0, bp.voxel_size = voxel_size;
+    bp.cell_keys = b.cell_keys, bp.cell_count = b.cell_count, bp.cell_start = b.cell_start, bp.cell_list = b.cell_list;
+    bp.mask = b.mask, bp.counters = b.counters, bp.qinfo = b.qinfo, bp.sorted_src = b.sorted_src, bp.items = b.items;
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(256), 0, r->stream, bp);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, r->stream, bp);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid), dim3(256), 0, r->stream, bp);
+}
 
-// enqueue the collective between the partial reduction and the solve (multi-GPU only)
+// enqueue the collective between the limb reduction and the solve (multi-GPU only)
 int enqueue_allreduce(kicp_reg *r) {
-    double *buf = r->d_state->reduced;
+    long long *buf = r->d_state->reduce;
     if (r->allreduce_fn) {
-        if (r->allreduce_fn(r->allreduce_user, buf, kNumSums, static_cast<void *>(r->stream)) != 0)
+        if (r->allreduce_fn(r->allreduce_user, buf, kReduceWords, static_cast<void *>(r->stream)) != 0)
             return fail(KICP_ERR_COMM, "user all-reduce callback failed");
         return KICP_OK;
     }
-    const ncclResult_t rc = g_comm.AllReduce(buf, buf, kNumSums, ncclFloat64, ncclSum, r->comm, r->stream);
+    const ncclResult_t rc = g_comm.AllReduce(buf, buf, kReduceWords, ncclInt64, ncclSum, r->comm, r->stream);
     if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclAllReduce: ") + g_comm.GetErrorString(rc));
     return KICP_OK;
+}
+
+// wait until the record carries `call_id` with at least `min_iter` completed iterations (or its done bit);
+// returns the observed seq.  Polls host-mapped memory; falls back to a stream sync when asked to or on a fault.
+int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool need_done, unsigned long long *seq_out) {
+    volatile unsigned long long *seq = &r->rec->seq;
+    if (r->wait_mode == 1) HIP_TRY(hipStreamSynchronize(r->stream));
+    for (unsigned long long spins = 0;; ++spins) {
+        const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+        if ((s >> 16) == call_id) {
+            const bool done = (s & 0x8000ull) != 0;
+            if (done || (!need_done && (s & 0x7FFFull) >= min_iter)) {
+                *seq_out = s;
+                return KICP_OK;
+            }
+        }
+        if (r->wait_mode == 1) return fail(KICP_ERR_HIP, "result record not written after stream synchronisation");
+        if ((spins & 0xFFFFF) == 0xFFFFF) {  // every ~1M polls: has the queue died or drained without an answer?
+            const hipError_t q = hipStreamQuery(r->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+            if (q == hipSuccess) {
+                const unsigned long long s2 = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+                if ((s2 >> 16) == call_id && ((s2 & 0x8000ull) || (!need_done && (s2 & 0x7FFFull) >= min_iter))) continue;
+                return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+            }
+        }
+    }
 }
 
 int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
@@ -209,68 +311,93 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         if (stats) stats->empty_map = 1;
         return KICP_OK;
     }
-    if (n > 0xFFFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
-    if (int rc = set_device(r->device)) return rc;
-    if (int rc = map_sync(map, r->device, r->stream)) return rc;
-    const int block = normalized_block(r->block);
-    const uint32_t grid = static_cast<uint32_t>((n + block - 1) / block);
-    if (int rc = ensure_partials(r, grid ? grid : 1)) return rc;
-    const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
     const int max_it = r->cfg.max_num_iterations;
-
-    PassParams pp{};
-    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
-    pp.partials = r->d_partials, pp.pose0 = T0;
-    FinalizeParams fp{};
-    fp.st = r->d_state, fp.partials = r->d_partials, fp.nblocks = grid, fp.pose0 = T0, fp.max_iterations = max_it;
-    fp.convergence_criterion = r->cfg.convergence_criterion, fp.adaptive = r->cfg.use_adaptive_odometry_regularization;
-    fp.fixed_regularization = r->cfg.fixed_regularization;
-
-    if (r->timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
     if (max_it <= 0) {  // the reference's loop body never runs: the prediction is returned (Registration.cpp:179,189)
         pose_to(T0, out_pose_qt);
         return KICP_OK;
     }
-    IcpState *hs = r->h_state;
-    for (int it = 0; it < max_it; ++it) {
-        pp.pass = it, fp.pass = it;
-        if (grid) launch_pass(r, pp, grid);
-        if (!multi) {
-            fp.stage = 0;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
-        } else {
-            fp.stage = 1;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
+    if (max_it > 0x7FFF) return fail(KICP_ERR_ARG, "max_num_iterations > 32767");
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (int rc = set_device(r->device)) return rc;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    const bool binned = r->pass_kernel == 2;
+    if (binned)
+        if (int rc = ensure_bin(r, n ? n : 1)) return rc;
+    if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
+    const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
+    const unsigned long long call_id = ++r->call_id;
+
+    PassParams pp{};
+    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.bin = BinView{r->bin.sorted_src, r->bin.items, r->bin.counters};
+    pp.partials = r->d_partials, pp.tickets = r->d_tickets;
+    pp.dbg = r->dbg;
+    SolveParams &sp = pp.sol;
+    sp.pose0 = T0, sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
+    sp.adaptive = r->cfg.use_adaptive_odometry_regularization, sp.fixed_regularization = r->cfg.fixed_regularization;
+    sp.mode = multi ? 1 : 0, sp.call_id = call_id, sp.rec = r->d_rec;
+
+    if (r->timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
+    if (binned) launch_binning(r, d_frame, n, T0, map->host.voxel_size());
+    const bool pass_events = r->timing == 2;
+    if (pass_events && !r->evp[0])
+        for (auto &e : r->evp) HIP_TRY(hipEventCreate(&e));
+    auto enqueue_iteration = [&](int it) -> int {
+        sp.pass = it;
+        const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
+        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
+        launch_pass(r, pp);
+        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
+        if (multi) {
             if (int rc = enqueue_allreduce(r)) return rc;
-            fp.stage = 2;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, r->stream, fp);
+            hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, r->stream, r->d_state, sp);
         }
-        if (r->loop_mode == 1) {  // host-stepped: look at the stop flag after every iteration
-            HIP_TRY(hipMemcpyAsync(&hs->done, &r->d_state->done, sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
-            HIP_TRY(hipStreamSynchronize(r->stream));
-            if (hs->done) break;
+        return KICP_OK;
+    };
+    unsigned long long seq = 0;
+    if (r->loop_mode == 0) {
+        for (int it = 0; it < max_it; ++it)
+            if (int rc = enqueue_iteration(it)) return rc;
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+        if (int rc = wait_record(r, call_id, 0, true, &seq)) return rc;
+    } else {
+        // stepped: iteration it+1 is already queued while the host waits for the stop flag of iteration it, so the
+        // GPU never idles on the host; at most one queued iteration turns out to be unnecessary (it exits at once).
+        int queued = 0;
+        if (int rc = enqueue_iteration(queued++)) return rc;
+        for (int it = 0;; ++it) {
+            if (queued < max_it)
+                if (int rc = enqueue_iteration(queued++)) return rc;
+            if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+            if (seq & 0x8000ull) break;
         }
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
     }
-    HIP_TRY(hipGetLastError());
-    if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
-    HIP_TRY(hipMemcpyAsync(hs, r->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    pose_to(hs->T, out_pose_qt);
+    const HostRecord *rec = r->rec;  // stable: after `done` no kernel writes the record again
+    pose_to(rec->T, out_pose_qt);
     if (stats) {
-        stats->iterations = hs->iter, stats->converged = hs->converged, stats->beta = hs->beta;
-        const int k = hs->iter < KICP_MAX_LOG_PASSES ? hs->iter : KICP_MAX_LOG_PASSES;
+        stats->iterations = rec->iter, stats->converged = rec->converged, stats->beta = rec->beta;
+        const int k = rec->iter < KICP_MAX_LOG_PASSES ? rec->iter : KICP_MAX_LOG_PASSES;
         for (int i = 0; i < k; ++i) {
-            stats->n_corr[i] = hs->log_ncorr[i];
-            for (int j = 0; j < 6; ++j) stats->sums[i][j] = hs->log_sums[i][j];
-            stats->dx[i][0] = hs->log_dx[i][0], stats->dx[i][1] = hs->log_dx[i][1];
+            stats->n_corr[i] = rec->log_ncorr[i];
+            for (int j = 0; j < 6; ++j) stats->sums[i][j] = rec->log_sums[i][j];
+            stats->dx[i][0] = rec->log_dx[i][0], stats->dx[i][1] = rec->log_dx[i][1];
         }
         if (r->timing) {
             float ms = 0.f;
+            HIP_TRY(hipEventSynchronize(r->ev1));
             HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
             stats->gpu_ms = ms;
+            for (int i = 0; pass_events && i < k; ++i) {
+                HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
+                stats->pass_ms[i] = ms;
+            }
         }
     }
-    return hs->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+    if (rec->nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
+    return rec->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
 }
 
 }  // namespace
@@ -373,7 +500,13 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (e == hipSuccess) e = hipEventCreate(&r->ev1);
     if (e == hipSuccess) e = hipMalloc(&r->d_state, sizeof(IcpState));
     if (e == hipSuccess) e = hipMemset(r->d_state, 0, sizeof(IcpState));
-    if (e == hipSuccess) e = hipHostMalloc(&r->h_state, sizeof(IcpState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&r->rec), sizeof(HostRecord), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) std::memset(r->rec, 0, sizeof(HostRecord));
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rec), r->rec, 0);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) r->num_cus = prop.multiProcessorCount;
+    }
     if (e != hipSuccess) {
         kicp_reg_destroy(r);
         return fail(KICP_ERR_HIP, std::string("kicp_reg_create: ") + hipGetErrorString(e));
@@ -381,6 +514,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env);
     if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
     if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
+    if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
     *out = r;
     return KICP_OK;
 }
@@ -390,11 +524,15 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->comm) g_comm.CommDestroy(reg->comm);
     if (reg->stream) hipStreamSynchronize(reg->stream);
     if (reg->d_state) hipFree(reg->d_state);
-    if (reg->h_state) hipHostFree(reg->h_state);
+    if (reg->rec) hipHostFree(reg->rec);
     if (reg->d_partials) hipFree(reg->d_partials);
+    if (reg->d_tickets) hipFree(reg->d_tickets);
+    free_bin(reg->bin);
     if (reg->d_frame) hipFree(reg->d_frame);
     if (reg->ev0) hipEventDestroy(reg->ev0);
     if (reg->ev1) hipEventDestroy(reg->ev1);
+    for (auto &e : reg->evp)
+        if (e) hipEventDestroy(e);
     if (reg->stream) hipStreamDestroy(reg->stream);
     delete reg;
 }
@@ -414,7 +552,10 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     if (k == "pass_kernel") reg->pass_kernel = static_cast<int>(value);
     else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
+    else if (k == "wait") reg->wait_mode = static_cast<int>(value);
+    else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
+    else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else return fail(KICP_ERR_ARG, "unknown option " + k);
     return KICP_OK;
 }
@@ -424,7 +565,10 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "pass_kernel") return reg->pass_kernel;
     if (k == "block") return reg->block;
     if (k == "loop") return reg->loop_mode;
+    if (k == "wait") return reg->wait_mode;
+    if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
+    if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;
     return -1.0;
 }
 
@@ -452,21 +596,24 @@ int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t
     if (int rc = set_device(reg->device)) return rc;
     if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
     if (int rc = ensure_frame(reg, n)) return rc;
-    const int block = normalized_block(reg->block);
-    const uint32_t grid = static_cast<uint32_t>((n + block - 1) / block);
-    if (int rc = ensure_partials(reg, grid)) return rc;
+    const bool binned = reg->pass_kernel == 2;
+    if (binned)
+        if (int rc = ensure_bin(reg, n)) return rc;
+    if (int rc = ensure_partials(reg, pass_grid(reg, n))) return rc;
     HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
+    const unsigned long long call_id = ++reg->call_id;
     PassParams pp{};
+    pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
     pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
-    pp.st = reg->d_state, pp.partials = reg->d_partials, pp.pose0 = pose_from(pose_qt), pp.pass = 0;
-    launch_pass(reg, pp, grid);
-    FinalizeParams fp{};
-    fp.st = reg->d_state, fp.partials = reg->d_partials, fp.nblocks = grid, fp.pass = 0, fp.stage = 1;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, reg->stream, fp);
+    pp.st = reg->d_state, pp.bin = BinView{reg->bin.sorted_src, reg->bin.items, reg->bin.counters};
+    pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
+    if (binned) launch_binning(reg, reg->d_frame, n, pp.sol.pose0, map->host.voxel_size());
+    launch_pass(reg, pp);
+    hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(reg->h_state->reduced, reg->d_state->reduced, sizeof(double) * kNumSums, hipMemcpyDeviceToHost, reg->stream));
-    HIP_TRY(hipStreamSynchronize(reg->stream));
-    for (int i = 0; i < 7; ++i) out_sums[i] = reg->h_state->reduced[i];
+    unsigned long long seq = 0;
+    if (int rc = wait_record(reg, call_id, 1, true, &seq)) return rc;
+    for (int i = 0; i < 7; ++i) out_sums[i] = reg->rec->sums[i];
     return KICP_OK;
 }
 
@@ -496,6 +643,7 @@ int kicp_device_synchronize(int device) {
 // ---- multi-GPU ------------------------------------------------------------------------------------------------------
 int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]) {
     static_assert(KICP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    static_assert(KICP_REDUCE_WORDS == kReduceWords, "payload size");
     if (!id) return fail(KICP_ERR_ARG, "null argument");
     std::string err;
     if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);

@@ -1,16 +1,24 @@
 // kicp_kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the registration hot path.
 //
-//   k_pass_gather / k_pass_lds : fused DataAssociation + ComputePerturbation reduction (+ the pass-0 sum of
-//                                ComputeOdometryRegularization): registration/Registration.cpp:62-81, 83-118, 48-55,
-//                                with kiss_icp::VoxelHashMap::GetClosestNeighbor (kiss-icp v1.2.0)
-//                                inlined as the 27-voxel probe + bucket scan.  No correspondence list is materialised.
-//   k_finalize                 : fixed-order sum of the block partials, then Registration.cpp:119-125 (2x2 solve),
-//                                :159-167 (motion model), :181-184 (pose update + stop test) on one lane.
-//   k_closest                  : GetClosestNeighbor for a batch of queries (API parity / tests).
+//   k_pass_*    : fused DataAssociation + ComputePerturbation reduction (+ the pass-0 sum of
+//                 ComputeOdometryRegularization): registration/Registration.cpp:62-81, 83-118, 48-55, with
+//                 kiss_icp::VoxelHashMap::GetClosestNeighbor (kiss-icp v1.2.0) inlined as the
+//                 27-voxel probe + bucket scan.  No correspondence list is materialised.  The LAST workgroup to
+//                 finish also runs Registration.cpp:119-125 (2x2 solve), :159-167 (motion model) and :181-184
+//                 (pose update + stop test) on one lane, so one launch = one ICP iteration.
+//       k_pass_binned  variant 2 (default): queries were binned by 2x2x2-voxel cell (k_bin_*); one wave per run of
+//                      <= 64 queries of a cell stages the cell's voxel neighbourhood in LDS and every lane scans it.
+//       k_pass_lds     variant 1: same staging, but over consecutive queries in their given order.
+//       k_pass_gather  variant 0: thread-per-query straight from HBM/L2 (baseline / fallback).
+//   k_bin_*     : counting sort of the scan by cell at the predicted pose (once per scan).
+//   k_solve     : the solve/update step alone (multi-GPU: runs after the all-reduce).
+//   k_closest   : GetClosestNeighbor for a batch of queries (API parity / tests).
 //
-// Roofline: gather + reduction, ~0.02 flop/B -> memory bound, no MFMA.  All arithmetic is fp64,
-// evaluated in the reference's operation order (TU is compiled with -ffp-contract=off), so NN decisions and
-// per-point terms are those of the fp64 reference; only the summation order differs.
+// Roofline: gather + reduction, ~0.02 flop/B -> memory bound, no MFMA.
+// Numerics: per-point arithmetic is fp64 in the reference's operation order (TU compiled with -ffp-contract=off),
+// so NN decisions and per-correspondence terms equal the fp64 reference's.  The sums are accumulated EXACTLY:
+// each term is rounded once to a multiple of 2^-40 and added as a 128-bit integer, so the result does not depend
+// on summation order, kernel variant, binning order or the number of GPUs (bit-reproducible).
 #pragma once
 #include <cfloat>
 #include <climits>
@@ -21,17 +29,53 @@
 namespace kicp {
 
 constexpr int kMaxLog = 32;
-constexpr int kNumSums = 8;  // JTJ00 JTJ01 JTJ11 JTr0 JTr1 ssq count pad
+constexpr int kNumSums = 7;           // JTJ00 JTJ01 JTJ11 JTr0 JTr1 ssq count
+constexpr int kNumLimbs = 3 * kNumSums;
+constexpr int kReduceWords = 24;      // all-reduce payload: 21 limb sums + padding (int64)
+constexpr double kFixScale = 1099511627776.0;  // 2^40
+constexpr double kFixLimit = 8388608.0;        // 2^23: |term| must stay below this
+
+// Result record in host-mapped pinned memory: written by the finalising lane, polled by the host.
+struct HostRecord {
+    unsigned long long seq;  // (call_id << 16) | (done << 15) | completed iterations; written last, system-scope release
+    int32_t done, iter, converged, nan_flag;
+    Pose T;
+    double beta;
+    double log_ncorr[kMaxLog];
+    double log_sums[kMaxLog][6];
+    double log_dx[kMaxLog][2];
+    double sums[kNumSums];  // last pass, for kicp_pass_sums
+    uint32_t n_cells, n_items, not_staged, reserved;
+};
 
 // Device-resident loop state of one ComputeRobotMotion call.
 struct IcpState {
     Pose T;  // current_estimate
     double beta;
     int32_t done, iter, converged, nan_flag;
-    double log_ncorr[kMaxLog];
-    double log_sums[kMaxLog][6];
-    double log_dx[kMaxLog][2];
-    double reduced[kNumSums];  // all-reduce buffer (multi-GPU) / last pass sums
+    unsigned int not_staged;             // diagnostics: workgroups that fell back to the HBM search
+    long long reduce[kReduceWords];      // limb sums of the running pass (multi-GPU: all-reduced in place)
+    unsigned int pad_[32];
+    unsigned int ticket;                 // second-level arrival counter (own cache line)
+    unsigned int pad2_[31];
+};
+
+struct SolveParams {
+    Pose pose0;
+    int32_t pass;
+    int32_t max_iterations;
+    double convergence_criterion;
+    int32_t adaptive;
+    double fixed_regularization;
+    int32_t mode;  // 0 = solve inside the pass kernel; 1 = only publish limb sums (multi-GPU / kicp_pass_sums)
+    unsigned long long call_id;
+    HostRecord *rec;  // device pointer to the host-mapped record
+};
+
+struct BinView {
+    const double *sorted_src;  // scan points permuted by cell (AoS xyz fp64)
+    const uint2 *items;        // (first query, count <= 64) per work item
+    const uint32_t *counters;  // [0] n_cells, [1] n_items
 };
 
 struct PassParams {
@@ -40,22 +84,60 @@ struct PassParams {
     MapView map;
     double tau;
     IcpState *st;
-    double *partials;  // [gridDim.x][kNumSums]
-    Pose pose0;        // used when pass == 0 (the initial guess travels as a kernel argument)
-    int32_t pass;
+    unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
+    unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
+    BinView bin;
+    SolveParams sol;
+    int32_t dbg;  // experiments only: 1 = staging without matching, 2 = neither
 };
 
-struct FinalizeParams {
-    IcpState *st;
-    const double *partials;
-    uint32_t nblocks;
-    Pose pose0;
-    int32_t pass;
-    int32_t max_iterations;
-    double convergence_criterion;
-    int32_t adaptive;
-    double fixed_regularization;
-    int32_t stage;  // 0 = reduce + solve (single GPU); 1 = reduce only -> st->reduced; 2 = solve from st->reduced
+// ------------------------------------------------------------------------------------------------------------
+// exact accumulation
+// ------------------------------------------------------------------------------------------------------------
+struct I128 {
+    unsigned long long lo;
+    long long hi;
+};
+__device__ __forceinline__ void i128_add(I128 &a, const I128 &b) {
+    const unsigned long long old = a.lo;
+    a.lo += b.lo;
+    a.hi += b.hi + (a.lo < old ? 1 : 0);
+}
+__device__ __forceinline__ void i128_add_fixed(I128 &a, double x, int &range_error) {
+    if (!(fabs(x) < kFixLimit)) {
+        range_error = 1;
+        return;
+    }
+    const long long v = __double2ll_rn(x * kFixScale);
+    const unsigned long long old = a.lo;
+    a.lo += static_cast<unsigned long long>(v);
+    a.hi += (v >> 63) + (a.lo < old ? 1 : 0);
+}
+// T = l0 + l1*2^40 + l2*2^80 with 0 <= l0,l1 < 2^40, l2 signed
+__device__ __forceinline__ void i128_to_limbs(const I128 &t, long long l[3]) {
+    const unsigned long long m40 = (1ull << 40) - 1;
+    l[0] = static_cast<long long>(t.lo & m40);
+    l[1] = static_cast<long long>(((t.lo >> 40) | (static_cast<unsigned long long>(t.hi) << 24)) & m40);
+    l[2] = t.hi >> 16;
+}
+__device__ __forceinline__ double limbs_to_double(const long long l[3]) {
+    // recombine (limb sums may exceed 40 bits and be negative), then convert the 128-bit magnitude
+    I128 t{static_cast<unsigned long long>(l[0]), l[0] >> 63};
+    I128 a{static_cast<unsigned long long>(l[1]) << 40, l[1] >> 24};
+    I128 b{0ull, static_cast<long long>(static_cast<unsigned long long>(l[2]) << 16)};
+    i128_add(t, a), i128_add(t, b);
+    const bool neg = t.hi < 0;
+    if (neg) {
+        t.lo = ~t.lo + 1ull;
+        t.hi = ~t.hi + (t.lo == 0ull ? 1 : 0);
+    }
+    const double mag = static_cast<double>(static_cast<unsigned long long>(t.hi)) * 18446744073709551616.0 + static_cast<double>(t.lo);
+    return (neg ? -mag : mag) / kFixScale;
+}
+
+struct Acc {
+    I128 v[kNumSums];
+    int range_error;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -64,27 +146,31 @@ struct FinalizeParams {
 struct Query {
     double x, y, z;      // transformed point T*p
     int32_t vx, vy, vz;  // PointToVoxel(T*p)
-    double fm[3], fp[3]; // squared distance to the -/+ faces of the own voxel, per axis
+};
+// squared distances to the -/+ faces of the own voxel per axis, and the culling slack
+struct Faces {
+    double fm[3], fp[3];
     double slack;
 };
 
 __device__ __forceinline__ void make_query(Query &q, double x, double y, double z, double vs) {
     q.x = x, q.y = y, q.z = z;
-    const double fx = floor(x / vs), fy = floor(y / vs), fz = floor(z / vs);
-    q.vx = static_cast<int32_t>(fx), q.vy = static_cast<int32_t>(fy), q.vz = static_cast<int32_t>(fz);
-    const double lx = x - fx * vs, ly = y - fy * vs, lz = z - fz * vs;
-    q.fm[0] = lx * lx, q.fm[1] = ly * ly, q.fm[2] = lz * lz;
-    q.fp[0] = (vs - lx) * (vs - lx), q.fp[1] = (vs - ly) * (vs - ly), q.fp[2] = (vs - lz) * (vs - lz);
+    q.vx = static_cast<int32_t>(floor(x / vs)), q.vy = static_cast<int32_t>(floor(y / vs)), q.vz = static_cast<int32_t>(floor(z / vs));
+}
+__device__ __forceinline__ void make_faces(Faces &f, const Query &q, double vs) {
+    const double lx = q.x - q.vx * vs, ly = q.y - q.vy * vs, lz = q.z - q.vz * vs;
+    f.fm[0] = lx * lx, f.fm[1] = ly * ly, f.fm[2] = lz * lz;
+    f.fp[0] = (vs - lx) * (vs - lx), f.fp[1] = (vs - ly) * (vs - ly), f.fp[2] = (vs - lz) * (vs - lz);
     // culling slack: far above fp64 rounding of the face distances, far below anything that matters
-    q.slack = 4.0 * vs * 9.1e-13 * (fabs(x) + fabs(y) + fabs(z) + vs);
+    f.slack = 4.0 * vs * 9.1e-13 * (fabs(q.x) + fabs(q.y) + fabs(q.z) + vs);
 }
 
 // lower bound of the squared distance from the query to any point of neighbour voxel (dx,dy,dz)
-__device__ __forceinline__ double box_d2(const Query &q, int dx, int dy, int dz) {
+__device__ __forceinline__ double box_d2(const Faces &f, int dx, int dy, int dz) {
     double d = 0.0;
-    d += dx > 0 ? q.fp[0] : (dx < 0 ? q.fm[0] : 0.0);
-    d += dy > 0 ? q.fp[1] : (dy < 0 ? q.fm[1] : 0.0);
-    d += dz > 0 ? q.fp[2] : (dz < 0 ? q.fm[2] : 0.0);
+    d += dx > 0 ? f.fp[0] : (dx < 0 ? f.fm[0] : 0.0);
+    d += dy > 0 ? f.fp[1] : (dy < 0 ? f.fm[1] : 0.0);
+    d += dz > 0 ? f.fp[2] : (dz < 0 ? f.fm[2] : 0.0);
     return d;
 }
 
@@ -101,7 +187,18 @@ __device__ __forceinline__ uint32_t table_lookup(const MapView &m, int32_t x, in
 // scan one bucket in insertion order; strict '<' keeps the first minimum (std::min_element + `distance < closest`)
 __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32_t count, uint32_t base_index, const Query &q,
                                             double &best, uint32_t &best_idx) {
-    for (uint32_t k = 0; k < count; ++k) {
+    uint32_t k = 0;
+    for (; k + 2 <= count; k += 2) {  // two points per trip: independent loads in flight
+        const double ax = p[3 * k], ay = p[3 * k + 1], az = p[3 * k + 2];
+        const double bx = p[3 * k + 3], by = p[3 * k + 4], bz = p[3 * k + 5];
+        const double adx = ax - q.x, ady = ay - q.y, adz = az - q.z;
+        const double bdx = bx - q.x, bdy = by - q.y, bdz = bz - q.z;
+        const double a2 = adx * adx + ady * ady + adz * adz;
+        const double b2 = bdx * bdx + bdy * bdy + bdz * bdz;
+        if (a2 < best) best = a2, best_idx = base_index + k;
+        if (b2 < best) best = b2, best_idx = base_index + k + 1;
+    }
+    if (k < count) {
         const double dx = p[3 * k] - q.x, dy = p[3 * k + 1] - q.y, dz = p[3 * k + 2] - q.z;
         const double d2 = dx * dx + dy * dy + dz * dz;
         if (d2 < best) best = d2, best_idx = base_index + k;
@@ -110,10 +207,12 @@ __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32
 
 // 27-voxel 1-NN straight from HBM/L2.  `best` enters as the acceptance bound (or DBL_MAX).
 __device__ __forceinline__ void search_global(const MapView &m, const Query &q, double &best, uint32_t &best_idx) {
+    Faces f;
+    make_faces(f, q, m.voxel_size);
 #pragma unroll 1
     for (int s = 0; s < 27; ++s) {
         const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-        if (box_d2(q, dx, dy, dz) > best + q.slack) continue;  // no point in there can beat `best`
+        if (box_d2(f, dx, dy, dz) > best + f.slack) continue;  // no point in there can beat `best`
         const uint32_t val = table_lookup(m, q.vx + dx, q.vy + dy, q.vz + dz);
         if (val == kEmptyVal) continue;
         const uint32_t bucket = val >> 8;
@@ -122,59 +221,189 @@ __device__ __forceinline__ void search_global(const MapView &m, const Query &q, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// per-correspondence terms (Registration.cpp:86-93,108-113) and the block reduction
+// per-correspondence terms (Registration.cpp:86-93,108-113)
 // ------------------------------------------------------------------------------------------------------------
-struct Acc {
-    double v[7];  // JTJ00 JTJ01 JTJ11 JTr0 JTr1 ssq count
-};
-
 __device__ __forceinline__ void accumulate(Acc &a, const Pose &T, double sx, double sy, double qx, double qy, double qz, double tx,
                                            double ty, double tz) {
     const double rx = qx - tx, ry = qy - ty, rz = qz - tz;  // residual = T*source - target
     double j0x, j0y, j0z, j1x, j1y, j1z;
     quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
     quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)
-    a.v[0] += j0x * j0x + j0y * j0y + j0z * j0z;
-    a.v[1] += j0x * j1x + j0y * j1y + j0z * j1z;
-    a.v[2] += j1x * j1x + j1y * j1y + j1z * j1z;
-    a.v[3] += j0x * rx + j0y * ry + j0z * rz;
-    a.v[4] += j1x * rx + j1y * ry + j1z * rz;
-    a.v[5] += rx * rx + ry * ry + rz * rz;
-    a.v[6] += 1.0;
+    i128_add_fixed(a.v[0], j0x * j0x + j0y * j0y + j0z * j0z, a.range_error);
+    i128_add_fixed(a.v[1], j0x * j1x + j0y * j1y + j0z * j1z, a.range_error);
+    i128_add_fixed(a.v[2], j1x * j1x + j1y * j1y + j1z * j1z, a.range_error);
+    i128_add_fixed(a.v[3], j0x * rx + j0y * ry + j0z * rz, a.range_error);
+    i128_add_fixed(a.v[4], j1x * rx + j1y * ry + j1z * rz, a.range_error);
+    i128_add_fixed(a.v[5], rx * rx + ry * ry + rz * rz, a.range_error);
+    a.v[6].lo += static_cast<unsigned long long>(kFixScale);  // 1.0; cannot carry for < 2^24 points per lane
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// solve + pose update (Registration.cpp:119-125, 159-167, 181-184), one lane
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams &f, const long long limbs[kNumLimbs], int range_error) {
+    double sums[kNumSums];
+#pragma unroll
+    for (int i = 0; i < kNumSums; ++i) sums[i] = limbs_to_double(limbs + 3 * i);
+    HostRecord *rec = f.rec;
+    const double n = sums[6];
+    Pose T = f.pass == 0 ? f.pose0 : st->T;
+    double beta;
+    if (f.pass == 0) {  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
+        beta = f.adaptive ? 1.0 / (sums[5] / n + DBL_MIN) : f.fixed_regularization;
+        st->beta = beta;
+        st->converged = 0, st->nan_flag = 0;
+    } else {
+        beta = st->beta;
+    }
+    double dx0, dx1;
+    solve_perturbation(sums, n, beta, dx0, dx1);
+    T = pose_mul(T, motion_model(dx0, dx1));  // current_estimate * delta_motion (Registration.cpp:181-182)
+    st->T = T;
+    int converged = f.pass == 0 ? 0 : st->converged, nan_flag = f.pass == 0 ? 0 : st->nan_flag;
+    int done = 0;
+    if (sqrt(dx0 * dx0 + dx1 * dx1) < f.convergence_criterion) done = 1, converged = 1;  // Registration.cpp:184
+    if (f.pass + 1 >= f.max_iterations) done = 1;
+    if (!(n > 0.0) || range_error) done = 1, nan_flag = 1 + (range_error ? 1 : 0);  // 0/0: NaN pose from here on, as in the reference
+    st->iter = f.pass + 1, st->converged = converged, st->nan_flag = nan_flag, st->done = done;
+    if (rec) {
+        if (f.pass < kMaxLog) {
+            rec->log_ncorr[f.pass] = n;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rec->log_sums[f.pass][i] = sums[i];
+            rec->log_dx[f.pass][0] = dx0, rec->log_dx[f.pass][1] = dx1;
+        }
+        rec->T = T, rec->beta = beta;
+        rec->done = done, rec->iter = f.pass + 1, rec->converged = converged, rec->nan_flag = nan_flag;
+        rec->not_staged = st->not_staged;
+        __hip_atomic_store(&rec->seq, (f.call_id << 16) | (done ? 0x8000ull : 0ull) | static_cast<unsigned long long>(f.pass + 1),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Workgroup epilogue of every pass kernel: exact workgroup sum -> two-level last-arriver tree -> the last workgroup
+// finishes the iteration.  Inter-workgroup traffic follows cdna_hip_programming.md Guideline 16 (form R1): payload
+// as 8-byte write-through (sc1) stores, `s_waitcnt vmcnt(0)`, ONE relaxed agent-scope ticket atomic per workgroup;
+// readers use sc1 loads.  No fences, no same-line atomic fan-in (tickets live on separate 128-B lines).
+constexpr int kGroup = 32;        // workgroups per first-level group
+constexpr int kTicketStride = 32; // uint32 words between group tickets (128 B)
+
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lanes 0..47 cooperatively sum `count` rows of kReduceWords words; the totals end up in lanes 0..23
+__device__ __forceinline__ long long sum_rows(const unsigned long long *rows, uint32_t count, int lane) {
+    long long v = 0;
+    if (lane < 2 * kReduceWords) {
+        const int word = lane % kReduceWords;
+        for (uint32_t j = lane / kReduceWords; j < count; j += 2) v += static_cast<long long>(ld_sc1(rows + static_cast<size_t>(j) * kReduceWords + word));
+    }
+    return v + __shfl_down(v, kReduceWords, 64);
 }
 
 template <int BLOCK>
-__device__ __forceinline__ void block_reduce_store(const Acc &a, double *__restrict__ out, double (*s_red)[8]) {
+__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*s_red)[kNumSums], int *s_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double v[7];
+    IcpState *st = p.st;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        double x = a.v[i];
+    for (int i = 0; i < kNumSums; ++i) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        v[i] = x;
+        for (int off = 32; off > 0; off >>= 1) {
+            I128 o;
+            o.lo = __shfl_down(a.v[i].lo, off, 64);
+            o.hi = __shfl_down(a.v[i].hi, off, 64);
+            i128_add(a.v[i], o);
+        }
     }
-    if (lane == 0) {
+    int range_error = __any(a.range_error) ? 1 : 0;
+    if (BLOCK > 64) {
+        if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) s_red[wave][i] = v[i];
+            for (int i = 0; i < kNumSums; ++i) s_red[wave][i] = a.v[i];
+            if (range_error) atomicOr(s_flag, 2);
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        range_error = (*s_flag & 2) ? 1 : 0;
     }
-    __syncthreads();
-    if (threadIdx.x < 7) {
-        double x = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) x += s_red[w][threadIdx.x];
-        out[threadIdx.x] = x;
+    // wave 0 only from here.  Lane i < 7 takes the workgroup total of sum i and publishes its three limbs.
+    I128 t{0ull, 0ll};
+#pragma unroll
+    for (int i = 0; i < kNumSums; ++i) {
+        I128 o;
+        o.lo = __shfl(a.v[i].lo, 0, 64), o.hi = __shfl(a.v[i].hi, 0, 64);
+        if (lane == i) t = o;
     }
+    const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
+    unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
+    if (lane < kNumSums) {
+        if (BLOCK > 64) {
+            t = s_red[0][lane];
+            for (int w = 1; w < BLOCK / 64; ++w) i128_add(t, s_red[w][lane]);
+        }
+        long long l[3];
+        i128_to_limbs(t, l);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st_sc1(row + 3 * lane + j, static_cast<unsigned long long>(l[j]));
+    } else if (lane < kNumSums + 3) {
+        st_sc1(row + kNumLimbs + (lane - kNumSums), lane == kNumSums ? static_cast<unsigned long long>(range_error) : 0ull);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
+    if (ticket != group_size - 1) return;
+    // ---- last workgroup of its group: fold the group's rows into one ---------------------------------------
+    if (lane == 0) __hip_atomic_store(p.tickets + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long total = sum_rows(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane);
+    if (ngroups > 1) {
+        unsigned long long *grow = p.partials + (static_cast<size_t>(nblocks) + g) * kReduceWords;
+        if (lane < kReduceWords) st_sc1(grow + lane, static_cast<unsigned long long>(total));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket != ngroups - 1) return;
+        if (lane == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total = sum_rows(p.partials + static_cast<size_t>(nblocks) * kReduceWords, ngroups, lane);
+    }
+    // ---- last workgroup of the launch ------------------------------------------------------------------------
+    if (lane < kReduceWords) st->reduce[lane] = total;
+    long long limbs[kNumLimbs + 1];
+#pragma unroll
+    for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
+    if (lane != 0 || p.sol.mode != 0) return;
+    solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
 }
 
-__device__ __forceinline__ Pose load_pose(const PassParams &p) { return p.pass == 0 ? p.pose0 : p.st->T; }
+// wave-uniform values belong in SGPRs: tell the compiler explicitly
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane(static_cast<int>(b)), hi = __builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+__device__ __forceinline__ Pose load_pose(const PassParams &p) {
+    if (p.sol.pass == 0) return p.sol.pose0;
+    const Pose T = p.st->T;
+    return Pose{uniform_d(T.qx), uniform_d(T.qy), uniform_d(T.qz), uniform_d(T.qw), uniform_d(T.tx), uniform_d(T.ty), uniform_d(T.tz)};
+}
+
+#define KICP_PASS_SHARED(BLOCK)                       \
+    __shared__ I128 s_red[(BLOCK) / 64][kNumSums];    \
+    __shared__ int s_flag;                            \
+    if (threadIdx.x == 0) s_flag = 0;
 
 // ------------------------------------------------------------------------------------------------------------
-// K1+K2 variant A: thread-per-query gather from HBM/L2
+// variant 0: thread-per-query gather from HBM/L2
 // ------------------------------------------------------------------------------------------------------------
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
-    __shared__ double s_red[BLOCK / 64][8];
-    if (p.pass != 0 && p.st->done) return;
+    KICP_PASS_SHARED(BLOCK)
+    if (p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     Acc acc{};
@@ -192,186 +421,477 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
             accumulate(acc, T, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
         }
     }
-    block_reduce_store<BLOCK>(acc, p.partials + static_cast<size_t>(blockIdx.x) * kNumSums, s_red);
+    if (BLOCK > 64) __syncthreads();
+    finish_pass<BLOCK>(acc, p, s_red, &s_flag);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1+K2 variant B: the block's voxel neighbourhood is staged in LDS once, then scanned by every query
+// Wave-level staged matching, shared by variants 1 and 2.  One wave handles a group of <= 64 queries:
+//   1. bounding box of the group's query voxels (+1 voxel halo) = the "region";
+//   2. one table probe per region voxel, all first probes in flight together;
+//   3. the occupied buckets are copied to LDS as fp32 offsets from the region origin (every load of the copy in
+//      flight together), each staged point tagged with its index in the HBM pool;
+//   4. every lane scans its 27 neighbour voxels out of LDS in fp32, tracking the smallest and second smallest
+//      squared distance; voxels that cannot contain a closer point are culled per lane;
+//   5. the winner is re-evaluated in fp64 from HBM.  fp32 only PRE-SELECTS: when the runner-up is within the fp32
+//      error margin of the winner the lane repeats the scan, evaluating every near-minimal candidate in fp64 in
+//      the reference's visiting order - so the chosen neighbour and its distance are exactly the fp64 reference's.
+// If the region exceeds the LDS budget the group is split in halves (down to single queries, whose region is 27
+// voxels), so any input order is handled; order only costs time.
 // ------------------------------------------------------------------------------------------------------------
-// LDS budget scales with the block: BLOCK*4 region voxels, BLOCK*6 staged points (256 threads: 1024 voxels,
-// 1536 points = 36 KiB of fp64 xyz, ~49 KiB per block -> 3 blocks/CU; 128 threads: ~25 KiB -> 6 blocks/CU).
-constexpr uint32_t kNotStaged = 0xFFFFFFFFu;
+constexpr int kSlots = 256;    // region voxels per staging (6x6x6 = 216 fits)
+constexpr int kPoints = 640;   // staged map points per staging
+constexpr int kCopyRounds = kPoints / 64;
+constexpr int kCopyBatch = 5;  // point loads in flight per lane during the copy
+constexpr uint32_t kNotStaged = 0xFFFFu;
+constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pass_lds(const PassParams p) {
-    __shared__ double s_red[BLOCK / 64][8];
-    __shared__ int s_bb[6];
-    __shared__ uint32_t s_used, s_nlist;
-    constexpr int kLdsSlots = BLOCK * 4;   // voxels of the (bbox + 1 halo) region a block may stage
-    constexpr int kLdsPoints = BLOCK * 6;  // staged map points
-    __shared__ uint32_t s_val[kLdsSlots];   // table value (bucket<<8 | count) of each region voxel, or kEmptyVal
-    __shared__ uint32_t s_off[kLdsSlots];   // first staged point of that voxel in s_pts, or kNotStaged
-    __shared__ uint32_t s_list[kLdsSlots];  // region slots whose bucket must be copied
-    __shared__ double s_pts[kLdsPoints * 3];
+struct WaveLds {
+    uint32_t val[kSlots];        // table value (bucket<<8 | count) of each region voxel, or kEmptyVal
+    uint16_t off[kSlots];        // first staged point of that voxel, or kNotStaged
+    uint16_t owner[kPoints];     // region slot a staged point belongs to
+    float4 pts[kPoints];         // (x,y,z) relative to the region origin, w = bit pattern of the HBM pool index
+};
 
-    if (p.pass != 0 && p.st->done) return;
-    const Pose T = load_pose(p);
-    const MapView &m = p.map;
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = i < p.n;
-
-    double sx = 0, sy = 0, sz = 0;
+struct GroupQuery {
+    double sx, sy;  // source point (x,y) in the base frame (the Jacobian needs them)
     Query q;
-    if (valid) {
-        sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
-        double rx, ry, rz;
-        quat_rotate(T, sx, sy, sz, rx, ry, rz);
-        make_query(q, rx + T.tx, ry + T.ty, rz + T.tz, m.voxel_size);
-    } else {
-        make_query(q, 0.0, 0.0, 0.0, m.voxel_size);
-    }
+    bool valid;
+};
 
-    // ---- block bounding box of the query voxels -------------------------------------------------------------
-    if (threadIdx.x == 0) {
-        s_bb[0] = s_bb[1] = s_bb[2] = INT_MAX;
-        s_bb[3] = s_bb[4] = s_bb[5] = INT_MIN;
-        s_used = 0, s_nlist = 0;
-    }
-    __syncthreads();
-    {
-        int lo[3] = {valid ? q.vx : INT_MAX, valid ? q.vy : INT_MAX, valid ? q.vz : INT_MAX};
-        int hi[3] = {valid ? q.vx : INT_MIN, valid ? q.vy : INT_MIN, valid ? q.vz : INT_MIN};
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
-                hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) atomicMin(&s_bb[a], lo[a]), atomicMax(&s_bb[3 + a], hi[a]);
-        }
-    }
-    __syncthreads();
-    const int bx = s_bb[0] - 1, by = s_bb[1] - 1, bz = s_bb[2] - 1;  // region origin (one voxel of halo)
-    const long long ex = static_cast<long long>(s_bb[3]) - s_bb[0] + 3, ey = static_cast<long long>(s_bb[4]) - s_bb[1] + 3,
-                    ez = static_cast<long long>(s_bb[5]) - s_bb[2] + 3;
-    const bool staged = s_bb[3] >= s_bb[0] && ex * ey * ez <= kLdsSlots;  // block-uniform
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
 
-    if (staged) {
-        const int nslots = static_cast<int>(ex * ey * ez), iex = static_cast<int>(ex), iey = static_cast<int>(ey);
-        // ---- one table probe per region voxel; reserve LDS space for the occupied ones -----------------------
-        for (int s = threadIdx.x; s < nslots; s += BLOCK) {
-            const int ix = s % iex, iy = (s / iex) % iey, iz = s / (iex * iey);
-            const uint32_t val = table_lookup(m, bx + ix, by + iy, bz + iz);
-            uint32_t off = kNotStaged;
-            if (val != kEmptyVal) {
-                const uint32_t cnt = val & 0xffu;
-                const uint32_t o = atomicAdd(&s_used, cnt);
-                if (o + cnt <= kLdsPoints) {
-                    off = o;
-                    s_list[atomicAdd(&s_nlist, 1u)] = static_cast<uint32_t>(s);
+// exact fp64 evaluation of one candidate from the HBM pool
+__device__ __forceinline__ double exact_d2(const MapView &m, uint32_t gidx, const Query &q) {
+    const double *t = m.pool + static_cast<size_t>(gidx) * 3;
+    const double dx = t[0] - q.x, dy = t[1] - q.y, dz = t[2] - q.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// Steps 1-5 for the lanes with `active` set.  On return best/best_idx hold the exact fp64 result per lane
+// (best_idx == kNoIndex: no candidate below the bound).  Returns false (nothing done) if the region does not fit.
+__device__ __forceinline__ bool stage_and_match(WaveLds &L, const MapView &m, const Query &q, bool active, double bound_d2, double &best,
+                                                uint32_t &best_idx) {
+    const int lane = threadIdx.x & 63;
+    // ---- 1. region ---------------------------------------------------------------------------------------------
+    const int lox = uniform_i(wave_min_i(active ? q.vx : INT_MAX)), loy = uniform_i(wave_min_i(active ? q.vy : INT_MAX)),
+              loz = uniform_i(wave_min_i(active ? q.vz : INT_MAX));
+    const int hix = uniform_i(wave_max_i(active ? q.vx : INT_MIN)), hiy = uniform_i(wave_max_i(active ? q.vy : INT_MIN)),
+              hiz = uniform_i(wave_max_i(active ? q.vz : INT_MIN));
+    if (hix < lox) return true;  // no active lane
+    const long long ex = static_cast<long long>(hix) - lox + 3, ey = static_cast<long long>(hiy) - loy + 3, ez = static_cast<long long>(hiz) - loz + 3;
+    if (ex * ey * ez > kSlots) return false;
+    const int bx = lox - 1, by = loy - 1, bz = loz - 1, iex = static_cast<int>(ex), iey = static_cast<int>(ey);
+    const int nslots = static_cast<int>(ex * ey * ez);
+    const double vs = m.voxel_size;
+    const double ox = bx * vs, oy = by * vs, oz = bz * vs;  // region origin (world)
+    __syncthreads();  // previous staging fully consumed
+    // ---- 2. probes ---------------------------------------------------------------------------------------------
+    constexpr int kRounds = kSlots / 64;
+    int4 e[kRounds];
+    int kx[kRounds], ky[kRounds], kz[kRounds];
+    uint32_t h[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int s = lane + r * 64;
+        if (s < nslots) {
+            kx[r] = bx + s % iex, ky[r] = by + (s / iex) % iey, kz[r] = bz + s / (iex * iey);
+            h[r] = voxel_hash(kx[r], ky[r], kz[r]) & m.mask;
+            e[r] = *reinterpret_cast<const int4 *>(m.table + h[r]);
+        }
+    }
+    uint32_t used = 0, npts = 0;  // wave-uniform: running allocation; end of the densely staged prefix
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int s = lane + r * 64;
+        uint32_t val = kEmptyVal;
+        if (s < nslots) {
+            for (;;) {  // collision chain (rare: load factor <= 0.25)
+                if (static_cast<uint32_t>(e[r].w) == kEmptyVal) break;
+                if (e[r].x == kx[r] && e[r].y == ky[r] && e[r].z == kz[r]) {
+                    val = static_cast<uint32_t>(e[r].w);
+                    break;
                 }
+                h[r] = (h[r] + 1) & m.mask;
+                e[r] = *reinterpret_cast<const int4 *>(m.table + h[r]);
             }
-            s_val[s] = val, s_off[s] = off;
         }
-        __syncthreads();
-        // ---- copy the buckets: one wave per bucket, 8 B per lane, coalesced ---------------------------------
-        const uint32_t nlist = s_nlist;
-        for (uint32_t j = threadIdx.x >> 6; j < nlist; j += BLOCK / 64) {
-            const uint32_t s = s_list[j];
-            const uint32_t val = s_val[s], cnt3 = (val & 0xffu) * 3;
-            const double *src = m.pool + static_cast<size_t>(val >> 8) * m.cap * 3;
-            double *dst = s_pts + static_cast<size_t>(s_off[s]) * 3;
-            for (uint32_t d = lane; d < cnt3; d += 64) dst[d] = src[d];
+        const uint32_t cnt = (val != kEmptyVal) ? (val & 0xffu) : 0u;
+        uint32_t incl = cnt;  // inclusive wave scan of the point counts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
         }
-        __syncthreads();
+        const uint32_t first = used + incl - cnt;
+        used += static_cast<uint32_t>(uniform_i(static_cast<int>(__shfl(incl, 63, 64))));
+        uint32_t my_end = 0;
+        if (s < nslots) {
+            uint32_t o = kNotStaged;
+            if (cnt && first + cnt <= kPoints) {
+                o = first, my_end = first + cnt;
+                for (uint32_t k = 0; k < cnt; ++k) L.owner[first + k] = static_cast<uint16_t>(s);
+            }
+            L.val[s] = val, L.off[s] = static_cast<uint16_t>(o);
+        }
+        // allocation is in prefix order, so the staged buckets form the dense range [0, max end)
+        npts = max(npts, static_cast<uint32_t>(uniform_i(wave_max_i(static_cast<int>(my_end)))));
+        if (r * 64 + 64 >= nslots) break;  // wave-uniform
     }
-
-    Acc acc{};
-    if (valid) {
-        double best = p.tau * p.tau * (1.0 + 9.1e-13);
-        uint32_t best_idx = 0xFFFFFFFFu;  // bit 31 set: index into s_pts; clear: index into the global pool
-        if (staged) {
-            const int iex = static_cast<int>(ex), iey = static_cast<int>(ey);
-            const int cx = q.vx - bx, cy = q.vy - by, cz = q.vz - bz;
+    __syncthreads();
+    // ---- 3. copy: lane handles points lane, lane+64, ...; all loads issued before the first LDS store ---------------
+#pragma unroll
+    for (int batch = 0; batch < kCopyRounds; batch += kCopyBatch) {
+        if (static_cast<uint32_t>(batch * 64) >= npts) break;  // wave-uniform
+        double cx[kCopyBatch], cy[kCopyBatch], cz[kCopyBatch];
+        uint32_t gi[kCopyBatch];
+#pragma unroll
+        for (int r = 0; r < kCopyBatch; ++r) {
+            const uint32_t pt = lane + (batch + r) * 64;
+            gi[r] = kNoIndex;
+            if (pt < npts) {
+                const uint32_t s = L.owner[pt];
+                gi[r] = (L.val[s] >> 8) * m.cap + (pt - L.off[s]);
+                const double *src = m.pool + static_cast<size_t>(gi[r]) * 3;
+                cx[r] = src[0], cy[r] = src[1], cz[r] = src[2];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kCopyBatch; ++r) {
+            const uint32_t pt = lane + (batch + r) * 64;
+            if (gi[r] != kNoIndex)
+                L.pts[pt] = make_float4(static_cast<float>(cx[r] - ox), static_cast<float>(cy[r] - oy), static_cast<float>(cz[r] - oz),
+                                        __uint_as_float(gi[r]));
+        }
+    }
+    __syncthreads();
+    // ---- 4. fp32 scan -------------------------------------------------------------------------------------------
+    // fp32 error model: coordinates relative to the region origin are < 8 voxels, so each rounded coordinate is off
+    // by <= 2^-24 * 8 vs; a squared distance below (1.2 vs)^2 is then off by < 3e-6 vs^2.  kMargin covers twice that.
+    const float vs2 = static_cast<float>(vs * vs);
+    const float margin = 8e-6f * vs2;
+    const float bound32 = static_cast<float>(bound_d2) * 1.00001f + margin;
+    const float qx = static_cast<float>(q.x - ox), qy = static_cast<float>(q.y - oy), qz = static_cast<float>(q.z - oz);
+    // conservative (rounded-down) squared distances to the faces of the own voxel
+    float fm[3], fp[3];
+    {
+        const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
+        const float fvs = static_cast<float>(vs);
+        fm[0] = lx * lx, fm[1] = ly * ly, fm[2] = lz * lz;
+        fp[0] = (fvs - lx) * (fvs - lx), fp[1] = (fvs - ly) * (fvs - ly), fp[2] = (fvs - lz) * (fvs - lz);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) fm[a] = fm[a] * 0.99999f - margin, fp[a] = fp[a] * 0.99999f - margin;
+    }
+    const int cx0 = q.vx - bx, cy0 = q.vy - by, cz0 = q.vz - bz;
+    float b1 = bound32, b2 = bound32;
+    uint32_t i1 = kNoIndex;
+    bool overflow = false;
+    if (active) {
+#pragma unroll 1
+        for (int s = 0; s < 27; ++s) {
+            const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
+            const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
+                              (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
+            if (box > b1 + margin) continue;  // nothing in there can come within the margin of the current minimum
+            const int slot = ((cz0 + dz) * iey + (cy0 + dy)) * iex + (cx0 + dx);
+            const uint32_t val = L.val[slot];
+            if (val == kEmptyVal) continue;
+            const uint32_t o = L.off[slot], cnt = val & 0xffu;
+            if (o == kNotStaged) {
+                overflow = true;  // bucket did not fit into LDS: this lane is resolved from HBM below
+                continue;
+            }
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 c = L.pts[o + k];
+                const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
+                const float d = ddx * ddx + ddy * ddy + ddz * ddz;
+                const bool lt = d < b1;
+                b2 = lt ? b1 : fminf(b2, d);
+                i1 = lt ? __float_as_uint(c.w) : i1;
+                b1 = lt ? d : b1;
+            }
+        }
+    }
+    // ---- 5. exact resolution ---------------------------------------------------------------------------------------
+    best = bound_d2, best_idx = kNoIndex;
+    const bool found = active && !overflow && i1 != kNoIndex;
+    const bool ambiguous = found && (b2 - b1 <= margin);
+    if (found && !ambiguous) {
+        const double d2 = exact_d2(m, i1, q);
+        if (d2 < bound_d2) best = d2, best_idx = i1;
+    }
+    if (__any(ambiguous)) {
+        if (ambiguous) {  // repeat the scan; every candidate within the margin of the fp32 minimum is evaluated exactly, in order
+            const float lim = b1 + margin;
 #pragma unroll 1
             for (int s = 0; s < 27; ++s) {
                 const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-                if (box_d2(q, dx, dy, dz) > best + q.slack) continue;
-                const int slot = ((cz + dz) * iey + (cy + dy)) * iex + (cx + dx);
-                const uint32_t val = s_val[slot];
+                const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
+                                  (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
+                if (box > lim) continue;
+                const int slot = ((cz0 + dz) * iey + (cy0 + dy)) * iex + (cx0 + dx);
+                const uint32_t val = L.val[slot];
                 if (val == kEmptyVal) continue;
-                const uint32_t off = s_off[slot], cnt = val & 0xffu;
-                if (off != kNotStaged) {
-                    scan_points(s_pts + static_cast<size_t>(off) * 3, cnt, 0x80000000u | off, q, best, best_idx);
-                } else {  // LDS pool overflow: this bucket stays in HBM
-                    const uint32_t bucket = val >> 8;
-                    scan_points(m.pool + static_cast<size_t>(bucket) * m.cap * 3, cnt, bucket * m.cap, q, best, best_idx);
+                const uint32_t o = L.off[slot], cnt = val & 0xffu;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 c = L.pts[o + k];
+                    const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
+                    const float d = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (d <= lim) {
+                        const uint32_t gi = __float_as_uint(c.w);
+                        const double d2 = exact_d2(m, gi, q);
+                        if (d2 < best) best = d2, best_idx = gi;
+                    }
                 }
             }
-        } else {
-            search_global(m, q, best, best_idx);
-        }
-        if (best_idx != 0xFFFFFFFFu && sqrt(best) < p.tau) {
-            const double *t = (best_idx & 0x80000000u) ? s_pts + static_cast<size_t>(best_idx & 0x7FFFFFFFu) * 3
-                                                         : m.pool + static_cast<size_t>(best_idx) * 3;
-            accumulate(acc, T, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
         }
     }
-    block_reduce_store<BLOCK>(acc, p.partials + static_cast<size_t>(blockIdx.x) * kNumSums, s_red);
+    if (__any(active && overflow)) {
+        if (active && overflow) search_global(m, q, best, best_idx);  // exact fp64 search straight from HBM
+    }
+    return true;
+}
+
+// Match a group of up to 64 queries (one per lane), splitting it while its region does not fit; accepted
+// correspondences are accumulated.  Returns the number of splits (diagnostics).
+__device__ __forceinline__ uint32_t match_group(WaveLds &L, Acc &acc, const PassParams &p, const Pose &T, const GroupQuery &g) {
+    const int lane = threadIdx.x & 63;
+    const double bound = p.tau * p.tau * (1.0 + 9.1e-13);
+    uint32_t splits = 0;
+    // stackless binary subdivision of the lane range [lo, lo+len); wave-uniform control flow
+    int lo = 0, len = 64;
+    while (lo < 64) {
+        const bool active = g.valid && lane >= lo && lane < lo + len;
+        double best;
+        uint32_t best_idx;
+        if (!stage_and_match(L, p.map, g.q, active, bound, best, best_idx)) {
+            len >>= 1;  // len >= 2 here: a single query's region is 27 voxels and always fits
+            ++splits;
+            continue;
+        }
+        if (active && best_idx != kNoIndex && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+            const double *t = p.map.pool + static_cast<size_t>(best_idx) * 3;
+            accumulate(acc, T, g.sx, g.sy, g.q.x, g.q.y, g.q.z, t[0], t[1], t[2]);
+        }
+        lo += len;
+        len = lo ? (lo & -lo) : 64;  // largest aligned block that starts at lo
+    }
+    return splits;
+}
+
+__device__ __forceinline__ void load_group_query(GroupQuery &g, const double *src, uint32_t i, bool valid, const Pose &T, double vs) {
+    double sx = 0, sy = 0, sz = 0;
+    if (valid) sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    double rx, ry, rz;
+    quat_rotate(T, sx, sy, sz, rx, ry, rz);
+    make_query(g.q, rx + T.tx, ry + T.ty, rz + T.tz, vs);
+    g.sx = sx, g.sy = sy, g.valid = valid;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3: fixed-order reduction of the partials + solve + pose update (one 256-thread block)
+// variant 1: groups of 64 consecutive queries in the order given (persistent grid)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(const FinalizeParams f) {
-    __shared__ double s_red[4][8];
-    IcpState *st = f.st;
-    if (f.pass != 0 && st->done) return;
-    double sums[7];
-    if (f.stage != 2) {
-        Acc a{};
-        for (uint32_t b = threadIdx.x; b < f.nblocks; b += 256) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) a.v[i] += f.partials[static_cast<size_t>(b) * kNumSums + i];
+__global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
+    KICP_PASS_SHARED(64)
+    __shared__ WaveLds L;
+    if (p.sol.pass != 0 && p.st->done) return;
+    const Pose T = load_pose(p);
+    const uint32_t n_groups = (p.n + 63) / 64;
+    Acc acc{};
+    uint32_t splits = 0;
+    for (uint32_t w = blockIdx.x; w < n_groups; w += gridDim.x) {
+        const uint32_t i = w * 64 + threadIdx.x;
+        GroupQuery g;
+        load_group_query(g, p.src, i, i < p.n, T, p.map.voxel_size);
+        if (p.dbg == 0) splits += match_group(L, acc, p, T, g);
+    }
+    if (splits && threadIdx.x == 0) atomicAdd(&p.st->not_staged, splits);
+    finish_pass<64>(acc, p, s_red, &s_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// variant 2: one wave per work item (<= 64 queries of one 2x2x2-voxel cell), persistent over the item list
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kCellShift = 1;  // cell = 2x2x2 voxels
+constexpr int kRunLen = 64;    // queries per work item
+
+__global__ __launch_bounds__(64, 3) void k_pass_binned(const PassParams p) {
+    KICP_PASS_SHARED(64)
+    __shared__ WaveLds L;
+    if (p.sol.pass != 0 && p.st->done) return;
+    const Pose T = load_pose(p);
+    const uint32_t n_items = p.bin.counters[1];
+    Acc acc{};
+    uint32_t splits = 0;
+    for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+        const uint2 item = p.bin.items[w];
+        GroupQuery g;
+        load_group_query(g, p.bin.sorted_src, item.x + threadIdx.x, threadIdx.x < item.y, T, p.map.voxel_size);
+        if (p.dbg == 0) splits += match_group(L, acc, p, T, g);
+    }
+    if (splits && threadIdx.x == 0) atomicAdd(&p.st->not_staged, splits);
+    finish_pass<64>(acc, p, s_red, &s_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// binning: counting sort of the scan by cell at the predicted pose (count -> scan -> scatter)
+// ------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kEmptyCell = ~0ull;
+
+struct BinParams {
+    const double *src;
+    uint32_t n;
+    Pose pose0;
+    double voxel_size;
+    unsigned long long *cell_keys;  // [mask+1], kEmptyCell when free
+    uint32_t *cell_count;           // [mask+1]
+    uint32_t *cell_start;           // [mask+1]
+    uint32_t *cell_list;            // occupied slots in arrival order
+    uint32_t mask;
+    uint32_t *counters;             // [0] n_cells, [1] n_items
+    uint2 *qinfo;                   // (slot, rank) per query
+    double *sorted_src;
+    uint2 *items;
+};
+
+__device__ __forceinline__ unsigned long long pack_cell(int32_t vx, int32_t vy, int32_t vz) {
+    const unsigned long long cx = static_cast<unsigned long long>((vx >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
+    const unsigned long long cy = static_cast<unsigned long long>((vy >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
+    const unsigned long long cz = static_cast<unsigned long long>((vz >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
+    return (cz << 42) | (cy << 21) | cx;
+}
+__device__ __forceinline__ uint32_t hash_cell(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return static_cast<uint32_t>(k);
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(const BinParams b) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < b.n;
+    unsigned long long key = kEmptyCell;
+    if (valid) {
+        const double sx = b.src[3 * i], sy = b.src[3 * i + 1], sz = b.src[3 * i + 2];
+        double rx, ry, rz;
+        quat_rotate(b.pose0, sx, sy, sz, rx, ry, rz);
+        const double vs = b.voxel_size;
+        key = pack_cell(static_cast<int32_t>(floor((rx + b.pose0.tx) / vs)), static_cast<int32_t>(floor((ry + b.pose0.ty) / vs)),
+                        static_cast<int32_t>(floor((rz + b.pose0.tz) / vs)));
+    }
+    // runs of equal keys among consecutive lanes share one table insertion and one counter update
+    const unsigned long long prev = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes <= mine
+    const int leader = 63 - __clzll(below);
+    const unsigned long long above = heads & ~((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes > mine
+    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : 64;
+    __shared__ uint32_t s_new, s_base;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
+    uint32_t slot = 0, base = 0, my_new = 0xFFFFFFFFu;
+    if (head && valid) {
+        const uint32_t run = static_cast<uint32_t>(run_end - lane);
+        slot = hash_cell(key) & b.mask;
+        for (;;) {
+            const unsigned long long seen = atomicCAS(b.cell_keys + slot, kEmptyCell, key);
+            if (seen == kEmptyCell) {  // claimed a fresh cell: its list position is assigned per workgroup below
+                my_new = atomicAdd(&s_new, 1u);
+                break;
+            }
+            if (seen == key) break;
+            slot = (slot + 1) & b.mask;
         }
-        block_reduce_store<256>(a, st->reduced, s_red);
+        base = atomicAdd(b.cell_count + slot, run);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_new) s_base = atomicAdd(b.counters, s_new);  // one same-address atomic per workgroup
+    __syncthreads();
+    if (my_new != 0xFFFFFFFFu) b.cell_list[s_base + my_new] = slot;
+    slot = __shfl(slot, leader, 64), base = __shfl(base, leader, 64);
+    if (valid) b.qinfo[i] = make_uint2(slot, base + static_cast<uint32_t>(lane - leader));
+}
+
+// single workgroup: exclusive scans over the occupied cells -> first query / first work item per cell; emits the
+// item list; leaves the cell table clean for the next scan
+__global__ __launch_bounds__(1024) void k_bin_scan(const BinParams b) {
+    __shared__ uint32_t s_wave[16][2];
+    __shared__ uint32_t s_carry[2];
+    const uint32_t n_cells = b.counters[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry[0] = s_carry[1] = 0;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < n_cells; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t slot = 0, c = 0;
+        if (j < n_cells) {
+            slot = b.cell_list[j];
+            c = b.cell_count[slot];
+            b.cell_count[slot] = 0, b.cell_keys[slot] = kEmptyCell;  // self-cleaning table
+        }
+        const uint32_t it = (c + kRunLen - 1) / kRunLen;
+        uint32_t pc = c, pi = it;  // inclusive wave scans
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t tc = __shfl_up(pc, off, 64), ti = __shfl_up(pi, off, 64);
+            if (lane >= off) pc += tc, pi += ti;
+        }
+        if (lane == 63) s_wave[wave][0] = pc, s_wave[wave][1] = pi;
         __syncthreads();
-        if (f.stage == 1) return;
+        uint32_t wc = 0, wi = 0;
+        for (int w = 0; w < wave; ++w) wc += s_wave[w][0], wi += s_wave[w][1];
+        const uint32_t start = s_carry[0] + wc + pc - c, first_item = s_carry[1] + wi + pi - it;
+        if (j < n_cells) {
+            b.cell_start[slot] = start;
+            for (uint32_t t = 0; t < it; ++t)
+                b.items[first_item + t] = make_uint2(start + t * kRunLen, min(static_cast<uint32_t>(kRunLen), c - t * kRunLen));
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry[0] += wc + pc, s_carry[1] += wi + pi;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) b.counters[1] = s_carry[1], b.counters[2] = n_cells, b.counters[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(const BinParams b) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= b.n) return;
+    const uint2 qi = b.qinfo[i];
+    const uint32_t dst = b.cell_start[qi.x] + qi.y;
+    b.sorted_src[3 * dst] = b.src[3 * i], b.sorted_src[3 * dst + 1] = b.src[3 * i + 1], b.sorted_src[3 * dst + 2] = b.src[3 * i + 2];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// solve step alone: multi-GPU (after the all-reduce of st->reduce)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f) {
     if (threadIdx.x != 0) return;
+    if (f.pass != 0 && st->done) return;
+    long long limbs[kNumLimbs];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) sums[i] = st->reduced[i];
-    const double n = sums[6];
-    Pose T = f.pass == 0 ? f.pose0 : st->T;
-    double beta;
-    if (f.pass == 0) {  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
-        beta = f.adaptive ? 1.0 / (sums[5] / n + DBL_MIN) : f.fixed_regularization;
-        st->beta = beta;
-        st->converged = 0, st->nan_flag = 0;
-    } else {
-        beta = st->beta;
-    }
-    double dx0, dx1;
-    solve_perturbation(sums, n, beta, dx0, dx1);
-    T = pose_mul(T, motion_model(dx0, dx1));  // current_estimate * delta_motion (Registration.cpp:181-182)
-    st->T = T;
-    if (f.pass < kMaxLog) {
-        st->log_ncorr[f.pass] = n;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) st->log_sums[f.pass][i] = sums[i];
-        st->log_dx[f.pass][0] = dx0, st->log_dx[f.pass][1] = dx1;
-    }
-    st->iter = f.pass + 1;
-    int done = 0;
-    if (sqrt(dx0 * dx0 + dx1 * dx1) < f.convergence_criterion) done = 1, st->converged = 1;  // Registration.cpp:184
-    if (f.pass + 1 >= f.max_iterations) done = 1;
-    if (!(n > 0.0)) done = 1, st->nan_flag = 1;  // 0/0: the pose is NaN from here on, exactly as in the reference
-    st->done = done;
+    for (int i = 0; i < kNumLimbs; ++i) limbs[i] = st->reduce[i];
+    solve_and_update(st, f, limbs, st->reduce[kNumLimbs] != 0);
+}
+
+// publish the raw sums of the last pass (kicp_pass_sums)
+__global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *rec, unsigned long long call_id) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < kNumSums; ++i) rec->sums[i] = limbs_to_double(st->reduce + 3 * i);
+    rec->not_staged = st->not_staged;
+    __hip_atomic_store(&rec->seq, (call_id << 16) | 0x8001ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------------------
