@@ -120,6 +120,12 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
 int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                    double max_correspondence_distance, double out_sums[7]);
 
+/* Same pass, but returns the raw all-reduce payload: KICP_REDUCE_WORDS int64 words = 3 limbs per sum (value * 2^40 =
+ * l0 + l1*2^40 + l2*2^80) + range flag + padding.  Summing the words of disjoint shards element-wise gives exactly the
+ * words' value of the union: this is what the multi-GPU mode all-reduces. */
+int kicp_pass_words(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                    double max_correspondence_distance, long long out_words[24]);
+
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */
 int kicp_device_malloc(int device, size_t bytes, void **out_dptr);
 int kicp_device_free(int device, void *dptr);

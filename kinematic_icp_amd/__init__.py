@@ -76,6 +76,7 @@ _SIGNATURES = {
     "kicp_register": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
+    "kicp_pass_words": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_longlong)]),
     "kicp_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "kicp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "kicp_device_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -262,6 +263,15 @@ class KinematicRegistration:
         _, q = _d(pose)
         out = np.zeros(7, dtype=np.float64)
         _check(lib().kicp_pass_sums(self._h, voxel_map._h, p, a.size // 3, q, max_correspondence_distance, out.ctypes.data_as(_dp)))
+        return out
+
+    def pass_words(self, frame, voxel_map, pose, max_correspondence_distance):
+        """The same pass as raw int64[24] limb words (the multi-GPU all-reduce payload; see sharding.py)."""
+        a, p = _d(frame)
+        _, q = _d(pose)
+        out = np.zeros(24, dtype=np.int64)
+        _check(lib().kicp_pass_words(self._h, voxel_map._h, p, a.size // 3, q, max_correspondence_distance,
+                                     out.ctypes.data_as(C.POINTER(C.c_longlong))))
         return out
 
     # ---- multi-GPU ----

@@ -119,6 +119,7 @@ struct kicp_reg {
     int waves_per_cu = 12; // persistent grid of variants 1/2
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
     int dbg = 0;
+    int query_every = 64;  // polls between hipStreamQuery calls while waiting
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -277,25 +278,31 @@ int enqueue_allreduce(kicp_reg *r) {
 // returns the observed seq.  Polls host-mapped memory; falls back to a stream sync when asked to or on a fault.
 int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool need_done, unsigned long long *seq_out) {
     volatile unsigned long long *seq = &r->rec->seq;
-    if (r->wait_mode == 1) HIP_TRY(hipStreamSynchronize(r->stream));
-    for (unsigned long long spins = 0;; ++spins) {
+    auto ready = [&](unsigned long long s) {
+        return (s >> 16) == call_id && ((s & 0x8000ull) || (!need_done && (s & 0x7FFFull) >= min_iter));
+    };
+    if (r->wait_mode == 1) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
         const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
-        if ((s >> 16) == call_id) {
-            const bool done = (s & 0x8000ull) != 0;
-            if (done || (!need_done && (s & 0x7FFFull) >= min_iter)) {
-                *seq_out = s;
-                return KICP_OK;
-            }
+        if (!ready(s)) return fail(KICP_ERR_HIP, "result record not written after stream synchronisation");
+        *seq_out = s;
+        return KICP_OK;
+    }
+    // Poll the host-mapped record.  hipStreamQuery every `query_every` polls: it makes the runtime flush any command
+    // it still holds back (some HIP runtimes batch the tail of the queue) and reports device faults.
+    const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
+    unsigned drained = 0;
+    for (unsigned long long spins = 1;; ++spins) {
+        const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+        if (ready(s)) {
+            *seq_out = s;
+            return KICP_OK;
         }
-        if (r->wait_mode == 1) return fail(KICP_ERR_HIP, "result record not written after stream synchronisation");
-        if ((spins & 0xFFFFF) == 0xFFFFF) {  // every ~1M polls: has the queue died or drained without an answer?
+        if (spins % query_every == 0) {
             const hipError_t q = hipStreamQuery(r->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
-            if (q == hipSuccess) {
-                const unsigned long long s2 = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
-                if ((s2 >> 16) == call_id && ((s2 & 0x8000ull) || (!need_done && (s2 & 0x7FFFull) >= min_iter))) continue;
+            if (q == hipSuccess && ++drained > 4 && !ready(__atomic_load_n(seq, __ATOMIC_ACQUIRE)))
                 return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
-            }
         }
     }
 }
@@ -556,6 +563,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
+    else if (k == "query_every") reg->query_every = static_cast<int>(value);
     else return fail(KICP_ERR_ARG, "unknown option " + k);
     return KICP_OK;
 }
@@ -588,10 +596,25 @@ int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t 
     }
     return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
 }
+static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                     double max_correspondence_distance, double out_sums[7], long long out_words[24]);
 int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                    double max_correspondence_distance, double out_sums[7]) {
-    if (!reg || !map || (!frame_xyz && n) || !pose_qt || !out_sums) return fail(KICP_ERR_ARG, "null argument");
+    if (!out_sums) return fail(KICP_ERR_ARG, "null argument");
+    return pass_once(reg, map, frame_xyz, n, pose_qt, max_correspondence_distance, out_sums, nullptr);
+}
+int kicp_pass_words(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                    double max_correspondence_distance, long long out_words[24]) {
+    if (!out_words) return fail(KICP_ERR_ARG, "null argument");
+    double sums[7];
+    return pass_once(reg, map, frame_xyz, n, pose_qt, max_correspondence_distance, sums, out_words);
+}
+static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                     double max_correspondence_distance, double out_sums[7], long long out_words[24]) {
+    if (!reg || !map || (!frame_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
     for (int i = 0; i < 7; ++i) out_sums[i] = 0.0;
+    if (out_words)
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
     if (map->host.Empty() || n == 0) return KICP_OK;
     if (int rc = set_device(reg->device)) return rc;
     if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
@@ -614,6 +637,7 @@ int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t
     unsigned long long seq = 0;
     if (int rc = wait_record(reg, call_id, 1, true, &seq)) return rc;
     for (int i = 0; i < 7; ++i) out_sums[i] = reg->rec->sums[i];
+    if (out_words) HIP_TRY(hipMemcpy(out_words, reg->d_state->reduce, sizeof(long long) * kReduceWords, hipMemcpyDeviceToHost));
     return KICP_OK;
 }
 

@@ -139,3 +139,65 @@ def test_random_order_input(case1):
     a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
     b = reg.ComputeRobotMotion(s["frame"][perm], gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
     assert np.array_equal(a, b)  # order-independent sums
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "registration_small.npz")
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_golden_vectors(name, kernel):
+    """The committed fixtures (multi-iteration small cases, incl. two that exhaust max_num_iterations)."""
+    g = np.load(GOLD)
+    m = K.VoxelHashMap(float(g[name + "_voxel"]), float(g[name + "_maxrange"]), 20)
+    m.AddPoints(g[name + "_map"])
+    reg = _reg(kernel, 128)
+    p = reg.ComputeRobotMotion(g[name + "_frame"], m, g[name + "_last"], g[name + "_rel"], float(g[name + "_tau"]))
+    st = reg.last_stats
+    assert st.iterations == int(g[name + "_iters"]) and st.converged == int(g[name + "_converged"])
+    np.testing.assert_allclose(p, g[name + "_pose"], rtol=0, atol=POSE_TOL)
+    np.testing.assert_array_equal(np.array(st.n_corr[:st.iterations]), g[name + "_ncorr"])
+    np.testing.assert_allclose(np.array([list(st.dx[i]) for i in range(st.iterations)]), g[name + "_dx"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(st.beta, float(g[name + "_beta"]), rtol=1e-10)
+    s0 = reg.pass_sums(g[name + "_frame"], m, syn.pose_mul(g[name + "_last"], g[name + "_rel"]), float(g[name + "_tau"]))
+    np.testing.assert_allclose(s0, g[name + "_sums0"], rtol=SUM_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_shard_words_add_up_exactly(case1, kernel):
+    """G-GPU emulation on one device: the limb words of disjoint shards sum to the words' value of the whole scan,
+    bit for bit, for G in {2,4,8} -- the property that makes the multi-GPU pose independent of G."""
+    from kinematic_icp_amd import sharding as sh
+    cfg, scans, gmap, omap = case1
+    s = scans[0]
+    guess = syn.pose_mul(s["last_pose"], s["rel_odom"])
+    reg = _reg(kernel, 128)
+    tau = cfg.first_frame_tau()
+    full = reg.pass_words(s["frame"], gmap, guess, tau)
+    total = [sh.from_limbs(full[3 * i:3 * i + 3]) for i in range(7)]
+    assert total[6] == int(reg.pass_sums(s["frame"], gmap, guess, tau)[6]) << 40
+    for g in (2, 4, 8):
+        words = np.sum([reg.pass_words(s["frame"][slice(*sh.shard_bounds(len(s["frame"]), g, r))], gmap, guess, tau) for r in range(g)], axis=0)
+        assert [sh.from_limbs(words[3 * i:3 * i + 3]) for i in range(7)] == total
+    np.testing.assert_allclose(sh.unpack(full), okicp.icp_pass(omap, s["frame"], guess, tau)[0], rtol=1e-11, atol=1e-9)
+
+
+def test_single_rank_communicator_and_callback(case1):
+    """The multi-GPU code path (limb publish -> all-reduce -> separate solve kernel) with world size 1:
+    built-in RCCL communicator and user callback both reproduce the single-GPU bits."""
+    cfg, scans, gmap, omap = case1
+    s = scans[1]
+    rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(0.8)))
+    tau = cfg.first_frame_tau()
+    base = K.KinematicRegistration().ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+    reg = K.KinematicRegistration()
+    reg.comm_init(1, 0, K.comm_unique_id())
+    a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+    reg.comm_destroy()
+    assert np.array_equal(a, base)
+    calls = []
+    reg2 = K.KinematicRegistration()
+    reg2.set_allreduce(lambda ptr, count, stream: calls.append((ptr != 0, count)))  # world size 1: in-place sum is a no-op
+    b = reg2.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+    assert np.array_equal(b, base)
+    assert calls and all(ok and c == 24 for ok, c in calls) and len(calls) >= reg2.last_stats.iterations

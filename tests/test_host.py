@@ -1,0 +1,127 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol include/kicp.h declares,
+the host voxel map (kinematic_icp_amd/csrc/kicp_host_map.hpp, behind kicp_map_*) reproduces the oracle's
+kiss_icp::VoxelHashMap semantics, and the device entry points fail LOUDLY (no CPU fallback) without a GPU.
+No kernel is launched here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import kinematic_icp_amd as K
+from conftest import ROOT, sort_rows
+from kinematic_icp_amd import synthetic as syn
+from oracle import okicp
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "kicp.h")).read()
+    declared = set(re.findall(r"\b(kicp_[a-z0-9_]+)\s*\(", hdr)) - {"kicp_allreduce_fn"}
+    assert len(declared) >= 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", K.LIB_PATH], text=True)
+    exported = set(re.findall(r"\b(kicp_[a-z0-9_]+)\b", out))
+    assert declared <= exported, sorted(declared - exported)
+    assert declared == set(K._SIGNATURES), sorted(declared ^ set(K._SIGNATURES))
+    lib = K.lib()
+    assert lib.kicp_version() == 100
+
+
+def test_library_contains_gfx950_code_and_no_oracle():
+    out = subprocess.run(["strings", "-n", "6", K.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert "okicp_" not in out  # the product never links the oracle
+    src = "".join(open(os.path.join(ROOT, "kinematic_icp_amd", f)).read() for f in ("__init__.py", "synthetic.py"))
+    assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "") or "import oracle" not in src
+    for f in os.listdir(os.path.join(ROOT, "kinematic_icp_amd", "csrc")):
+        assert "oracle/" not in open(os.path.join(ROOT, "kinematic_icp_amd", "csrc", f)).read()
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    if K.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(K.KicpError) as e:
+        K.KinematicRegistration()
+    assert e.value.code == K.KICP_ERR_HIP and "no CPU fallback" in str(e.value)
+    m = K.VoxelHashMap(1.0, 100.0, 20)
+    m.AddPoints(np.random.default_rng(0).uniform(-3, 3, (50, 3)))
+    with pytest.raises(K.KicpError):
+        m.GetClosestNeighbor(np.zeros((1, 3)))  # the search runs on the device or not at all
+
+
+def test_argument_and_capacity_errors():
+    with pytest.raises(K.KicpError) as e:
+        K.VoxelHashMap(1.0, 100.0, 256)
+    assert e.value.code == K.KICP_ERR_CAPACITY
+    with pytest.raises(K.KicpError) as e:
+        K.VoxelHashMap(0.0, 100.0, 20)
+    assert e.value.code == K.KICP_ERR_ARG
+
+
+def test_host_map_equals_oracle_map():
+    rng = np.random.default_rng(21)
+    pts = rng.normal(0, 6, (40000, 3)) * np.array([1, 1, 0.2])
+    for vs, cap, md in ((1.0, 20, 100.0), (0.3, 7, 12.0), (2.5, 1, 9.0)):
+        g, o = K.VoxelHashMap(vs, md, cap), okicp.VoxelHashMap(vs, md, cap)
+        assert g.Empty() and o.Empty()
+        g.AddPoints(pts[:15000]), o.AddPoints(pts[:15000])
+        assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels())
+        np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+        for k in range(5):  # a short trajectory of Update(points, pose): transform + add + prune
+            pose = syn.planar_pose(2.0 * k, -1.0 * k, 0.3 * k)
+            chunk = pts[15000 + 5000 * k: 20000 + 5000 * k]
+            g.Update(chunk, pose), o.Update(chunk, pose)
+            assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels())
+        np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+        g.Update(pts[:100], np.array([50.0, 50.0, 0.0])), o.Update(pts[:100], np.array([50.0, 50.0, 0.0]))  # origin overload
+        np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+        g.Clear()
+        assert g.Empty() and g.num_points() == 0 and g.Pointcloud().shape == (0, 3)
+        g.AddPoints(pts[:10])  # usable after Clear (SetPose path, KinematicICP.hpp:86-90)
+        assert g.num_points() > 0
+
+
+def test_host_map_insertion_order_inside_a_bucket():
+    # the query's tie rule depends on insertion order, so Pointcloud must list a voxel's points in that order
+    g = K.VoxelHashMap(1.0, 100.0, 20)
+    p = np.array([[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.5, 0.5, 0.9], [0.1, 0.1, 0.5]])
+    g.AddPoints(p)
+    np.testing.assert_array_equal(g.Pointcloud(), p)
+
+
+def test_empty_map_registration_needs_no_gpu():
+    # Registration.cpp:157: the early-out is host arithmetic; it works even where no device exists
+    lib = K.lib()
+    m = K.VoxelHashMap(1.0, 100.0, 20)
+    last, rel = syn.planar_pose(1.0, 2.0, 0.3), syn.planar_pose(0.5, 0.0, 0.1)
+    expect = okicp.se3_mul(last, rel)
+    if K.device_count() > 0:
+        reg = K.KinematicRegistration()
+        np.testing.assert_allclose(reg.ComputeRobotMotion(np.zeros((4, 3)), m, last, rel, 1.0), expect, atol=1e-15)
+    else:
+        # product pose composition (kicp_se3.hpp) == oracle's, checked through the Update(points, pose) path instead
+        g, o = K.VoxelHashMap(1.0, 100.0, 20), okicp.VoxelHashMap(1.0, 100.0, 20)
+        pts = np.random.default_rng(3).uniform(-5, 5, (300, 3))
+        g.Update(pts, expect), o.Update(pts, expect)
+        np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+    assert lib.kicp_map_empty(m._h) == 1
+
+
+def test_synthetic_generator_is_deterministic_and_sized():
+    c1 = syn.make_case("cfg1", n_scans=2)
+    c2 = syn.make_case("cfg1", n_scans=2)
+    assert c1[2][0]["frame"].shape == (16384, 3)
+    for a, b in zip(c1[2], c2[2]):
+        np.testing.assert_array_equal(a["frame"], b["frame"])
+        np.testing.assert_array_equal(a["last_pose"], b["last_pose"])
+    assert syn.CONFIGS["cfg2"].n_points == 131072 and syn.CONFIGS["cfg4"].n_points == 1080 and syn.CONFIGS["cfg5"].n_points == 500000
+    np.testing.assert_allclose(syn.CONFIGS["cfg2"].first_frame_tau(), 0.6708203932499369)
+    # every ray returns (closed scene) and stays inside max_range
+    r = np.linalg.norm(c1[2][0]["frame"], axis=1)
+    assert np.isfinite(r).all() and r.max() < syn.CONFIGS["cfg1"].max_range
+    # the initial guess is never exactly the truth (reference quirk F9) and the pose helpers agree with the oracle
+    s = c1[2][0]
+    guess = syn.pose_mul(s["last_pose"], s["rel_odom"])
+    assert np.abs(guess - s["true_pose"]).max() > 1e-4
+    np.testing.assert_allclose(guess, okicp.se3_mul(s["last_pose"], s["rel_odom"]), atol=1e-14)
+    np.testing.assert_allclose(syn.pose_act(guess, s["frame"][:50]), okicp.se3_act(guess, s["frame"][:50]), atol=1e-12)

@@ -1,0 +1,139 @@
+"""The N>1 path on CPU: world_size-2 processes over gloo run the sharded registration protocol (contiguous point
+shards, replicated map, one int64 limb all-reduce per ICP iteration, identical solve on every rank) with the oracle
+standing in for the per-shard GPU pass.  Checks: every rank ends with the bit-identical pose, equal to the unsharded
+result, for G = 2; plus G in {1,2,4,8} emulated in-process."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from kinematic_icp_amd import sharding as sh
+from kinematic_icp_amd import synthetic as syn
+from oracle import okicp
+
+
+def _world(seed=31):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    scene = syn.make_scene(rng, half=14.0, height=4.0, n_boxes=5, box_xy=(2.0, 5.0), box_z=(1.5, 3.5), keep_clear=2.5)
+    cfg = syn.Config("shard", 8, 256, 6000, max_range=40.0, sensor_height=1.2)
+    omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    syn.build_map_points(scene, cfg, omap.AddPoints, omap.num_points, rng, batch=4000)
+    true_pose = syn.planar_pose(0.7, -0.4, 0.3)
+    frame = syn.make_scan(scene, true_pose, syn.beam_directions(8, 256), cfg.sensor_height, rng)
+    rel = syn.planar_pose(0.4, 0.0, np.deg2rad(2.0))
+    last = syn.pose_mul(syn.pose_mul(true_pose, syn.planar_pose(0.2, 0.0, np.deg2rad(1.0))), syn.pose_inverse(rel))
+    return cfg, omap, frame, last, rel
+
+
+def shard_pass_fixed(omap, shard, T, tau):
+    """What one rank's pass kernel produces for its shard: the seven sums as exact fixed-point integers."""
+    tot = [0] * sh.NUM_SUMS
+    if len(shard) == 0:
+        return tot
+    q = okicp.se3_act(T, shard)
+    nn, d = omap.GetClosestNeighbor(q)
+    keep = d < tau
+    s, r = shard[keep], q[keep] - nn[keep]
+    rot = lambda v: okicp.se3_act(np.concatenate([T[:4], np.zeros(3)]), v)  # noqa: E731
+    j0 = rot(np.array([[1.0, 0.0, 0.0]]))[0]
+    j1 = rot(np.stack([-s[:, 1], s[:, 0], np.zeros(len(s))], 1))
+    terms = [np.full(len(s), j0 @ j0), j1 @ j0, np.sum(j1 * j1, 1), r @ j0, np.sum(j1 * r, 1), np.sum(r * r, 1), np.ones(len(s))]
+    for i, t in enumerate(terms):
+        tot[i] = int(sum(sh.quantize(x) for x in t))
+    return tot
+
+
+def sharded_registration(omap, frame, last, rel, tau, world, rank, allreduce, max_iter=10, conv=1e-3):
+    lo, hi = sh.shard_bounds(len(frame), world, rank)
+    shard = frame[lo:hi]
+    T = okicp.se3_mul(last, rel)
+    beta = None
+    for it in range(max_iter):
+        words = sh.pack(shard_pass_fixed(omap, shard, T, tau))
+        words = allreduce(words)
+        sums = sh.unpack(words)
+        if it == 0:
+            beta = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+        dx = okicp.solve(sums[:5], sums[6], beta)
+        T = okicp.se3_mul(T, okicp.motion_model(dx))
+        if np.hypot(dx[0], dx[1]) < conv:
+            return T, it + 1
+    return T, max_iter
+
+
+def test_limb_roundtrip():
+    rng = np.random.default_rng(0)
+    for t in [0, 1, -1, (1 << 100) + 12345, -(1 << 100) - 999, (1 << 40) - 1, -(1 << 40)] + [int(x) for x in rng.integers(-2**62, 2**62, 50)]:
+        assert sh.from_limbs(sh.to_limbs(t)) == t
+    parts = [int(x) << 30 for x in rng.integers(-2**50, 2**50, 64)]
+    words = np.sum([sh.pack([p] * 7) for p in parts], axis=0)  # summing limb-wise == summing the integers
+    assert sh.from_limbs(words[:3]) == sum(parts)
+    assert sh.shard_bounds(10, 4, 0) == (0, 2) and sh.shard_bounds(10, 4, 3) == (7, 10)
+    assert sum(b - a for a, b in (sh.shard_bounds(131072, 8, r) for r in range(8))) == 131072
+
+
+def test_emulated_world_sizes_give_identical_bits():
+    cfg, omap, frame, last, rel = _world()
+    tau = cfg.first_frame_tau()
+    ref = okicp.KinematicRegistration()
+    expect = ref.ComputeRobotMotion(frame, omap, last, rel, tau)
+    results = {}
+    for g in (1, 2, 4, 8):
+        # emulate the collective: every rank contributes its words, everybody sees the sum
+        def run(g=g):
+            # lock-step emulation
+            T = [okicp.se3_mul(last, rel) for _ in range(g)]
+            beta, its = None, 0
+            for it in range(10):
+                words = np.sum([sh.pack(shard_pass_fixed(omap, frame[slice(*sh.shard_bounds(len(frame), g, r))], T[r], tau)) for r in range(g)], 0)
+                sums = sh.unpack(words)
+                if it == 0:
+                    beta = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+                dx = okicp.solve(sums[:5], sums[6], beta)
+                T = [okicp.se3_mul(t, okicp.motion_model(dx)) for t in T]
+                its = it + 1
+                if np.hypot(dx[0], dx[1]) < 1e-3:
+                    break
+            for t in T[1:]:
+                assert np.array_equal(t, T[0])
+            return T[0], its
+        results[g] = run()
+    for g in (2, 4, 8):
+        assert np.array_equal(results[g][0], results[1][0]) and results[g][1] == results[1][1]  # exact, not approximately
+    assert results[1][1] == ref.last_stats.iterations
+    np.testing.assert_allclose(results[1][0], expect, atol=1e-9)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, omap, frame, last, rel = _world()
+
+    def allreduce(words):
+        t = torch.from_numpy(words.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    T, its = sharded_registration(omap, frame, last, rel, cfg.first_frame_tau(), world, rank, allreduce)
+    np.save(os.path.join(out_dir, "pose_%d.npy" % rank), np.concatenate([T, [its]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "pose_0.npy"), np.load(tmp_path / "pose_1.npy")
+    assert np.array_equal(p0, p1)  # every rank ran the identical solve on identical all-reduced integers
+    cfg, omap, frame, last, rel = _world()
+    ref = okicp.KinematicRegistration()
+    expect = ref.ComputeRobotMotion(frame, omap, last, rel, cfg.first_frame_tau())
+    assert int(p0[7]) == ref.last_stats.iterations
+    np.testing.assert_allclose(p0[:7], expect, atol=1e-9)
