@@ -1,0 +1,37 @@
+// kicp_bridge.hpp -- glue between the reference's C++ value types and the C-ABI of include/kicp.h.
+// With the real Eigen/Sophus the same code compiles: only the two param-conversion helpers differ.
+#pragma once
+#include <Eigen/Core>
+#include <sophus/se3.hpp>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kicp.h"
+
+namespace kicp_bridge {
+inline void to_params(const Sophus::SE3d &T, double p[7]) {
+#ifdef KICP_COMPAT_SOPHUS
+    T.toParams(p);
+#else
+    const auto &q = T.unit_quaternion();
+    p[0] = q.x(), p[1] = q.y(), p[2] = q.z(), p[3] = q.w();
+    p[4] = T.translation().x(), p[5] = T.translation().y(), p[6] = T.translation().z();
+#endif
+}
+inline Sophus::SE3d from_params(const double p[7]) {
+#ifdef KICP_COMPAT_SOPHUS
+    return Sophus::SE3d::fromParams(p);
+#else
+    return Sophus::SE3d(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]));
+#endif
+}
+inline const double *xyz(const std::vector<Eigen::Vector3d> &v) {
+    static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d must be 3 packed doubles");
+    return v.empty() ? nullptr : v.front().data();
+}
+// The reference's core throws nothing; a backend failure must not return garbage silently.
+inline void check(int rc, const char *what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + kicp_last_error());
+}
+}  // namespace kicp_bridge

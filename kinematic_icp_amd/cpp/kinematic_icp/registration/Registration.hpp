@@ -1,0 +1,61 @@
+// kinematic_icp/registration/Registration.hpp -- drop-in for the reference header of the same path
+// (/root/reference/cpp/kinematic_icp/registration/Registration.hpp:23-51): same struct, constructor signature,
+// ComputeRobotMotion signature and public fields; the body runs on the MI355X through include/kicp.h.
+#pragma once
+#include <Eigen/Core>
+#include <kiss_icp/core/VoxelHashMap.hpp>
+#include <sophus/se3.hpp>
+#include <vector>
+
+#include "kicp_bridge.hpp"
+
+namespace kinematic_icp {
+struct KinematicRegistration {
+    explicit KinematicRegistration(const int max_num_iteration, const double convergence_criterion, const int max_num_threads,
+                                   const bool use_adaptive_odometry_regularization, const double fixed_regularization)
+        : max_num_iterations_(max_num_iteration),
+          convergence_criterion_(convergence_criterion),
+          max_num_threads_(max_num_threads),  // kept for API parity: the GPU path has no host thread pool to size
+          use_adaptive_odometry_regularization_(use_adaptive_odometry_regularization),
+          fixed_regularization_(fixed_regularization) {
+        const kicp_reg_config c = config();
+        kicp_bridge::check(kicp_reg_create(&c, device_, &handle_), "KinematicRegistration");
+    }
+    ~KinematicRegistration() { kicp_reg_destroy(handle_); }
+    KinematicRegistration(const KinematicRegistration &) = delete;
+    KinematicRegistration &operator=(const KinematicRegistration &) = delete;
+
+    Sophus::SE3d ComputeRobotMotion(const std::vector<Eigen::Vector3d> &frame, const kiss_icp::VoxelHashMap &voxel_map,
+                                    const Sophus::SE3d &last_robot_pose, const Sophus::SE3d &relative_wheel_odometry,
+                                    const double max_correspondence_distance) {
+        const kicp_reg_config c = config();  // the fields are public and mutable in the reference: honour edits
+        kicp_bridge::check(kicp_reg_set_config(handle_, &c), "KinematicRegistration");
+        double last[7], rel[7], out[7];
+        kicp_bridge::to_params(last_robot_pose, last);
+        kicp_bridge::to_params(relative_wheel_odometry, rel);
+        kicp_bridge::check(kicp_register(handle_, voxel_map.handle(), kicp_bridge::xyz(frame), frame.size(), last, rel,
+                                         max_correspondence_distance, out, &last_stats_),
+                           "KinematicRegistration::ComputeRobotMotion");
+        return kicp_bridge::from_params(out);
+    }
+
+    int max_num_iterations_;
+    double convergence_criterion_;
+    int max_num_threads_;
+    bool use_adaptive_odometry_regularization_;
+    double fixed_regularization_;
+
+    // backend access (not part of the reference API)
+    kicp_reg *handle() const { return handle_; }
+    const kicp_stats &last_stats() const { return last_stats_; }
+
+private:
+    kicp_reg_config config() const {
+        return kicp_reg_config{max_num_iterations_, convergence_criterion_, max_num_threads_, use_adaptive_odometry_regularization_ ? 1 : 0,
+                               fixed_regularization_};
+    }
+    int device_ = 0;
+    kicp_reg *handle_ = nullptr;
+    kicp_stats last_stats_{};
+};
+}  // namespace kinematic_icp

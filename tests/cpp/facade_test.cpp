@@ -1,0 +1,79 @@
+// facade_test.cpp -- exercises the drop-in C++ headers exactly the way the reference's callers do
+// (registration: pipeline/KinematicICP.cpp:68-72; pipeline: ros/.../LidarOdometryServer.cpp:105,205-206).
+// Input: a little binary file written by tests/test_facade.py; output: poses as text on stdout.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kinematic_icp/pipeline/KinematicICP.hpp"
+
+static std::vector<double> read_doubles(FILE *f, size_t n) {
+    std::vector<double> v(n);
+    if (n && fread(v.data(), sizeof(double), n, f) != n) {
+        fprintf(stderr, "short read\n");
+        exit(2);
+    }
+    return v;
+}
+static std::vector<Eigen::Vector3d> to_points(const std::vector<double> &v) {
+    std::vector<Eigen::Vector3d> p(v.size() / 3);
+    if (!p.empty()) std::memcpy(p.front().data(), v.data(), v.size() * sizeof(double));
+    return p;
+}
+static void print_pose(const char *tag, const Sophus::SE3d &T) {
+    double p[7];
+    kicp_bridge::to_params(T, p);
+    printf("%s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", tag, p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 1;
+    const std::string mode = argv[1];
+    FILE *f = fopen(argv[2], "rb");
+    if (!f) return 1;
+    try {
+        if (mode == "reg") {
+            const auto h = read_doubles(f, 5);  // n_map, n_frame, voxel, max_range, tau
+            const auto map_pts = to_points(read_doubles(f, static_cast<size_t>(h[0]) * 3));
+            const auto frame = to_points(read_doubles(f, static_cast<size_t>(h[1]) * 3));
+            const auto last = read_doubles(f, 7), rel = read_doubles(f, 7);
+            kiss_icp::VoxelHashMap map(h[2], h[3], 20);
+            map.AddPoints(map_pts);
+            kinematic_icp::KinematicRegistration reg(10, 1e-3, 1, true, 0.0);
+            const Sophus::SE3d pose = reg.ComputeRobotMotion(frame, map, kicp_bridge::from_params(last.data()),
+                                                             kicp_bridge::from_params(rel.data()), h[4]);
+            print_pose("pose", pose);
+            printf("iterations %d converged %d\n", reg.last_stats().iterations, reg.last_stats().converged);
+            const auto [nn, d] = map.GetClosestNeighbor(frame[0]);
+            printf("closest %.17g %.17g %.17g %.17g\n", nn.x(), nn.y(), nn.z(), d);
+            reg.max_num_iterations_ = 1;  // public mutable field, as in the reference
+            reg.ComputeRobotMotion(frame, map, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]);
+            printf("iterations_after_edit %d\n", reg.last_stats().iterations);
+        } else if (mode == "pipeline") {
+            const auto h = read_doubles(f, 4);  // n_frames, voxel, max_range, deskew
+            kinematic_icp::pipeline::Config cfg;
+            cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
+            kinematic_icp::pipeline::KinematicICP icp(cfg);
+            const auto ext = read_doubles(f, 7);
+            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+                const auto n = read_doubles(f, 1);
+                const auto frame = to_points(read_doubles(f, static_cast<size_t>(n[0]) * 3));
+                const auto stamps = read_doubles(f, static_cast<size_t>(n[0]));
+                const auto delta = read_doubles(f, 7);
+                const auto [deskewed, source] = icp.RegisterFrame(frame, stamps, kicp_bridge::from_params(ext.data()),
+                                                                  kicp_bridge::from_params(delta.data()));
+                print_pose("pose", icp.pose());
+                printf("sizes %zu %zu %zu\n", deskewed.size(), source.size(), icp.LocalMap().size());
+            }
+            icp.SetPose(Sophus::SE3d());
+            printf("after_setpose %zu %d\n", icp.LocalMap().size(), icp.VoxelMap().Empty() ? 1 : 0);
+        }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 3;
+    }
+    fclose(f);
+    return 0;
+}
