@@ -120,6 +120,7 @@ struct kicp_reg {
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
     int dbg = 0;
     int query_every = 64;  // polls between hipStreamQuery calls while waiting
+    int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -369,16 +370,21 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
         if (int rc = wait_record(r, call_id, 0, true, &seq)) return rc;
     } else {
-        // stepped: iteration it+1 is already queued while the host waits for the stop flag of iteration it, so the
-        // GPU never idles on the host; at most one queued iteration turns out to be unnecessary (it exits at once).
+        // stepped: the host polls the stop flag after every iteration.  When the previous scan needed more than one
+        // iteration, iteration it+1 is queued before the flag of iteration it is known, so the GPU never idles on the
+        // host (at most one queued iteration turns out to be unnecessary and exits at once); when scans converge in
+        // one iteration - the usual case with good wheel odometry - nothing is queued speculatively.
         int queued = 0;
         if (int rc = enqueue_iteration(queued++)) return rc;
         for (int it = 0;; ++it) {
-            if (queued < max_it)
+            if (r->speculate && queued < max_it && queued == it + 1)
                 if (int rc = enqueue_iteration(queued++)) return rc;
             if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
             if (seq & 0x8000ull) break;
+            if (queued == it + 1)
+                if (int rc = enqueue_iteration(queued++)) return rc;
         }
+        r->speculate = (seq & 0x7FFFull) > 1 ? 1 : 0;
         HIP_TRY(hipGetLastError());
         if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
     }
