@@ -73,6 +73,7 @@ struct DeviceMirror {
     int device = -1;
     Slot *d_table = nullptr;
     double *d_pool = nullptr;
+    float4 *d_pool32 = nullptr;
     size_t table_slots = 0, pool_doubles = 0;  // allocated sizes
     uint64_t synced_epoch = ~0ull;
     MapView view{};
@@ -144,6 +145,7 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
         hipSetDevice(mr.device);
         if (mr.d_table) hipFree(mr.d_table);
         if (mr.d_pool) hipFree(mr.d_pool);
+        if (mr.d_pool32) hipFree(mr.d_pool32);
         mr = DeviceMirror{};
         hipSetDevice(device);
     }
@@ -158,15 +160,18 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
     }
     if (pool_doubles > mr.pool_doubles) {
         if (mr.d_pool) HIP_TRY(hipFree(mr.d_pool));
-        mr.d_pool = nullptr;
-        const size_t want = pool_doubles + pool_doubles / 4 + 1024;
+        if (mr.d_pool32) HIP_TRY(hipFree(mr.d_pool32));
+        mr.d_pool = nullptr, mr.d_pool32 = nullptr;
+        const size_t want = pool_doubles + pool_doubles / 4 + 3 * 1024;
         HIP_TRY(hipMalloc(&mr.d_pool, want * sizeof(double)));
+        HIP_TRY(hipMalloc(&mr.d_pool32, want / 3 * sizeof(float4)));
         mr.pool_doubles = want;
     }
     HIP_TRY(hipMemcpyAsync(mr.d_table, h.table().data(), slots * sizeof(Slot), hipMemcpyHostToDevice, stream));
     if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool, h.pool().data(), pool_doubles * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool32, h.pool32().data(), pool_doubles / 3 * sizeof(float4), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, h.cap(), h.voxel_size()};
+    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, h.cap(), h.voxel_size()};
     mr.synced_epoch = h.epoch();
     return KICP_OK;
 }
@@ -177,7 +182,7 @@ void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
 }
 int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
 uint32_t pass_grid(const kicp_reg *r, size_t n) {
-    if (r->pass_kernel != 0) {  // persistent one-wave workgroups
+    if (r->pass_kernel == 1 || r->pass_kernel == 2) {  // persistent one-wave workgroups
         const size_t max_groups = (n + 63) / 64 + (r->pass_kernel == 2 ? n / 8 : 0);  // more workgroups than groups would only idle
         const size_t want = static_cast<size_t>(r->num_cus) * r->waves_per_cu;
         return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
@@ -193,6 +198,14 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
     }
     if (r->pass_kernel == 1) {
         hipLaunchKernelGGL(k_pass_lds, dim3(grid), dim3(64), 0, r->stream, p);
+        return;
+    }
+    if (r->pass_kernel == 3) {
+        switch (normalized_block(r->block)) {
+            case 64: hipLaunchKernelGGL(k_pass_gather32<64>, dim3(grid), dim3(64), 0, r->stream, p); break;
+            case 256: hipLaunchKernelGGL(k_pass_gather32<256>, dim3(grid), dim3(256), 0, r->stream, p); break;
+            default: hipLaunchKernelGGL(k_pass_gather32<128>, dim3(grid), dim3(128), 0, r->stream, p); break;
+        }
         return;
     }
     switch (normalized_block(r->block)) {
@@ -439,6 +452,7 @@ void kicp_map_destroy(kicp_map *map) {
         hipSetDevice(map->mirror.device);
         if (map->mirror.d_table) hipFree(map->mirror.d_table);
         if (map->mirror.d_pool) hipFree(map->mirror.d_pool);
+        if (map->mirror.d_pool32) hipFree(map->mirror.d_pool32);
     }
     delete map;
 }
@@ -583,6 +597,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
     if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;
+    if (k.rfind("tstamp", 0) == 0 && reg->rec) return static_cast<double>(reg->rec->tstamp[std::atoi(k.c_str() + 6)]);
     return -1.0;
 }
 

@@ -7,14 +7,24 @@
 
 namespace kicp {
 
-// One slot of the open-addressing voxel table, 16 B = one global_load_dwordx4.
+// One slot of the open-addressing voxel table: 128 B = one cache line.
 //   key : the reference's Voxel = Eigen::Vector3i (kiss-icp v1.2.0 core/VoxelUtils.hpp)
-//   val : (bucket_index << 8) | point_count ; kEmptyVal marks a free slot.
-struct alignas(16) Slot {
+//   val : (bucket_index << 8) | point_count ; kEmptyVal marks a free slot; kHaloVal an entry without points.
+//   nbr : bit s set <=> voxel key + shift[s] holds points (s in the reference's visiting order, bit 0 = this voxel).
+//   nb  : bucket index of voxel key + shift[s] for every set bit of nbr (that bucket's point count sits in the
+//         bucket itself, see MapView::pool32).
+// Besides the occupied voxels the table holds "halo" entries for every empty voxel that has an occupied neighbour,
+// so ONE probe at a query's own voxel yields the buckets of all 27 neighbours: empty space is never probed, and
+// neighbour voxels need no probe of their own.
+struct alignas(128) Slot {
     int32_t x, y, z;
     uint32_t val;
+    uint32_t nbr;
+    uint32_t nb[27];
 };
+static_assert(sizeof(Slot) == 128, "Slot must be one cache line");
 constexpr uint32_t kEmptyVal = 0xFFFFFFFFu;
+constexpr uint32_t kHaloVal = 0xFFFFFF00u;  // no bucket, zero points
 constexpr uint32_t kMaxBuckets = (1u << 24) - 2;
 constexpr uint32_t kMaxPointsPerVoxel = 255;
 
@@ -37,6 +47,8 @@ struct MapView {
     const Slot *table;    // capacity = mask + 1 (power of two), linear probing, no tombstones
     uint32_t mask;
     const double *pool;   // bucket b holds <= cap points at pool + b * cap * 3 (AoS xyz, insertion order)
+    const float4 *pool32; // fp32 mirror: point k of bucket b at pool32[b * cap + k] = offset from the voxel corner in
+                          // xyz; the w of point 0 carries the bucket's point count (integer bits)
     uint32_t cap;         // max_points_per_voxel
     double voxel_size;
 };

@@ -3,6 +3,9 @@
 // directly in the layout the gfx950 kernels read (kicp_common.hpp: Slot table + fixed-stride bucket pool), so
 // that "upload" is two plain copies and no per-scan re-packing happens.
 //
+// Besides the occupied voxels the table carries halo entries and per-entry 27-bit neighbour-occupancy masks
+// (kicp_common.hpp::Slot), maintained here whenever a voxel gains its first / loses its last point.
+//
 // Insertion keeps the reference's order-dependent semantics (first come first kept, <= max_points_per_voxel,
 // min spacing = voxel_size / sqrt(max_points_per_voxel) inside one voxel), which is why it stays sequential on
 // the host for now (device-side maintenance is a section 8f "next" row).
@@ -32,11 +35,14 @@ public:
     bool Empty() const { return n_voxels_ == 0; }
     const std::vector<Slot> &table() const { return table_; }
     const std::vector<double> &pool() const { return pool_; }
+    const std::vector<float> &pool32() const { return pool32_; }  // (x,y,z,0) offsets from the voxel corner, stride cap*4
     size_t buckets_in_use_hi() const { return n_buckets_hi_; }  // pool prefix that may hold live buckets
 
     void Clear() {
-        table_.assign(kMinTable, Slot{0, 0, 0, kEmptyVal});
+        table_.assign(kMinTable, empty_slot());
+        n_entries_ = 0, n_dead_ = 0;
         pool_.clear();
+        pool32_.clear();
         free_.clear();
         n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
         ++epoch_;
@@ -49,7 +55,7 @@ public:
             const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
             const int32_t vx = to_voxel(px), vy = to_voxel(py), vz = to_voxel(pz);
             const int64_t s = find(vx, vy, vz);
-            if (s >= 0) {
+            if (s >= 0 && (table_[static_cast<size_t>(s)].val & 0xffu) != 0) {
                 Slot &slot = table_[static_cast<size_t>(s)];
                 const uint32_t count = slot.val & 0xffu, bucket = slot.val >> 8;
                 if (count == cap_) continue;
@@ -64,13 +70,17 @@ public:
                 }
                 if (too_close) continue;
                 b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
+                store32(bucket, count, px, py, pz, vx, vy, vz);
+                set_count32(bucket, count + 1);
                 slot.val = (bucket << 8) | (count + 1);
             } else {
                 if (n_voxels_ + 1 > kMaxBuckets) return false;
                 const uint32_t bucket = alloc_bucket();
                 double *b = &pool_[static_cast<size_t>(bucket) * cap_ * 3];
                 b[0] = px, b[1] = py, b[2] = pz;
-                insert_new(vx, vy, vz, (bucket << 8) | 1u);
+                store32(bucket, 0, px, py, pz, vx, vy, vz);
+                set_count32(bucket, 1);
+                occupy(vx, vy, vz, (bucket << 8) | 1u);
             }
             ++n_points_;
         }
@@ -81,17 +91,14 @@ public:
     // RemovePointsFarFromLocation(origin) -- App. A.6: drop a voxel when its FIRST point is >= max_distance away.
     void RemovePointsFarFromLocation(const double origin[3]) {
         const double max_distance2 = max_distance_ * max_distance_;
-        for (size_t i = 0; i < table_.size();) {
+        for (size_t i = 0; i < table_.size(); ++i) {  // no entry moves during the sweep (erase leaves a halo/dead entry)
             const Slot &slot = table_[i];
-            if (slot.val != kEmptyVal) {
-                const double *b = &pool_[static_cast<size_t>(slot.val >> 8) * cap_ * 3];
-                const double dx = b[0] - origin[0], dy = b[1] - origin[1], dz = b[2] - origin[2];
-                if (dx * dx + dy * dy + dz * dz >= max_distance2) {
-                    if (erase_at(i)) continue;  // an element was shifted into i: test it too
-                }
-            }
-            ++i;
+            if (slot.val == kEmptyVal || (slot.val & 0xffu) == 0) continue;
+            const double *b = &pool_[static_cast<size_t>(slot.val >> 8) * cap_ * 3];
+            const double dx = b[0] - origin[0], dy = b[1] - origin[1], dz = b[2] - origin[2];
+            if (dx * dx + dy * dy + dz * dz >= max_distance2) erase_voxel(i);
         }
+        if (n_dead_ * 4 > n_entries_) rebuild(table_.size());
         ++epoch_;
     }
 
@@ -117,7 +124,7 @@ public:
         size_t w = 0;
         for (const Slot &slot : table_) {
             if (slot.val == kEmptyVal) continue;
-            const uint32_t count = slot.val & 0xffu;
+            const uint32_t count = slot.val & 0xffu;  // 0 for halo entries
             const double *b = &pool_[static_cast<size_t>(slot.val >> 8) * cap_ * 3];
             for (uint32_t k = 0; k < count && w < cap_points; ++k, ++w) std::memcpy(out + 3 * w, b + 3 * k, 24);
         }
@@ -128,6 +135,14 @@ private:
     static constexpr size_t kMinTable = 1024;
     int32_t to_voxel(double c) const { return static_cast<int32_t>(std::floor(c / voxel_size_)); }  // PointToVoxel, App. A.1
 
+    // fp32 mirror used by the pre-selection pass: offset from the voxel corner (|offset| <~ voxel_size, so the rounding
+    // error is <= 2^-24 * voxel_size regardless of how far the map is from the origin)
+    void store32(uint32_t bucket, uint32_t k, double px, double py, double pz, int32_t vx, int32_t vy, int32_t vz) {
+        float *f = &pool32_[(static_cast<size_t>(bucket) * cap_ + k) * 4];
+        f[0] = static_cast<float>(px - vx * voxel_size_), f[1] = static_cast<float>(py - vy * voxel_size_);
+        f[2] = static_cast<float>(pz - vz * voxel_size_), f[3] = 0.f;
+    }
+    void set_count32(uint32_t bucket, uint32_t count) { std::memcpy(&pool32_[static_cast<size_t>(bucket) * cap_ * 4 + 3], &count, 4); }
     int64_t find(int32_t x, int32_t y, int32_t z) const {
         const size_t mask = table_.size() - 1;
         for (size_t i = voxel_hash(x, y, z) & mask;; i = (i + 1) & mask) {
@@ -136,21 +151,62 @@ private:
             if (s.x == x && s.y == y && s.z == z) return static_cast<int64_t>(i);
         }
     }
-    void place(int32_t x, int32_t y, int32_t z, uint32_t val) {
-        const size_t mask = table_.size() - 1;
-        size_t i = voxel_hash(x, y, z) & mask;
-        while (table_[i].val != kEmptyVal) i = (i + 1) & mask;
-        table_[i] = Slot{x, y, z, val};
+    static Slot empty_slot() {
+        Slot e{};
+        e.val = kEmptyVal;
+        return e;
     }
-    void insert_new(int32_t x, int32_t y, int32_t z, uint32_t val) {
-        if ((n_voxels_ + 1) * 4 > table_.size()) {  // keep load factor <= 0.25: misses end after ~1.2 probes
-            std::vector<Slot> old(table_.size() * 2, Slot{0, 0, 0, kEmptyVal});
-            old.swap(table_);
-            for (const Slot &s : old)
-                if (s.val != kEmptyVal) place(s.x, s.y, s.z, s.val);
-        }
-        place(x, y, z, val);
+    size_t place(const Slot &e) {
+        const size_t mask = table_.size() - 1;
+        size_t i = voxel_hash(e.x, e.y, e.z) & mask;
+        while (table_[i].val != kEmptyVal) i = (i + 1) & mask;
+        table_[i] = e;
+        return i;
+    }
+    // re-hash the live entries (occupied voxels and halo entries that still have an occupied neighbour)
+    void rebuild(size_t slots) {
+        std::vector<Slot> old(slots, empty_slot());
+        old.swap(table_);
+        n_entries_ = 0, n_dead_ = 0;
+        for (const Slot &e : old)
+            if (e.val != kEmptyVal && ((e.val & 0xffu) != 0 || e.nbr != 0)) place(e), ++n_entries_;
+    }
+    static bool is_dead(const Slot &e) { return (e.val & 0xffu) == 0 && e.nbr == 0; }  // halo entry nobody needs any more
+    template <typename F>
+    void mutate(size_t i, F f) {
+        const bool before = is_dead(table_[i]);
+        f(table_[i]);
+        n_dead_ += static_cast<size_t>(is_dead(table_[i])) - static_cast<size_t>(before);
+    }
+    // slot index of the entry for voxel (x,y,z), created as a (for now dead) halo entry if absent; never re-hashes
+    size_t find_or_insert(int32_t x, int32_t y, int32_t z) {
+        const int64_t s = find(x, y, z);
+        if (s >= 0) return static_cast<size_t>(s);
+        ++n_entries_, ++n_dead_;
+        Slot e{};
+        e.x = x, e.y = y, e.z = z, e.val = kHaloVal;
+        return place(e);
+    }
+    // voxel (x,y,z) receives its first point: give it a bucket and tell the 27 voxels that see it
+    void occupy(int32_t x, int32_t y, int32_t z, uint32_t val) {
+        while ((n_entries_ + 27) * 2 > table_.size()) rebuild(table_.size() * 2);  // load factor <= 0.5, no re-hash below
+        mutate(find_or_insert(x, y, z), [&](Slot &e) { e.val = val; });
         ++n_voxels_;
+        for (int s = 0; s < 27; ++s)  // U + shift[s] == this voxel  <=>  U = this - shift[s]
+            mutate(find_or_insert(x - kShiftTable[s][0], y - kShiftTable[s][1], z - kShiftTable[s][2]),
+                   [&](Slot &e) { e.nbr |= 1u << s, e.nb[s] = val >> 8; });
+    }
+    // the voxel at slot i loses all its points (entries never move here)
+    void erase_voxel(size_t i) {
+        const int32_t x = table_[i].x, y = table_[i].y, z = table_[i].z;
+        n_points_ -= table_[i].val & 0xffu;
+        free_.push_back(table_[i].val >> 8);
+        mutate(i, [&](Slot &e) { e.val = kHaloVal; });
+        --n_voxels_;
+        for (int s = 0; s < 27; ++s) {
+            const int64_t u = find(x - kShiftTable[s][0], y - kShiftTable[s][1], z - kShiftTable[s][2]);
+            if (u >= 0) mutate(static_cast<size_t>(u), [&](Slot &e) { e.nbr &= ~(1u << s); });
+        }
     }
     uint32_t alloc_bucket() {
         if (!free_.empty()) {
@@ -159,37 +215,21 @@ private:
             return b;
         }
         const uint32_t b = static_cast<uint32_t>(n_buckets_hi_++);
-        if (pool_.size() < n_buckets_hi_ * cap_ * 3) pool_.resize(std::max<size_t>(pool_.size() * 2, n_buckets_hi_ * cap_ * 3 + 1024 * cap_ * 3));
+        if (pool_.size() < n_buckets_hi_ * cap_ * 3) {
+            const size_t buckets = std::max<size_t>(pool_.size() / (cap_ * 3) * 2, n_buckets_hi_ + 1024);
+            pool_.resize(buckets * cap_ * 3);
+            pool32_.resize(buckets * cap_ * 4);
+        }
         return b;
     }
-    // backward-shift deletion (keeps the table tombstone-free so device probes stop at the first empty slot)
-    bool erase_at(size_t i) {
-        const size_t mask = table_.size() - 1;
-        n_points_ -= table_[i].val & 0xffu;
-        free_.push_back(table_[i].val >> 8);
-        table_[i].val = kEmptyVal;
-        --n_voxels_;
-        bool moved_into_i = false;
-        size_t hole = i;
-        for (size_t j = (i + 1) & mask; table_[j].val != kEmptyVal; j = (j + 1) & mask) {
-            const size_t home = voxel_hash(table_[j].x, table_[j].y, table_[j].z) & mask;
-            const bool stays = (hole <= j) ? (home > hole && home <= j) : (home > hole || home <= j);
-            if (!stays) {
-                table_[hole] = table_[j];
-                table_[j].val = kEmptyVal;
-                if (hole == i) moved_into_i = true;
-                hole = j;
-            }
-        }
-        return moved_into_i;
-    }
-
     double voxel_size_, max_distance_;
     uint32_t cap_;
     std::vector<Slot> table_;
     std::vector<double> pool_;
+    std::vector<float> pool32_;
     std::vector<uint32_t> free_;
     size_t n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
+    size_t n_entries_ = 0, n_dead_ = 0;  // table entries (occupied + halo); halo entries with no occupied neighbour left
     uint64_t epoch_ = 0;
 };
 

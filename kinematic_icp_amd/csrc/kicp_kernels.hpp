@@ -46,6 +46,7 @@ struct HostRecord {
     double log_dx[kMaxLog][2];
     double sums[kNumSums];  // last pass, for kicp_pass_sums
     uint32_t n_cells, n_items, not_staged, reserved;
+    long long tstamp[12];  // experiments: s_memtime stamps of the finishing workgroup
 };
 
 // Device-resident loop state of one ComputeRobotMotion call.
@@ -89,6 +90,7 @@ struct PassParams {
     BinView bin;
     SolveParams sol;
     int32_t dbg;  // experiments only: 1 = staging without matching, 2 = neither
+    long long tstart;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -174,12 +176,33 @@ __device__ __forceinline__ double box_d2(const Faces &f, int dx, int dy, int dz)
     return d;
 }
 
+// bucket value of voxel (x,y,z), or kEmptyVal when it holds no points (absent or halo entry)
 __device__ __forceinline__ uint32_t table_lookup(const MapView &m, int32_t x, int32_t y, int32_t z) {
     uint32_t h = voxel_hash(x, y, z) & m.mask;
     for (;;) {
         const int4 e = *reinterpret_cast<const int4 *>(m.table + h);
         if (static_cast<uint32_t>(e.w) == kEmptyVal) return kEmptyVal;
-        if (e.x == x && e.y == y && e.z == z) return static_cast<uint32_t>(e.w);
+        if (e.x == x && e.y == y && e.z == z) return (e.w & 0xff) ? static_cast<uint32_t>(e.w) : kEmptyVal;
+        h = (h + 1) & m.mask;
+    }
+}
+// the whole entry: bucket value and the 27-bit neighbour-occupancy mask (0 when the voxel has no entry at all,
+// i.e. none of its 27 neighbours holds a point)
+// slot index of the entry (for its nb[] record) and the 27-bit neighbour-occupancy mask; nbr == 0 when the voxel has
+// no entry at all, i.e. none of its 27 neighbours holds a point
+__device__ __forceinline__ void table_lookup_entry(const MapView &m, int32_t x, int32_t y, int32_t z, uint32_t &slot, uint32_t &nbr) {
+    uint32_t h = voxel_hash(x, y, z) & m.mask;
+    for (;;) {
+        const int4 e = *reinterpret_cast<const int4 *>(m.table + h);
+        const uint32_t n = m.table[h].nbr;  // same cache line: issued together with the key
+        if (static_cast<uint32_t>(e.w) == kEmptyVal) {
+            slot = 0u, nbr = 0u;
+            return;
+        }
+        if (e.x == x && e.y == y && e.z == z) {
+            slot = h, nbr = n;
+            return;
+        }
         h = (h + 1) & m.mask;
     }
 }
@@ -218,6 +241,14 @@ __device__ __forceinline__ void search_global(const MapView &m, const Query &q, 
         const uint32_t bucket = val >> 8;
         scan_points(m.pool + static_cast<size_t>(bucket) * m.cap * 3, val & 0xffu, bucket * m.cap, q, best, best_idx);
     }
+}
+
+constexpr uint32_t kNoIndex32 = 0xFFFFFFFFu;
+// exact fp64 evaluation of one candidate from the HBM pool
+__device__ __forceinline__ double exact_d2(const MapView &m, uint32_t gidx, const Query &q) {
+    const double *t = m.pool + static_cast<size_t>(gidx) * 3;
+    const double dx = t[0] - q.x, dy = t[1] - q.y, dz = t[2] - q.z;
+    return dx * dx + dy * dy + dz * dz;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -267,17 +298,26 @@ __device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams
     if (!(n > 0.0) || range_error) done = 1, nan_flag = 1 + (range_error ? 1 : 0);  // 0/0: NaN pose from here on, as in the reference
     st->iter = f.pass + 1, st->converged = converged, st->nan_flag = nan_flag, st->done = done;
     if (rec) {
+        // The record lives in host memory: every field goes out as a system-scope write-through store, then ONE wait,
+        // then the sequence word (no release fence: that would write back the whole L2 first).
+        auto put_d = [](double *p, double v) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        };
+        auto put_i = [](int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
         if (f.pass < kMaxLog) {
-            rec->log_ncorr[f.pass] = n;
+            put_d(&rec->log_ncorr[f.pass], n);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) rec->log_sums[f.pass][i] = sums[i];
-            rec->log_dx[f.pass][0] = dx0, rec->log_dx[f.pass][1] = dx1;
+            for (int i = 0; i < 6; ++i) put_d(&rec->log_sums[f.pass][i], sums[i]);
+            put_d(&rec->log_dx[f.pass][0], dx0), put_d(&rec->log_dx[f.pass][1], dx1);
         }
-        rec->T = T, rec->beta = beta;
-        rec->done = done, rec->iter = f.pass + 1, rec->converged = converged, rec->nan_flag = nan_flag;
-        rec->not_staged = st->not_staged;
+        put_d(&rec->T.qx, T.qx), put_d(&rec->T.qy, T.qy), put_d(&rec->T.qz, T.qz), put_d(&rec->T.qw, T.qw);
+        put_d(&rec->T.tx, T.tx), put_d(&rec->T.ty, T.ty), put_d(&rec->T.tz, T.tz), put_d(&rec->beta, beta);
+        put_i(&rec->done, done), put_i(&rec->iter, f.pass + 1), put_i(&rec->converged, converged), put_i(&rec->nan_flag, nan_flag);
+        put_i(reinterpret_cast<int32_t *>(&rec->not_staged), static_cast<int32_t>(st->not_staged));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&rec->seq, (f.call_id << 16) | (done ? 0x8000ull : 0ull) | static_cast<unsigned long long>(f.pass + 1),
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -294,12 +334,21 @@ __device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p
 __device__ __forceinline__ void st_sc1(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// lanes 0..47 cooperatively sum `count` rows of kReduceWords words; the totals end up in lanes 0..23
+// lanes 0..47 cooperatively sum `count` <= kGroup rows of kReduceWords words; the totals end up in lanes 0..23.
+// All loads of a lane are issued before the first is consumed (one round trip, not count/2 of them).
 __device__ __forceinline__ long long sum_rows(const unsigned long long *rows, uint32_t count, int lane) {
     long long v = 0;
     if (lane < 2 * kReduceWords) {
         const int word = lane % kReduceWords;
-        for (uint32_t j = lane / kReduceWords; j < count; j += 2) v += static_cast<long long>(ld_sc1(rows + static_cast<size_t>(j) * kReduceWords + word));
+        const uint32_t first = lane / kReduceWords;
+        unsigned long long t[kGroup / 2];
+#pragma unroll
+        for (int u = 0; u < kGroup / 2; ++u) {
+            const uint32_t j = first + 2 * u;
+            t[u] = (j < count) ? ld_sc1(rows + static_cast<size_t>(j) * kReduceWords + word) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kGroup / 2; ++u) v += static_cast<long long>(t[u]);
     }
     return v + __shfl_down(v, kReduceWords, 64);
 }
@@ -308,6 +357,8 @@ template <int BLOCK>
 __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*s_red)[kNumSums], int *s_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
+    long long ts[10];
+    ts[0] = clock64();
 #pragma unroll
     for (int i = 0; i < kNumSums; ++i) {
 #pragma unroll
@@ -337,6 +388,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         o.lo = __shfl(a.v[i].lo, 0, 64), o.hi = __shfl(a.v[i].hi, 0, 64);
         if (lane == i) t = o;
     }
+    ts[1] = clock64();
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
     if (lane < kNumSums) {
@@ -352,14 +404,18 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         st_sc1(row + kNumLimbs + (lane - kNumSums), lane == kNumSums ? static_cast<unsigned long long>(range_error) : 0ull);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[2] = clock64();
     unsigned int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0, 64);
+    ts[3] = clock64();
     const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
     if (ticket != group_size - 1) return;
     // ---- last workgroup of its group: fold the group's rows into one ---------------------------------------
     if (lane == 0) __hip_atomic_store(p.tickets + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long long total = sum_rows(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane);
+    ts[4] = clock64();
+    ts[5] = ts[6] = ts[4];
     if (ngroups > 1) {
         unsigned long long *grow = p.partials + (static_cast<size_t>(nblocks) + g) * kReduceWords;
         if (lane < kReduceWords) st_sc1(grow + lane, static_cast<unsigned long long>(total));
@@ -367,16 +423,26 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         if (lane == 0) ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __shfl(ticket, 0, 64);
         if (ticket != ngroups - 1) return;
+        ts[5] = clock64();
         if (lane == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        total = sum_rows(p.partials + static_cast<size_t>(nblocks) * kReduceWords, ngroups, lane);
+        total = 0;
+        for (uint32_t base = 0; base < ngroups; base += kGroup)
+            total += sum_rows(p.partials + (static_cast<size_t>(nblocks) + base) * kReduceWords, min(static_cast<uint32_t>(kGroup), ngroups - base), lane);
     }
     // ---- last workgroup of the launch ------------------------------------------------------------------------
+    ts[6] = clock64();
     if (lane < kReduceWords) st->reduce[lane] = total;
     long long limbs[kNumLimbs + 1];
 #pragma unroll
     for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
     if (lane != 0 || p.sol.mode != 0) return;
+    if (p.sol.rec && p.dbg) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) p.sol.rec->tstamp[i] = ts[i];
+        p.sol.rec->tstamp[8] = p.tstart;
+    }
     solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
+    if (p.sol.rec && p.dbg) p.sol.rec->tstamp[7] = clock64();
 }
 
 // wave-uniform values belong in SGPRs: tell the compiler explicitly
@@ -415,10 +481,135 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
         make_query(q, rx + T.tx, ry + T.ty, rz + T.tz, p.map.voxel_size);
         double best = p.tau * p.tau * (1.0 + 9.1e-13);
         uint32_t best_idx = 0xFFFFFFFFu;
-        search_global(p.map, q, best, best_idx);
-        if (best_idx != 0xFFFFFFFFu && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+        if (p.dbg != 2) search_global(p.map, q, best, best_idx);
+        if (p.dbg == 0 && best_idx != 0xFFFFFFFFu && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
             const double *t = p.map.pool + static_cast<size_t>(best_idx) * 3;
             accumulate(acc, T, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
+        }
+    }
+    if (BLOCK > 64) __syncthreads();
+    finish_pass<BLOCK>(acc, p, s_red, &s_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// variant 3: thread-per-query gather over the fp32 mirror, per-lane work lists
+//   * candidates are read from the fp32 mirror (one 16-byte load per point, offsets from the voxel corner) and
+//     compared in fp32; the three smallest squared distances are tracked with the indices/visiting order of the two
+//     smallest.  fp32 only PRE-SELECTS: the winner (and the runner-up when it lies within the fp32 error margin) is
+//     re-evaluated in fp64 from the fp64 pool, ties resolved by the reference's visiting order; if even the third
+//     smallest is within the margin the lane falls back to the exact fp64 search.  The chosen neighbour and its
+//     distance are therefore exactly the fp64 reference's.
+//   * each lane walks ITS OWN list of neighbour voxels (bit mask over the 27 shifts, in the reference's order):
+//     culled voxels cost ALU only, so a wave iterates max-over-lanes(#voxels actually visited) times instead of
+//     over the union of the lanes' shifts; every bucket is scanned five points per trip (five loads in flight).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kTrip = 10;  // bucket points in flight per lane and trip
+struct Best3 {
+    float b1, b2, b3;
+    uint32_t i1, i2, o1, o2;  // pool index and visiting order (shift * 256 + k) of the two smallest
+};
+__device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, uint32_t ord) {
+    const bool lt1 = d < t.b1, lt2 = d < t.b2, lt3 = d < t.b3;
+    t.b3 = lt2 ? t.b2 : (lt3 ? d : t.b3);
+    t.b2 = lt1 ? t.b1 : (lt2 ? d : t.b2);
+    t.i2 = lt1 ? t.i1 : (lt2 ? idx : t.i2);
+    t.o2 = lt1 ? t.o1 : (lt2 ? ord : t.o2);
+    t.b1 = lt1 ? d : t.b1;
+    t.i1 = lt1 ? idx : t.i1;
+    t.o1 = lt1 ? ord : t.o1;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pass_gather32(const PassParams p) {
+    KICP_PASS_SHARED(BLOCK)
+    if (p.sol.pass != 0 && p.st->done) return;
+    const Pose T = load_pose(p);
+    const MapView &m = p.map;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = i < p.n && p.dbg != 7;
+    Acc acc{};
+    double sx = 0, sy = 0, sz = 0;
+    if (valid) sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
+    double rx, ry, rz;
+    quat_rotate(T, sx, sy, sz, rx, ry, rz);
+    Query q;
+    make_query(q, rx + T.tx, ry + T.ty, rz + T.tz, m.voxel_size);
+    const double vs = m.voxel_size;
+    const double bound = p.tau * p.tau * (1.0 + 9.1e-13);
+    const float fvs = static_cast<float>(vs);
+    // fp32 error model: mirror offsets and the query offset are < ~2 voxel sizes in magnitude, each rounded once
+    // (<= 2^-23 vs), so a squared distance below (1.2 vs)^2 is off by < 2e-6 vs^2; the margin covers twice that.
+    const float margin = 8e-6f * fvs * fvs;
+    const float bound32 = static_cast<float>(bound) * 1.00001f + margin;
+    const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
+    // conservative (rounded-down) squared distances to the faces of the own voxel
+    float fm[3] = {lx * lx, ly * ly, lz * lz}, fp[3] = {(fvs - lx) * (fvs - lx), (fvs - ly) * (fvs - ly), (fvs - lz) * (fvs - lz)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) fm[a] = fm[a] * 0.99999f - margin, fp[a] = fp[a] * 0.99999f - margin;
+
+    Best3 t{bound32, bound32, bound32, kNoIndex32, kNoIndex32, 0u, 0u};
+    // ONE probe at the own voxel: its bucket and the occupancy mask of the 27 neighbours (bit s = shift s of the
+    // reference's order).  Only voxels that hold points are ever visited; empty space costs nothing.
+    uint32_t slot0 = 0u, todo = 0u;
+    if (valid && p.dbg != 2) table_lookup_entry(m, q.vx, q.vy, q.vz, slot0, todo);
+    if (p.dbg == 3) todo &= 1u;     // experiments: own voxel only
+    if (p.dbg == 5) todo &= 0x7Fu;  // own + faces
+    while (__any(todo != 0u)) {
+        // pop shifts until one survives the cull (ALU only)
+        int s = -1, dx = 0, dy = 0, dz = 0;
+        while (todo) {
+            const int c = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            dx = shift_component(kShiftX, c), dy = shift_component(kShiftY, c), dz = shift_component(kShiftZ, c);
+            const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
+                              (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
+            if (box <= t.b1 + margin) {  // something in there could come within the margin of the current minimum
+                s = c;
+                break;
+            }
+        }
+        if (s >= 0 && p.dbg != 4) {
+            // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
+            const uint32_t base = m.table[slot0].nb[s] * m.cap;
+            const float4 *b = m.pool32 + base;
+            // the query as seen from that voxel's corner
+            const float qx = lx - dx * fvs, qy = ly - dy * fvs, qz = lz - dz * fvs;
+            // Branch-free loads (indices clamped into the bucket) so that the compiler keeps a whole trip in flight:
+            // kTrip points per trip; the count arrives with point 0 (its w).
+            uint32_t cnt = kTrip;
+            const uint32_t last = m.cap - 1;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += kTrip) {
+                float4 c[kTrip];
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) c[u] = b[min(k0 + u, last)];
+                if (k0 == 0) cnt = __float_as_uint(c[0].w);
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const float ddx = c[u].x - qx, ddy = c[u].y - qy, ddz = c[u].z - qz;
+                    const float d = (k0 + u < cnt) ? ddx * ddx + ddy * ddy + ddz * ddz : 3.0e38f;
+                    best3_update(t, d, base + k0 + u, static_cast<uint32_t>(s) * 256u + k0 + u);
+                }
+            }
+        }
+    }
+    // ---- exact resolution -----------------------------------------------------------------------------------------
+    if (valid && t.i1 != kNoIndex32 && p.dbg == 0) {
+        double best = bound;
+        uint32_t best_idx = kNoIndex32;
+        if (t.b3 - t.b1 <= margin) {  // three near-equal candidates: leave it to the exact fp64 search
+            search_global(m, q, best, best_idx);
+        } else {
+            const double d1 = exact_d2(m, t.i1, q);
+            if (d1 < best) best = d1, best_idx = t.i1;
+            if (t.b2 - t.b1 <= margin) {
+                const double d2 = exact_d2(m, t.i2, q);
+                // the reference keeps the FIRST candidate (in visiting order) that attains the strict minimum
+                if (d2 < bound && (best_idx == kNoIndex32 || d2 < best || (d2 == best && t.o2 < t.o1))) best = d2, best_idx = t.i2;
+            }
+        }
+        if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+            const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
+            accumulate(acc, T, sx, sy, q.x, q.y, q.z, tp[0], tp[1], tp[2]);
         }
     }
     if (BLOCK > 64) __syncthreads();
@@ -470,13 +661,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// exact fp64 evaluation of one candidate from the HBM pool
-__device__ __forceinline__ double exact_d2(const MapView &m, uint32_t gidx, const Query &q) {
-    const double *t = m.pool + static_cast<size_t>(gidx) * 3;
-    const double dx = t[0] - q.x, dy = t[1] - q.y, dz = t[2] - q.z;
-    return dx * dx + dy * dy + dz * dz;
-}
-
 // Steps 1-5 for the lanes with `active` set.  On return best/best_idx hold the exact fp64 result per lane
 // (best_idx == kNoIndex: no candidate below the bound).  Returns false (nothing done) if the region does not fit.
 __device__ __forceinline__ bool stage_and_match(WaveLds &L, const MapView &m, const Query &q, bool active, double bound_d2, double &best,
@@ -518,7 +702,7 @@ __device__ __forceinline__ bool stage_and_match(WaveLds &L, const MapView &m, co
             for (;;) {  // collision chain (rare: load factor <= 0.25)
                 if (static_cast<uint32_t>(e[r].w) == kEmptyVal) break;
                 if (e[r].x == kx[r] && e[r].y == ky[r] && e[r].z == kz[r]) {
-                    val = static_cast<uint32_t>(e[r].w);
+                    if (e[r].w & 0xff) val = static_cast<uint32_t>(e[r].w);  // halo entries hold no points
                     break;
                 }
                 h[r] = (h[r] + 1) & m.mask;
@@ -889,9 +1073,12 @@ __global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f)
 // publish the raw sums of the last pass (kicp_pass_sums)
 __global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *rec, unsigned long long call_id) {
     if (threadIdx.x != 0) return;
-    for (int i = 0; i < kNumSums; ++i) rec->sums[i] = limbs_to_double(st->reduce + 3 * i);
-    rec->not_staged = st->not_staged;
-    __hip_atomic_store(&rec->seq, (call_id << 16) | 0x8001ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = 0; i < kNumSums; ++i)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&rec->sums[i]),
+                           static_cast<unsigned long long>(__double_as_longlong(limbs_to_double(st->reduce + 3 * i))), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&rec->seq, (call_id << 16) | 0x8001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------------------

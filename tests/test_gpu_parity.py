@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-9
 SUM_RTOL = 1e-10
-VARIANTS = [(0, 64), (0, 128), (0, 256), (1, 64), (2, 64)]
+VARIANTS = [(0, 64), (0, 128), (0, 256), (1, 64), (2, 64), (3, 64), (3, 128), (3, 256)]
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +145,7 @@ GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os")
 
 
 @pytest.mark.parametrize("name", ["a", "b", "c"])
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_golden_vectors(name, kernel):
     """The committed fixtures (multi-iteration small cases, incl. two that exhaust max_num_iterations)."""
     g = np.load(GOLD)
@@ -163,7 +163,7 @@ def test_golden_vectors(name, kernel):
     np.testing.assert_allclose(s0, g[name + "_sums0"], rtol=SUM_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_shard_words_add_up_exactly(case1, kernel):
     """G-GPU emulation on one device: the limb words of disjoint shards sum to the words' value of the whole scan,
     bit for bit, for G in {2,4,8} -- the property that makes the multi-GPU pose independent of G."""
@@ -201,3 +201,39 @@ def test_single_rank_communicator_and_callback(case1):
     b = reg2.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
     assert np.array_equal(b, base)
     assert calls and all(ok and c == 24 for ok, c in calls) and len(calls) >= reg2.last_stats.iterations
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+def test_registration_after_updates_with_pruning(kernel):
+    """Map built by a sequence of Update(points, pose) calls that also prune (RemovePointsFarFromLocation), re-using freed
+    buckets: the HBM mirror, its halo entries and neighbour-occupancy masks must track every change."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    scene = syn.make_scene(rng, half=30.0, height=5.0, n_boxes=14, box_xy=(2.0, 6.0), box_z=(1.5, 4.0), keep_clear=3.0)
+    dirs = syn.beam_directions(16, 512, (-22.0, 6.0))
+    vs, max_range = 0.5, 12.0  # small range: voxels leave the map as the robot drives
+    gmap, omap = K.VoxelHashMap(vs, max_range, 20), okicp.VoxelHashMap(vs, max_range, 20)
+    reg, oreg = _reg(kernel, 128), okicp.KinematicRegistration()
+    pose = syn.planar_pose(-18.0, -15.0, 0.6)
+    removed_any = False
+    for k in range(14):
+        step = syn.planar_pose(2.2, 0.0, np.deg2rad(3.0))
+        true_next = syn.pose_mul(pose, step)
+        scan = syn.make_scan(scene, true_next, dirs, 1.0, rng)
+        scan = scan[np.linalg.norm(scan, axis=1) < max_range]
+        if k > 0:
+            rel = syn.pose_mul(step, syn.planar_pose(0.05, 0.0, np.deg2rad(0.4)))
+            a = reg.ComputeRobotMotion(scan, gmap, pose, rel, 3 * vs / np.sqrt(20))
+            b = oreg.ComputeRobotMotion(scan, omap, pose, rel, 3 * vs / np.sqrt(20))
+            assert reg.last_stats.iterations == oreg.last_stats.iterations
+            np.testing.assert_allclose(a, b, rtol=0, atol=POSE_TOL)
+            k_it = reg.last_stats.iterations
+            np.testing.assert_array_equal(np.array(reg.last_stats.n_corr[:k_it]), np.array(oreg.last_stats.n_corr[:k_it]))
+        before = gmap.num_voxels()
+        gmap.Update(scan, true_next), omap.Update(scan, true_next)
+        removed_any |= gmap.num_voxels() < before + 1 and k > 3
+        assert (gmap.num_points(), gmap.num_voxels()) == (omap.num_points(), omap.num_voxels())
+        pose = true_next
+    nn_g, d_g = gmap.GetClosestNeighbor(scan[:2000])
+    nn_o, d_o = omap.GetClosestNeighbor(scan[:2000])
+    assert np.array_equal(d_g, d_o) and np.array_equal(nn_g, nn_o)
+    assert omap.num_points() < 14 * len(scan) // 4  # the sliding window really dropped old voxels

@@ -1,4 +1,4 @@
-"""Experiment: split of the binned pass kernel's time (dbg modes)."""
+"""Experiment: where the pass kernels' time goes (dbg 0 = full, 1 = search without accumulation, 2 = neither)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,15 +11,16 @@ syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
 gmap.sync(0)
 tau = cfg.first_frame_tau()
 df = [K.DeviceFrame(s["frame"]) for s in scans]
-for wpc in (4, 8, 16):
-    for dbg in (0, 1, 2):
+for kern, block in ((3, 64), (3, 128), (3, 256)):
+    for dbg in (0, 2, 3, 5):
         reg = K.KinematicRegistration()
+        reg.set_option("pass_kernel", kern); reg.set_option("block", block)
         reg.set_option("dbg", dbg)
-        reg.set_option("waves_per_cu", wpc)
-        reg.set_option("timing", 1)
+        reg.set_option("timing", 2)
         reg.max_num_iterations_ = 1
         ms = []
-        for i in range(12):
+        for i in range(14):
             reg.ComputeRobotMotion(df[i % 2], gmap, scans[i % 2]["last_pose"], scans[i % 2]["rel_odom"], tau)
-            ms.append(reg.last_stats.gpu_ms)
-        print("waves_per_cu %2d dbg %d: gpu %.1f us" % (wpc, dbg, np.median(ms[2:]) * 1e3), flush=True)
+            ms.append(reg.last_stats.pass_ms[0])
+        ts = [reg.get_option("tstamp%d" % k) for k in range(8)]
+        print("kernel %d block %3d dbg %d: pass %.1f us" % (kern, block, dbg, np.median(ms[4:]) * 1e3), " phase ticks (100MHz?):", [int(ts[k + 1] - ts[k]) for k in range(7)], flush=True)

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("cfg", nargs="?", default="cfg2")
     ap.add_argument("--scans", type=int, default=30)
     ap.add_argument("--order", default="ring")
-    ap.add_argument("--variants", default="0:128,1:64,2:64")
+    ap.add_argument("--variants", default="0:128,3:64,3:128,3:256")
     ap.add_argument("--loops", default="0,1")
     ap.add_argument("--big", type=float, default=0.0, help="extra initial-guess yaw error in degrees (more iterations)")
     args = ap.parse_args()
