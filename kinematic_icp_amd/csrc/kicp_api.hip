@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
 
 #include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +32,18 @@ int fail(int code, const std::string &msg) {
             return fail(KICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
                                           std::to_string(__LINE__) + ")");                                    \
     } while (0)
+
+// host twin of kicp::limbs_to_double (same operations, so host- and device-side solves see the same doubles)
+double host_limbs_to_double(const long long l[3]) {
+    unsigned __int128 t = static_cast<unsigned __int128>(static_cast<__int128>(l[0]));
+    t += static_cast<unsigned __int128>(static_cast<__int128>(l[1])) << 40;
+    t += static_cast<unsigned __int128>(static_cast<__int128>(l[2])) << 80;
+    const bool neg = static_cast<__int128>(t) < 0;
+    if (neg) t = ~t + 1;
+    const double mag = static_cast<double>(static_cast<unsigned long long>(t >> 64)) * 18446744073709551616.0 +
+                       static_cast<double>(static_cast<unsigned long long>(t));
+    return (neg ? -mag : mag) / kFixScale;
+}
 
 Pose pose_from(const double p[7]) { return Pose{p[0], p[1], p[2], p[3], p[4], p[5], p[6]}; }
 void pose_to(const Pose &T, double p[7]) { p[0] = T.qx, p[1] = T.qy, p[2] = T.qz, p[3] = T.qw, p[4] = T.tx, p[5] = T.ty, p[6] = T.tz; }
@@ -113,7 +127,7 @@ struct kicp_reg {
     size_t frame_cap = 0;
     BinBuffers bin;
     // options
-    int pass_kernel = 0;  // 0 gather, 1 lds (given order), 2 binned by cell
+    int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather, 1 lds (given order), 2 binned by cell
     int block = 128;      // workgroup size of variants 0/1
     int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
     int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
@@ -122,6 +136,7 @@ struct kicp_reg {
     int dbg = 0;
     int query_every = 64;  // polls between hipStreamQuery calls while waiting
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
+    int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -376,6 +391,66 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         return KICP_OK;
     };
     unsigned long long seq = 0;
+    if (r->host_solve) {
+        // ---- host-side solve: one launch per iteration, the pose travels as a kernel argument ----------------------
+        HostRecord *rec = r->rec;
+        Pose T = T0;
+        double beta = 0.0;
+        int iter = 0, converged = 0, nan_flag = 0;
+        for (int it = 0; it < max_it; ++it) {
+            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : 2;
+            const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
+            if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
+            launch_pass(r, pp);
+            if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
+            if (multi) {
+                if (int rc = enqueue_allreduce(r)) return rc;
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, r->stream, r->d_state, r->d_rec, call_id, it);
+            }
+            if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+            double sums[kNumSums];
+            for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(rec->words + 3 * i);
+            const bool range_error = rec->words[kNumLimbs] != 0;
+            const double n = sums[6];
+            if (it == 0)  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
+                beta = r->cfg.use_adaptive_odometry_regularization ? 1.0 / (sums[5] / n + DBL_MIN) : r->cfg.fixed_regularization;
+            double dx0, dx1;
+            solve_perturbation(sums, n, beta, dx0, dx1);    // Registration.cpp:119-125
+            T = pose_mul(T, motion_model(dx0, dx1));        // Registration.cpp:159-167,181-182
+            iter = it + 1;
+            if (stats && it < KICP_MAX_LOG_PASSES) {
+                stats->n_corr[it] = n;
+                for (int j = 0; j < 6; ++j) stats->sums[it][j] = sums[j];
+                stats->dx[it][0] = dx0, stats->dx[it][1] = dx1;
+            }
+            if (std::sqrt(dx0 * dx0 + dx1 * dx1) < r->cfg.convergence_criterion) {  // Registration.cpp:184
+                converged = 1;
+                break;
+            }
+            if (!(n > 0.0) || range_error) {  // 0/0: NaN pose from here on, exactly as in the reference
+                nan_flag = range_error ? 2 : 1;
+                break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+        pose_to(T, out_pose_qt);
+        if (stats) {
+            stats->iterations = iter, stats->converged = converged, stats->beta = beta;
+            if (r->timing) {
+                float ms = 0.f;
+                HIP_TRY(hipEventSynchronize(r->ev1));
+                HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+                stats->gpu_ms = ms;
+                for (int i = 0; pass_events && i < iter && i < KICP_MAX_LOG_PASSES; ++i) {
+                    HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
+                    stats->pass_ms[i] = ms;
+                }
+            }
+        }
+        if (nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
+        return nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+    }
     if (r->loop_mode == 0) {
         for (int it = 0; it < max_it; ++it)
             if (int rc = enqueue_iteration(it)) return rc;
@@ -580,6 +655,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
+    else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
@@ -594,6 +670,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "block") return reg->block;
     if (k == "loop") return reg->loop_mode;
     if (k == "wait") return reg->wait_mode;
+    if (k == "host_solve") return reg->host_solve;
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
     if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;

@@ -47,6 +47,7 @@ struct HostRecord {
     double sums[kNumSums];  // last pass, for kicp_pass_sums
     uint32_t n_cells, n_items, not_staged, reserved;
     long long tstamp[12];  // experiments: s_memtime stamps of the finishing workgroup
+    long long words[kReduceWords];  // limb totals of the last pass (host-side solve / kicp_pass_words)
 };
 
 // Device-resident loop state of one ComputeRobotMotion call.
@@ -68,7 +69,10 @@ struct SolveParams {
     double convergence_criterion;
     int32_t adaptive;
     double fixed_regularization;
-    int32_t mode;  // 0 = solve inside the pass kernel; 1 = only publish limb sums (multi-GPU / kicp_pass_sums)
+    int32_t mode;  // 0 = solve inside the pass kernel; 1 = leave the limb totals in st->reduce (multi-GPU: all-reduce follows);
+                   // 3 = as 1, but the pose of every pass comes from the kernel argument (host-side solve, multi-GPU);
+                   // 2 = publish the limb totals to the host record, the HOST solves (default single-GPU mode: a CPU core
+                   //     does the ~2000 serial fp64 instructions of the solve in 0.2 us, one GPU lane needs ~5 us)
     unsigned long long call_id;
     HostRecord *rec;  // device pointer to the host-mapped record
 };
@@ -435,6 +439,15 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
     long long limbs[kNumLimbs + 1];
 #pragma unroll
     for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
+    if (p.sol.mode == 2) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
+        HostRecord *rec = p.sol.rec;
+        if (lane < kReduceWords) __hip_atomic_store(&rec->words[lane], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(&rec->seq, (p.sol.call_id << 16) | static_cast<unsigned long long>(p.sol.pass + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (lane != 0 || p.sol.mode != 0) return;
     if (p.sol.rec && p.dbg) {
 #pragma unroll
@@ -453,7 +466,7 @@ __device__ __forceinline__ double uniform_d(double v) {
     return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 __device__ __forceinline__ Pose load_pose(const PassParams &p) {
-    if (p.sol.pass == 0) return p.sol.pose0;
+    if (p.sol.pass == 0 || p.sol.mode >= 2) return p.sol.pose0;
     const Pose T = p.st->T;
     return Pose{uniform_d(T.qx), uniform_d(T.qy), uniform_d(T.qz), uniform_d(T.qw), uniform_d(T.tx), uniform_d(T.ty), uniform_d(T.tz)};
 }
@@ -469,7 +482,7 @@ __device__ __forceinline__ Pose load_pose(const PassParams &p) {
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
-    if (p.sol.pass != 0 && p.st->done) return;
+    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     Acc acc{};
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
 //     culled voxels cost ALU only, so a wave iterates max-over-lanes(#voxels actually visited) times instead of
 //     over the union of the lanes' shifts; every bucket is scanned five points per trip (five loads in flight).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kTrip = 10;  // bucket points in flight per lane and trip
+constexpr int kTrip = 20;  // bucket points in flight per lane and trip
 struct Best3 {
     float b1, b2, b3;
     uint32_t i1, i2, o1, o2;  // pool index and visiting order (shift * 256 + k) of the two smallest
@@ -522,7 +535,7 @@ __device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, ui
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pass_gather32(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
-    if (p.sol.pass != 0 && p.st->done) return;
+    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const MapView &m = p.map;
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -887,7 +900,7 @@ __device__ __forceinline__ void load_group_query(GroupQuery &g, const double *sr
 __global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
     KICP_PASS_SHARED(64)
     __shared__ WaveLds L;
-    if (p.sol.pass != 0 && p.st->done) return;
+    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const uint32_t n_groups = (p.n + 63) / 64;
     Acc acc{};
@@ -911,7 +924,7 @@ constexpr int kRunLen = 64;    // queries per work item
 __global__ __launch_bounds__(64, 3) void k_pass_binned(const PassParams p) {
     KICP_PASS_SHARED(64)
     __shared__ WaveLds L;
-    if (p.sol.pass != 0 && p.st->done) return;
+    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const uint32_t n_items = p.bin.counters[1];
     Acc acc{};
@@ -1068,6 +1081,14 @@ __global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f)
 #pragma unroll
     for (int i = 0; i < kNumLimbs; ++i) limbs[i] = st->reduce[i];
     solve_and_update(st, f, limbs, st->reduce[kNumLimbs] != 0);
+}
+
+// multi-GPU with host-side solve: hand the all-reduced limb totals to the host
+__global__ __launch_bounds__(64) void k_publish_words(IcpState *st, HostRecord *rec, unsigned long long call_id, int pass) {
+    const int lane = threadIdx.x;
+    if (lane < kReduceWords) __hip_atomic_store(&rec->words[lane], st->reduce[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&rec->seq, (call_id << 16) | static_cast<unsigned long long>(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // publish the raw sums of the last pass (kicp_pass_sums)

@@ -63,11 +63,12 @@ def test_pass_sums_match_oracle(case1, kernel, block):
 
 
 @pytest.mark.parametrize("kernel,block", VARIANTS)
-@pytest.mark.parametrize("loop", [0, 1])
+@pytest.mark.parametrize("loop", [0, 1, 2])
 def test_registration_matches_oracle(case1, kernel, block, loop):
     cfg, scans, gmap, omap = case1
     reg = _reg(kernel, block)
-    reg.set_option("loop", loop)
+    reg.set_option("host_solve", 1 if loop == 2 else 0)  # 2 = default mode: host-side solve
+    reg.set_option("loop", min(loop, 1))
     oreg = okicp.KinematicRegistration()
     for s in scans:
         # make the initial guess bad enough to need several iterations
@@ -119,16 +120,23 @@ def test_all_variants_bit_identical(case1):
     cfg, scans, gmap, omap = case1
     s = scans[2]
     rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(0.8)))
-    poses = []
-    for kernel, block in VARIANTS:
-        for loop in (0, 1):
-            for wait in (0, 1):
-                reg = _reg(kernel, block)
-                reg.set_option("loop", loop)
-                reg.set_option("wait", wait)
-                poses.append(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, cfg.first_frame_tau()))
-    for p in poses[1:]:
-        assert np.array_equal(p, poses[0])
+    by_mode = {}
+    for host_solve in (1, 0):
+        poses = []
+        for kernel, block in VARIANTS:
+            for loop in (0, 1):
+                for wait in (0, 1):
+                    reg = _reg(kernel, block)
+                    reg.set_option("host_solve", host_solve)
+                    reg.set_option("loop", loop)
+                    reg.set_option("wait", wait)
+                    poses.append(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, cfg.first_frame_tau()))
+                    assert reg.last_stats.iterations > 1
+        for p in poses[1:]:
+            assert np.array_equal(p, poses[0])
+        by_mode[host_solve] = poses[0]
+    # host-side and device-side solves run the same formulas on the same exact sums; only libm vs device sin/cos differ
+    np.testing.assert_allclose(by_mode[0], by_mode[1], rtol=0, atol=1e-13)
 
 
 def test_random_order_input(case1):

@@ -12,7 +12,7 @@ gmap.sync(0)
 tau = cfg.first_frame_tau()
 df = [K.DeviceFrame(s["frame"]) for s in scans]
 for kern, block in ((3, 64), (3, 128), (3, 256)):
-    for dbg in (0, 2, 3, 5):
+    for dbg in (0, 2, 3):
         reg = K.KinematicRegistration()
         reg.set_option("pass_kernel", kern); reg.set_option("block", block)
         reg.set_option("dbg", dbg)
