@@ -110,8 +110,9 @@ def _check(rc):
 
 
 def _d(a):
-    a = np.ascontiguousarray(a, dtype=np.float64)
-    return a, a.ctypes.data_as(_dp)
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, C.cast(a.ctypes.data, _dp)
 
 
 def device_count():
@@ -208,7 +209,10 @@ class KinematicRegistration:
         h = C.c_void_p()
         _check(lib().kicp_reg_create(C.byref(cfg), device, C.byref(h)))
         self._h, self.device = h, device
-        self.last_stats, self.last_status = None, 0
+        self.last_stats, self.last_status = Stats(), 0
+        self._stats_ref = C.byref(self.last_stats)
+        self._out = np.zeros(7, dtype=np.float64)
+        self._out_p = C.cast(self._out.ctypes.data, _dp)
         self._cb = None
 
     def __del__(self):
@@ -243,19 +247,17 @@ class KinematicRegistration:
 
     def ComputeRobotMotion(self, frame, voxel_map, last_robot_pose, relative_wheel_odometry, max_correspondence_distance):
         """frame: (N,3) float64 host array, or a DeviceFrame already resident in HBM."""
-        _, lp = _d(last_robot_pose)
-        _, ro = _d(relative_wheel_odometry)
-        out = np.zeros(7, dtype=np.float64)
-        st = Stats()
+        a1, lp = _d(last_robot_pose)
+        a2, ro = _d(relative_wheel_odometry)
         if isinstance(frame, DeviceFrame):
-            rc = lib().kicp_register_device(self._h, voxel_map._h, frame.ptr, frame.n, lp, ro, max_correspondence_distance,
-                                            out.ctypes.data_as(_dp), C.byref(st))
+            rc = _lib.kicp_register_device(self._h, voxel_map._h, frame.ptr, frame.n, lp, ro, max_correspondence_distance,
+                                           self._out_p, self._stats_ref)
         else:
             a, p = _d(frame)
-            rc = lib().kicp_register(self._h, voxel_map._h, p, a.size // 3, lp, ro, max_correspondence_distance,
-                                     out.ctypes.data_as(_dp), C.byref(st))
-        self.last_status, self.last_stats = _check(rc), st
-        return out
+            rc = _lib.kicp_register(self._h, voxel_map._h, p, a.size // 3, lp, ro, max_correspondence_distance,
+                                    self._out_p, self._stats_ref)
+        self.last_status = rc if rc >= 0 else _check(rc)
+        return self._out.copy()
 
     def pass_sums(self, frame, voxel_map, pose, max_correspondence_distance):
         """One fused association+accumulation pass at a fixed pose -> [JTJ00,JTJ01,JTJ11,JTr0,JTr1,ssq,N]."""
