@@ -136,6 +136,7 @@ struct kicp_reg {
     int dbg = 0;
     int query_every = 64;  // polls between hipStreamQuery calls while waiting
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
+    int lanes_per_query = 1;  // variant 3: sub-lanes sharing one query (1, 2 or 4)
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -203,7 +204,8 @@ uint32_t pass_grid(const kicp_reg *r, size_t n) {
         return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
     }
     const int block = normalized_block(r->block);
-    return static_cast<uint32_t>(std::max<size_t>(1, (n + block - 1) / block));
+    const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(r->lanes_per_query) : n;
+    return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
 }
 void launch_pass(const kicp_reg *r, const PassParams &p) {
     const uint32_t grid = pass_grid(r, p.n);
@@ -216,11 +218,12 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
         return;
     }
     if (r->pass_kernel == 3) {
-        switch (normalized_block(r->block)) {
-            case 64: hipLaunchKernelGGL(k_pass_gather32<64>, dim3(grid), dim3(64), 0, r->stream, p); break;
-            case 256: hipLaunchKernelGGL(k_pass_gather32<256>, dim3(grid), dim3(256), 0, r->stream, p); break;
-            default: hipLaunchKernelGGL(k_pass_gather32<128>, dim3(grid), dim3(128), 0, r->stream, p); break;
-        }
+        const int b = normalized_block(r->block), g = r->lanes_per_query;
+#define KICP_G32(B, G) hipLaunchKernelGGL((k_pass_gather32<B, G>), dim3(grid), dim3(B), 0, r->stream, p)
+        if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
+        else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
+        else { if (b == 64) KICP_G32(64, 4); else if (b == 256) KICP_G32(256, 4); else KICP_G32(128, 4); }
+#undef KICP_G32
         return;
     }
     switch (normalized_block(r->block)) {
@@ -656,6 +659,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
     else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
+    else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : 1);
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
@@ -671,6 +675,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "loop") return reg->loop_mode;
     if (k == "wait") return reg->wait_mode;
     if (k == "host_solve") return reg->host_solve;
+    if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
     if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;

@@ -532,13 +532,25 @@ __device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, ui
     t.o1 = lt1 ? ord : t.o1;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pass_gather32(const PassParams p) {
+// merge the three-smallest record of another lane into `t`
+__device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
+    best3_update(t, o.b1, o.i1, o.o1);
+    best3_update(t, o.b2, o.i2, o.o2);
+    t.b3 = fminf(t.b3, o.b3);  // o.b3 can never undercut the runner-up of a set that already holds o.b1 <= o.b2
+}
+
+// G consecutive lanes serve one query: the occupied neighbour voxels are dealt round-robin to the G sub-lanes, which
+// halves/quarters each lane's dependent chain and multiplies the resident waves; the sub-lanes share their running
+// minimum for culling and merge their records with shuffles at the end.
+template <int BLOCK, int G>
+__global__ __launch_bounds__(BLOCK, (G > 1 ? 4 : 2)) void k_pass_gather32(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const MapView &m = p.map;
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t gt = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = gt / G;
+    const int sub = static_cast<int>(gt % G);
     const bool valid = i < p.n && p.dbg != 7;
     Acc acc{};
     double sx = 0, sy = 0, sz = 0;
@@ -555,33 +567,43 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather32(const PassParams p) {
     const float margin = 8e-6f * fvs * fvs;
     const float bound32 = static_cast<float>(bound) * 1.00001f + margin;
     const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
-    // conservative (rounded-down) squared distances to the faces of the own voxel
-    float fm[3] = {lx * lx, ly * ly, lz * lz}, fp[3] = {(fvs - lx) * (fvs - lx), (fvs - ly) * (fvs - ly), (fvs - lz) * (fvs - lz)};
+    // conservative (rounded-down) squared distances to the faces of the own voxel, indexed by shift component + 1
+    float face[3][3] = {{lx * lx, 0.f, (fvs - lx) * (fvs - lx)}, {ly * ly, 0.f, (fvs - ly) * (fvs - ly)}, {lz * lz, 0.f, (fvs - lz) * (fvs - lz)}};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) fm[a] = fm[a] * 0.99999f - margin, fp[a] = fp[a] * 0.99999f - margin;
+    for (int a = 0; a < 3; ++a) face[a][0] = face[a][0] * 0.99999f - margin, face[a][2] = face[a][2] * 0.99999f - margin;
 
     Best3 t{bound32, bound32, bound32, kNoIndex32, kNoIndex32, 0u, 0u};
-    // ONE probe at the own voxel: its bucket and the occupancy mask of the 27 neighbours (bit s = shift s of the
-    // reference's order).  Only voxels that hold points are ever visited; empty space costs nothing.
-    uint32_t slot0 = 0u, todo = 0u;
-    if (valid && p.dbg != 2) table_lookup_entry(m, q.vx, q.vy, q.vz, slot0, todo);
-    if (p.dbg == 3) todo &= 1u;     // experiments: own voxel only
-    if (p.dbg == 5) todo &= 0x7Fu;  // own + faces
-    while (__any(todo != 0u)) {
-        // pop shifts until one survives the cull (ALU only)
-        int s = -1, dx = 0, dy = 0, dz = 0;
-        while (todo) {
-            const int c = __ffs(todo) - 1;
-            todo &= todo - 1u;
-            dx = shift_component(kShiftX, c), dy = shift_component(kShiftY, c), dz = shift_component(kShiftZ, c);
-            const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
-                              (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
-            if (box <= t.b1 + margin) {  // something in there could come within the margin of the current minimum
-                s = c;
-                break;
-            }
+    // ONE probe at the own voxel: the occupancy mask of the 27 neighbours (bit s = shift s of the reference's order) and
+    // the record of their buckets.  Only voxels that hold points are ever visited; empty space costs nothing.
+    uint32_t slot0 = 0u, nbr = 0u;
+    if (valid && p.dbg != 2) table_lookup_entry(m, q.vx, q.vy, q.vz, slot0, nbr);
+    if (p.dbg == 3) nbr &= 1u;     // experiments: own voxel only
+    if (p.dbg == 5) nbr &= 0x7Fu;  // own + faces
+    uint32_t todo = nbr;
+    if (G > 1) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
+        todo = 0u;
+        uint32_t rest = nbr;
+        for (int r = 0; rest; ++r) {
+            const uint32_t low = rest & (0u - rest);
+            rest ^= low;
+            if (r % G == sub) todo |= low;
         }
-        if (s >= 0 && p.dbg != 4) {
+    }
+    float cull = bound32;  // running minimum shared by the G sub-lanes (culling only)
+    while (__any(todo != 0u)) {
+        // which of the 27 neighbours could still hold something within the margin of the current minimum (branch-free)
+        const float lim = cull + margin;
+        uint32_t alive = 0u;
+#pragma unroll
+        for (int c = 0; c < 27; ++c) {
+            const float box = face[0][kShiftTable[c][0] + 1] + face[1][kShiftTable[c][1] + 1] + face[2][kShiftTable[c][2] + 1];
+            alive |= (box <= lim) ? (1u << c) : 0u;
+        }
+        todo &= alive;
+        if (todo && p.dbg != 4) {
+            const int s = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
             // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
             const uint32_t base = m.table[slot0].nb[s] * m.cap;
             const float4 *b = m.pool32 + base;
@@ -604,9 +626,20 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather32(const PassParams p) {
                 }
             }
         }
+        cull = t.b1;
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) cull = fminf(cull, __shfl_xor(cull, off, 64));
     }
-    // ---- exact resolution -----------------------------------------------------------------------------------------
-    if (valid && t.i1 != kNoIndex32 && p.dbg == 0) {
+    // ---- merge the sub-lanes' records (butterfly: every sub-lane ends up with the query's record) ------------------------
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        Best3 o;
+        o.b1 = __shfl_xor(t.b1, off, 64), o.b2 = __shfl_xor(t.b2, off, 64), o.b3 = __shfl_xor(t.b3, off, 64);
+        o.i1 = __shfl_xor(t.i1, off, 64), o.i2 = __shfl_xor(t.i2, off, 64), o.o1 = __shfl_xor(t.o1, off, 64), o.o2 = __shfl_xor(t.o2, off, 64);
+        best3_merge(t, o);
+    }
+    // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
+    if (valid && sub == 0 && t.i1 != kNoIndex32 && p.dbg == 0) {
         double best = bound;
         uint32_t best_idx = kNoIndex32;
         if (t.b3 - t.b1 <= margin) {  // three near-equal candidates: leave it to the exact fp64 search

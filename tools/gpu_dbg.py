@@ -11,9 +11,10 @@ syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
 gmap.sync(0)
 tau = cfg.first_frame_tau()
 df = [K.DeviceFrame(s["frame"]) for s in scans]
-for kern, block in ((3, 64), (3, 128), (3, 256)):
-    for dbg in (0, 2, 3):
+for kern, block, G in ((3, 128, 1), (3, 256, 1)):
+    for dbg in (0, 3, 2):
         reg = K.KinematicRegistration()
+        reg.set_option("lanes_per_query", G)
         reg.set_option("pass_kernel", kern); reg.set_option("block", block)
         reg.set_option("dbg", dbg)
         reg.set_option("timing", 2)
@@ -23,4 +24,4 @@ for kern, block in ((3, 64), (3, 128), (3, 256)):
             reg.ComputeRobotMotion(df[i % 2], gmap, scans[i % 2]["last_pose"], scans[i % 2]["rel_odom"], tau)
             ms.append(reg.last_stats.pass_ms[0])
         ts = [reg.get_option("tstamp%d" % k) for k in range(8)]
-        print("kernel %d block %3d dbg %d: pass %.1f us" % (kern, block, dbg, np.median(ms[4:]) * 1e3), " phase ticks (100MHz?):", [int(ts[k + 1] - ts[k]) for k in range(7)], flush=True)
+        print("kernel %d block %3d G %d dbg %d: pass %.1f us" % (kern, block, G, dbg, np.median(ms[4:]) * 1e3), " phase ticks (100MHz?):", [int(ts[k + 1] - ts[k]) for k in range(7)], flush=True)
