@@ -136,7 +136,7 @@ struct kicp_reg {
     int dbg = 0;
     int query_every = 64;  // polls between hipStreamQuery calls while waiting
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
-    int lanes_per_query = 1;  // variant 3: sub-lanes sharing one query (1, 2 or 4)
+    int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -197,6 +197,13 @@ void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
     hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
 }
 int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
+// Sub-lanes per query of variant 3.  Small scans are latency bound (few waves, each lane's chain of dependent bucket
+// visits decides the kernel time): spreading a query's neighbour voxels over 2-4 lanes shortens that chain.  Large
+// scans already fill the machine and only pay for the extra waves.
+int lanes_for(const kicp_reg *r, size_t n) {
+    if (r->lanes_per_query > 0) return r->lanes_per_query;
+    return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
+}
 uint32_t pass_grid(const kicp_reg *r, size_t n) {
     if (r->pass_kernel == 1 || r->pass_kernel == 2) {  // persistent one-wave workgroups
         const size_t max_groups = (n + 63) / 64 + (r->pass_kernel == 2 ? n / 8 : 0);  // more workgroups than groups would only idle
@@ -204,7 +211,7 @@ uint32_t pass_grid(const kicp_reg *r, size_t n) {
         return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
     }
     const int block = normalized_block(r->block);
-    const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(r->lanes_per_query) : n;
+    const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
     return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
 }
 void launch_pass(const kicp_reg *r, const PassParams &p) {
@@ -218,7 +225,7 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
         return;
     }
     if (r->pass_kernel == 3) {
-        const int b = normalized_block(r->block), g = r->lanes_per_query;
+        const int b = normalized_block(r->block), g = lanes_for(r, p.n);
 #define KICP_G32(B, G) hipLaunchKernelGGL((k_pass_gather32<B, G>), dim3(grid), dim3(B), 0, r->stream, p)
         if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
         else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
@@ -659,7 +666,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
     else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
-    else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : 1);
+    else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
