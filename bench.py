@@ -213,8 +213,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: %d-pt 64-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
-                               "(mean %.2f per scan, reference %.2f)" % (cfg.name, n_total, gmap.num_points(), gmap.num_voxels(),
+        "config": {"workload": "%s: %d-pt %d-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
+                               "(mean %.2f per scan, reference %.2f)" % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(),
                                                                          cfg.voxel_size, tau, iters_gpu, float(np.mean(iters_ref))),
                    "points_per_gpu": hi - lo, "parallelism": ("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU",
                    "pass_kernel": int(reg.get_option("pass_kernel")), "max_pose_abs_diff_vs_oracle": max_pose_err},
@@ -222,7 +222,9 @@ def main():
                      "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(world),
                      "kernel": "fused association+accumulation pass", "kernel_avg_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_launch": round(bytes_per_launch), "launches_timed": int(pass_ms.size),
-                     "note": "working set (map ~45 MB) is L2/Infinity-Cache resident, so algorithmic GB/s may exceed DRAM traffic"},
+                     "note": "algorithmic bytes = what the reference algorithm touches (27 probes + every scanned bucket point per query); "
+                             "the map mirror is L2/Infinity-Cache resident and provably irrelevant neighbour voxels are skipped, so "
+                             "achieved can exceed the DRAM peak while PMC traffic stays at a few MB per launch"},
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
