@@ -89,6 +89,9 @@ int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_
 /* Make the HBM mirror on `device` current (a no-op when nothing changed since the last upload).
  * kicp_register* call it implicitly; exposed so map upload can be kept out of a timed region. */
 int kicp_map_sync(kicp_map *map, int device);
+/* What the last upload of the mirror moved: bytes sent host->device and whether it was a full re-send (1) or a delta
+ * of the changed table slots / buckets (0).  A re-hash of the table or Clear() forces a full re-send. */
+int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full);
 
 /* ---- kinematic_icp::KinematicRegistration (registration/Registration.hpp:32-50) ------------------------- */
 int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out);

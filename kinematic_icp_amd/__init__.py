@@ -67,6 +67,7 @@ _SIGNATURES = {
     "kicp_map_pointcloud": (C.c_size_t, [C.c_void_p, _dp, C.c_size_t]),
     "kicp_map_closest": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, _dp, _dp]),
     "kicp_map_sync": (C.c_int, [C.c_void_p, C.c_int]),
+    "kicp_map_last_upload": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_reg_create": (C.c_int, [C.POINTER(RegConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "kicp_reg_destroy": (None, [C.c_void_p]),
     "kicp_reg_get_config": (C.c_int, [C.c_void_p, C.POINTER(RegConfig)]),
@@ -180,6 +181,12 @@ class VoxelHashMap:
 
     def sync(self, device=0):
         _check(lib().kicp_map_sync(self._h, device))
+
+    def last_upload(self):
+        """(bytes sent by the last mirror upload, True if it was a full re-send rather than a delta)."""
+        b, f = C.c_size_t(), C.c_int()
+        _check(lib().kicp_map_last_upload(self._h, C.byref(b), C.byref(f)))
+        return b.value, bool(f.value)
 
 
 class DeviceFrame:

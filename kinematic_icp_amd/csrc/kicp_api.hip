@@ -89,7 +89,14 @@ struct DeviceMirror {
     double *d_pool = nullptr;
     float4 *d_pool32 = nullptr;
     size_t table_slots = 0, pool_doubles = 0;  // allocated sizes
-    uint64_t synced_epoch = ~0ull;
+    size_t live_slots = 0;                     // table size the mirror currently represents
+    uint64_t synced_epoch = ~0ull, synced_generation = ~0ull;
+    // staging for delta uploads (device)
+    uint2 *d_stage = nullptr;
+    uint32_t *d_index = nullptr;
+    size_t stage_words = 0, index_cap = 0;
+    size_t last_upload_bytes = 0;
+    int last_upload_full = 1;
     MapView view{};
 };
 }  // namespace
@@ -152,9 +159,37 @@ int set_device(int device) {
     return KICP_OK;
 }
 
+// scatter `rows` staged rows of `row_words` 8-byte words each into dst at the given row indices
+int upload_rows(DeviceMirror &mr, const std::vector<uint2> &staged, const std::vector<uint32_t> &index, uint32_t row_words, void *dst,
+                hipStream_t stream) {
+    if (index.empty()) return KICP_OK;
+    if (staged.size() > mr.stage_words) {
+        if (mr.d_stage) HIP_TRY(hipFree(mr.d_stage));
+        mr.d_stage = nullptr;
+        mr.stage_words = staged.size() + staged.size() / 2;
+        HIP_TRY(hipMalloc(&mr.d_stage, mr.stage_words * sizeof(uint2)));
+    }
+    if (index.size() > mr.index_cap) {
+        if (mr.d_index) HIP_TRY(hipFree(mr.d_index));
+        mr.d_index = nullptr;
+        mr.index_cap = index.size() + index.size() / 2;
+        HIP_TRY(hipMalloc(&mr.d_index, mr.index_cap * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(mr.d_stage, staged.data(), staged.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(mr.d_index, index.data(), index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    const size_t total = staged.size();
+    const uint32_t grid = static_cast<uint32_t>(std::min<size_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_scatter_rows, dim3(grid), dim3(256), 0, stream, mr.d_stage, mr.d_index, static_cast<uint32_t>(index.size()), row_words,
+                       static_cast<uint2 *>(dst));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors are reused by the caller
+    mr.last_upload_bytes += staged.size() * sizeof(uint2) + index.size() * sizeof(uint32_t);
+    return KICP_OK;
+}
+
 int map_sync(kicp_map *map, int device, hipStream_t stream) {
     DeviceMirror &mr = map->mirror;
-    const HostMap &h = map->host;
+    HostMap &h = map->host;
     if (mr.device == device && mr.synced_epoch == h.epoch()) return KICP_OK;
     if (int rc = set_device(device)) return rc;
     if (mr.device != device && mr.device >= 0) {  // mirror lives on another GPU: drop it
@@ -162,33 +197,67 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
         if (mr.d_table) hipFree(mr.d_table);
         if (mr.d_pool) hipFree(mr.d_pool);
         if (mr.d_pool32) hipFree(mr.d_pool32);
+        if (mr.d_stage) hipFree(mr.d_stage);
+        if (mr.d_index) hipFree(mr.d_index);
         mr = DeviceMirror{};
         hipSetDevice(device);
     }
     mr.device = device;
     const size_t slots = h.table().size();
-    const size_t pool_doubles = h.buckets_in_use_hi() * static_cast<size_t>(h.cap()) * 3;
+    const uint32_t cap = h.cap();
+    const size_t pool_doubles = h.buckets_in_use_hi() * static_cast<size_t>(cap) * 3;
+    bool full = mr.synced_generation != h.generation() || mr.live_slots != slots;
     if (slots > mr.table_slots) {
         if (mr.d_table) HIP_TRY(hipFree(mr.d_table));
         mr.d_table = nullptr;
         HIP_TRY(hipMalloc(&mr.d_table, slots * sizeof(Slot)));
         mr.table_slots = slots;
+        full = true;
     }
-    if (pool_doubles > mr.pool_doubles) {
+    if (pool_doubles > mr.pool_doubles) {  // grow the pools, keeping what is already there (device-side copy)
+        const size_t want = pool_doubles + pool_doubles / 2 + 3 * 1024;
+        double *np = nullptr;
+        float4 *np32 = nullptr;
+        HIP_TRY(hipMalloc(&np, want * sizeof(double)));
+        HIP_TRY(hipMalloc(&np32, want / 3 * sizeof(float4)));
+        if (mr.d_pool && !full) {
+            HIP_TRY(hipMemcpyAsync(np, mr.d_pool, mr.pool_doubles * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(np32, mr.d_pool32, mr.pool_doubles / 3 * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
         if (mr.d_pool) HIP_TRY(hipFree(mr.d_pool));
         if (mr.d_pool32) HIP_TRY(hipFree(mr.d_pool32));
-        mr.d_pool = nullptr, mr.d_pool32 = nullptr;
-        const size_t want = pool_doubles + pool_doubles / 4 + 3 * 1024;
-        HIP_TRY(hipMalloc(&mr.d_pool, want * sizeof(double)));
-        HIP_TRY(hipMalloc(&mr.d_pool32, want / 3 * sizeof(float4)));
-        mr.pool_doubles = want;
+        mr.d_pool = np, mr.d_pool32 = np32, mr.pool_doubles = want;
     }
-    HIP_TRY(hipMemcpyAsync(mr.d_table, h.table().data(), slots * sizeof(Slot), hipMemcpyHostToDevice, stream));
-    if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool, h.pool().data(), pool_doubles * sizeof(double), hipMemcpyHostToDevice, stream));
-    if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool32, h.pool32().data(), pool_doubles / 3 * sizeof(float4), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, h.cap(), h.voxel_size()};
-    mr.synced_epoch = h.epoch();
+    mr.last_upload_bytes = 0;
+    // delta only pays off while the changed part is small
+    if (!full && (h.dirty_slots().size() * 4 > slots || h.dirty_buckets().size() * 2 > h.buckets_in_use_hi())) full = true;
+    if (full) {
+        HIP_TRY(hipMemcpyAsync(mr.d_table, h.table().data(), slots * sizeof(Slot), hipMemcpyHostToDevice, stream));
+        if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool, h.pool().data(), pool_doubles * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool32, h.pool32().data(), pool_doubles / 3 * sizeof(float4), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        mr.last_upload_bytes = slots * sizeof(Slot) + pool_doubles * sizeof(double) + pool_doubles / 3 * sizeof(float4);
+    } else {
+        // gather the changed rows on the host, ship them with their indices, scatter on the device
+        std::vector<uint2> staged;
+        const std::vector<uint32_t> &ds = h.dirty_slots(), &db = h.dirty_buckets();
+        staged.resize(ds.size() * (sizeof(Slot) / 8));
+        for (size_t i = 0; i < ds.size(); ++i) std::memcpy(&staged[i * (sizeof(Slot) / 8)], &h.table()[ds[i]], sizeof(Slot));
+        if (int rc = upload_rows(mr, staged, ds, sizeof(Slot) / 8, mr.d_table, stream)) return rc;
+        staged.resize(db.size() * static_cast<size_t>(cap) * 3);
+        for (size_t i = 0; i < db.size(); ++i)
+            std::memcpy(&staged[i * static_cast<size_t>(cap) * 3], &h.pool()[static_cast<size_t>(db[i]) * cap * 3], static_cast<size_t>(cap) * 24);
+        if (int rc = upload_rows(mr, staged, db, cap * 3, mr.d_pool, stream)) return rc;
+        staged.resize(db.size() * static_cast<size_t>(cap) * 2);
+        for (size_t i = 0; i < db.size(); ++i)
+            std::memcpy(&staged[i * static_cast<size_t>(cap) * 2], &h.pool32()[static_cast<size_t>(db[i]) * cap * 4], static_cast<size_t>(cap) * 16);
+        if (int rc = upload_rows(mr, staged, db, cap * 2, mr.d_pool32, stream)) return rc;
+    }
+    mr.last_upload_full = full ? 1 : 0;
+    h.mark_synced(full);
+    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, h.voxel_size()};
+    mr.synced_epoch = h.epoch(), mr.synced_generation = h.generation(), mr.live_slots = slots;
     return KICP_OK;
 }
 
@@ -538,6 +607,8 @@ void kicp_map_destroy(kicp_map *map) {
         if (map->mirror.d_table) hipFree(map->mirror.d_table);
         if (map->mirror.d_pool) hipFree(map->mirror.d_pool);
         if (map->mirror.d_pool32) hipFree(map->mirror.d_pool32);
+        if (map->mirror.d_stage) hipFree(map->mirror.d_stage);
+        if (map->mirror.d_index) hipFree(map->mirror.d_index);
     }
     delete map;
 }
@@ -574,6 +645,11 @@ int kicp_map_sync(kicp_map *map, int device) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (int rc = set_device(device)) return rc;
     return map_sync(map, device, nullptr);
+}
+int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full) {
+    if (!map || !bytes || !was_full) return fail(KICP_ERR_ARG, "null argument");
+    *bytes = map->mirror.last_upload_bytes, *was_full = map->mirror.last_upload_full;
+    return KICP_OK;
 }
 int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist) {
     if (!map || (!queries_xyz && n) || !out_nn_xyz || !out_dist) return fail(KICP_ERR_ARG, "null argument");

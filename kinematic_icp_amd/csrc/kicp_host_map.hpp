@@ -10,6 +10,7 @@
 // min spacing = voxel_size / sqrt(max_points_per_voxel) inside one voxel), which is why it stays sequential on
 // the host for now (device-side maintenance is a section 8f "next" row).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -38,9 +39,28 @@ public:
     const std::vector<float> &pool32() const { return pool32_; }  // (x,y,z,0) offsets from the voxel corner, stride cap*4
     size_t buckets_in_use_hi() const { return n_buckets_hi_; }  // pool prefix that may hold live buckets
 
+    // ---- change tracking for the HBM mirror (delta upload) ----------------------------------------------------------
+    // generation() changes whenever slot positions change wholesale (Clear, re-hash): the mirror must then be re-sent
+    // in full.  Otherwise dirty_slots()/dirty_buckets() list what changed since the last mark_synced().
+    uint64_t generation() const { return generation_; }
+    const std::vector<uint32_t> &dirty_slots() const { return dirty_slots_; }
+    const std::vector<uint32_t> &dirty_buckets() const { return dirty_buckets_; }
+    void mark_synced(bool was_full) {
+        if (was_full) {  // after a re-hash every flag was raised without listing the slots
+            std::fill(slot_flag_.begin(), slot_flag_.end(), 0);
+            std::fill(bucket_flag_.begin(), bucket_flag_.end(), 0);
+        } else {
+            for (uint32_t i : dirty_slots_) slot_flag_[i] = 0;
+            for (uint32_t b : dirty_buckets_) bucket_flag_[b] = 0;
+        }
+        dirty_slots_.clear(), dirty_buckets_.clear();
+    }
+
     void Clear() {
         table_.assign(kMinTable, empty_slot());
         n_entries_ = 0, n_dead_ = 0;
+        slot_flag_.assign(kMinTable, 0), bucket_flag_.clear(), dirty_slots_.clear(), dirty_buckets_.clear();
+        ++generation_;
         pool_.clear();
         pool32_.clear();
         free_.clear();
@@ -73,6 +93,7 @@ public:
                 store32(bucket, count, px, py, pz, vx, vy, vz);
                 set_count32(bucket, count + 1);
                 slot.val = (bucket << 8) | (count + 1);
+                touch_slot(static_cast<size_t>(s)), touch_bucket(bucket);
             } else {
                 if (n_voxels_ + 1 > kMaxBuckets) return false;
                 const uint32_t bucket = alloc_bucket();
@@ -80,6 +101,7 @@ public:
                 b[0] = px, b[1] = py, b[2] = pz;
                 store32(bucket, 0, px, py, pz, vx, vy, vz);
                 set_count32(bucket, 1);
+                touch_bucket(bucket);
                 occupy(vx, vy, vz, (bucket << 8) | 1u);
             }
             ++n_points_;
@@ -161,13 +183,23 @@ private:
         size_t i = voxel_hash(e.x, e.y, e.z) & mask;
         while (table_[i].val != kEmptyVal) i = (i + 1) & mask;
         table_[i] = e;
+        touch_slot(i);
         return i;
+    }
+    void touch_slot(size_t i) {
+        if (!slot_flag_[i]) slot_flag_[i] = 1, dirty_slots_.push_back(static_cast<uint32_t>(i));
+    }
+    void touch_bucket(uint32_t b) {
+        if (bucket_flag_.size() <= b) bucket_flag_.resize(std::max<size_t>(2 * bucket_flag_.size(), b + 1024), 0);
+        if (!bucket_flag_[b]) bucket_flag_[b] = 1, dirty_buckets_.push_back(b);
     }
     // re-hash the live entries (occupied voxels and halo entries that still have an occupied neighbour)
     void rebuild(size_t slots) {
         std::vector<Slot> old(slots, empty_slot());
         old.swap(table_);
         n_entries_ = 0, n_dead_ = 0;
+        slot_flag_.assign(slots, 1), dirty_slots_.clear();  // every slot moved: the mirror is re-sent in full
+        ++generation_;
         for (const Slot &e : old)
             if (e.val != kEmptyVal && ((e.val & 0xffu) != 0 || e.nbr != 0)) place(e), ++n_entries_;
     }
@@ -176,6 +208,7 @@ private:
     void mutate(size_t i, F f) {
         const bool before = is_dead(table_[i]);
         f(table_[i]);
+        touch_slot(i);
         n_dead_ += static_cast<size_t>(is_dead(table_[i])) - static_cast<size_t>(before);
     }
     // slot index of the entry for voxel (x,y,z), created as a (for now dead) halo entry if absent; never re-hashes
@@ -230,6 +263,9 @@ private:
     std::vector<uint32_t> free_;
     size_t n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
     size_t n_entries_ = 0, n_dead_ = 0;  // table entries (occupied + halo); halo entries with no occupied neighbour left
+    std::vector<uint8_t> slot_flag_, bucket_flag_;
+    std::vector<uint32_t> dirty_slots_, dirty_buckets_;
+    uint64_t generation_ = 0;
     uint64_t epoch_ = 0;
 };
 

@@ -1136,6 +1136,19 @@ __global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *r
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// delta upload of the map mirror: scatter staged rows (8-byte words) to their places
+//   row r of `staged` (row_words uint2 each) goes to dst + index[r] * row_words
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_rows(const uint2 *__restrict__ staged, const uint32_t *__restrict__ index, uint32_t rows,
+                                                      uint32_t row_words, uint2 *__restrict__ dst) {
+    const size_t total = static_cast<size_t>(rows) * row_words;
+    for (size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<size_t>(gridDim.x) * 256) {
+        const uint32_t r = static_cast<uint32_t>(e / row_words), w = static_cast<uint32_t>(e % row_words);
+        dst[static_cast<size_t>(index[r]) * row_words + w] = staged[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // GetClosestNeighbor for a batch (API parity; same search code as the fused kernel, no acceptance bound)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_closest(const double *__restrict__ queries, uint32_t n, const MapView m,

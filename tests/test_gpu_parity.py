@@ -223,6 +223,7 @@ def test_registration_after_updates_with_pruning(kernel):
     reg, oreg = _reg(kernel, 128), okicp.KinematicRegistration()
     pose = syn.planar_pose(-18.0, -15.0, 0.6)
     removed_any = False
+    uploads = []
     for k in range(14):
         step = syn.planar_pose(2.2, 0.0, np.deg2rad(3.0))
         true_next = syn.pose_mul(pose, step)
@@ -236,6 +237,8 @@ def test_registration_after_updates_with_pruning(kernel):
             np.testing.assert_allclose(a, b, rtol=0, atol=POSE_TOL)
             k_it = reg.last_stats.iterations
             np.testing.assert_array_equal(np.array(reg.last_stats.n_corr[:k_it]), np.array(oreg.last_stats.n_corr[:k_it]))
+        if k > 0:
+            uploads.append(gmap.last_upload())
         before = gmap.num_voxels()
         gmap.Update(scan, true_next), omap.Update(scan, true_next)
         removed_any |= gmap.num_voxels() < before + 1 and k > 3
@@ -245,3 +248,7 @@ def test_registration_after_updates_with_pruning(kernel):
     nn_o, d_o = omap.GetClosestNeighbor(scan[:2000])
     assert np.array_equal(d_g, d_o) and np.array_equal(nn_g, nn_o)
     assert omap.num_points() < 14 * len(scan) // 4  # the sliding window really dropped old voxels
+    # most per-frame mirror updates were deltas (changed slots/buckets only), far smaller than a full re-send
+    deltas = [b for b, full in uploads if not full]
+    fulls = [b for b, full in uploads if full]
+    assert len(deltas) >= len(uploads) // 2 and fulls and max(deltas) < max(fulls)
