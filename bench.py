@@ -47,6 +47,12 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="exercise the multi-GPU code path (all-reduce + separate solve) even with one rank")
     args = ap.parse_args()
 
+    # Everything except the final JSON line goes to stderr - also what C libraries print (RCCL writes a version banner to
+    # the C stdout, possibly after Python's own output): fd 1 is pointed at fd 2 until the very end.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,9 +156,13 @@ def main():
     barrier()
     reg.set_option("timing", 0)
     poses = [step(i) for i in range(len(scans))]
-
-    if rank != 0:
+    barrier()
+    if use_comm:  # all GPU work is done: tear the communicators down on every rank before rank 0's CPU-only epilogue
+        if args.comm == "rccl":
+            reg.comm_destroy()
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
         return
 
     # ---- algorithmic bytes of the passes actually executed (counted by the oracle = the reference's own work) ---
@@ -227,9 +237,11 @@ def main():
                              "achieved can exceed the DRAM peak while PMC traffic stays at a few MB per launch"},
         "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
-    if use_comm:
-        dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
 
 
 def _pmc_traffic(world):
