@@ -10,8 +10,10 @@ default ICP parameters (max 10 iterations, 1e-3 stop, adaptive regularisation), 
 Inputs (scan, map mirror) are resident in HBM when the timed region starts; map build/upload is outside it.
 
 N > 1: the scan's points are sharded contiguously across the N ranks, the map is replicated, and every ICP
-iteration all-reduces 24 int64 words (the exact limb sums of the 2x2 normal equations) over RCCL, so every rank
-returns the bit-identical pose.  Total work is fixed -> "scaling": "strong".
+iteration sums 24 int64 words per rank (the exact limb sums of the 2x2 normal equations), so every rank returns the
+bit-identical pose.  The exchange is selectable (--comm): "shm" (default) - every GPU writes its words into its slot of a
+node-wide host shared segment and every rank's host adds them: no device collective at all; "rccl" - the built-in RCCL
+all-reduce over xGMI; "torch" - torch.distributed all-reduce.  Total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
   "roofline"     the dominant kernel (fused association+accumulation pass): algorithmic bytes per launch / live
@@ -43,7 +45,10 @@ def main():
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1: built-in RCCL communicator or torch.distributed callback")
+    ap.add_argument("--comm", default="shm", choices=["shm", "rccl", "torch"],
+                    help="N>1 exchange of the per-iteration sums: host shared segment written by every GPU (default, no device "
+                         "collective), built-in RCCL all-reduce, or torch.distributed all-reduce callback")
+    ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for barriers/timing")
     ap.add_argument("--force-comm", action="store_true", help="exercise the multi-GPU code path (all-reduce + separate solve) even with one rank")
     args = ap.parse_args()
 
@@ -73,6 +78,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     device = local_rank if world > 1 else 0
+    if "KICP_BENCH_DEVICE" in os.environ:  # testing aid: several ranks on one GPU (works with --comm shm --pg-backend gloo)
+        device = int(os.environ["KICP_BENCH_DEVICE"])
     torch.cuda.set_device(device)
     use_comm = world > 1 or args.force_comm
     if use_comm:
@@ -81,7 +88,11 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        if args.pg_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")
+    pg_dev = "cuda" if args.pg_backend == "nccl" else "cpu"
 
     # ---- synthetic workload (identical on every rank: seeded) ---------------------------------------------------
     cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=args.scans)
@@ -96,8 +107,16 @@ def main():
     reg = K.KinematicRegistration(device=device)  # reference defaults (KinematicICP.hpp:51-56)
     keep = []
     if use_comm:
-        if args.comm == "rccl":
-            uid = torch.zeros(K.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if args.comm == "shm":
+            name = "kicp_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
+            if rank == 0:
+                reg.shm_init(world, 0, name)  # creates and zeroes the segment
+            dist.barrier()
+            if rank != 0:
+                reg.shm_init(world, rank, name)
+            dist.barrier()
+        elif args.comm == "rccl":
+            uid = torch.zeros(K.COMM_ID_BYTES, dtype=torch.uint8, device=pg_dev)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(K.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
@@ -142,7 +161,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -161,6 +180,8 @@ def main():
         if args.comm == "rccl":
             reg.comm_destroy()
         dist.barrier()
+        if args.comm == "shm":
+            reg.shm_destroy()
         dist.destroy_process_group()
     if rank != 0:
         return

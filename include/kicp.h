@@ -149,6 +149,14 @@ int kicp_device_synchronize(int device);
 int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]); /* rank 0 creates, the caller broadcasts the bytes */
 int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]); /* RCCL comm on reg's device */
 int kicp_reg_comm_destroy(kicp_reg *reg);
+/* Single-node alternative without any device collective: all ranks map one POSIX shared-memory segment (`name`, created
+ * by rank 0 - call it there first, e.g. before a barrier) as host-mapped pinned memory.  Each rank's pass kernel writes
+ * its 24 limb words + a sequence word straight into its own slot of the segment; every rank's host polls all slots, adds
+ * the integers and solves.  The "all-reduce" thus costs no more than the single-GPU hand-off (a 192-byte RCCL all-reduce
+ * costs tens of microseconds per ICP iteration, as long as the kernel itself).  Every rank must issue the same sequence
+ * of kicp_register* calls. */
+int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name);
+int kicp_reg_shm_destroy(kicp_reg *reg);
 /* Alternative to the built-in RCCL communicator: the caller supplies the sum-all-reduce (e.g. torch.distributed).
  * Called once per ICP iteration with a device buffer of `count` int64 values to be sum-reduced IN PLACE, ordered
  * on `stream` (a hipStream_t).  Return 0 on success.  Pass NULL to remove. */

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "kicp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "kicp_reg_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "kicp_reg_comm_destroy": (C.c_int, [C.c_void_p]),
+    "kicp_reg_shm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "kicp_reg_shm_destroy": (C.c_int, [C.c_void_p]),
     "kicp_reg_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
 }
 
@@ -289,6 +291,13 @@ class KinematicRegistration:
 
     def comm_destroy(self):
         _check(lib().kicp_reg_comm_destroy(self._h))
+
+    def shm_init(self, nranks, rank, name):
+        """Single-node multi-process mode without a device collective (see kicp.h); rank 0 first, then the others."""
+        _check(lib().kicp_reg_shm_init(self._h, nranks, rank, name.encode()))
+
+    def shm_destroy(self):
+        _check(lib().kicp_reg_shm_destroy(self._h))
 
     def set_allreduce(self, fn):
         """fn(device_ptr:int, count:int, stream:int) -> None: sum-all-reduce `count` doubles in place on `stream`."""

@@ -1,6 +1,10 @@
 // kicp_api.hip -- implementation of include/kicp.h: handles, HBM mirror of the voxel map, the registration loop
 // (kernel enqueue / early exit / read-back), and the optional RCCL all-reduce.  gfx950 only; no CPU fallback.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
 
@@ -150,6 +154,17 @@ struct kicp_reg {
     int nranks = 1, rank = 0;
     kicp_allreduce_fn allreduce_fn = nullptr;
     void *allreduce_user = nullptr;
+    // node-wide shared segment (multi-process, no device collective)
+    struct ShmSlot {
+        unsigned long long seq;
+        long long words[kReduceWords];
+        unsigned long long pad[7];  // 256 bytes
+    };
+    ShmSlot *shm = nullptr;    // host view: [2 buffers][nranks]
+    ShmSlot *d_shm = nullptr;  // device view of the same memory
+    size_t shm_bytes = 0;
+    unsigned long long shm_step = 0;  // hand-offs issued so far (same on every rank)
+    std::string shm_name;
 };
 
 namespace {
@@ -415,6 +430,24 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
     }
 }
 
+// wait until every rank's slot of the current buffer carries `value`, then add the limb words (exact, order independent)
+int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceWords]) {
+    const kicp_reg::ShmSlot *buf = r->shm + ((value - 1) & 1) * r->nranks;
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    for (int k = 0; k < r->nranks; ++k) {
+        const volatile unsigned long long *seq = &buf[k].seq;
+        for (unsigned long long spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != value; ++spins) {
+            if (spins % 4096 == 0) {
+                const hipError_t q = hipStreamQuery(r->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (spins > (1ull << 34)) return fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off");
+            }
+        }
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] += buf[k].words[i];
+    }
+    return KICP_OK;
+}
+
 int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
                      const double rel_odom_qt[7], double tau, double out_pose_qt[7], kicp_stats *stats) {
     if (!r || !map || !last_pose_qt || !rel_odom_qt || !out_pose_qt) return fail(KICP_ERR_ARG, "null argument");
@@ -439,7 +472,9 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (binned)
         if (int rc = ensure_bin(r, n ? n : 1)) return rc;
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
+    const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
+    if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
     const unsigned long long call_id = ++r->call_id;
 
     PassParams pp{};
@@ -478,6 +513,15 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         int iter = 0, converged = 0, nan_flag = 0;
         for (int it = 0; it < max_it; ++it) {
             sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : 2;
+            long long words[kReduceWords];
+            if (shm) {  // this rank's slot of the shared segment, double-buffered by hand-off parity
+                const unsigned long long step = r->shm_step++;
+                kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
+                sp.pub_words = mine->words, sp.pub_seq = &mine->seq, sp.pub_value = step + 1;
+            } else {
+                sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
+                sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
+            }
             const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
             launch_pass(r, pp);
@@ -486,10 +530,15 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
                 if (int rc = enqueue_allreduce(r)) return rc;
                 hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, r->stream, r->d_state, r->d_rec, call_id, it);
             }
-            if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+            if (shm) {
+                if (int rc = wait_shm(r, sp.pub_value, words)) return rc;
+            } else {
+                if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+                for (int i = 0; i < kReduceWords; ++i) words[i] = rec->words[i];
+            }
             double sums[kNumSums];
-            for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(rec->words + 3 * i);
-            const bool range_error = rec->words[kNumLimbs] != 0;
+            for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(words + 3 * i);
+            const bool range_error = words[kNumLimbs] != 0;
             const double n = sums[6];
             if (it == 0)  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
                 beta = r->cfg.use_adaptive_odometry_regularization ? 1.0 / (sums[5] / n + DBL_MIN) : r->cfg.fixed_regularization;
@@ -711,6 +760,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     hipSetDevice(reg->device);
     if (reg->comm) g_comm.CommDestroy(reg->comm);
     if (reg->stream) hipStreamSynchronize(reg->stream);
+    if (reg->shm) kicp_reg_shm_destroy(reg);
     if (reg->d_state) hipFree(reg->d_state);
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->d_partials) hipFree(reg->d_partials);
@@ -888,6 +938,47 @@ int kicp_reg_comm_destroy(kicp_reg *reg) {
         reg->comm = nullptr;
     }
     reg->nranks = 1, reg->rank = 0;
+    return KICP_OK;
+}
+int kicp_reg_shm_destroy(kicp_reg *reg) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    if (reg->shm) {
+        hipSetDevice(reg->device);
+        hipStreamSynchronize(reg->stream);
+        hipHostUnregister(reg->shm);
+        munmap(reg->shm, reg->shm_bytes);
+        if (reg->rank == 0) shm_unlink(reg->shm_name.c_str());
+        reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_bytes = 0;
+    }
+    reg->nranks = 1, reg->rank = 0;
+    return KICP_OK;
+}
+int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
+    if (!reg || !name || nranks < 1 || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad shared-segment arguments");
+    if (reg->comm) return fail(KICP_ERR_ARG, "an RCCL communicator is already attached");
+    kicp_reg_shm_destroy(reg);
+    if (int rc = set_device(reg->device)) return rc;
+    const size_t bytes = 2 * static_cast<size_t>(nranks) * sizeof(kicp_reg::ShmSlot);
+    const std::string nm = std::string(name[0] == '/' ? "" : "/") + name;
+    const int fd = shm_open(nm.c_str(), rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) return fail(KICP_ERR_COMM, "shm_open(" + nm + ") failed (rank 0 must create it first)");
+    if (rank == 0 && ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+        close(fd);
+        return fail(KICP_ERR_COMM, "ftruncate on the shared segment failed");
+    }
+    void *ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
+    if (rank == 0) std::memset(ptr, 0, bytes);
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    void *dptr = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, ptr, 0);
+    if (e != hipSuccess) {
+        munmap(ptr, bytes);
+        return fail(KICP_ERR_HIP, std::string("registering the shared segment: ") + hipGetErrorString(e));
+    }
+    reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr), reg->d_shm = static_cast<kicp_reg::ShmSlot *>(dptr);
+    reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
     return KICP_OK;
 }
 int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user) {

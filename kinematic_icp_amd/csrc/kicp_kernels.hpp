@@ -75,6 +75,11 @@ struct SolveParams {
                    //     does the ~2000 serial fp64 instructions of the solve in 0.2 us, one GPU lane needs ~5 us)
     unsigned long long call_id;
     HostRecord *rec;  // device pointer to the host-mapped record
+    // mode 2 hand-off target (host-mapped memory: the handle's own record, or this rank's slot of the node-wide
+    // shared segment in multi-process mode): 24 limb words, then the sequence word set to pub_value
+    long long *pub_words;
+    unsigned long long *pub_seq;
+    unsigned long long pub_value;
 };
 
 struct BinView {
@@ -440,12 +445,9 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
 #pragma unroll
     for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
     if (p.sol.mode == 2) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
-        HostRecord *rec = p.sol.rec;
-        if (lane < kReduceWords) __hip_atomic_store(&rec->words[lane], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane < kReduceWords) __hip_atomic_store(p.sol.pub_words + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            __hip_atomic_store(&rec->seq, (p.sol.call_id << 16) | static_cast<unsigned long long>(p.sol.pass + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(p.sol.pub_seq, p.sol.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     if (lane != 0 || p.sol.mode != 0) return;
