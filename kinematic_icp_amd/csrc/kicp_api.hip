@@ -812,7 +812,6 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
     if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;
-    if (k.rfind("tstamp", 0) == 0 && reg->rec) return static_cast<double>(reg->rec->tstamp[std::atoi(k.c_str() + 6)]);
     return -1.0;
 }
 

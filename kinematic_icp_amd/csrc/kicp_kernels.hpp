@@ -46,7 +46,6 @@ struct HostRecord {
     double log_dx[kMaxLog][2];
     double sums[kNumSums];  // last pass, for kicp_pass_sums
     uint32_t n_cells, n_items, not_staged, reserved;
-    long long tstamp[12];  // experiments: s_memtime stamps of the finishing workgroup
     long long words[kReduceWords];  // limb totals of the last pass (host-side solve / kicp_pass_words)
 };
 
@@ -98,8 +97,7 @@ struct PassParams {
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     BinView bin;
     SolveParams sol;
-    int32_t dbg;  // experiments only: 1 = staging without matching, 2 = neither
-    long long tstart;
+    int32_t dbg;  // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -366,8 +364,6 @@ template <int BLOCK>
 __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*s_red)[kNumSums], int *s_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
-    long long ts[10];
-    ts[0] = clock64();
 #pragma unroll
     for (int i = 0; i < kNumSums; ++i) {
 #pragma unroll
@@ -397,7 +393,6 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         o.lo = __shfl(a.v[i].lo, 0, 64), o.hi = __shfl(a.v[i].hi, 0, 64);
         if (lane == i) t = o;
     }
-    ts[1] = clock64();
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
     if (lane < kNumSums) {
@@ -413,18 +408,14 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         st_sc1(row + kNumLimbs + (lane - kNumSums), lane == kNumSums ? static_cast<unsigned long long>(range_error) : 0ull);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ts[2] = clock64();
     unsigned int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0, 64);
-    ts[3] = clock64();
     const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
     if (ticket != group_size - 1) return;
     // ---- last workgroup of its group: fold the group's rows into one ---------------------------------------
     if (lane == 0) __hip_atomic_store(p.tickets + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long long total = sum_rows(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane);
-    ts[4] = clock64();
-    ts[5] = ts[6] = ts[4];
     if (ngroups > 1) {
         unsigned long long *grow = p.partials + (static_cast<size_t>(nblocks) + g) * kReduceWords;
         if (lane < kReduceWords) st_sc1(grow + lane, static_cast<unsigned long long>(total));
@@ -432,14 +423,12 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         if (lane == 0) ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __shfl(ticket, 0, 64);
         if (ticket != ngroups - 1) return;
-        ts[5] = clock64();
         if (lane == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         total = 0;
         for (uint32_t base = 0; base < ngroups; base += kGroup)
             total += sum_rows(p.partials + (static_cast<size_t>(nblocks) + base) * kReduceWords, min(static_cast<uint32_t>(kGroup), ngroups - base), lane);
     }
     // ---- last workgroup of the launch ------------------------------------------------------------------------
-    ts[6] = clock64();
     if (lane < kReduceWords) st->reduce[lane] = total;
     long long limbs[kNumLimbs + 1];
 #pragma unroll
@@ -451,13 +440,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         return;
     }
     if (lane != 0 || p.sol.mode != 0) return;
-    if (p.sol.rec && p.dbg) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) p.sol.rec->tstamp[i] = ts[i];
-        p.sol.rec->tstamp[8] = p.tstart;
-    }
     solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
-    if (p.sol.rec && p.dbg) p.sol.rec->tstamp[7] = clock64();
 }
 
 // wave-uniform values belong in SGPRs: tell the compiler explicitly
@@ -532,6 +515,26 @@ __device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, ui
     t.b1 = lt1 ? d : t.b1;
     t.i1 = lt1 ? idx : t.i1;
     t.o1 = lt1 ? ord : t.o1;
+}
+
+// minimum of N register-resident values and the (first) position attaining it, as a balanced tournament
+template <int N>
+__device__ __forceinline__ void tree_min_index(const float (&v)[N], float &m, int &k) {
+    float a[N];
+    int ia[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = v[u], ia[u] = u;
+#pragma unroll
+    for (int width = N; width > 1; width = (width + 1) / 2) {
+#pragma unroll
+        for (int u = 0; u < width / 2; ++u) {
+            const int r = width - 1 - u;  // pair u with its mirror; the lower position wins ties
+            const bool take = a[r] < a[u];
+            a[u] = take ? a[r] : a[u];
+            ia[u] = take ? ia[r] : ia[u];
+        }
+    }
+    m = a[0], k = ia[0];
 }
 
 // merge the three-smallest record of another lane into `t`
@@ -620,11 +623,32 @@ __global__ __launch_bounds__(BLOCK, (G > 1 ? 4 : 2)) void k_pass_gather32(const 
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) c[u] = b[min(k0 + u, last)];
                 if (k0 == 0) cnt = __float_as_uint(c[0].w);
+                // all distances first (independent), then tournament trees instead of a 20-long dependent chain: a lone
+                // wave cannot hide VALU latency, and the slowest wave sets the kernel's time
+                float d[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
                     const float ddx = c[u].x - qx, ddy = c[u].y - qy, ddz = c[u].z - qz;
-                    const float d = (k0 + u < cnt) ? ddx * ddx + ddy * ddy + ddz * ddz : 3.0e38f;
-                    best3_update(t, d, base + k0 + u, static_cast<uint32_t>(s) * 256u + k0 + u);
+                    d[u] = (k0 + u < cnt) ? ddx * ddx + ddy * ddy + ddz * ddz : 3.0e38f;
+                }
+                float m1;
+                int k1;
+                tree_min_index<kTrip>(d, m1, k1);
+                if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
+                    float e[kTrip];
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) e[u] = (u == k1) ? 3.0e38f : d[u];
+                    float m2;
+                    int k2;
+                    tree_min_index<kTrip>(e, m2, k2);
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) e[u] = (u == k2) ? 3.0e38f : e[u];
+                    float m3 = e[0];
+#pragma unroll
+                    for (int u = 1; u < kTrip; ++u) m3 = fminf(m3, e[u]);
+                    Best3 o{m1, m2, m3, base + k0 + k1, base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1,
+                            static_cast<uint32_t>(s) * 256u + k0 + k2};
+                    best3_merge(t, o);
                 }
             }
         }

@@ -23,5 +23,4 @@ for kern, block, G in ((3, 128, 1), (3, 256, 1)):
         for i in range(14):
             reg.ComputeRobotMotion(df[i % 2], gmap, scans[i % 2]["last_pose"], scans[i % 2]["rel_odom"], tau)
             ms.append(reg.last_stats.pass_ms[0])
-        ts = [reg.get_option("tstamp%d" % k) for k in range(8)]
-        print("kernel %d block %3d G %d dbg %d: pass %.1f us" % (kern, block, G, dbg, np.median(ms[4:]) * 1e3), " phase ticks (100MHz?):", [int(ts[k + 1] - ts[k]) for k in range(7)], flush=True)
+        print("kernel %d block %3d G %d dbg %d: pass %.1f us" % (kern, block, G, dbg, np.median(ms[4:]) * 1e3), flush=True)
