@@ -133,6 +133,26 @@ int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t
 int kicp_pass_words(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                     double max_correspondence_distance, long long out_words[24]);
 
+/* ---- pre-steps of the pipeline on the GPU (pipeline/KinematicICP.cpp:54-62) -----------
+ * A kicp_pre owns KICP_PRE_BUFFERS device point buffers.  Results stay in HBM (feed kicp_register_device with
+ * kicp_pre_device_ptr) and are downloaded only when the host needs them (map update, return values). */
+#define KICP_PRE_BUFFERS 4
+typedef struct kicp_pre kicp_pre;
+int kicp_pre_create(int device, kicp_pre **out);
+void kicp_pre_destroy(kicp_pre *pre);
+/* kiss_icp::Preprocessor::Preprocess(frame, timestamps, relative_motion) followed by transform_points(., lidar_to_base):
+ * optional constant-velocity deskew to the scan end (when `deskew` and n_timestamps != 0), crop to
+ * min_range < |p| < max_range in the sensor frame, then into the base frame.  Order preserved.  Host input. */
+int kicp_pre_preprocess(kicp_pre *pre, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                        const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range,
+                        int deskew, int dst_buffer, size_t *out_n);
+/* kiss_icp::VoxelDownsample(buffer src, voxel_size) -> buffer dst: the first point (lowest index) of every voxel, in
+ * first-seen order. */
+int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, int dst_buffer, size_t *out_n);
+int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
+int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
+const double *kicp_pre_device_ptr(const kicp_pre *pre, int buffer, size_t *out_n);
+
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */
 int kicp_device_malloc(int device, size_t bytes, void **out_dptr);
 int kicp_device_free(int device, void *dptr);

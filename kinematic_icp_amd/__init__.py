@@ -78,6 +78,14 @@ _SIGNATURES = {
     "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "kicp_pass_words": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_longlong)]),
+    "kicp_pre_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "kicp_pre_destroy": (None, [C.c_void_p]),
+    "kicp_pre_preprocess": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      C.POINTER(C.c_size_t)]),
+    "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
+    "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
+    "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kicp_pre_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "kicp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "kicp_device_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -203,7 +211,7 @@ class DeviceFrame:
             _check(lib().kicp_device_upload(device, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def __del__(self):
-        if getattr(self, "ptr", None) and _lib is not None:
+        if getattr(self, "ptr", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.kicp_device_free(self.device, self.ptr)
             self.ptr = None
 
@@ -317,6 +325,54 @@ class KinematicRegistration:
 
         self._cb = ALLREDUCE_FN(tramp)
         _check(lib().kicp_reg_set_allreduce(self._h, self._cb, None))
+
+
+class PreSteps:
+    """The pipeline's pre-steps on the GPU: kiss_icp::Preprocessor::Preprocess + transform_points, kiss_icp::VoxelDownsample
+    (pipeline/KinematicICP.cpp:54-62).  Results live in numbered device buffers; frame(b) wraps one for ComputeRobotMotion."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().kicp_pre_create(device, C.byref(h)))
+        self._h, self.device = h, device
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.kicp_pre_destroy(self._h)
+            self._h = None
+
+    def Preprocess(self, frame, timestamps, relative_motion, lidar_to_base, max_range, min_range, deskew, dst=0):
+        a, p = _d(frame)
+        t, tp = _d(timestamps if timestamps is not None else np.zeros(0))
+        _, r = _d(relative_motion)
+        _, e = _d(lidar_to_base)
+        n = C.c_size_t()
+        _check(lib().kicp_pre_preprocess(self._h, p, a.size // 3, tp, t.size, r, e, max_range, min_range, int(deskew), dst, C.byref(n)))
+        return n.value
+
+    def VoxelDownsample(self, src, voxel_size, dst):
+        n = C.c_size_t()
+        _check(lib().kicp_pre_voxel_downsample(self._h, src, voxel_size, dst, C.byref(n)))
+        return n.value
+
+    def upload(self, buffer, points):
+        a, p = _d(points)
+        _check(lib().kicp_pre_upload(self._h, buffer, p, a.size // 3))
+
+    def download(self, buffer):
+        n = C.c_size_t()
+        _check(lib().kicp_pre_download(self._h, buffer, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.float64)
+        _check(lib().kicp_pre_download(self._h, buffer, out.ctypes.data_as(_dp), n.value, C.byref(n)))
+        return out
+
+    def frame(self, buffer):
+        """A DeviceFrame view of a buffer (no copy; valid until the buffer is overwritten)."""
+        n = C.c_size_t()
+        ptr = lib().kicp_pre_device_ptr(self._h, buffer, C.byref(n))
+        f = DeviceFrame.__new__(DeviceFrame)
+        f.n, f.device, f.ptr, f._borrowed = n.value, self.device, C.c_void_p(ptr), True
+        return f
 
 
 def comm_unique_id():

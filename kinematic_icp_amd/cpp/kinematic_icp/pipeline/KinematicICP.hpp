@@ -1,8 +1,10 @@
 // kinematic_icp/pipeline/KinematicICP.hpp -- drop-in for the reference header of the same path
 // (/root/reference/cpp/kinematic_icp/pipeline/KinematicICP.{hpp,cpp}): same Config fields and defaults, same class
 // surface (RegisterFrame, SetPose, LocalMap, VoxelMap, pose), so ros/src/.../LidarOdometryServer.cpp compiles
-// against it unchanged.  The ICP (registration_ + local_map_) runs on the MI355X; deskew/crop/voxelize and the
-// threshold bookkeeping are host pre/post steps exactly as in the reference.
+// against it unchanged.  The ICP (registration_ + local_map_) and - unless KICP_HOST_PRESTEPS is defined - the
+// pre-steps (deskew + crop + transform, two-level voxel downsample: kicp_pre_*) run on the MI355X; the registration
+// source never leaves HBM.  The threshold bookkeeping and the order-dependent map insertion stay on the host
+// (SURVEY.md section 8f rows 1, 2 and 4).
 #pragma once
 #include <Eigen/Core>
 #include <cmath>
@@ -51,12 +53,42 @@ public:
           correspondence_threshold_(config.map_resolution(), config.max_range, config.use_adaptive_threshold, config.fixed_threshold),
           config_(config),
           preprocessor_(config.max_range, config.min_range, config.deskew, config.max_num_threads),
-          local_map_(config.voxel_size, config.max_range, config.max_points_per_voxel) {}
+          local_map_(config.voxel_size, config.max_range, config.max_points_per_voxel) {
+#ifndef KICP_HOST_PRESTEPS
+        kicp_bridge::check(kicp_pre_create(0, &pre_), "KinematicICP");
+#endif
+    }
+    ~KinematicICP() { kicp_pre_destroy(pre_); }
+    KinematicICP(const KinematicICP &) = delete;
+    KinematicICP &operator=(const KinematicICP &) = delete;
 
     // pipeline/KinematicICP.cpp:48-85
     Vector3dVectorTuple RegisterFrame(const std::vector<Eigen::Vector3d> &frame, const std::vector<double> &timestamps,
                                       const Sophus::SE3d &lidar_to_base, const Sophus::SE3d &relative_odometry) {
         const Sophus::SE3d relative_odometry_in_lidar = lidar_to_base.inverse() * relative_odometry * lidar_to_base;
+#ifndef KICP_HOST_PRESTEPS
+        double rel_lidar[7], ext[7];
+        kicp_bridge::to_params(relative_odometry_in_lidar, rel_lidar);
+        kicp_bridge::to_params(lidar_to_base, ext);
+        size_t n_frame = 0, n_down = 0, n_source = 0;
+        kicp_bridge::check(kicp_pre_preprocess(pre_, kicp_bridge::xyz(frame), frame.size(), timestamps.data(), timestamps.size(), rel_lidar,
+                                               ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, 0, &n_frame),
+                           "Preprocess");
+        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
+        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
+        const double tau_dev = correspondence_threshold_.ComputeThreshold();
+        const auto new_pose_dev = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
+                                                                        relative_odometry, tau_dev);
+        Vector3dVector frame_in_base(n_frame), down(n_down), src(n_source);
+        auto fetch = [&](int b, Vector3dVector &v) {
+            kicp_bridge::check(kicp_pre_download(pre_, b, v.empty() ? nullptr : v.front().data(), v.size(), nullptr), "download");
+        };
+        fetch(0, frame_in_base), fetch(1, down), fetch(2, src);
+        correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose_dev);
+        local_map_.Update(down, new_pose_dev);
+        last_pose_ = new_pose_dev;
+        return {frame_in_base, src};
+#else
         const auto preprocessed_frame = preprocessor_.Preprocess(frame, timestamps, relative_odometry_in_lidar);
         Vector3dVector preprocessed_frame_in_base(preprocessed_frame.size());
         for (size_t i = 0; i < preprocessed_frame.size(); ++i) preprocessed_frame_in_base[i] = lidar_to_base * preprocessed_frame[i];
@@ -69,6 +101,7 @@ public:
         local_map_.Update(frame_downsample, new_pose);
         last_pose_ = new_pose;
         return {preprocessed_frame_in_base, source};
+#endif
     }
 
     inline void SetPose(const Sophus::SE3d &pose) {
@@ -90,6 +123,7 @@ protected:
     Config config_;
     kiss_icp::Preprocessor preprocessor_;
     kiss_icp::VoxelHashMap local_map_;
+    kicp_pre *pre_ = nullptr;  // device workspace of the pre-steps (backend detail)
 };
 
 }  // namespace kinematic_icp::pipeline

@@ -39,6 +39,21 @@ struct KinematicRegistration {
         return kicp_bridge::from_params(out);
     }
 
+    // backend extension: the frame is already in HBM (output of the on-device pre-steps)
+    Sophus::SE3d ComputeRobotMotionDevice(const double *d_frame_xyz, size_t n, const kiss_icp::VoxelHashMap &voxel_map,
+                                          const Sophus::SE3d &last_robot_pose, const Sophus::SE3d &relative_wheel_odometry,
+                                          const double max_correspondence_distance) {
+        const kicp_reg_config c = config();
+        kicp_bridge::check(kicp_reg_set_config(handle_, &c), "KinematicRegistration");
+        double last[7], rel[7], out[7];
+        kicp_bridge::to_params(last_robot_pose, last);
+        kicp_bridge::to_params(relative_wheel_odometry, rel);
+        kicp_bridge::check(kicp_register_device(handle_, voxel_map.handle(), d_frame_xyz, n, last, rel, max_correspondence_distance, out,
+                                                &last_stats_),
+                           "KinematicRegistration::ComputeRobotMotionDevice");
+        return kicp_bridge::from_params(out);
+    }
+
     int max_num_iterations_;
     double convergence_criterion_;
     int max_num_threads_;

@@ -20,6 +20,7 @@
 #include "../../include/kicp.h"
 #include "kicp_host_map.hpp"
 #include "kicp_kernels.hpp"
+#include "kicp_pre.hpp"
 
 namespace {
 using namespace kicp;
@@ -874,6 +875,166 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     for (int i = 0; i < 7; ++i) out_sums[i] = reg->rec->sums[i];
     if (out_words) HIP_TRY(hipMemcpy(out_words, reg->d_state->reduce, sizeof(long long) * kReduceWords, hipMemcpyDeviceToHost));
     return KICP_OK;
+}
+
+// ---- pre-steps ------------------------------------------------------------------------------------------------------
+}  // extern "C"
+struct kicp_pre {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    double *buf[KICP_PRE_BUFFERS] = {};
+    size_t buf_cap[KICP_PRE_BUFFERS] = {}, buf_n[KICP_PRE_BUFFERS] = {};
+    double *d_in = nullptr, *d_ts = nullptr, *d_staged = nullptr;
+    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_slot_of = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error
+    unsigned long long *d_keys = nullptr;
+    uint32_t *d_min_index = nullptr;
+    size_t cap_n = 0, table_slots = 0;
+};
+namespace {
+int pre_ensure(kicp_pre *p, size_t n) {
+    if (n <= p->cap_n) return KICP_OK;
+    const size_t cap = n + n / 4 + 1024;
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
+    hipFree(p->d_keys), hipFree(p->d_min_index);
+    HIP_TRY(hipMalloc(&p->d_in, cap * 24));
+    HIP_TRY(hipMalloc(&p->d_ts, cap * 8));
+    HIP_TRY(hipMalloc(&p->d_staged, cap * 24));
+    HIP_TRY(hipMalloc(&p->d_flags, cap * 4));
+    HIP_TRY(hipMalloc(&p->d_block_counts, (cap / 256 + 2) * 4));
+    HIP_TRY(hipMalloc(&p->d_slot_of, cap * 4));
+    size_t slots = 1024;
+    while (slots < 2 * cap) slots <<= 1;
+    HIP_TRY(hipMalloc(&p->d_keys, slots * 8));
+    HIP_TRY(hipMalloc(&p->d_min_index, slots * 4));
+    p->cap_n = cap, p->table_slots = slots;
+    return KICP_OK;
+}
+int pre_ensure_buf(kicp_pre *p, int b, size_t n) {
+    if (n <= p->buf_cap[b]) return KICP_OK;
+    if (p->buf[b]) HIP_TRY(hipFree(p->buf[b]));
+    p->buf[b] = nullptr;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc(&p->buf[b], cap * 24));
+    p->buf_cap[b] = cap;
+    return KICP_OK;
+}
+// flags + block counts are in place: scan, compact staged -> buffer dst, return the survivor count
+int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *out_n) {
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    if (int rc = pre_ensure_buf(p, dst, n)) return rc;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, p->d_flags, p->d_block_counts, static_cast<uint32_t>(n), p->buf[dst]);
+    HIP_TRY(hipGetLastError());
+    uint32_t misc[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (misc[1]) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
+    p->buf_n[dst] = misc[0];
+    if (out_n) *out_n = misc[0];
+    return KICP_OK;
+}
+}  // namespace
+extern "C" {
+int kicp_pre_create(int device, kicp_pre **out) {
+    if (!out) return fail(KICP_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(KICP_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(KICP_ERR_ARG, "device index out of range");
+    if (int rc = set_device(device)) return rc;
+    kicp_pre *p = new kicp_pre;
+    p->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&p->d_misc, 16);
+    if (e == hipSuccess) e = hipMemset(p->d_misc, 0, 16);
+    if (e != hipSuccess) {
+        kicp_pre_destroy(p);
+        return fail(KICP_ERR_HIP, std::string("kicp_pre_create: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return KICP_OK;
+}
+void kicp_pre_destroy(kicp_pre *p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (double *b : p->buf) hipFree(b);
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
+    hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                        const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range,
+                        int deskew, int dst_buffer, size_t *out_n) {
+    if (!p || (!frame_xyz && n) || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
+        return fail(KICP_ERR_ARG, "bad argument");
+    const bool do_deskew = deskew && n_timestamps != 0;  // Preprocessing.cpp: `if (deskew_ && !timestamps.empty())`
+    if (do_deskew && (!timestamps || n_timestamps < n)) return fail(KICP_ERR_ARG, "one timestamp per point is required for deskewing");
+    if (int rc = set_device(p->device)) return rc;
+    if (n == 0) {
+        p->buf_n[dst_buffer] = 0;
+        if (out_n) *out_n = 0;
+        return KICP_OK;
+    }
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (int rc = pre_ensure(p, n)) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_in, frame_xyz, n * 24, hipMemcpyHostToDevice, p->stream));
+    if (do_deskew) HIP_TRY(hipMemcpyAsync(p->d_ts, timestamps, n * 8, hipMemcpyHostToDevice, p->stream));
+    PreprocessParams pp{};
+    pp.in = p->d_in, pp.timestamps = p->d_ts, pp.n = static_cast<uint32_t>(n), pp.deskew = do_deskew ? 1 : 0;
+    const Pose rel = pose_from(relative_motion_qt);
+    pose_log(rel, pp.omega);
+    pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
+    pp.max_range = max_range, pp.min_range = min_range;
+    pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
+    hipLaunchKernelGGL(k_preprocess, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, p->stream, pp);
+    return pre_compact(p, p->d_staged, n, dst_buffer, out_n);
+}
+int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, size_t *out_n) {
+    if (!p || src < 0 || src >= KICP_PRE_BUFFERS || dst < 0 || dst >= KICP_PRE_BUFFERS || src == dst || !(voxel_size > 0.0))
+        return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t n = p->buf_n[src];
+    if (n == 0) {
+        p->buf_n[dst] = 0;
+        if (out_n) *out_n = 0;
+        return KICP_OK;
+    }
+    if (int rc = pre_ensure(p, n)) return rc;
+    size_t slots = 1024;  // this call's table: the smallest power of two >= 2n keeps the memset small
+    while (slots < 2 * n) slots <<= 1;
+    HIP_TRY(hipMemsetAsync(p->d_keys, 0xFF, slots * 8, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_min_index, 0xFF, slots * 4, p->stream));
+    DownsampleParams dp{};
+    dp.in = p->buf[src], dp.n = static_cast<uint32_t>(n), dp.voxel_size = voxel_size, dp.keys = p->d_keys, dp.min_index = p->d_min_index;
+    dp.mask = static_cast<uint32_t>(slots - 1), dp.slot_of = p->d_slot_of, dp.flags = p->d_flags, dp.block_counts = p->d_block_counts;
+    dp.error = p->d_misc + 1;
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
+    hipLaunchKernelGGL(k_downsample_flag, dim3(grid), dim3(256), 0, p->stream, dp);
+    return pre_compact(p, p->buf[src], n, dst, out_n);
+}
+int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    if (int rc = pre_ensure_buf(p, buffer, n ? n : 1)) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(p->buf[buffer], xyz, n * 24, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->buf_n[buffer] = n;
+    return KICP_OK;
+}
+int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap_points, size_t *out_n) {
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t n = p->buf_n[buffer], k = std::min(n, cap_points);
+    if (k && out_xyz) HIP_TRY(hipMemcpy(out_xyz, p->buf[buffer], k * 24, hipMemcpyDeviceToHost));
+    if (out_n) *out_n = n;
+    return KICP_OK;
+}
+const double *kicp_pre_device_ptr(const kicp_pre *p, int buffer, size_t *out_n) {
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return nullptr;
+    if (out_n) *out_n = p->buf_n[buffer];
+    return p->buf[buffer];
 }
 
 // ---- device helpers -------------------------------------------------------------------------------------------------

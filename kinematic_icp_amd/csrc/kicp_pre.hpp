@@ -1,0 +1,165 @@
+// kicp_pre.hpp -- the pipeline's pre-steps on the GPU (reference call sites
+// pipeline/KinematicICP.cpp:54-62): kiss_icp::Preprocessor::Preprocess (constant-velocity deskew + range crop, kiss-icp
+// v1.2.0 core/Preprocessing.cpp) fused with transform_points (KinematicICP.cpp:31-36), and kiss_icp::VoxelDownsample
+// (core/VoxelUtils.cpp: first point of every voxel wins).  All of them are order-sensitive on the CPU; here the order is
+// made explicit - survivors keep their input order, and "first" means lowest input index (atomicMin) - so the results
+// are deterministic and equal to the sequential reference up to the order of VoxelDownsample's output (the reference's
+// is its hash table's iteration order; ours is first-seen order).
+// HBM bound streaming kernels: 24-32 B read + <= 24 B written per point, fp64 throughout.
+#pragma once
+#include "kicp_common.hpp"
+#include "kicp_se3.hpp"
+
+namespace kicp {
+
+struct PreprocessParams {
+    const double *in;          // raw scan, sensor frame
+    const double *timestamps;  // normalised to [0,1], or nullptr
+    uint32_t n;
+    int32_t deskew;
+    double omega[6];           // log(relative_motion)
+    Pose motion_inverse;       // relative_motion^-1
+    Pose lidar_to_base;
+    double max_range, min_range;
+    uint32_t *flags;           // 1 = survives the crop
+    double *staged;            // transformed point of every input (base frame), compacted afterwards
+    uint32_t *block_counts;    // survivors per 256-thread block
+};
+
+// block-wide count of set predicates -> block_counts[blockIdx.x] (lane 0 of wave 0 writes)
+__device__ __forceinline__ void block_count_store(bool pred, uint32_t *block_counts) {
+    __shared__ uint32_t s_cnt[4];
+    const unsigned long long ballot = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(ballot));
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(const PreprocessParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < p.n) {
+        double x = p.in[3 * i], y = p.in[3 * i + 1], z = p.in[3 * i + 2];
+        if (p.deskew) {  // p' = (relative_motion^-1 * exp(t_i * omega)) * p_i : deskew to the scan end
+            const double t = p.timestamps[i];
+            const double xi[6] = {t * p.omega[0], t * p.omega[1], t * p.omega[2], t * p.omega[3], t * p.omega[4], t * p.omega[5]};
+            const Pose M = pose_mul(p.motion_inverse, pose_exp(xi));
+            double rx, ry, rz;
+            quat_rotate(M, x, y, z, rx, ry, rz);
+            x = rx + M.tx, y = ry + M.ty, z = rz + M.tz;
+        }
+        const double r = sqrt(x * x + y * y + z * z);
+        keep = r < p.max_range && r > p.min_range;  // strict on both sides
+        double bx, by, bz;
+        quat_rotate(p.lidar_to_base, x, y, z, bx, by, bz);  // transform_points: into the base frame
+        p.staged[3 * i] = bx + p.lidar_to_base.tx, p.staged[3 * i + 1] = by + p.lidar_to_base.ty, p.staged[3 * i + 2] = bz + p.lidar_to_base.tz;
+        p.flags[i] = keep ? 1u : 0u;
+    }
+    block_count_store(keep, p.block_counts);
+}
+
+// exclusive scan of the per-block counts (one workgroup; up to 1024 * 64 blocks = 16.7M points)
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *block_counts, uint32_t nblocks, uint32_t *total) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t c = b < nblocks ? block_counts[b] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (b < nblocks) block_counts[b] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+// order-preserving compaction: survivor i goes to block_offset + (number of survivors before it in its block)
+__global__ __launch_bounds__(256) void k_compact(const double *staged, const uint32_t *flags, const uint32_t *block_offsets, uint32_t n,
+                                                 double *out) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool keep = i < n && flags[i] != 0u;
+    const unsigned long long ballot = __ballot(keep);
+    if (lane == 0) s_wave[wave] = static_cast<uint32_t>(__popcll(ballot));
+    __syncthreads();
+    if (!keep) return;
+    uint32_t pos = block_offsets[blockIdx.x] + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    out[3 * pos] = staged[3 * i], out[3 * pos + 1] = staged[3 * i + 1], out[3 * pos + 2] = staged[3 * i + 2];
+}
+
+// ---- VoxelDownsample ----------------------------------------------------------------------------------------------------
+constexpr unsigned long long kEmptyVoxelKey = ~0ull;
+struct DownsampleParams {
+    const double *in;
+    uint32_t n;
+    double voxel_size;
+    unsigned long long *keys;  // [mask+1], kEmptyVoxelKey when free
+    uint32_t *min_index;       // [mask+1], 0xFFFFFFFF initially
+    uint32_t mask;
+    uint32_t *slot_of;         // table slot of every input point
+    uint32_t *flags;
+    uint32_t *block_counts;
+    uint32_t *error;           // set when a voxel coordinate leaves the 21-bit packable range
+};
+
+__device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y, int32_t z, bool &ok) {
+    const int lim = 1 << 20;
+    ok = x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim;
+    return (static_cast<unsigned long long>(static_cast<uint32_t>(z + lim) & 0x1FFFFFu) << 42) |
+           (static_cast<unsigned long long>(static_cast<uint32_t>(y + lim) & 0x1FFFFFu) << 21) |
+           static_cast<unsigned long long>(static_cast<uint32_t>(x + lim) & 0x1FFFFFu);
+}
+__device__ __forceinline__ uint32_t hash_u64(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return static_cast<uint32_t>(k);
+}
+
+// pass 1: every point claims / finds its voxel's slot and lowers the slot's winner to its own index
+__global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const double vs = p.voxel_size;
+    bool ok;
+    const unsigned long long key = pack_voxel21(static_cast<int32_t>(floor(p.in[3 * i] / vs)), static_cast<int32_t>(floor(p.in[3 * i + 1] / vs)),
+                                                static_cast<int32_t>(floor(p.in[3 * i + 2] / vs)), ok);
+    if (!ok) *p.error = 1u;
+    uint32_t slot = hash_u64(key) & p.mask;
+    for (;;) {
+        const unsigned long long seen = atomicCAS(p.keys + slot, kEmptyVoxelKey, key);
+        if (seen == kEmptyVoxelKey || seen == key) break;
+        slot = (slot + 1) & p.mask;
+    }
+    atomicMin(p.min_index + slot, i);
+    p.slot_of[i] = slot;
+}
+// pass 2: the winners are the points whose index is their voxel's minimum
+__global__ __launch_bounds__(256) void k_downsample_flag(const DownsampleParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < p.n) {
+        keep = p.min_index[p.slot_of[i]] == i;
+        p.flags[i] = keep ? 1u : 0u;
+    }
+    block_count_store(keep, p.block_counts);
+}
+
+}  // namespace kicp

@@ -101,6 +101,44 @@ KICP_HD Pose pose_exp(const double xi[6]) {
     return T;
 }
 
+KICP_HD Pose pose_inverse(const Pose &a) {
+    Pose r;
+    r.qx = -a.qx, r.qy = -a.qy, r.qz = -a.qz, r.qw = a.qw;
+    double x, y, z;
+    quat_rotate(r, -a.tx, -a.ty, -a.tz, x, y, z);
+    r.tx = x, r.ty = y, r.tz = z;
+    return r;
+}
+
+// SE3 logarithm -> twist (v, w), Sophus' formulas (used once per frame for the deskewing velocity; kiss-icp v1.2.0
+// core/Preprocessing.cpp)
+KICP_HD void pose_log(const Pose &T, double xi[6]) {
+    const double sn = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz, w = T.qw;
+    double k, theta;
+    if (sn < 1e-20) {
+        k = 2.0 / w - (2.0 / 3.0) * sn / (w * w * w);
+        theta = 2.0 * sn / w;
+    } else {
+        const double n = sqrt(sn);
+        const double a = (w < 0.0) ? atan2(-n, -w) : atan2(n, w);
+        k = 2.0 * a / n;
+        theta = k * n;
+    }
+    const double ox = k * T.qx, oy = k * T.qy, oz = k * T.qz;
+    // V^-1 t = t - 1/2 w x t + c w x (w x t)
+    const double ax = oy * T.tz - oz * T.ty, ay = oz * T.tx - ox * T.tz, az = ox * T.ty - oy * T.tx;
+    const double bx = oy * az - oz * ay, by = oz * ax - ox * az, bz = ox * ay - oy * ax;
+    double c;
+    if (fabs(theta) < 1e-10) {
+        c = 1.0 / 12.0;
+    } else {
+        const double h = 0.5 * theta;
+        c = (1.0 - theta * cos(h) / (2.0 * sin(h))) / (theta * theta);
+    }
+    xi[0] = T.tx - 0.5 * ax + c * bx, xi[1] = T.ty - 0.5 * ay + c * by, xi[2] = T.tz - 0.5 * az + c * bz;
+    xi[3] = ox, xi[4] = oy, xi[5] = oz;
+}
+
 // motion_model(integrated_controls) -- Registration.cpp:159-167.  NB theta == 0.0 exactly gives dx(0) = 0
 // (epsilon = DBL_MIN only avoids 0/0): the reference's own behaviour, kept.
 KICP_HD Pose motion_model(double displacement, double theta) {

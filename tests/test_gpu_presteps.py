@@ -1,0 +1,86 @@
+"""The pipeline's pre-steps on the GPU against the oracle's restatements of kiss-icp v1.2.0
+Preprocessor::Preprocess / VoxelDownsample and pipeline/KinematicICP.cpp:31-44,54-62.
+fp64 throughout: points agree to 1e-12 (device vs host sin/cos), survivor sets and counts are identical."""
+import numpy as np
+import pytest
+
+import kinematic_icp_amd as K
+from kinematic_icp_amd import synthetic as syn
+from oracle import okicp
+
+pytestmark = pytest.mark.gpu
+
+
+def first_seen_downsample(pts, vs):
+    keys = np.floor(pts / vs).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    return pts[np.sort(first)]
+
+
+@pytest.fixture(scope="module")
+def raw():
+    cfg, scene, scans, rng = syn.make_case("cfg1", n_scans=1)
+    ext = np.concatenate([[0.01, -0.02, np.sin(0.05), np.sqrt(1 - np.sin(0.05) ** 2 - 5e-4)], [0.3, 0.1, 0.9]])
+    ext[:4] /= np.linalg.norm(ext[:4])
+    frame = okicp.se3_act(okicp.se3_inverse(ext), scans[0]["frame"])  # sensor-frame points
+    ts = np.linspace(0.0, 1.0, len(frame))
+    rel = syn.pose_mul(syn.planar_pose(0.6, 0.05, 0.04), np.array([0.004, -0.003, 0, np.sqrt(1 - 25e-6), 0, 0, 0.01]))
+    return frame, ts, rel, ext
+
+
+@pytest.mark.parametrize("deskew", [0, 1])
+def test_preprocess_matches_oracle(raw, deskew):
+    frame, ts, rel, ext = raw
+    pre = K.PreSteps()
+    n = pre.Preprocess(frame, ts, rel, ext, 30.0, 3.0, deskew, dst=0)
+    ref = okicp.se3_act(ext, okicp.preprocess(frame, ts, rel, 30.0, 3.0, bool(deskew)))
+    assert 0 < n == len(ref) < len(frame)  # the crop removed something on both sides
+    np.testing.assert_allclose(pre.download(0), ref, rtol=0, atol=1e-11)
+    # no timestamps -> no deskew even when asked (Preprocessing.cpp: deskew_ && !timestamps.empty())
+    n2 = pre.Preprocess(frame, None, rel, ext, 30.0, 3.0, 1, dst=1)
+    ref2 = okicp.se3_act(ext, okicp.preprocess(frame, None, rel, 30.0, 3.0, True))
+    assert n2 == len(ref2)
+    np.testing.assert_allclose(pre.download(1), ref2, rtol=0, atol=1e-12)
+
+
+def test_voxel_downsample_matches_oracle(raw):
+    frame, ts, rel, ext = raw
+    pre = K.PreSteps()
+    pre.upload(0, frame)
+    for vs, (src, dst) in ((0.5, (0, 1)), (1.5, (1, 2))):  # the pipeline's two levels: 0.5 * voxel, then 1.5 * voxel
+        n = pre.VoxelDownsample(src, vs, dst)
+        got = pre.download(dst)
+        inp = pre.download(src)
+        ref = first_seen_downsample(inp, vs)
+        assert n == len(ref)
+        np.testing.assert_array_equal(got, ref)  # the very same points, in first-seen order
+        from conftest import sort_rows
+        np.testing.assert_array_equal(sort_rows(got), sort_rows(okicp.voxel_downsample(inp, vs)))  # the oracle's set
+    # determinism and the all-in-one-voxel / all-distinct edge cases
+    assert pre.VoxelDownsample(0, 1e6, 3) == len(np.unique(np.floor(frame / 1e6), axis=0)) <= 8  # one voxel per octant
+    assert np.array_equal(pre.download(3)[0], frame[0])
+    assert pre.VoxelDownsample(0, 1e-3, 3) == len(np.unique(np.floor(frame / 1e-3), axis=0))
+    with pytest.raises(K.KicpError) as e:  # documented limit: voxel coordinates must fit +-2^20
+        pre.VoxelDownsample(0, 1e-6, 3)
+    assert e.value.code == K.KICP_ERR_CAPACITY
+
+
+def test_presteps_feed_registration_without_leaving_the_gpu(raw):
+    frame, ts, rel, ext = raw
+    cfg, scene, scans, rng = syn.make_case("cfg1", n_scans=1)
+    gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
+    s = scans[0]
+    pre = K.PreSteps()
+    pre.Preprocess(frame, ts, syn.IDENTITY, ext, 100.0, 0.0, 0, dst=0)
+    pre.VoxelDownsample(0, 0.5 * cfg.voxel_size, 1)
+    pre.VoxelDownsample(1, 1.5 * cfg.voxel_size, 2)
+    reg = K.KinematicRegistration()
+    a = reg.ComputeRobotMotion(pre.frame(2), gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    b = reg.ComputeRobotMotion(pre.download(2), gmap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    assert np.array_equal(a, b)
+    omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    omap.AddPoints(gmap.Pointcloud())
+    src = first_seen_downsample(first_seen_downsample(okicp.se3_act(ext, frame), 0.5), 1.5)
+    ref = okicp.KinematicRegistration().ComputeRobotMotion(src, omap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
+    np.testing.assert_allclose(a, ref, rtol=0, atol=1e-9)
