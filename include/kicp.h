@@ -86,6 +86,9 @@ size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_poin
  * search (the same 27-voxel 1-NN code path the fused registration kernel uses) on `device`.
  * No candidate -> nn = (0,0,0), dist = DBL_MAX, exactly like the reference. */
 int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist);
+/* Debug aid: verifies the table invariants the kernels rely on (neighbour masks, bucket records, halo entries, fp32
+ * mirror, counters) on the host copy; returns the number of violations, 0 when consistent. */
+size_t kicp_map_check(const kicp_map *map);
 /* Make the HBM mirror on `device` current (a no-op when nothing changed since the last upload).
  * kicp_register* call it implicitly; exposed so map upload can be kept out of a timed region. */
 int kicp_map_sync(kicp_map *map, int device);

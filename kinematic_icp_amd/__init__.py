@@ -66,6 +66,7 @@ _SIGNATURES = {
     "kicp_map_num_voxels": (C.c_size_t, [C.c_void_p]),
     "kicp_map_pointcloud": (C.c_size_t, [C.c_void_p, _dp, C.c_size_t]),
     "kicp_map_closest": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, _dp, _dp]),
+    "kicp_map_check": (C.c_size_t, [C.c_void_p]),
     "kicp_map_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "kicp_map_last_upload": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_reg_create": (C.c_int, [C.POINTER(RegConfig), C.c_int, C.POINTER(C.c_void_p)]),
@@ -188,6 +189,10 @@ class VoxelHashMap:
         d = np.empty(n, dtype=np.float64)
         _check(lib().kicp_map_closest(self._h, device, p, n, nn.ctypes.data_as(_dp), d.ctypes.data_as(_dp)))
         return nn, d
+
+    def check(self):
+        """Number of violated table invariants on the host copy (0 = consistent); debug aid."""
+        return lib().kicp_map_check(self._h)
 
     def sync(self, device=0):
         _check(lib().kicp_map_sync(self._h, device))

@@ -691,6 +691,7 @@ size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_poin
     if (!map) return 0;
     return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
 }
+size_t kicp_map_check(const kicp_map *map) { return map ? map->host.CheckInvariants() : 1; }
 int kicp_map_sync(kicp_map *map, int device) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (int rc = set_device(device)) return rc;

@@ -153,6 +153,50 @@ public:
         return n_points_;
     }
 
+    // Self-check of the table invariants the kernels rely on; returns the number of violations (0 = consistent):
+    //  * every occupied voxel has a live bucket whose fp32 header carries its count and whose fp32 points are the
+    //    rounded offsets of the fp64 points from the voxel corner;
+    //  * for every entry E and every shift s: bit s of E.nbr is set  <=>  voxel E.key + shift[s] is occupied, and then
+    //    E.nb[s] is that voxel's bucket;
+    //  * every voxel within one step of an occupied voxel has an entry (halo completeness);
+    //  * the counters agree with the table.
+    size_t CheckInvariants() const {
+        size_t bad = 0, occupied = 0, points = 0, entries = 0, dead = 0;
+        for (const Slot &e : table_) {
+            if (e.val == kEmptyVal) continue;
+            ++entries;
+            const uint32_t count = e.val & 0xffu;
+            if (count == 0 && e.nbr == 0) ++dead;
+            if (count) {
+                ++occupied, points += count;
+                const uint32_t b = e.val >> 8;
+                if (b >= n_buckets_hi_ || count > cap_) ++bad;
+                uint32_t hdr;
+                std::memcpy(&hdr, &pool32_[static_cast<size_t>(b) * cap_ * 4 + 3], 4);
+                if (hdr != count) ++bad;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const double *p = &pool_[(static_cast<size_t>(b) * cap_ + k) * 3];
+                    const float *f = &pool32_[(static_cast<size_t>(b) * cap_ + k) * 4];
+                    if (to_voxel(p[0]) != e.x || to_voxel(p[1]) != e.y || to_voxel(p[2]) != e.z) ++bad;
+                    if (f[0] != static_cast<float>(p[0] - e.x * voxel_size_) || f[1] != static_cast<float>(p[1] - e.y * voxel_size_) ||
+                        f[2] != static_cast<float>(p[2] - e.z * voxel_size_))
+                        ++bad;
+                }
+            } else if (e.val != kHaloVal) {
+                ++bad;
+            }
+            for (int s = 0; s < 27; ++s) {
+                const int64_t n = find(e.x + kShiftTable[s][0], e.y + kShiftTable[s][1], e.z + kShiftTable[s][2]);
+                const bool occ = n >= 0 && (table_[static_cast<size_t>(n)].val & 0xffu) != 0;
+                if (occ != (((e.nbr >> s) & 1u) != 0)) ++bad;
+                if (occ && e.nb[s] != (table_[static_cast<size_t>(n)].val >> 8)) ++bad;
+                if (count && n < 0) ++bad;  // halo completeness around occupied voxels
+            }
+        }
+        if (occupied != n_voxels_ || points != n_points_ || entries != n_entries_ || dead != n_dead_) ++bad;
+        return bad;
+    }
+
 private:
     static constexpr size_t kMinTable = 1024;
     int32_t to_voxel(double c) const { return static_cast<int32_t>(std::floor(c / voxel_size_)); }  // PointToVoxel, App. A.1

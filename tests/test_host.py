@@ -125,3 +125,29 @@ def test_synthetic_generator_is_deterministic_and_sized():
     assert np.abs(guess - s["true_pose"]).max() > 1e-4
     np.testing.assert_allclose(guess, okicp.se3_mul(s["last_pose"], s["rel_odom"]), atol=1e-14)
     np.testing.assert_allclose(syn.pose_act(guess, s["frame"][:50]), okicp.se3_act(guess, s["frame"][:50]), atol=1e-12)
+
+
+def test_table_invariants_under_random_updates():
+    """Neighbour masks, bucket records, halo entries, the fp32 mirror and the counters stay consistent through random
+    AddPoints / Update(pose) / RemovePointsFarFromLocation / Clear sequences, incl. re-hashes and bucket re-use."""
+    rng = np.random.default_rng(123)
+    for vs, cap, md in ((1.0, 20, 15.0), (0.25, 3, 6.0), (2.0, 1, 30.0)):
+        g, o = K.VoxelHashMap(vs, md, cap), okicp.VoxelHashMap(vs, md, cap)
+        assert g.check() == 0
+        centre = np.zeros(3)
+        for step in range(40):
+            op = rng.integers(0, 10)
+            pts = centre + rng.normal(0, md / 2, (int(rng.integers(1, 1500)), 3)) * np.array([1, 1, 0.15])
+            if op < 5:
+                g.AddPoints(pts), o.AddPoints(pts)
+            elif op < 8:
+                centre = centre + rng.normal(0, md / 4, 3) * np.array([1, 1, 0])
+                pose = syn.planar_pose(centre[0], centre[1], rng.uniform(-3, 3))
+                g.Update(pts - centre, pose), o.Update(pts - centre, pose)
+            elif op < 9:
+                g.RemovePointsFarFromLocation(centre), o.RemovePointsFarFromLocation(centre)
+            else:
+                g.Clear(), o.Clear()
+            assert g.check() == 0, "step %d op %d" % (step, op)
+            assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels())
+        np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
