@@ -62,6 +62,8 @@ _SIGNATURES = {
     "kicp_map_remove_far": (C.c_int, [C.c_void_p, _dp]),
     "kicp_map_update_origin": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
     "kicp_map_update_pose": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
+    "kicp_map_update_pose_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _dp]),
+    "kicp_map_last_update_on_device": (C.c_int, [C.c_void_p]),
     "kicp_map_num_points": (C.c_size_t, [C.c_void_p]),
     "kicp_map_num_voxels": (C.c_size_t, [C.c_void_p]),
     "kicp_map_pointcloud": (C.c_size_t, [C.c_void_p, _dp, C.c_size_t]),
@@ -168,6 +170,13 @@ class VoxelHashMap:
             _check(lib().kicp_map_update_origin(self._h, p, a.size // 3, q))
         else:
             raise ValueError("Update expects a 7-vector pose or a 3-vector origin")
+
+    def UpdateDevice(self, device_frame, pose):
+        """Update(points, pose) with the points already in HBM (DeviceFrame / PreSteps.frame); returns True if it ran on
+        the GPU, False if the host fallback (table or pool growth) was taken."""
+        _, q = _d(pose)
+        _check(lib().kicp_map_update_pose_device(self._h, device_frame.device, device_frame.ptr, device_frame.n, q))
+        return bool(lib().kicp_map_last_update_on_device(self._h))
 
     def num_points(self):
         return lib().kicp_map_num_points(self._h)

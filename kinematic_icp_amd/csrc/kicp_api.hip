@@ -20,6 +20,7 @@
 #include "../../include/kicp.h"
 #include "kicp_host_map.hpp"
 #include "kicp_kernels.hpp"
+#include "kicp_mapdev.hpp"
 #include "kicp_pre.hpp"
 
 namespace {
@@ -103,12 +104,25 @@ struct DeviceMirror {
     size_t last_upload_bytes = 0;
     int last_upload_full = 1;
     MapView view{};
+    // device-side maintenance (kicp_mapdev.hpp): per-slot and per-update scratch
+    unsigned long long *d_keys64 = nullptr;
+    uint32_t *d_cnt = nullptr, *d_seg_start = nullptr, *d_free_list = nullptr;
+    DevMapCounters *d_ctr = nullptr;
+    size_t aux_slots = 0, free_cap = 0;
+    double *d_world = nullptr;
+    uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
+    size_t upd_cap = 0;
 };
 }  // namespace
 
 struct kicp_map {
     HostMap host;
     DeviceMirror mirror;
+    // set while the HBM copy is newer than the host copy (after a device-side Update); the host copy is refreshed on
+    // demand by ensure_host_current().  Counters of the device state for the cheap queries:
+    bool device_ahead = false;
+    DevMapCounters dev{};
+    int last_update_on_device = 0;
     kicp_map(double vs, double md, uint32_t cap) : host(vs, md, cap) {}
 };
 
@@ -175,6 +189,42 @@ int set_device(int device) {
     return KICP_OK;
 }
 
+int ensure_host_current(kicp_map *map);
+
+// per-slot helper arrays, free list and counters of the device-side maintenance, rebuilt after every upload
+int sync_aux(kicp_map *map, hipStream_t stream) {
+    DeviceMirror &mr = map->mirror;
+    const HostMap &h = map->host;
+    const size_t slots = h.table().size();
+    if (slots != mr.aux_slots) {
+        hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start);
+        mr.d_keys64 = nullptr, mr.d_cnt = nullptr, mr.d_seg_start = nullptr;
+        HIP_TRY(hipMalloc(&mr.d_keys64, slots * 8));
+        HIP_TRY(hipMalloc(&mr.d_cnt, slots * 4));
+        HIP_TRY(hipMalloc(&mr.d_seg_start, slots * 4));
+        HIP_TRY(hipMemsetAsync(mr.d_cnt, 0, slots * 4, stream));
+        mr.aux_slots = slots;
+    }
+    const size_t bucket_cap = mr.pool_doubles / (static_cast<size_t>(h.cap()) * 3);
+    if (bucket_cap > mr.free_cap) {
+        hipFree(mr.d_free_list);
+        mr.d_free_list = nullptr;
+        HIP_TRY(hipMalloc(&mr.d_free_list, (bucket_cap + 1) * 4));
+        mr.free_cap = bucket_cap;
+    }
+    if (!mr.d_ctr) HIP_TRY(hipMalloc(&mr.d_ctr, sizeof(DevMapCounters)));
+    hipLaunchKernelGGL(k_build_keys64, dim3(static_cast<uint32_t>(std::min<size_t>((slots + 255) / 256, 4096))), dim3(256), 0, stream, mr.d_table,
+                       static_cast<uint32_t>(slots), mr.d_keys64);
+    DevMapCounters c{};
+    c.n_points = h.num_points(), c.n_voxels = static_cast<uint32_t>(h.num_voxels()), c.n_entries = static_cast<uint32_t>(h.num_entries());
+    c.n_buckets_hi = static_cast<uint32_t>(h.buckets_in_use_hi()), c.free_count = static_cast<uint32_t>(h.free_list().size());
+    if (c.free_count) HIP_TRY(hipMemcpyAsync(mr.d_free_list, h.free_list().data(), c.free_count * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(mr.d_ctr, &c, sizeof c, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    map->dev = c;
+    return KICP_OK;
+}
+
 // scatter `rows` staged rows of `row_words` 8-byte words each into dst at the given row indices
 int upload_rows(DeviceMirror &mr, const std::vector<uint2> &staged, const std::vector<uint32_t> &index, uint32_t row_words, void *dst,
                 hipStream_t stream) {
@@ -206,6 +256,10 @@ int upload_rows(DeviceMirror &mr, const std::vector<uint2> &staged, const std::v
 int map_sync(kicp_map *map, int device, hipStream_t stream) {
     DeviceMirror &mr = map->mirror;
     HostMap &h = map->host;
+    if (map->device_ahead) {
+        if (mr.device == device) return KICP_OK;  // the HBM copy is the current one
+        if (int rc = ensure_host_current(map)) return rc;
+    }
     if (mr.device == device && mr.synced_epoch == h.epoch()) return KICP_OK;
     if (int rc = set_device(device)) return rc;
     if (mr.device != device && mr.device >= 0) {  // mirror lives on another GPU: drop it
@@ -271,9 +325,130 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
         if (int rc = upload_rows(mr, staged, db, cap * 2, mr.d_pool32, stream)) return rc;
     }
     mr.last_upload_full = full ? 1 : 0;
+    if (int rc = sync_aux(map, stream)) return rc;
     h.mark_synced(full);
     mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, h.voxel_size()};
     mr.synced_epoch = h.epoch(), mr.synced_generation = h.generation(), mr.live_slots = slots;
+    return KICP_OK;
+}
+
+// bring the host copy up to date after device-side updates: same layouts, so this is a plain download
+int ensure_host_current(kicp_map *map) {
+    if (!map->device_ahead) return KICP_OK;
+    DeviceMirror &mr = map->mirror;
+    if (int rc = set_device(mr.device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    DevMapCounters c{};
+    HIP_TRY(hipMemcpy(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost));
+    const uint32_t cap = map->host.cap();
+    std::vector<Slot> table(mr.live_slots);
+    std::vector<double> pool(static_cast<size_t>(c.n_buckets_hi) * cap * 3);
+    std::vector<float> pool32(static_cast<size_t>(c.n_buckets_hi) * cap * 4);
+    std::vector<uint32_t> free_list(c.free_count);
+    HIP_TRY(hipMemcpy(table.data(), mr.d_table, table.size() * sizeof(Slot), hipMemcpyDeviceToHost));
+    if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), mr.d_pool, pool.size() * 8, hipMemcpyDeviceToHost));
+    if (!pool32.empty()) HIP_TRY(hipMemcpy(pool32.data(), mr.d_pool32, pool32.size() * 4, hipMemcpyDeviceToHost));
+    if (!free_list.empty()) HIP_TRY(hipMemcpy(free_list.data(), mr.d_free_list, free_list.size() * 4, hipMemcpyDeviceToHost));
+    map->host.Adopt(std::move(table), std::move(pool), std::move(pool32), c.n_buckets_hi, std::move(free_list));
+    map->host.mark_synced(true);
+    mr.synced_epoch = map->host.epoch(), mr.synced_generation = map->host.generation();  // the mirror already holds this state
+    map->device_ahead = false;
+    return KICP_OK;
+}
+
+// make the device pools (and the free-list stack) hold at least `want_buckets` buckets, keeping their contents
+int grow_pools(kicp_map *map, size_t want_buckets) {
+    DeviceMirror &mr = map->mirror;
+    const uint32_t cap = map->host.cap();
+    const size_t have = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
+    if (want_buckets <= have && have <= mr.free_cap) return KICP_OK;
+    const size_t buckets = std::max(want_buckets + want_buckets / 2 + 1024, have);
+    const size_t doubles = buckets * cap * 3;
+    double *np = nullptr;
+    float4 *np32 = nullptr;
+    uint32_t *nf = nullptr;
+    HIP_TRY(hipMalloc(&np, doubles * sizeof(double)));
+    HIP_TRY(hipMalloc(&np32, doubles / 3 * sizeof(float4)));
+    HIP_TRY(hipMalloc(&nf, (buckets + 1) * 4));
+    if (mr.d_pool) HIP_TRY(hipMemcpy(np, mr.d_pool, mr.pool_doubles * sizeof(double), hipMemcpyDeviceToDevice));
+    if (mr.d_pool32) HIP_TRY(hipMemcpy(np32, mr.d_pool32, mr.pool_doubles / 3 * sizeof(float4), hipMemcpyDeviceToDevice));
+    if (mr.d_free_list && mr.free_cap) HIP_TRY(hipMemcpy(nf, mr.d_free_list, std::min(mr.free_cap, buckets) * 4, hipMemcpyDeviceToDevice));
+    hipFree(mr.d_pool), hipFree(mr.d_pool32), hipFree(mr.d_free_list);
+    mr.d_pool = np, mr.d_pool32 = np32, mr.d_free_list = nf, mr.pool_doubles = doubles, mr.free_cap = buckets;
+    mr.view.pool = mr.d_pool, mr.view.pool32 = mr.d_pool32;
+    return KICP_OK;
+}
+
+int ensure_update_scratch(DeviceMirror &mr, size_t n) {
+    if (n <= mr.upd_cap) return KICP_OK;
+    hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
+    mr.d_world = nullptr, mr.d_slot_of = nullptr, mr.d_order = nullptr, mr.d_touched = nullptr;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc(&mr.d_world, cap * 24));
+    HIP_TRY(hipMalloc(&mr.d_slot_of, cap * 4));
+    HIP_TRY(hipMalloc(&mr.d_order, cap * 4));
+    HIP_TRY(hipMalloc(&mr.d_touched, cap * 4));
+    mr.upd_cap = cap;
+    return KICP_OK;
+}
+
+// VoxelHashMap::Update(points, pose) with the points already in HBM.  Runs on the device whenever the table and the
+// pools have room (the common case); otherwise - first frames, table growth - falls back to the host map, which also
+// re-hashes with generous head-room so that the following frames stay on the device.
+int map_update_device(kicp_map *map, int device, const double *d_points, size_t n, const Pose &pose) {
+    DeviceMirror &mr = map->mirror;
+    map->last_update_on_device = 0;
+    auto host_fallback = [&]() -> int {
+        std::vector<double> pts(3 * n);
+        if (n) HIP_TRY(hipMemcpy(pts.data(), d_points, n * 24, hipMemcpyDeviceToHost));
+        if (int rc = ensure_host_current(map)) return rc;
+        map->host.ReserveEntries(32 * n + 1024);
+        return map->host.Update(pts.data(), n, pose) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
+    };
+    if (n == 0 || n > 0x7FFFFFF0ull / 3) return host_fallback();
+    if (int rc = set_device(device)) return rc;
+    if (int rc = map_sync(map, device, nullptr)) return rc;
+    const uint32_t cap = map->host.cap();
+    // room for the points' own voxels: <= n new buckets (the pools grow on the device) and <= n new table entries
+    // without leaving the probing regime (the table only grows on the host)
+    if (int rc = grow_pools(map, map->dev.n_buckets_hi + n)) return rc;
+    const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
+    if ((map->dev.n_entries + n) * 2 > slots) return host_fallback();
+    if (int rc = ensure_update_scratch(mr, n)) return rc;
+    UpdateParams up{};
+    up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, static_cast<uint32_t>(bucket_cap),
+                  map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
+    up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
+    up.touched = mr.d_touched;
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched + error
+    hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
+    DevMapCounters c{};
+    HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries
+    if (c.error) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
+    // every newly occupied voxel may add up to 26 halo entries: only continue with head-room, else let the host grow
+    const size_t new_entries = c.n_entries - map->dev.n_entries;
+    map->dev = c;
+    if ((c.n_entries + 26 * new_entries) * 4 > slots * 3) {
+        // undo nothing: the extra entries are harmless halo entries; the per-slot counters must be cleared though
+        HIP_TRY(hipMemsetAsync(mr.d_cnt, 0, slots * 4, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return host_fallback();
+    }
+    hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
+    hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
+    hipLaunchKernelGGL(k_up_apply, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
+    hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((slots + 255) / 256, 8192))), dim3(256), 0, st, up.m, pose.tx,
+                       pose.ty, pose.tz);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
+    map->dev = c;
+    map->last_update_on_device = 1;
     return KICP_OK;
 }
 
@@ -455,7 +630,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (stats) std::memset(stats, 0, sizeof(*stats));
     // current_estimate = last_robot_pose * relative_wheel_odometry   (Registration.cpp:156)
     const Pose T0 = pose_mul(pose_from(last_pose_qt), pose_from(rel_odom_qt));
-    if (map->host.Empty()) {  // Registration.cpp:157
+    if (kicp_map_empty(map)) {  // Registration.cpp:157
         pose_to(T0, out_pose_qt);
         if (stats) stats->empty_map = 1;
         return KICP_OK;
@@ -659,39 +834,65 @@ void kicp_map_destroy(kicp_map *map) {
         if (map->mirror.d_pool32) hipFree(map->mirror.d_pool32);
         if (map->mirror.d_stage) hipFree(map->mirror.d_stage);
         if (map->mirror.d_index) hipFree(map->mirror.d_index);
+        DeviceMirror &mr = map->mirror;
+        hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
+        hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
     }
     delete map;
 }
 int kicp_map_clear(kicp_map *map) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
+    map->device_ahead = false;  // whatever the device holds is obsolete now
     map->host.Clear();
     return KICP_OK;
 }
-int kicp_map_empty(const kicp_map *map) { return (!map || map->host.Empty()) ? 1 : 0; }
+int kicp_map_empty(const kicp_map *map) {
+    if (!map) return 1;
+    return (map->device_ahead ? map->dev.n_voxels == 0 : map->host.Empty()) ? 1 : 0;
+}
 int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n) {
     if (!map || (!xyz && n)) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = ensure_host_current(map)) return rc;
     return map->host.AddPoints(xyz, n) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
 int kicp_map_remove_far(kicp_map *map, const double origin[3]) {
     if (!map || !origin) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = ensure_host_current(map)) return rc;
     map->host.RemovePointsFarFromLocation(origin);
     return KICP_OK;
 }
 int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]) {
     if (!map || (!xyz && n) || !origin) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = ensure_host_current(map)) return rc;
     return map->host.Update(xyz, n, origin) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
 int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose_qt[7]) {
     if (!map || (!xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = ensure_host_current(map)) return rc;
     return map->host.Update(xyz, n, pose_from(pose_qt)) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
-size_t kicp_map_num_points(const kicp_map *map) { return map ? map->host.num_points() : 0; }
-size_t kicp_map_num_voxels(const kicp_map *map) { return map ? map->host.num_voxels() : 0; }
+int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]) {
+    if (!map || (!d_points_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    return map_update_device(map, device, d_points_xyz, n, pose_from(pose_qt));
+}
+int kicp_map_last_update_on_device(const kicp_map *map) { return map ? map->last_update_on_device : 0; }
+size_t kicp_map_num_points(const kicp_map *map) {
+    if (!map) return 0;
+    return map->device_ahead ? static_cast<size_t>(map->dev.n_points) : map->host.num_points();
+}
+size_t kicp_map_num_voxels(const kicp_map *map) {
+    if (!map) return 0;
+    return map->device_ahead ? map->dev.n_voxels : map->host.num_voxels();
+}
 size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points) {
     if (!map) return 0;
+    if (ensure_host_current(const_cast<kicp_map *>(map)) != KICP_OK) return 0;  // logically const: refreshes the host copy
     return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
 }
-size_t kicp_map_check(const kicp_map *map) { return map ? map->host.CheckInvariants() : 1; }
+size_t kicp_map_check(const kicp_map *map) {
+    if (!map || ensure_host_current(const_cast<kicp_map *>(map)) != KICP_OK) return 1;
+    return map->host.CheckInvariants();
+}
 int kicp_map_sync(kicp_map *map, int device) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (int rc = set_device(device)) return rc;
@@ -705,7 +906,7 @@ int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full) {
 int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist) {
     if (!map || (!queries_xyz && n) || !out_nn_xyz || !out_dist) return fail(KICP_ERR_ARG, "null argument");
     if (n == 0) return KICP_OK;
-    if (map->host.Empty()) {
+    if (kicp_map_empty(map)) {
         for (size_t i = 0; i < n; ++i) out_nn_xyz[3 * i] = out_nn_xyz[3 * i + 1] = out_nn_xyz[3 * i + 2] = 0.0, out_dist[i] = DBL_MAX;
         return KICP_OK;
     }
@@ -826,7 +1027,7 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
 int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
                   const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
     if (!reg || !map || (!frame_xyz && n)) return fail(KICP_ERR_ARG, "null argument");
-    if (!map->host.Empty() && n) {
+    if (!kicp_map_empty(map) && n) {
         if (int rc = set_device(reg->device)) return rc;
         if (int rc = ensure_frame(reg, n)) return rc;
         HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
@@ -852,7 +1053,7 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     for (int i = 0; i < 7; ++i) out_sums[i] = 0.0;
     if (out_words)
         for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
-    if (map->host.Empty() || n == 0) return KICP_OK;
+    if (kicp_map_empty(map) || n == 0) return KICP_OK;
     if (int rc = set_device(reg->device)) return rc;
     if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
     if (int rc = ensure_frame(reg, n)) return rc;

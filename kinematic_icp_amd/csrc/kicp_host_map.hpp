@@ -39,6 +39,32 @@ public:
     const std::vector<float> &pool32() const { return pool32_; }  // (x,y,z,0) offsets from the voxel corner, stride cap*4
     size_t buckets_in_use_hi() const { return n_buckets_hi_; }  // pool prefix that may hold live buckets
 
+    // ---- hand-over with the device-side maintenance (kicp_mapdev.hpp) ---------------------------------------------------
+    const std::vector<uint32_t> &free_list() const { return free_; }
+    size_t num_entries() const { return n_entries_; }
+    // make room so that `extra_entries` more table entries keep the load factor <= 0.25 (re-hashes if necessary)
+    void ReserveEntries(size_t extra_entries) {
+        size_t want = table_.size();
+        while ((n_entries_ + extra_entries) * 4 > want) want *= 2;
+        if (want != table_.size()) rebuild(want), ++epoch_;
+    }
+    // take over the state the device produced (same layouts): table, pools, free list; counters are recounted
+    void Adopt(std::vector<Slot> &&table, std::vector<double> &&pool, std::vector<float> &&pool32, size_t n_buckets_hi,
+               std::vector<uint32_t> &&free_list) {
+        table_ = std::move(table), pool_ = std::move(pool), pool32_ = std::move(pool32), free_ = std::move(free_list);
+        n_buckets_hi_ = n_buckets_hi;
+        n_voxels_ = n_points_ = n_entries_ = n_dead_ = 0;
+        for (const Slot &e : table_) {
+            if (e.val == kEmptyVal) continue;
+            ++n_entries_;
+            const uint32_t c = e.val & 0xffu;
+            if (c) ++n_voxels_, n_points_ += c;
+            else if (e.nbr == 0) ++n_dead_;
+        }
+        slot_flag_.assign(table_.size(), 0), bucket_flag_.assign(n_buckets_hi_ + 1024, 0), dirty_slots_.clear(), dirty_buckets_.clear();
+        ++generation_, ++epoch_;
+    }
+
     // ---- change tracking for the HBM mirror (delta upload) ----------------------------------------------------------
     // generation() changes whenever slot positions change wholesale (Clear, re-hash): the mirror must then be re-sent
     // in full.  Otherwise dirty_slots()/dirty_buckets() list what changed since the last mark_synced().

@@ -1,0 +1,240 @@
+// kicp_mapdev.hpp -- VoxelHashMap::Update(points, pose) on the GPU (kiss-icp v1.2.0
+// core/VoxelHashMap.cpp: transform, AddPoints, RemovePointsFarFromLocation; call site pipeline/KinematicICP.cpp:79).
+//
+// AddPoints is order dependent (first come first kept: a point is dropped when its voxel is full or an earlier point
+// of the same voxel lies closer than map_resolution), but the dependence never crosses a voxel.  So the new points are
+// grouped by voxel and every touched voxel is processed by ONE thread that walks its group in input-index order with
+// the reference's fp64 arithmetic: the accepted set and the order inside each bucket are exactly the sequential
+// reference's, while voxels proceed in parallel.  Table slots are claimed with a 64-bit CAS on a parallel array of
+// packed voxel keys (voxel coordinates must fit +-2^20); first-time occupation updates the 27 neighbour masks / bucket
+// records with atomics, creating halo entries on demand.  Only what the host map would do is done; table growth and
+// dead-entry cleanup stay host-side fallbacks (kicp_api.hip).
+#pragma once
+#include "kicp_common.hpp"
+#include "kicp_se3.hpp"
+
+namespace kicp {
+
+constexpr unsigned long long kEmptyKey64 = ~0ull;
+
+struct DevMapCounters {
+    unsigned long long n_points;
+    uint32_t n_voxels, n_entries, n_buckets_hi, free_count;
+    uint32_t touched, error, pad0, pad1;
+};
+
+struct DevMap {
+    Slot *table;
+    unsigned long long *keys64;  // packed key of every live entry, kEmptyKey64 otherwise (find-or-insert by CAS)
+    uint32_t mask;
+    double *pool;
+    float4 *pool32;
+    uint32_t cap;
+    uint32_t bucket_capacity;    // buckets the pools can hold
+    double voxel_size, max_distance;
+    uint32_t *free_list;         // stack of reusable bucket ids
+    uint32_t *cnt;               // per slot: new points of the running update (zero between updates)
+    uint32_t *seg_start;         // per slot: start of the voxel's group in `order`
+    DevMapCounters *ctr;
+};
+
+struct UpdateParams {
+    DevMap m;
+    const double *in;  // points in the local frame (device)
+    uint32_t n;
+    Pose pose;
+    double *world;     // [n*3] transformed points
+    uint32_t *slot_of; // [n]
+    uint32_t *order;   // [n] point indices grouped by voxel
+    uint32_t *touched; // [n] slots that received points
+};
+
+__device__ __forceinline__ unsigned long long pack_key64(int32_t x, int32_t y, int32_t z, bool &ok) {
+    const int lim = 1 << 20;
+    ok = x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim;
+    return (static_cast<unsigned long long>(static_cast<uint32_t>(z + lim) & 0x1FFFFFu) << 42) |
+           (static_cast<unsigned long long>(static_cast<uint32_t>(y + lim) & 0x1FFFFFu) << 21) |
+           static_cast<unsigned long long>(static_cast<uint32_t>(x + lim) & 0x1FFFFFu);
+}
+
+// slot of voxel (x,y,z); creates a halo entry when absent.  Same probe sequence as the host map (voxel_hash, linear).
+__device__ __forceinline__ uint32_t dev_find_or_insert(const DevMap &m, int32_t x, int32_t y, int32_t z) {
+    bool ok;
+    const unsigned long long key = pack_key64(x, y, z, ok);
+    if (!ok) m.ctr->error = 1u;
+    uint32_t h = voxel_hash(x, y, z) & m.mask;
+    for (;;) {
+        const unsigned long long seen = atomicCAS(m.keys64 + h, kEmptyKey64, key);
+        if (seen == kEmptyKey64) {  // this thread owns the new entry: key fields and the halo marker (nbr is already 0)
+            m.table[h].x = x, m.table[h].y = y, m.table[h].z = z;
+            m.table[h].val = kHaloVal;
+            atomicAdd(&m.ctr->n_entries, 1u);
+            return h;
+        }
+        if (seen == key) return h;
+        h = (h + 1) & m.mask;
+    }
+}
+// read-only lookup; 0xFFFFFFFF when the voxel has no entry
+__device__ __forceinline__ uint32_t dev_find(const DevMap &m, int32_t x, int32_t y, int32_t z) {
+    bool ok;
+    const unsigned long long key = pack_key64(x, y, z, ok);
+    uint32_t h = voxel_hash(x, y, z) & m.mask;
+    for (;;) {
+        const unsigned long long seen = m.keys64[h];
+        if (seen == kEmptyKey64) return 0xFFFFFFFFu;
+        if (seen == key) return h;
+        h = (h + 1) & m.mask;
+    }
+}
+
+// keys64 from the table (after every host -> device upload)
+__global__ __launch_bounds__(256) void k_build_keys64(const Slot *table, uint32_t slots, unsigned long long *keys64) {
+    for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
+        bool ok;
+        keys64[h] = table[h].val == kEmptyVal ? kEmptyKey64 : pack_key64(table[h].x, table[h].y, table[h].z, ok);
+    }
+}
+
+// 1. transform, find/claim the voxel's slot, count the voxel's new points
+__global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    double rx, ry, rz;
+    quat_rotate(p.pose, p.in[3 * i], p.in[3 * i + 1], p.in[3 * i + 2], rx, ry, rz);
+    const double wx = rx + p.pose.tx, wy = ry + p.pose.ty, wz = rz + p.pose.tz;  // pose * point
+    p.world[3 * i] = wx, p.world[3 * i + 1] = wy, p.world[3 * i + 2] = wz;
+    const double vs = p.m.voxel_size;
+    const uint32_t h = dev_find_or_insert(p.m, static_cast<int32_t>(floor(wx / vs)), static_cast<int32_t>(floor(wy / vs)),
+                                          static_cast<int32_t>(floor(wz / vs)));
+    p.slot_of[i] = h;
+    if (atomicAdd(p.m.cnt + h, 1u) == 0u) p.touched[atomicAdd(&p.m.ctr->touched, 1u)] = h;
+}
+
+// 2. exclusive scan of the touched voxels' counts -> group starts; counts are zeroed to serve as fill cursors
+__global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t n_touched = p.m.ctr->touched;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < n_touched; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t h = 0, c = 0;
+        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (j < n_touched) p.m.seg_start[h] = before + incl - c, p.m.cnt[h] = 0;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+// 3. scatter the point indices into their voxel's group (any order; the apply step walks a group by ascending index)
+__global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const uint32_t h = p.slot_of[i];
+    p.order[p.m.seg_start[h] + atomicAdd(p.m.cnt + h, 1u)] = i;
+}
+
+// 4. one thread per touched voxel: the reference's AddPoints rule over the voxel's new points in input order
+__global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    const DevMap &m = p.m;
+    if (t >= m.ctr->touched) return;
+    const uint32_t h = p.touched[t];
+    const uint32_t g = m.cnt[h], start = m.seg_start[h];
+    m.cnt[h] = 0;  // leave the per-slot scratch clean for the next update
+    Slot &e = m.table[h];
+    const uint32_t old_count = e.val & 0xffu;
+    uint32_t count = old_count, bucket = e.val >> 8;
+    if (old_count == 0) {  // first points of this voxel: take a bucket (re-use a freed one if any)
+        const uint32_t f = atomicSub(&m.ctr->free_count, 1u);
+        if (f != 0u && f <= m.bucket_capacity) {
+            bucket = m.free_list[f - 1];
+        } else {
+            atomicAdd(&m.ctr->free_count, 1u);
+            bucket = atomicAdd(&m.ctr->n_buckets_hi, 1u);
+            if (bucket >= m.bucket_capacity) {  // cannot happen: the host checked the capacity beforehand
+                m.ctr->error = 2u;
+                return;
+            }
+        }
+    }
+    const double vs = m.voxel_size;
+    const double map_resolution = sqrt(vs * vs / m.cap);
+    double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
+    float4 *b32 = m.pool32 + static_cast<size_t>(bucket) * m.cap;
+    // walk the group in ascending input index (selection; groups are small: the pipeline feeds <= 8 points per voxel)
+    uint32_t last = 0;
+    bool first = true;
+    for (uint32_t step = 0; step < g && count < m.cap; ++step) {
+        uint32_t idx = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < g; ++k) {
+            const uint32_t c = p.order[start + k];
+            if ((first || c > last) && c < idx) idx = c;
+        }
+        first = false, last = idx;
+        const double px = p.world[3 * idx], py = p.world[3 * idx + 1], pz = p.world[3 * idx + 2];
+        bool too_close = false;
+        for (uint32_t k = 0; k < count; ++k) {
+            const double dx = b[3 * k] - px, dy = b[3 * k + 1] - py, dz = b[3 * k + 2] - pz;
+            if (sqrt(dx * dx + dy * dy + dz * dz) < map_resolution) {
+                too_close = true;
+                break;
+            }
+        }
+        if (too_close) continue;
+        b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
+        b32[count] = make_float4(static_cast<float>(px - e.x * vs), static_cast<float>(py - e.y * vs), static_cast<float>(pz - e.z * vs), 0.f);
+        ++count;
+    }
+    if (count == old_count) return;
+    reinterpret_cast<uint32_t *>(b32)[3] = count;  // the bucket's count travels in the w of point 0
+    e.val = (bucket << 8) | count;
+    atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
+    if (old_count == 0) {  // newly occupied: tell the 27 voxels that see this one (U + shift[s] == this  <=>  U = this - shift[s])
+        atomicAdd(&m.ctr->n_voxels, 1u);
+        for (int s = 0; s < 27; ++s) {
+            const uint32_t u = dev_find_or_insert(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
+            m.table[u].nb[s] = bucket;
+            atomicOr(&m.table[u].nbr, 1u << s);
+        }
+    }
+}
+
+// 5. RemovePointsFarFromLocation(origin): a voxel goes when its FIRST point is >= max_distance away
+__global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, double oy, double oz) {
+    const uint32_t slots = m.mask + 1;
+    const double max_distance2 = m.max_distance * m.max_distance;
+    for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
+        Slot &e = m.table[h];
+        const uint32_t val = e.val;
+        if (val == kEmptyVal || (val & 0xffu) == 0u) continue;
+        const uint32_t bucket = val >> 8;
+        const double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
+        const double dx = b[0] - ox, dy = b[1] - oy, dz = b[2] - oz;
+        if (!(dx * dx + dy * dy + dz * dz >= max_distance2)) continue;
+        e.val = kHaloVal;
+        m.free_list[atomicAdd(&m.ctr->free_count, 1u)] = bucket;
+        atomicSub(&m.ctr->n_voxels, 1u);
+        atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val & 0xffu) + 1ull);
+        for (int s = 0; s < 27; ++s) {
+            const uint32_t u = dev_find(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
+            if (u != 0xFFFFFFFFu) atomicAnd(&m.table[u].nbr, ~(1u << s));
+        }
+    }
+}
+
+}  // namespace kicp
