@@ -3,7 +3,8 @@
 // surface (RegisterFrame, SetPose, LocalMap, VoxelMap, pose), so ros/src/.../LidarOdometryServer.cpp compiles
 // against it unchanged.  The ICP (registration_ + local_map_) and - unless KICP_HOST_PRESTEPS is defined - the
 // pre-steps (deskew + crop + transform, two-level voxel downsample: kicp_pre_*) run on the MI355X; the registration
-// source never leaves HBM.  The threshold bookkeeping and the order-dependent map insertion stay on the host
+// source and the frame that goes into the map never leave HBM, and the map update itself (kiss-icp Update: ordered
+// insertion + far-voxel removal) runs there too.  The threshold bookkeeping stays on the host
 // (SURVEY.md section 8f rows 1, 2 and 4).
 #pragma once
 #include <Eigen/Core>
@@ -79,13 +80,13 @@ public:
         const double tau_dev = correspondence_threshold_.ComputeThreshold();
         const auto new_pose_dev = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
                                                                         relative_odometry, tau_dev);
-        Vector3dVector frame_in_base(n_frame), down(n_down), src(n_source);
+        Vector3dVector frame_in_base(n_frame), src(n_source);
         auto fetch = [&](int b, Vector3dVector &v) {
             kicp_bridge::check(kicp_pre_download(pre_, b, v.empty() ? nullptr : v.front().data(), v.size(), nullptr), "download");
         };
-        fetch(0, frame_in_base), fetch(1, down), fetch(2, src);
+        fetch(0, frame_in_base), fetch(2, src);
         correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose_dev);
-        local_map_.Update(down, new_pose_dev);
+        local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose_dev);
         last_pose_ = new_pose_dev;
         return {frame_in_base, src};
 #else

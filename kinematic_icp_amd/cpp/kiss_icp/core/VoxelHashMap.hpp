@@ -1,5 +1,5 @@
 // kiss_icp/core/VoxelHashMap.hpp -- drop-in for kiss-icp v1.2.0's header of the same path, backed by the
-// MI355X library (host-authoritative map + HBM mirror).  Same struct name, constructor, methods and public
+// MI355X library (host map + HBM mirror, either side may hold the newest state).  Same struct name, constructor, methods and public
 // configuration fields (reference call sites: registration/Registration.cpp:63,74,157,
 // pipeline/KinematicICP.hpp:79,88,92,94-95, pipeline/KinematicICP.cpp:79).
 // Not reproduced: the public `map_` member (a tsl::robin_map; an implementation detail no caller in the
@@ -36,6 +36,12 @@ struct VoxelHashMap {
         double p[7];
         kicp_bridge::to_params(pose, p);
         kicp_bridge::check(kicp_map_update_pose(handle_, kicp_bridge::xyz(points), points.size(), p), "VoxelHashMap::Update");
+    }
+    // Update(points, pose) with the points already in HBM on device_ (e.g. a kicp_pre buffer); backend extension
+    void UpdateDevice(const double *d_points_xyz, size_t n, const Sophus::SE3d &pose) {
+        double p[7];
+        kicp_bridge::to_params(pose, p);
+        kicp_bridge::check(kicp_map_update_pose_device(handle_, device_, d_points_xyz, n, p), "VoxelHashMap::Update");
     }
     void AddPoints(const std::vector<Eigen::Vector3d> &points) {
         kicp_bridge::check(kicp_map_add_points(handle_, kicp_bridge::xyz(points), points.size()), "VoxelHashMap::AddPoints");

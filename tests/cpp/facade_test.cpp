@@ -1,6 +1,7 @@
 // facade_test.cpp -- exercises the drop-in C++ headers exactly the way the reference's callers do
 // (registration: pipeline/KinematicICP.cpp:68-72; pipeline: ros/.../LidarOdometryServer.cpp:105,205-206).
 // Input: a little binary file written by tests/test_facade.py; output: poses as text on stdout.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,6 +70,26 @@ int main(int argc, char **argv) {
             }
             icp.SetPose(Sophus::SE3d());
             printf("after_setpose %zu %d\n", icp.LocalMap().size(), icp.VoxelMap().Empty() ? 1 : 0);
+        } else if (mode == "pipeline_timed") {  // same input file; RegisterFrame alone inside the clock, no map download
+            const auto h = read_doubles(f, 4);
+            kinematic_icp::pipeline::Config cfg;
+            cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
+            kinematic_icp::pipeline::KinematicICP icp(cfg);
+            const auto ext = read_doubles(f, 7);
+            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+                const auto n = read_doubles(f, 1);
+                const auto frame = to_points(read_doubles(f, static_cast<size_t>(n[0]) * 3));
+                const auto stamps = read_doubles(f, static_cast<size_t>(n[0]));
+                const auto delta = read_doubles(f, 7);
+                const auto t0 = std::chrono::steady_clock::now();
+                const auto [deskewed, source] = icp.RegisterFrame(frame, stamps, kicp_bridge::from_params(ext.data()),
+                                                                  kicp_bridge::from_params(delta.data()));
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                printf("frame %d ms %.4f in %zu source %zu map_on_device %d\n", k, ms, deskewed.size(), source.size(),
+                       kicp_map_last_update_on_device(icp.VoxelMap().handle()));
+                print_pose("pose", icp.pose());
+            }
+            printf("map %zu\n", icp.LocalMap().size());
         }
     } catch (const std::exception &e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -1,0 +1,100 @@
+"""Whole-frame timing of the drop-in KinematicICP::RegisterFrame (pre-steps + registration + map update, all on the
+GPU) on a synthetic drive, next to the same frames through the CPU oracle's pieces.  Not the headline metric
+(that is bench.py's registration-only scans/s); this is the number a user of the ROS node sees per frame.
+
+    python tools/bench_pipeline.py [--frames 40] [--beams 64] [--az 2048] [--oracle-frames 5]
+or, keeping the timed process free of this script's memory footprint (what profiles/ quotes):
+    python tools/bench_pipeline.py --dump /tmp/pipe.bin && tests/cpp/facade_test pipeline_timed /tmp/pipe.bin > /tmp/pipe.txt
+    python tools/bench_pipeline.py --check /tmp/pipe.txt --oracle-frames 40
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from kinematic_icp_amd import synthetic as syn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--beams", type=int, default=64)
+    ap.add_argument("--az", type=int, default=2048)
+    ap.add_argument("--voxel", type=float, default=1.0)
+    ap.add_argument("--max-range", type=float, default=100.0)
+    ap.add_argument("--deskew", type=int, default=1)
+    ap.add_argument("--oracle-frames", type=int, default=5)
+    ap.add_argument("--dump", default="", help="only write the input file for tests/cpp/facade_test (e.g. to run it under rocprofv3)")
+    ap.add_argument("--check", default="", help="output of `facade_test pipeline_timed <dump>` to analyse instead of running it here")
+    a = ap.parse_args()
+    import test_facade
+    rng = np.random.Generator(np.random.PCG64(2025))
+    scene = syn.make_scene(rng)
+    dirs = syn.beam_directions(a.beams, a.az)
+    ext = np.concatenate([[0, 0, np.sin(0.05), np.cos(0.05)], [0.3, 0.0, 1.8]])
+    poses, frames, stamps, deltas = [syn.planar_pose(0.0, 0.0, 0.1)], [], [], []
+    for k in range(a.frames):
+        delta_true = syn.planar_pose(0.5, 0.0, np.deg2rad(1.0 + 0.1 * k))
+        poses.append(syn.pose_mul(poses[-1], delta_true))
+        wl = syn.pose_mul(poses[-1], ext)
+        R = syn.quat_to_matrix(wl[:4])
+        t = scene.raycast(wl[4:], dirs @ R.T) + rng.normal(0, 0.01, len(dirs))
+        frames.append(dirs * t[:, None])
+        stamps.append(np.linspace(0.0, 1.0, len(dirs)))
+        deltas.append(syn.pose_mul(delta_true, syn.planar_pose(0.01 * (-1) ** k, 0.0, np.deg2rad(0.1))))
+    with tempfile.TemporaryDirectory() as td:
+        f = a.dump or os.path.join(td, "pipe.bin")
+        with open(os.devnull if a.check else f, "wb") as fh:
+            np.array([len(frames), a.voxel, a.max_range, float(a.deskew)]).tofile(fh)
+            ext.tofile(fh)
+            for fr, st, dl in zip(frames, stamps, deltas):
+                np.array([float(len(fr))]).tofile(fh)
+                np.ascontiguousarray(fr).tofile(fh), st.tofile(fh), dl.tofile(fh)
+        if a.dump:
+            print(test_facade.build_facade(), "pipeline_timed", f)
+            return
+        if a.check:
+            out = open(a.check).read().splitlines()
+        else:
+            out = subprocess.check_output([test_facade.build_facade(), "pipeline_timed", f], text=True).splitlines()
+    ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
+    ondev = np.array([int(l.split()[-1]) for l in out if l.startswith("frame")])
+    for l in out:
+        if not l.startswith("pose"):
+            print(l)
+    steady = ms[len(ms) // 2:]
+    print("GPU RegisterFrame: median %.3f ms (second half), first %.1f ms, map updates on device %d/%d" %
+          (np.median(steady), ms[0], ondev.sum(), len(ondev)))
+    gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
+    if a.oracle_frames:
+        from oracle import okicp
+        omap = okicp.VoxelHashMap(a.voxel, a.max_range, 20)
+        thr = okicp.CorrespondenceThreshold(a.voxel / np.sqrt(20), a.max_range, True, 1.0)
+        reg = okicp.KinematicRegistration()
+        last = okicp.IDENTITY.copy()
+        cpu = []
+        for k in range(min(a.oracle_frames, a.frames)):
+            t0 = time.perf_counter()
+            rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), deltas[k]), ext)
+            pre = okicp.preprocess(frames[k], stamps[k], rel_lidar, a.max_range, 0.0, bool(a.deskew))
+            in_base = okicp.se3_act(ext, pre)
+            down = test_facade._first_seen_downsample(in_base, a.voxel * 0.5)  # the order the device pre-steps emit
+            source = test_facade._first_seen_downsample(down, a.voxel * 1.5)
+            new = reg.ComputeRobotMotion(source, omap, last, deltas[k], thr.ComputeThreshold())
+            thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, deltas[k])), new))
+            omap.Update(down, new)
+            last = new
+            cpu.append((time.perf_counter() - t0) * 1e3)
+            print("frame %d |gpu - oracle| max = %.3g  oracle map %d source %d" % (k, np.abs(gpu_poses[k] - last).max(), omap.num_points(), len(source)))
+        print("CPU oracle pipeline: " + " ".join("%.1f" % c for c in cpu) + " ms/frame (all host cores for the ICP)")
+
+
+if __name__ == "__main__":
+    main()
