@@ -156,6 +156,32 @@ void kicp_pre_destroy(kicp_pre *pre);
 int kicp_pre_preprocess(kicp_pre *pre, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
                         const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range,
                         int deskew, int dst_buffer, size_t *out_n);
+/* PointCloud2 wire-format ingest: the raw message bytes go to the GPU (point_step bytes per
+ * point instead of 32 B of fp64 xyz + stamp) and are decoded there.  Replaces
+ *   ros/src/kinematic_icp_ros/utils/RosUtils.cpp:30-39        PointCloud2ToEigen(msg, T): FLOAT32 x,y,z -> T * Vector3d
+ *   ros/src/kinematic_icp_ros/utils/TimeStampHandler.cpp:57-104  per-point stamp (UINT32 / FLOAT32 / FLOAT64) -> seconds as
+ *                                                             double; values with more than 10 integer digits are ns
+ *   ros/src/kinematic_icp_ros/utils/TimeStampHandler.cpp:106,121-128  min / max and normalisation (t - min) / (max - min)
+ * `data` = msg->data.data(), n_points = width * height, borrowed for the call.  sensor_pose_qt may be NULL (= the identity
+ * LidarOdometryServer.cpp:203 passes).  out_min/max_stamp (seconds; 0 when the cloud has no stamp field or is empty)
+ * are what ProcessTimestamps needs for its begin/end-stamp logic (TimeStampHandler.cpp:111-119).  Any other stamp
+ * datatype -> KICP_ERR_ARG ("timestamp field type not supported", TimeStampHandler.cpp:103). */
+#define KICP_FIELD_UINT32 6  /* sensor_msgs::msg::PointField datatype codes */
+#define KICP_FIELD_FLOAT32 7
+#define KICP_FIELD_FLOAT64 8
+typedef struct kicp_cloud_layout {
+    unsigned int point_step;                  /* msg->point_step */
+    unsigned int offset_x, offset_y, offset_z; /* offsets of the FLOAT32 fields "x", "y", "z" */
+    int stamp_datatype;                       /* 0 = no "t"/"timestamp"/"time"/"stamps" field, else its datatype code */
+    unsigned int offset_stamp;
+} kicp_cloud_layout;
+int kicp_pre_ingest(kicp_pre *pre, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
+                    double *out_min_stamp, double *out_max_stamp);
+/* kicp_pre_preprocess on the ingested cloud (no host input; deskews only if the cloud carried stamps) */
+int kicp_pre_preprocess_ingested(kicp_pre *pre, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
+                                 double min_range, int deskew, int dst_buffer, size_t *out_n);
+/* Download the decoded cloud (fp64 xyz) and its normalised stamps: what PointCloud2ToEigen / ProcessTimestamps return. */
+int kicp_pre_ingested(const kicp_pre *pre, double *out_xyz, double *out_stamps, size_t cap_points, size_t *out_n, int *out_has_stamps);
 /* kiss_icp::VoxelDownsample(buffer src, voxel_size) -> buffer dst: the first point (lowest index) of every voxel, in
  * first-seen order. */
 int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, int dst_buffer, size_t *out_n);

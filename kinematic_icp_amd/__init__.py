@@ -85,6 +85,9 @@ _SIGNATURES = {
     "kicp_pre_destroy": (None, [C.c_void_p]),
     "kicp_pre_preprocess": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
                                       C.POINTER(C.c_size_t)]),
+    "kicp_pre_ingest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp, _dp, _dp]),
+    "kicp_pre_preprocess_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -341,6 +344,15 @@ class KinematicRegistration:
         _check(lib().kicp_reg_set_allreduce(self._h, self._cb, None))
 
 
+class CloudLayout(C.Structure):
+    """kicp_cloud_layout (include/kicp.h): where x, y, z and the per-point stamp sit inside a PointCloud2 record."""
+    _fields_ = [("point_step", C.c_uint), ("offset_x", C.c_uint), ("offset_y", C.c_uint), ("offset_z", C.c_uint),
+                ("stamp_datatype", C.c_int), ("offset_stamp", C.c_uint)]
+
+
+FIELD_UINT32, FIELD_FLOAT32, FIELD_FLOAT64 = 6, 7, 8  # sensor_msgs::msg::PointField datatype codes
+
+
 class PreSteps:
     """The pipeline's pre-steps on the GPU: kiss_icp::Preprocessor::Preprocess + transform_points, kiss_icp::VoxelDownsample
     (pipeline/KinematicICP.cpp:54-62).  Results live in numbered device buffers; frame(b) wraps one for ComputeRobotMotion."""
@@ -363,6 +375,31 @@ class PreSteps:
         n = C.c_size_t()
         _check(lib().kicp_pre_preprocess(self._h, p, a.size // 3, tp, t.size, r, e, max_range, min_range, int(deskew), dst, C.byref(n)))
         return n.value
+
+    def Ingest(self, raw, n_points, point_step, offset_x, offset_y, offset_z, stamp_datatype=0, offset_stamp=0, sensor_pose=None):
+        """PointCloud2 wire-format ingest (RosUtils.cpp:30-39 PointCloud2ToEigen + TimeStampHandler.cpp:57-128): ships the raw
+        message bytes and decodes them on the GPU.  Returns (min_stamp, max_stamp) in seconds (0, 0 without a stamp field)."""
+        buf = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8))
+        layout = CloudLayout(point_step, offset_x, offset_y, offset_z, stamp_datatype, offset_stamp)
+        q = None if sensor_pose is None else _d(sensor_pose)[1]
+        lo, hi = C.c_double(), C.c_double()
+        _check(lib().kicp_pre_ingest(self._h, buf.ctypes.data if buf.size else None, n_points, C.byref(layout), q, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def PreprocessIngested(self, relative_motion, lidar_to_base, max_range, min_range, deskew, dst=0):
+        _, r = _d(relative_motion)
+        _, e = _d(lidar_to_base)
+        n = C.c_size_t()
+        _check(lib().kicp_pre_preprocess_ingested(self._h, r, e, max_range, min_range, int(deskew), dst, C.byref(n)))
+        return n.value
+
+    def ingested(self):
+        """(xyz (n,3) fp64, normalised stamps (n,) or None): what PointCloud2ToEigen / ProcessTimestamps hand to RegisterFrame."""
+        n, has = C.c_size_t(), C.c_int()
+        _check(lib().kicp_pre_ingested(self._h, None, None, 0, C.byref(n), C.byref(has)))
+        xyz, st = np.empty((n.value, 3)), np.empty(n.value)
+        _check(lib().kicp_pre_ingested(self._h, xyz.ctypes.data_as(_dp), st.ctypes.data_as(_dp), n.value, C.byref(n), C.byref(has)))
+        return xyz, (st if has.value else None)
 
     def VoxelDownsample(self, src, voxel_size, dst):
         n = C.c_size_t()

@@ -71,24 +71,11 @@ public:
         double rel_lidar[7], ext[7];
         kicp_bridge::to_params(relative_odometry_in_lidar, rel_lidar);
         kicp_bridge::to_params(lidar_to_base, ext);
-        size_t n_frame = 0, n_down = 0, n_source = 0;
+        size_t n_frame = 0;
         kicp_bridge::check(kicp_pre_preprocess(pre_, kicp_bridge::xyz(frame), frame.size(), timestamps.data(), timestamps.size(), rel_lidar,
                                                ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, 0, &n_frame),
                            "Preprocess");
-        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
-        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
-        const double tau_dev = correspondence_threshold_.ComputeThreshold();
-        const auto new_pose_dev = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
-                                                                        relative_odometry, tau_dev);
-        Vector3dVector frame_in_base(n_frame), src(n_source);
-        auto fetch = [&](int b, Vector3dVector &v) {
-            kicp_bridge::check(kicp_pre_download(pre_, b, v.empty() ? nullptr : v.front().data(), v.size(), nullptr), "download");
-        };
-        fetch(0, frame_in_base), fetch(2, src);
-        correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose_dev);
-        local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose_dev);
-        last_pose_ = new_pose_dev;
-        return {frame_in_base, src};
+        return RegisterPreprocessed(n_frame, relative_odometry);
 #else
         const auto preprocessed_frame = preprocessor_.Preprocess(frame, timestamps, relative_odometry_in_lidar);
         Vector3dVector preprocessed_frame_in_base(preprocessed_frame.size());
@@ -105,6 +92,30 @@ public:
 #endif
     }
 
+#ifndef KICP_HOST_PRESTEPS
+    // ---- backend extension: feed the PointCloud2 bytes directly ----
+    // IngestCloud replaces PointCloud2ToEigen(msg, {}) (RosUtils.cpp:30-39) and the per-point part of
+    // TimeStampHandler::ProcessTimestamps (TimeStampHandler.cpp:57-106,121-128): it returns {cloud has stamps, min stamp,
+    // max stamp} (seconds), which is all ProcessTimestamps' begin/end-stamp logic (:107-119) needs; the decoded points
+    // and normalised stamps stay in HBM.  RegisterIngestedFrame is RegisterFrame on that cloud.
+    std::tuple<bool, double, double> IngestCloud(const void *data, size_t n_points, const kicp_cloud_layout &layout) {
+        double lo = 0.0, hi = 0.0;
+        kicp_bridge::check(kicp_pre_ingest(pre_, data, n_points, &layout, nullptr, &lo, &hi), "IngestCloud");
+        return {layout.stamp_datatype != 0 && n_points != 0, lo, hi};
+    }
+    Vector3dVectorTuple RegisterIngestedFrame(const Sophus::SE3d &lidar_to_base, const Sophus::SE3d &relative_odometry) {
+        const Sophus::SE3d relative_odometry_in_lidar = lidar_to_base.inverse() * relative_odometry * lidar_to_base;
+        double rel_lidar[7], ext[7];
+        kicp_bridge::to_params(relative_odometry_in_lidar, rel_lidar);
+        kicp_bridge::to_params(lidar_to_base, ext);
+        size_t n_frame = 0;
+        kicp_bridge::check(kicp_pre_preprocess_ingested(pre_, rel_lidar, ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, 0,
+                                                        &n_frame),
+                           "Preprocess");
+        return RegisterPreprocessed(n_frame, relative_odometry);
+    }
+#endif
+
     inline void SetPose(const Sophus::SE3d &pose) {
         last_pose_ = pose;
         local_map_.Clear();
@@ -118,6 +129,27 @@ public:
     Sophus::SE3d &pose() { return last_pose_; }
 
 protected:
+#ifndef KICP_HOST_PRESTEPS
+    // pipeline/KinematicICP.cpp:56-84 from the preprocessed frame (pre_ buffer 0) on: downsample twice, register, update
+    // the threshold and the map - all on the device; only the two returned clouds come back to the host.
+    Vector3dVectorTuple RegisterPreprocessed(size_t n_frame, const Sophus::SE3d &relative_odometry) {
+        size_t n_down = 0, n_source = 0;
+        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
+        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
+        const double tau = correspondence_threshold_.ComputeThreshold();
+        const auto new_pose = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
+                                                                     relative_odometry, tau);
+        Vector3dVector frame_in_base(n_frame), src(n_source);
+        auto fetch = [&](int b, Vector3dVector &v) {
+            kicp_bridge::check(kicp_pre_download(pre_, b, v.empty() ? nullptr : v.front().data(), v.size(), nullptr), "download");
+        };
+        fetch(0, frame_in_base), fetch(2, src);
+        correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose);
+        local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose);
+        last_pose_ = new_pose;
+        return {frame_in_base, src};
+    }
+#endif
     Sophus::SE3d last_pose_;
     KinematicRegistration registration_;
     CorrespondenceThreshold correspondence_threshold_;

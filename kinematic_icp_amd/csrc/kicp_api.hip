@@ -1091,6 +1091,12 @@ struct kicp_pre {
     unsigned long long *d_keys = nullptr;
     uint32_t *d_min_index = nullptr;
     size_t cap_n = 0, table_slots = 0;
+    // wire-format ingest: the raw message bytes, the stamps' extrema, what d_in / d_ts currently hold
+    unsigned char *d_raw = nullptr;
+    size_t raw_cap = 0;
+    unsigned long long *d_minmax = nullptr;
+    size_t ingested_n = 0;
+    bool ingested = false, ingested_stamps = false;
 };
 namespace {
 int pre_ensure(kicp_pre *p, size_t n) {
@@ -1135,6 +1141,24 @@ int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *ou
     if (out_n) *out_n = misc[0];
     return KICP_OK;
 }
+// k_preprocess over what d_in / d_ts hold, then compaction into buffer dst
+int pre_run_preprocess(kicp_pre *p, size_t n, bool do_deskew, const double relative_motion_qt[7], const double lidar_to_base_qt[7],
+                       double max_range, double min_range, int dst_buffer, size_t *out_n) {
+    if (n == 0) {
+        p->buf_n[dst_buffer] = 0;
+        if (out_n) *out_n = 0;
+        return KICP_OK;
+    }
+    PreprocessParams pp{};
+    pp.in = p->d_in, pp.timestamps = p->d_ts, pp.n = static_cast<uint32_t>(n), pp.deskew = do_deskew ? 1 : 0;
+    const Pose rel = pose_from(relative_motion_qt);
+    pose_log(rel, pp.omega);
+    pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
+    pp.max_range = max_range, pp.min_range = min_range;
+    pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
+    hipLaunchKernelGGL(k_preprocess, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, p->stream, pp);
+    return pre_compact(p, p->d_staged, n, dst_buffer, out_n);
+}
 }  // namespace
 extern "C" {
 int kicp_pre_create(int device, kicp_pre **out) {
@@ -1161,7 +1185,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
-    hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc);
+    hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -1173,24 +1197,84 @@ int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const do
     const bool do_deskew = deskew && n_timestamps != 0;  // Preprocessing.cpp: `if (deskew_ && !timestamps.empty())`
     if (do_deskew && (!timestamps || n_timestamps < n)) return fail(KICP_ERR_ARG, "one timestamp per point is required for deskewing");
     if (int rc = set_device(p->device)) return rc;
-    if (n == 0) {
-        p->buf_n[dst_buffer] = 0;
-        if (out_n) *out_n = 0;
-        return KICP_OK;
-    }
     if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
-    if (int rc = pre_ensure(p, n)) return rc;
-    HIP_TRY(hipMemcpyAsync(p->d_in, frame_xyz, n * 24, hipMemcpyHostToDevice, p->stream));
-    if (do_deskew) HIP_TRY(hipMemcpyAsync(p->d_ts, timestamps, n * 8, hipMemcpyHostToDevice, p->stream));
-    PreprocessParams pp{};
-    pp.in = p->d_in, pp.timestamps = p->d_ts, pp.n = static_cast<uint32_t>(n), pp.deskew = do_deskew ? 1 : 0;
-    const Pose rel = pose_from(relative_motion_qt);
-    pose_log(rel, pp.omega);
-    pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
-    pp.max_range = max_range, pp.min_range = min_range;
-    pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
-    hipLaunchKernelGGL(k_preprocess, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, p->stream, pp);
-    return pre_compact(p, p->d_staged, n, dst_buffer, out_n);
+    if (n) {
+        if (int rc = pre_ensure(p, n)) return rc;
+        p->ingested = false;  // d_in / d_ts are overwritten
+        HIP_TRY(hipMemcpyAsync(p->d_in, frame_xyz, n * 24, hipMemcpyHostToDevice, p->stream));
+        if (do_deskew) HIP_TRY(hipMemcpyAsync(p->d_ts, timestamps, n * 8, hipMemcpyHostToDevice, p->stream));
+    }
+    return pre_run_preprocess(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, dst_buffer, out_n);
+}
+int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
+                    double *out_min_stamp, double *out_max_stamp) {
+    if (!p || !layout || (!data && n_points)) return fail(KICP_ERR_ARG, "bad argument");
+    const kicp_cloud_layout &L = *layout;
+    const int st = L.stamp_datatype;
+    if (st != 0 && st != KICP_FIELD_UINT32 && st != KICP_FIELD_FLOAT32 && st != KICP_FIELD_FLOAT64)
+        return fail(KICP_ERR_ARG, "timestamp field type not supported");  // TimeStampHandler.cpp:103
+    const uint32_t stamp_bytes = st == KICP_FIELD_FLOAT64 ? 8u : 4u;
+    if (L.point_step == 0 || L.offset_x + 4ull > L.point_step || L.offset_y + 4ull > L.point_step || L.offset_z + 4ull > L.point_step ||
+        (st != 0 && L.offset_stamp + static_cast<unsigned long long>(stamp_bytes) > L.point_step))
+        return fail(KICP_ERR_ARG, "field offsets do not fit inside point_step");
+    if (n_points > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "cloud too large");
+    if (int rc = set_device(p->device)) return rc;
+    p->ingested = true, p->ingested_n = n_points, p->ingested_stamps = st != 0 && n_points != 0;
+    if (out_min_stamp) *out_min_stamp = 0.0;
+    if (out_max_stamp) *out_max_stamp = 0.0;
+    if (n_points == 0) return KICP_OK;
+    if (int rc = pre_ensure(p, n_points)) return rc;
+    const size_t bytes = n_points * static_cast<size_t>(L.point_step);
+    if (bytes > p->raw_cap) {
+        hipFree(p->d_raw);
+        p->d_raw = nullptr, p->raw_cap = 0;
+        HIP_TRY(hipMalloc(&p->d_raw, bytes + bytes / 4 + 4096));
+        p->raw_cap = bytes + bytes / 4 + 4096;
+    }
+    if (!p->d_minmax) HIP_TRY(hipMalloc(&p->d_minmax, 16));
+    const unsigned long long init[2] = {~0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_raw, data, bytes, hipMemcpyHostToDevice, p->stream));
+    IngestParams ip{};
+    ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
+    ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
+    ip.transform = sensor_pose_qt ? 1 : 0;
+    if (sensor_pose_qt) ip.T = pose_from(sensor_pose_qt);
+    ip.out_xyz = p->d_in, ip.out_stamps = p->d_ts, ip.minmax = p->d_minmax;
+    const uint32_t grid = static_cast<uint32_t>((n_points + 255) / 256);
+    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, p->stream, ip);
+    if (st != 0) {
+        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, p->stream, p->d_ts, ip.n, p->d_minmax);
+        unsigned long long mm[2];
+        HIP_TRY(hipMemcpyAsync(mm, p->d_minmax, 16, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (out_min_stamp) *out_min_stamp = ordered_value(mm[0]);
+        if (out_max_stamp) *out_max_stamp = ordered_value(mm[1]);
+    } else {
+        HIP_TRY(hipStreamSynchronize(p->stream));  // `data` is borrowed for the call only
+    }
+    HIP_TRY(hipGetLastError());
+    return KICP_OK;
+}
+int kicp_pre_preprocess_ingested(kicp_pre *p, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
+                                 double min_range, int deskew, int dst_buffer, size_t *out_n) {
+    if (!p || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
+        return fail(KICP_ERR_ARG, "bad argument");
+    if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
+    if (int rc = set_device(p->device)) return rc;
+    return pre_run_preprocess(p, p->ingested_n, deskew && p->ingested_stamps, relative_motion_qt, lidar_to_base_qt, max_range, min_range,
+                              dst_buffer, out_n);
+}
+int kicp_pre_ingested(const kicp_pre *p, double *out_xyz, double *out_stamps, size_t cap_points, size_t *out_n, int *out_has_stamps) {
+    if (!p) return fail(KICP_ERR_ARG, "bad argument");
+    if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t k = std::min(p->ingested_n, cap_points);
+    if (k && out_xyz) HIP_TRY(hipMemcpy(out_xyz, p->d_in, k * 24, hipMemcpyDeviceToHost));
+    if (k && out_stamps && p->ingested_stamps) HIP_TRY(hipMemcpy(out_stamps, p->d_ts, k * 8, hipMemcpyDeviceToHost));
+    if (out_n) *out_n = p->ingested_n;
+    if (out_has_stamps) *out_has_stamps = p->ingested_stamps ? 1 : 0;
+    return KICP_OK;
 }
 int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, size_t *out_n) {
     if (!p || src < 0 || src >= KICP_PRE_BUFFERS || dst < 0 || dst >= KICP_PRE_BUFFERS || src == dst || !(voxel_size > 0.0))

@@ -162,4 +162,86 @@ __global__ __launch_bounds__(256) void k_downsample_flag(const DownsampleParams 
     block_count_store(keep, p.block_counts);
 }
 
+// ---- PointCloud2 wire-format ingest ----------------------------------------------------
+// ros/src/kinematic_icp_ros/utils/RosUtils.cpp:30-39 (PointCloud2ToEigen: float32 x,y,z at point_step stride -> fp64,
+// T * p) and TimeStampHandler.cpp:57-104 (per-point stamp of type uint32 / float32 / float64 -> double seconds, values
+// with more than 10 integer digits are nanoseconds) + :106,:121-128 (min/max, normalisation to [0,1]).
+// The raw message bytes are what crosses PCIe (point_step bytes per point instead of 32 B of inflated fp64).
+struct IngestParams {
+    const unsigned char *raw;
+    uint32_t n, point_step;
+    uint32_t off_x, off_y, off_z, off_t;
+    int32_t stamp_type;  // 0 none, 6 UINT32, 7 FLOAT32, 8 FLOAT64 (sensor_msgs::msg::PointField datatype codes)
+    int32_t transform;   // 0: identity (what LidarOdometryServer.cpp:203 passes)
+    Pose T;
+    double *out_xyz;
+    double *out_stamps;
+    unsigned long long *minmax;  // [0] min, [1] max of the stamps as order-preserving integer keys
+};
+
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const unsigned char *p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+// order-preserving map double -> uint64 (and back), so the block extrema can be merged with integer atomics
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+KICP_HD double ordered_value(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double v;
+    __builtin_memcpy(&v, &b, 8);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
+    __shared__ unsigned long long s_min[4], s_max[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    if (i < p.n) {
+        const unsigned char *rec = p.raw + static_cast<size_t>(i) * p.point_step;
+        double x = static_cast<double>(load_unaligned<float>(rec + p.off_x));
+        double y = static_cast<double>(load_unaligned<float>(rec + p.off_y));
+        double z = static_cast<double>(load_unaligned<float>(rec + p.off_z));
+        if (p.transform) {
+            double rx, ry, rz;
+            quat_rotate(p.T, x, y, z, rx, ry, rz);
+            x = rx + p.T.tx, y = ry + p.T.ty, z = rz + p.T.tz;
+        }
+        p.out_xyz[3 * i] = x, p.out_xyz[3 * i + 1] = y, p.out_xyz[3 * i + 2] = z;
+        if (p.stamp_type) {
+            double stamp;
+            if (p.stamp_type == 6) stamp = static_cast<double>(load_unaligned<uint32_t>(rec + p.off_t));
+            else if (p.stamp_type == 7) stamp = static_cast<double>(load_unaligned<float>(rec + p.off_t));
+            else stamp = load_unaligned<double>(rec + p.off_t);
+            // TimeStampHandler.cpp:60-63,73-78: floor(log10(uint64(round(stamp))) + 1) > 10  <=>  round(stamp) >= 1e10
+            if (round(stamp) >= 1e10) stamp *= 1e-9;
+            p.out_stamps[i] = stamp;
+            kmin = kmax = ordered_key(stamp);
+        }
+    }
+    if (!p.stamp_type) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+        kmin = a < kmin ? a : kmin, kmax = b > kmax ? b : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = kmin, s_max[threadIdx.x >> 6] = kmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) kmin = s_min[w] < kmin ? s_min[w] : kmin, kmax = s_max[w] > kmax ? s_max[w] : kmax;
+        atomicMin(p.minmax, kmin), atomicMax(p.minmax + 1, kmax);
+    }
+}
+// TimeStampHandler.cpp:121-128: (t - min) / (max - min), the same two fp64 operations
+__global__ __launch_bounds__(256) void k_normalize_stamps(double *stamps, uint32_t n, const unsigned long long *minmax) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double lo = ordered_value(minmax[0]), hi = ordered_value(minmax[1]);
+    stamps[i] = (stamps[i] - lo) / (hi - lo);
+}
+
 }  // namespace kicp

@@ -800,4 +800,53 @@ size_t okicp_preprocess(const double *xyz, size_t n, const double *timestamps, s
     if (!out.empty()) std::memcpy(out_xyz, out.data(), out.size() * sizeof(V3));
     return out.size();
 }
+
+// --- wire-format ingest ---
+// ros/src/kinematic_icp_ros/utils/RosUtils.cpp:30-39 : PointCloud2ToEigen(msg, T) walks a float iterator over field
+// "x" (y and z are the next two floats of the record as far as the iterator is concerned: iter[1], iter[2]) and stores
+// T * Vector3d.  The byte offsets of y and z are passed in explicitly here; callers with the usual packed x,y,z get the
+// iterator's behaviour.  stamp_type uses sensor_msgs PointField codes (6 UINT32, 7 FLOAT32, 8 FLOAT64; 0 = no field).
+// Returns -1 for an unsupported stamp type (TimeStampHandler.cpp:103 throws).
+int okicp_ingest(const unsigned char *data, size_t n, unsigned point_step, unsigned off_x, unsigned off_y, unsigned off_z, int stamp_type,
+                 unsigned off_t, const double *sensor_pose_qt, double *out_xyz, double *out_stamps, double out_minmax[2]) {
+    if (stamp_type != 0 && stamp_type != 6 && stamp_type != 7 && stamp_type != 8) return -1;
+    const SE3 T = sensor_pose_qt ? se3_from_qt(sensor_pose_qt) : SE3{};
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char *rec = data + i * point_step;
+        float x, y, z;
+        std::memcpy(&x, rec + off_x, 4), std::memcpy(&y, rec + off_y, 4), std::memcpy(&z, rec + off_z, 4);
+        const V3 q = se3_act(T, V3{static_cast<double>(x), static_cast<double>(y), static_cast<double>(z)});
+        out_xyz[3 * i] = q.x, out_xyz[3 * i + 1] = q.y, out_xyz[3 * i + 2] = q.z;
+    }
+    out_minmax[0] = out_minmax[1] = 0.0;
+    if (stamp_type == 0 || n == 0) return 0;
+    // TimeStampHandler.cpp:57-83 : ExtractTimestampsFromMsg
+    auto number_of_digits_integer_part = [](double stamp) {
+        const uint64_t number_of_seconds = static_cast<uint64_t>(std::round(stamp));
+        return number_of_seconds > 0 ? std::floor(std::log10(static_cast<double>(number_of_seconds)) + 1) : 1.0;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char *rec = data + i * point_step + off_t;
+        double stampd;
+        if (stamp_type == 6) {
+            uint32_t v;
+            std::memcpy(&v, rec, 4);
+            stampd = static_cast<double>(v);
+        } else if (stamp_type == 7) {
+            float v;
+            std::memcpy(&v, rec, 4);
+            stampd = static_cast<double>(v);
+        } else {
+            std::memcpy(&stampd, rec, 8);
+        }
+        if (number_of_digits_integer_part(stampd) > 10) stampd *= 1e-9;  // nanoseconds -> seconds
+        out_stamps[i] = stampd;
+    }
+    // TimeStampHandler.cpp:106,121-128 : minmax_element + normalisation
+    const auto mm = std::minmax_element(out_stamps, out_stamps + n);
+    const double lo = *mm.first, hi = *mm.second;
+    out_minmax[0] = lo, out_minmax[1] = hi;
+    for (size_t i = 0; i < n; ++i) out_stamps[i] = (out_stamps[i] - lo) / (hi - lo);
+    return 1;
+}
 }  // extern "C"

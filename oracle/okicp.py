@@ -94,6 +94,8 @@ def lib():
         L.okicp_threshold_reset.argtypes = [C.POINTER(Threshold)]
         L.okicp_voxel_downsample.restype = C.c_size_t
         L.okicp_voxel_downsample.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
+        L.okicp_ingest.restype = C.c_int
+        L.okicp_ingest.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint, _dp, _dp, _dp, _dp]
         L.okicp_preprocess.restype = C.c_size_t
         L.okicp_preprocess.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, C.c_double, C.c_int, _dp]
         _lib = L
@@ -287,3 +289,18 @@ def preprocess(points, timestamps, relative_motion_qt, max_range, min_range, des
     out = np.empty((max(n, 1), 3))
     k = lib().okicp_preprocess(p, n, tp, t.size, r, max_range, min_range, int(deskew), out.ctypes.data_as(_dp))
     return out[:k].copy()
+
+
+def ingest(raw, n, point_step, off_x, off_y, off_z, stamp_type=0, off_t=0, sensor_pose_qt=None):
+    """PointCloud2ToEigen + ExtractTimestampsFromMsg + normalisation on raw message bytes (RosUtils.cpp:30-39,
+    TimeStampHandler.cpp:57-104,106,121-128) -> (xyz (n,3), normalised stamps (n,) or None, (min, max) seconds)."""
+    buf = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8))
+    xyz = np.empty((max(n, 1), 3))
+    st = np.empty(max(n, 1))
+    mm = np.zeros(2)
+    q = None if sensor_pose_qt is None else _d(sensor_pose_qt)[1]
+    rc = lib().okicp_ingest(buf.ctypes.data, n, point_step, off_x, off_y, off_z, stamp_type, off_t, q, xyz.ctypes.data_as(_dp),
+                            st.ctypes.data_as(_dp), mm.ctypes.data_as(_dp))
+    if rc < 0:
+        raise RuntimeError("timestamp field type not supported")
+    return xyz[:n].copy(), (st[:n].copy() if rc == 1 else None), (float(mm[0]), float(mm[1]))

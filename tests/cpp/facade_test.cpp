@@ -70,6 +70,29 @@ int main(int argc, char **argv) {
             }
             icp.SetPose(Sophus::SE3d());
             printf("after_setpose %zu %d\n", icp.LocalMap().size(), icp.VoxelMap().Empty() ? 1 : 0);
+        } else if (mode == "pipeline_raw") {  // same input file, fed as PointCloud2-style records (x y z f32, pad, t f64; 24 B)
+            const auto h = read_doubles(f, 4);
+            kinematic_icp::pipeline::Config cfg;
+            cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
+            kinematic_icp::pipeline::KinematicICP icp(cfg);
+            const auto ext = read_doubles(f, 7);
+            const kicp_cloud_layout layout{24, 0, 4, 8, KICP_FIELD_FLOAT64, 16};
+            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+                const auto n = read_doubles(f, 1);
+                const size_t np = static_cast<size_t>(n[0]);
+                const auto xyz = read_doubles(f, np * 3), stamps = read_doubles(f, np);
+                const auto delta = read_doubles(f, 7);
+                std::vector<unsigned char> msg(np * 24);
+                for (size_t i = 0; i < np; ++i) {
+                    const float p[3] = {static_cast<float>(xyz[3 * i]), static_cast<float>(xyz[3 * i + 1]), static_cast<float>(xyz[3 * i + 2])};
+                    std::memcpy(&msg[24 * i], p, 12), std::memcpy(&msg[24 * i + 16], &stamps[i], 8);
+                }
+                const auto [has_stamps, lo, hi] = icp.IngestCloud(msg.data(), np, layout);
+                const auto [deskewed, source] = icp.RegisterIngestedFrame(kicp_bridge::from_params(ext.data()), kicp_bridge::from_params(delta.data()));
+                print_pose("pose", icp.pose());
+                printf("sizes %zu %zu %zu\n", deskewed.size(), source.size(), icp.LocalMap().size());
+                if (k == 0) printf("stamps %d %.17g %.17g\n", has_stamps ? 1 : 0, lo, hi);
+            }
         } else if (mode == "pipeline_timed") {  // same input file; RegisterFrame alone inside the clock, no map download
             const auto h = read_doubles(f, 4);
             kinematic_icp::pipeline::Config cfg;

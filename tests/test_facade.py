@@ -108,3 +108,30 @@ def test_facade_pipeline_matches_oracle_pipeline(tmp_path, deskew):
         sizes = [int(x) for x in out[2 * k + 1].split()[1:]]
         assert sizes == [len(in_base), len(source), omap.num_points()], "frame %d" % k
     assert out[-1] == "after_setpose 0 1"
+
+
+@pytest.mark.gpu
+def test_facade_pipeline_from_pointcloud2_bytes(tmp_path):
+    """IngestCloud + RegisterIngestedFrame on float32 records == RegisterFrame on the same values as fp64 vectors."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    scene = syn.make_scene(rng, half=16.0, height=4.0, n_boxes=6, box_xy=(2.0, 5.0), box_z=(1.5, 3.5), keep_clear=3.0)
+    dirs = syn.beam_directions(12, 512, (-20.0, 8.0))
+    ext = np.concatenate([[0, 0, np.sin(0.05), np.cos(0.05)], [0.3, 0.0, 0.9]])
+    pose = syn.planar_pose(0.0, 0.0, 0.1)
+    f = tmp_path / "pipe.bin"
+    with open(f, "wb") as fh:
+        np.array([5.0, 0.5, 30.0, 1.0]).tofile(fh)
+        ext.tofile(fh)
+        for k in range(5):
+            delta = syn.planar_pose(0.25, 0.0, np.deg2rad(2.0 + k))
+            pose = syn.pose_mul(pose, delta)
+            wl = syn.pose_mul(pose, ext)
+            t = scene.raycast(wl[4:], dirs @ syn.quat_to_matrix(wl[:4]).T) + rng.normal(0, 0.01, len(dirs))
+            fr = (dirs * t[:, None]).astype(np.float32).astype(np.float64)  # what a float32 message can carry
+            np.array([float(len(fr))]).tofile(fh)
+            np.ascontiguousarray(fr).tofile(fh), np.linspace(0.0, 1.0, len(dirs)).tofile(fh), delta.tofile(fh)
+    host = subprocess.check_output([build_facade(), "pipeline", str(f)], text=True).splitlines()
+    raw = subprocess.check_output([build_facade(), "pipeline_raw", str(f)], text=True).splitlines()
+    assert raw[2] == "stamps 1 0 1"
+    raw = raw[:2] + raw[3:]
+    assert raw == host[:len(raw)] and len(raw) == 10
