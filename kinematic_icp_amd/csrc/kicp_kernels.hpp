@@ -537,6 +537,24 @@ __device__ __forceinline__ void tree_min_index(const float (&v)[N], float &m, in
     m = a[0], k = ia[0];
 }
 
+// minimum of N register-resident unsigned keys (v_min3_u32 friendly reduction)
+constexpr uint32_t kFarKey = 0x7F000000u;  // 1.7e38 as a float: beyond every real squared distance
+template <int N>
+__device__ __forceinline__ uint32_t tree_min_u32(const uint32_t (&v)[N]) {
+    uint32_t a[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = v[u];
+#pragma unroll
+    for (int width = N; width > 1; width = (width + 2) / 3) {
+#pragma unroll
+        for (int u = 0; u < (width + 2) / 3; ++u) {
+            const int i0 = 3 * u, i1 = min(3 * u + 1, width - 1), i2 = min(3 * u + 2, width - 1);
+            a[u] = min(a[i0], min(a[i1], a[i2]));
+        }
+    }
+    return a[0];
+}
+
 // merge the three-smallest record of another lane into `t`
 __device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
     best3_update(t, o.b1, o.i1, o.o1);
@@ -548,7 +566,7 @@ __device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
 // halves/quarters each lane's dependent chain and multiplies the resident waves; the sub-lanes share their running
 // minimum for culling and merge their records with shuffles at the end.
 template <int BLOCK, int G>
-__global__ __launch_bounds__(BLOCK, (G > 1 ? 4 : 2)) void k_pass_gather32(const PassParams p) {
+__global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
@@ -567,9 +585,13 @@ __global__ __launch_bounds__(BLOCK, (G > 1 ? 4 : 2)) void k_pass_gather32(const 
     const double vs = m.voxel_size;
     const double bound = p.tau * p.tau * (1.0 + 9.1e-13);
     const float fvs = static_cast<float>(vs);
-    // fp32 error model: mirror offsets and the query offset are < ~2 voxel sizes in magnitude, each rounded once
-    // (<= 2^-23 vs), so a squared distance below (1.2 vs)^2 is off by < 2e-6 vs^2; the margin covers twice that.
-    const float margin = 8e-6f * fvs * fvs;
+    // fp32 error model.  Mirror offsets (< vs) and the query offset seen from a neighbour's corner (< 2 vs) are rounded
+    // once each and so is their difference (< 3 vs): per axis the difference is off by <= 3.6e-7 vs, which moves a squared
+    // distance D by <= 2 sqrt(3 D) * 3.6e-7 vs; the squares and sums add 1.8e-7 D and the 5 mantissa bits dropped for the
+    // integer tournament 3.9e-6 D.  Decisions compare two candidates no farther than the acceptance bound (and never
+    // farther than the 27-voxel neighbourhood reaches, D <= 12 vs^2): the margin covers both errors, with 10 % to spare.
+    const double bcap = fmin(bound, 12.0 * vs * vs);
+    const float margin = fmaxf(8e-6f * fvs * fvs, static_cast<float>(2.2 * (1.25e-6 * sqrt(bcap) * vs + 4.2e-6 * bcap)));
     const float bound32 = static_cast<float>(bound) * 1.00001f + margin;
     const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
     // conservative (rounded-down) squared distances to the faces of the own voxel, indexed by shift component + 1
@@ -623,31 +645,31 @@ __global__ __launch_bounds__(BLOCK, (G > 1 ? 4 : 2)) void k_pass_gather32(const 
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) c[u] = b[min(k0 + u, last)];
                 if (k0 == 0) cnt = __float_as_uint(c[0].w);
-                // all distances first (independent), then tournament trees instead of a 20-long dependent chain: a lone
-                // wave cannot hide VALU latency, and the slowest wave sets the kernel's time
-                float d[kTrip];
+                // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
+                // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
+                // and yields value and position at once (unique keys: the lower position wins a tie, like the
+                // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
+                uint32_t key[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
                     const float ddx = c[u].x - qx, ddy = c[u].y - qy, ddz = c[u].z - qz;
-                    d[u] = (k0 + u < cnt) ? ddx * ddx + ddy * ddy + ddz * ddz : 3.0e38f;
+                    const float d = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                    key[u] = (k0 + u < cnt) ? ((__float_as_uint(d) & ~31u) | static_cast<uint32_t>(u)) : (kFarKey | static_cast<uint32_t>(u));
                 }
-                float m1;
-                int k1;
-                tree_min_index<kTrip>(d, m1, k1);
+                const uint32_t key1 = tree_min_u32<kTrip>(key);
+                const float m1 = __uint_as_float(key1 & ~31u);
                 if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
-                    float e[kTrip];
+                    uint32_t rest[kTrip];
 #pragma unroll
-                    for (int u = 0; u < kTrip; ++u) e[u] = (u == k1) ? 3.0e38f : d[u];
-                    float m2;
-                    int k2;
-                    tree_min_index<kTrip>(e, m2, k2);
+                    for (int u = 0; u < kTrip; ++u) rest[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
+                    const uint32_t key2 = tree_min_u32<kTrip>(rest);
 #pragma unroll
-                    for (int u = 0; u < kTrip; ++u) e[u] = (u == k2) ? 3.0e38f : e[u];
-                    float m3 = e[0];
-#pragma unroll
-                    for (int u = 1; u < kTrip; ++u) m3 = fminf(m3, e[u]);
-                    Best3 o{m1, m2, m3, base + k0 + k1, base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1,
-                            static_cast<uint32_t>(s) * 256u + k0 + k2};
+                    for (int u = 0; u < kTrip; ++u) rest[u] = (rest[u] == key2) ? 0xFFFFFFFFu : rest[u];
+                    const uint32_t key3 = tree_min_u32<kTrip>(rest);
+                    const uint32_t k1 = key1 & 31u, k2 = key2 & 31u;
+                    // with fewer than three points the far key stands in (finite, beyond every real distance)
+                    Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k0 + k1,
+                            base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1, static_cast<uint32_t>(s) * 256u + k0 + k2};
                     best3_merge(t, o);
                 }
             }
