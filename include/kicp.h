@@ -116,6 +116,9 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
+ *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the
+ *                  host adds as they arrive (two dependent device-scope round trips); 0 the device folds everything into
+ *                  one record first (six)
  *   "loop"         device-side solve only: 1 stepped (host polls the stop flag), 0 all iterations queued up front
  *   "wait"         0 (default) poll the host-mapped result record; 1 hipStreamSynchronize
  *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[] */

@@ -149,12 +149,17 @@ struct kicp_reg {
     unsigned long long *d_partials = nullptr;  // limb rows of the reduction tree
     unsigned int *d_tickets = nullptr;
     size_t partial_blocks = 0;
+    // mode 4 hand-off: tagged rows of the first-level groups in host-mapped pinned memory, added up by the host
+    unsigned long long *rows = nullptr, *d_rows = nullptr;  // host / device view
+    size_t rows_groups = 0;
+    uint32_t tag = 0;       // tag of the last pass (1..65535)
+    int group_rows = 1;     // option "group_rows": 1 = mode 4 (default), 0 = the device folds everything (mode 2)
     double *d_frame = nullptr;  // staging for host frames
     size_t frame_cap = 0;
     BinBuffers bin;
     // options
     int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather, 1 lds (given order), 2 binned by cell
-    int block = 128;      // workgroup size of variants 0/1
+    int block = 128;      // workgroup size of variants 0/3
     int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
     int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
     int waves_per_cu = 12; // persistent grid of variants 1/2
@@ -509,7 +514,36 @@ int ensure_partials(kicp_reg *r, size_t blocks) {
     HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_partials, 0, (want + groups) * kReduceWords * sizeof(unsigned long long), r->stream));  // tag 0 = never valid
     r->partial_blocks = want;
+    return KICP_OK;
+}
+// host-mapped rows of the first-level groups (mode 4)
+int ensure_rows(kicp_reg *r, size_t groups) {
+    if (groups <= r->rows_groups) return KICP_OK;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->rows) HIP_TRY(hipHostFree(r->rows));
+    r->rows = nullptr, r->d_rows = nullptr, r->rows_groups = 0;
+    const size_t want = groups + groups / 2 + 64;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->rows), want * kReduceWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(r->rows, 0, want * kReduceWords * sizeof(unsigned long long));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rows), r->rows, 0));
+    r->rows_groups = want;
+    return KICP_OK;
+}
+// next pass tag; when the 16-bit tag wraps, every buffer that holds tagged words is cleared so that a word left over
+// from 65535 passes ago can never be mistaken for a fresh one
+int next_tag(kicp_reg *r, uint32_t *tag) {
+    if (r->tag >= 0xFFFFu) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->rows) std::memset(r->rows, 0, r->rows_groups * kReduceWords * sizeof(unsigned long long));
+        if (r->d_partials) {
+            const size_t groups = r->partial_blocks / kGroup + 2;
+            HIP_TRY(hipMemsetAsync(r->d_partials, 0, (r->partial_blocks + groups) * kReduceWords * sizeof(unsigned long long), r->stream));
+        }
+        r->tag = 0;
+    }
+    *tag = ++r->tag;
     return KICP_OK;
 }
 int ensure_frame(kicp_reg *r, size_t n) {
@@ -606,6 +640,36 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
     }
 }
 
+// mode 4: add the tagged rows of the `groups` first-level groups as they arrive (word = value << 16 | tag)
+int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kReduceWords]) {
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
+    unsigned drained = 0;
+    unsigned long long spins = 0;
+    for (size_t g = 0; g < groups; ++g) {
+        const unsigned long long *row = r->rows + g * kReduceWords;
+        long long v[kReduceWords];
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < kReduceWords; ++i) {
+                const unsigned long long w = __atomic_load_n(row + i, __ATOMIC_RELAXED);
+                ok = ok && (static_cast<uint32_t>(w) & 0xFFFFu) == tag;
+                v[i] = static_cast<long long>(w) >> 16;
+            }
+            if (ok) break;
+            if (r->wait_mode == 1 || ++spins % query_every == 0) {
+                // the query makes the runtime flush commands it may still hold back, and reports device faults
+                const hipError_t q = r->wait_mode == 1 ? hipStreamSynchronize(r->stream) : hipStreamQuery(r->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (q == hipSuccess && ++drained > 4) return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+            }
+        }
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] += v[i];
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return KICP_OK;
+}
+
 // wait until every rank's slot of the current buffer carries `value`, then add the limb words (exact, order independent)
 int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceWords]) {
     const kicp_reg::ShmSlot *buf = r->shm + ((value - 1) & 1) * r->nranks;
@@ -688,15 +752,25 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         double beta = 0.0;
         int iter = 0, converged = 0, nan_flag = 0;
         for (int it = 0; it < max_it; ++it) {
-            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : 2;
+            const bool rows_mode = !multi && r->group_rows != 0;
+            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : (rows_mode ? 4 : 2);
             long long words[kReduceWords];
+            unsigned long long shm_value = 0;
+            kicp_reg::ShmSlot *mine_host = nullptr;
             if (shm) {  // this rank's slot of the shared segment, double-buffered by hand-off parity
                 const unsigned long long step = r->shm_step++;
                 kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
-                sp.pub_words = mine->words, sp.pub_seq = &mine->seq, sp.pub_value = step + 1;
+                mine_host = r->shm + (step & 1) * r->nranks + r->rank;
+                sp.pub_words = mine->words, sp.pub_seq = &mine->seq, sp.pub_value = shm_value = step + 1;
             } else {
                 sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
                 sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
+            }
+            const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
+            if (rows_mode) {
+                if (int rc = ensure_rows(r, groups)) return rc;
+                if (int rc = next_tag(r, &sp.tag)) return rc;
+                sp.pub_rows = r->d_rows;
             }
             const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
@@ -706,7 +780,14 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
                 if (int rc = enqueue_allreduce(r)) return rc;
                 hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, r->stream, r->d_state, r->d_rec, call_id, it);
             }
-            if (shm) {
+            if (rows_mode) {
+                if (int rc = wait_rows(r, groups, sp.tag, words)) return rc;
+                if (shm) {  // this rank's totals go into its slot from the host side; then every rank adds all slots
+                    for (int i = 0; i < kReduceWords; ++i) mine_host->words[i] = words[i];
+                    __atomic_store_n(&mine_host->seq, shm_value, __ATOMIC_RELEASE);
+                    if (int rc = wait_shm(r, shm_value, words)) return rc;
+                }
+            } else if (shm) {
                 if (int rc = wait_shm(r, sp.pub_value, words)) return rc;
             } else {
                 if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
@@ -966,6 +1047,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->shm) kicp_reg_shm_destroy(reg);
     if (reg->d_state) hipFree(reg->d_state);
     if (reg->rec) hipHostFree(reg->rec);
+    if (reg->rows) hipHostFree(reg->rows);
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
     free_bin(reg->bin);
@@ -995,6 +1077,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
     else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
+    else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
@@ -1011,6 +1094,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "loop") return reg->loop_mode;
     if (k == "wait") return reg->wait_mode;
     if (k == "host_solve") return reg->host_solve;
+    if (k == "group_rows") return reg->group_rows;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;

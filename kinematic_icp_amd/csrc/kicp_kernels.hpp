@@ -70,8 +70,11 @@ struct SolveParams {
     double fixed_regularization;
     int32_t mode;  // 0 = solve inside the pass kernel; 1 = leave the limb totals in st->reduce (multi-GPU: all-reduce follows);
                    // 3 = as 1, but the pose of every pass comes from the kernel argument (host-side solve, multi-GPU);
-                   // 2 = publish the limb totals to the host record, the HOST solves (default single-GPU mode: a CPU core
-                   //     does the ~2000 serial fp64 instructions of the solve in 0.2 us, one GPU lane needs ~5 us)
+                   // 2 = publish the limb totals to the host record, the HOST solves (a CPU core does the ~2000 serial fp64
+                   //     instructions of the solve in 0.2 us, one GPU lane needs ~5 us);
+                   // 4 = as 2, but the reduction stops at the first-level groups: their tagged rows go to the host, which
+                   //     adds them (default: two dependent device-scope round trips instead of six).  Sending every
+                   //     workgroup's row was tried and is far slower: writes into host memory cost ~130 ns per transaction
     unsigned long long call_id;
     HostRecord *rec;  // device pointer to the host-mapped record
     // mode 2 hand-off target (host-mapped memory: the handle's own record, or this rank's slot of the node-wide
@@ -79,6 +82,10 @@ struct SolveParams {
     long long *pub_words;
     unsigned long long *pub_seq;
     unsigned long long pub_value;
+    // mode 4 hand-off (default single-GPU / shared-segment mode): every first-level group's row goes straight to the
+    // host, each word carrying the 16-bit tag of this pass; the host adds the rows as they arrive
+    unsigned long long *pub_rows;  // host-mapped [groups][kReduceWords]
+    uint32_t tag;                  // 1..65535, unique per pass within an epoch (the buffers are cleared when it wraps)
 };
 
 struct BinView {
@@ -360,10 +367,44 @@ __device__ __forceinline__ long long sum_rows(const unsigned long long *rows, ui
     return v + __shfl_down(v, kReduceWords, 64);
 }
 
+// mode 4: the same fold over tagged rows (word = value << 16 | tag).  Returns the sum of the values; `ok` tells whether
+// every word carried `tag`, i.e. whether every row had landed (the caller retries otherwise).
+__device__ __forceinline__ long long sum_rows_tagged(const unsigned long long *rows, uint32_t count, int lane, uint32_t tag, bool &ok) {
+    long long v = 0;
+    ok = true;
+    if (lane < 2 * kReduceWords) {
+        const int word = lane % kReduceWords;
+        const uint32_t first = lane / kReduceWords;
+        unsigned long long t[kGroup / 2];
+#pragma unroll
+        for (int u = 0; u < kGroup / 2; ++u) {
+            const uint32_t j = first + 2 * u;
+            t[u] = (j < count) ? ld_sc1(rows + static_cast<size_t>(j) * kReduceWords + word) : static_cast<unsigned long long>(tag);
+        }
+#pragma unroll
+        for (int u = 0; u < kGroup / 2; ++u) {
+            ok = ok && (static_cast<uint32_t>(t[u]) & 0xFFFFu) == tag;
+            v += static_cast<long long>(t[u]) >> 16;
+        }
+    }
+    return v + __shfl_down(v, kReduceWords, 64);
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*s_red)[kNumSums], int *s_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
+    if (p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
+        if (p.sol.mode == 4 && wave == 0 && blockIdx.x % kGroup == 0 && lane < kReduceWords)
+            __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(blockIdx.x / kGroup) * kReduceWords + lane, static_cast<unsigned long long>(p.sol.tag),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && wave == 0 && p.sol.mode == 2) {
+            if (lane < kReduceWords) __hip_atomic_store(p.sol.pub_words + lane, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(p.sol.pub_seq, p.sol.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kNumSums; ++i) {
 #pragma unroll
@@ -395,6 +436,39 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
+    if (p.sol.mode == 4) {
+        // Tagged rows: no store acknowledgement is awaited anywhere.  The ticket only elects the group's reader; whether
+        // a row has landed is visible in the row itself.  Values: limbs < 2^40 (the top limb is a small signed number
+        // within the documented range), so value << 16 | tag fits a word, and so does the sum of a group's 32 rows.
+        const unsigned long long tag = p.sol.tag;
+        if (lane < kNumSums) {
+            if (BLOCK > 64) {
+                t = s_red[0][lane];
+                for (int w = 1; w < BLOCK / 64; ++w) i128_add(t, s_red[w][lane]);
+            }
+            long long l[3];
+            i128_to_limbs(t, l);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) st_sc1(row + 3 * lane + j, (static_cast<unsigned long long>(l[j]) << 16) | tag);
+        } else if (lane < kNumSums + 3) {
+            st_sc1(row + kNumLimbs + (lane - kNumSums), ((lane == kNumSums ? static_cast<unsigned long long>(range_error) : 0ull) << 16) | tag);
+        }
+        unsigned int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __shfl(ticket, 0, 64);
+        const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
+        if (ticket != group_size - 1) return;
+        if (lane == 0) __hip_atomic_store(p.tickets + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long total;
+        bool ok;
+        do {
+            total = sum_rows_tagged(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
+        } while (!__all(ok));
+        if (lane < kReduceWords)
+            __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(g) * kReduceWords + lane, (static_cast<unsigned long long>(total) << 16) | tag,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (lane < kNumSums) {
         if (BLOCK > 64) {
             t = s_red[0][lane];
@@ -574,7 +648,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) 
     const uint32_t gt = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
-    const bool valid = i < p.n && p.dbg != 7;
+    const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
     Acc acc{};
     double sx = 0, sy = 0, sz = 0;
     if (valid) sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
@@ -606,6 +680,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) 
     if (valid && p.dbg != 2) table_lookup_entry(m, q.vx, q.vy, q.vz, slot0, nbr);
     if (p.dbg == 3) nbr &= 1u;     // experiments: own voxel only
     if (p.dbg == 5) nbr &= 0x7Fu;  // own + faces
+    if (p.dbg == 4) nbr = 0u;      // probe only, no bucket visit
     uint32_t todo = nbr;
     if (G > 1) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
         todo = 0u;
@@ -627,7 +702,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) 
             alive |= (box <= lim) ? (1u << c) : 0u;
         }
         todo &= alive;
-        if (todo && p.dbg != 4) {
+        if (todo) {
             const int s = __ffs(todo) - 1;
             todo &= todo - 1u;
             const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
