@@ -1036,6 +1036,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
     if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
+    if (const char *env = std::getenv("KICP_QUERY_EVERY")) r->query_every = std::atoi(env);
     *out = r;
     return KICP_OK;
 }
@@ -1078,6 +1079,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
     else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
     else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
+    else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
@@ -1095,6 +1097,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "wait") return reg->wait_mode;
     if (k == "host_solve") return reg->host_solve;
     if (k == "group_rows") return reg->group_rows;
+    if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;

@@ -252,3 +252,27 @@ def test_registration_after_updates_with_pruning(kernel):
     deltas = [b for b, full in uploads if not full]
     fulls = [b for b, full in uploads if full]
     assert len(deltas) >= len(uploads) // 2 and fulls and max(deltas) < max(fulls)
+
+
+def test_hand_off_modes_and_tag_wraparound(case1):
+    """The tagged-row hand-off (default), the single-record hand-off and the stream-sync wait give the same bits, also across
+    the 16-bit pass tag's wrap-around (where every buffer holding tagged words is cleared) and for scans of changing size."""
+    cfg, scans, gmap, omap = case1
+    tau = cfg.first_frame_tau()
+    rel = [syn.pose_mul(s["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(0.8))) for s in scans]
+    ref = K.KinematicRegistration()
+    ref.set_option("group_rows", 0)
+    sizes = [len(scans[0]["frame"]), 5000, 64, 12345, 1]
+    expected = [ref.ComputeRobotMotion(scans[i % 3]["frame"][:n], gmap, scans[i % 3]["last_pose"], rel[i % 3], tau) for i, n in enumerate(sizes)]
+    assert ref.last_stats.iterations >= 1
+    for wait in (0, 1):
+        reg = K.KinematicRegistration()
+        reg.set_option("wait", wait)
+        assert reg.get_option("group_rows") == 1
+        reg.set_option("debug_tag", 65535 - 7)  # a few passes before the wrap
+        assert reg.get_option("debug_tag") == 65528
+        for rounds in range(4):
+            for i, n in enumerate(sizes):
+                pose = reg.ComputeRobotMotion(scans[i % 3]["frame"][:n], gmap, scans[i % 3]["last_pose"], rel[i % 3], tau)
+                assert np.array_equal(pose, expected[i], equal_nan=True), (wait, rounds, i)
+        assert 0 < reg.get_option("debug_tag") < 65528  # the wrap happened inside the loop

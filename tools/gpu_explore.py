@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--order", default="ring")
     ap.add_argument("--variants", default="0:128,3:64,3:128,3:256")
     ap.add_argument("--loops", default="0,1")
+    ap.add_argument("--lanes", type=int, default=0, help="sub-lanes per query of variants 3/4 (0 = by scan size)")
     ap.add_argument("--big", type=float, default=0.0, help="extra initial-guess yaw error in degrees (more iterations)")
     args = ap.parse_args()
 
@@ -67,6 +68,7 @@ def main():
         reg = K.KinematicRegistration()
         reg.set_option("pass_kernel", kern)
         reg.set_option("block", block)
+        reg.set_option("lanes_per_query", args.lanes)
         # parity: per-pass sums and final pose
         worst_sum, worst_pose, iters_ok = 0.0, 0.0, True
         for s, e in zip(scans, exp):
