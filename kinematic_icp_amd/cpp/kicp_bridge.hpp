@@ -2,6 +2,9 @@
 // With the real Eigen/Sophus the same code compiles: only the two param-conversion helpers differ.
 #pragma once
 #include <Eigen/Core>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <sophus/se3.hpp>
 #include <stdexcept>
 #include <string>
@@ -34,4 +37,27 @@ inline const double *xyz(const std::vector<Eigen::Vector3d> &v) {
 inline void check(int rc, const char *what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + kicp_last_error());
 }
+// KICP_TRACE=1: host-side sections of the drop-in headers report their wall time on stderr, next to the library's own
+// per-call lines (debugging aid; a getenv once per process otherwise)
+struct Trace {
+    static bool enabled() {
+        static const bool on = [] {
+            const char *e = std::getenv("KICP_TRACE");
+            return e && *e && *e != '0';
+        }();
+        return on;
+    }
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit Trace(const char *n) : name(n) {
+        if (enabled()) t0 = std::chrono::steady_clock::now();
+    }
+    void lap(const char *next) {
+        if (!enabled()) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kicp host] %-30s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        name = next, t0 = t1;
+    }
+    ~Trace() { lap(""); }
+};
 }  // namespace kicp_bridge

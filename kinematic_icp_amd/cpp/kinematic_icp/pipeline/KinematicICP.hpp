@@ -133,21 +133,26 @@ protected:
     // pipeline/KinematicICP.cpp:56-84 from the preprocessed frame (pre_ buffer 0) on: downsample twice, register, update
     // the threshold and the map - all on the device; only the two returned clouds come back to the host.
     Vector3dVectorTuple RegisterPreprocessed(size_t n_frame, const Sophus::SE3d &relative_odometry) {
+        kicp_bridge::Trace trace("downsample");
         size_t n_down = 0, n_source = 0;
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
+        trace.lap("registration");
         const double tau = correspondence_threshold_.ComputeThreshold();
         const auto new_pose = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
                                                                      relative_odometry, tau);
-        Vector3dVector frame_in_base(n_frame), src(n_source);
+        trace.lap("allocate results");
+        Vector3dVectorTuple result{Vector3dVector(n_frame), Vector3dVector(n_source)};
+        trace.lap("download results");
         auto fetch = [&](int b, Vector3dVector &v) {
             kicp_bridge::check(kicp_pre_download(pre_, b, v.empty() ? nullptr : v.front().data(), v.size(), nullptr), "download");
         };
-        fetch(0, frame_in_base), fetch(2, src);
+        fetch(0, std::get<0>(result)), fetch(2, std::get<1>(result));
+        trace.lap("threshold + map update");
         correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose);
         local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose);
         last_pose_ = new_pose;
-        return {frame_in_base, src};
+        return result;  // built in place: no copy of the clouds on the way out
     }
 #endif
     Sophus::SE3d last_pose_;

@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -25,6 +26,23 @@
 
 namespace {
 using namespace kicp;
+
+// KICP_TRACE=1 in the environment: every traced C-ABI call reports its wall time on stderr (debugging aid)
+const bool g_trace = [] {
+    const char *e = std::getenv("KICP_TRACE");
+    return e && *e && *e != '0';
+}();
+struct TraceScope {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit TraceScope(const char *n) : name(n) {
+        if (g_trace) t0 = std::chrono::steady_clock::now();
+    }
+    ~TraceScope() {
+        if (g_trace) std::fprintf(stderr, "[kicp] %-32s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+#define KICP_TRACE_CALL() TraceScope trace_scope_(__func__)
 
 thread_local std::string g_error;
 int fail(int code, const std::string &msg) {
@@ -340,6 +358,7 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
 // bring the host copy up to date after device-side updates: same layouts, so this is a plain download
 int ensure_host_current(kicp_map *map) {
     if (!map->device_ahead) return KICP_OK;
+    TraceScope trace_scope_("  (host copy refreshed from HBM)");
     DeviceMirror &mr = map->mirror;
     if (int rc = set_device(mr.device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -922,6 +941,7 @@ void kicp_map_destroy(kicp_map *map) {
     delete map;
 }
 int kicp_map_clear(kicp_map *map) {
+    KICP_TRACE_CALL();
     if (!map) return fail(KICP_ERR_ARG, "null map");
     map->device_ahead = false;  // whatever the device holds is obsolete now
     map->host.Clear();
@@ -932,27 +952,32 @@ int kicp_map_empty(const kicp_map *map) {
     return (map->device_ahead ? map->dev.n_voxels == 0 : map->host.Empty()) ? 1 : 0;
 }
 int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n) {
+    KICP_TRACE_CALL();
     if (!map || (!xyz && n)) return fail(KICP_ERR_ARG, "null argument");
     if (int rc = ensure_host_current(map)) return rc;
     return map->host.AddPoints(xyz, n) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
 int kicp_map_remove_far(kicp_map *map, const double origin[3]) {
+    KICP_TRACE_CALL();
     if (!map || !origin) return fail(KICP_ERR_ARG, "null argument");
     if (int rc = ensure_host_current(map)) return rc;
     map->host.RemovePointsFarFromLocation(origin);
     return KICP_OK;
 }
 int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]) {
+    KICP_TRACE_CALL();
     if (!map || (!xyz && n) || !origin) return fail(KICP_ERR_ARG, "null argument");
     if (int rc = ensure_host_current(map)) return rc;
     return map->host.Update(xyz, n, origin) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
 int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose_qt[7]) {
+    KICP_TRACE_CALL();
     if (!map || (!xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
     if (int rc = ensure_host_current(map)) return rc;
     return map->host.Update(xyz, n, pose_from(pose_qt)) ? KICP_OK : fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
 }
 int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]) {
+    KICP_TRACE_CALL();
     if (!map || (!d_points_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
     return map_update_device(map, device, d_points_xyz, n, pose_from(pose_qt));
 }
@@ -966,6 +991,7 @@ size_t kicp_map_num_voxels(const kicp_map *map) {
     return map->device_ahead ? map->dev.n_voxels : map->host.num_voxels();
 }
 size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points) {
+    KICP_TRACE_CALL();
     if (!map) return 0;
     if (ensure_host_current(const_cast<kicp_map *>(map)) != KICP_OK) return 0;  // logically const: refreshes the host copy
     return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
@@ -975,6 +1001,7 @@ size_t kicp_map_check(const kicp_map *map) {
     return map->host.CheckInvariants();
 }
 int kicp_map_sync(kicp_map *map, int device) {
+    KICP_TRACE_CALL();
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (int rc = set_device(device)) return rc;
     return map_sync(map, device, nullptr);
@@ -985,6 +1012,7 @@ int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full) {
     return KICP_OK;
 }
 int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist) {
+    KICP_TRACE_CALL();
     if (!map || (!queries_xyz && n) || !out_nn_xyz || !out_dist) return fail(KICP_ERR_ARG, "null argument");
     if (n == 0) return KICP_OK;
     if (kicp_map_empty(map)) {
@@ -1108,11 +1136,13 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
 int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
                          const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
                          kicp_stats *stats) {
+    KICP_TRACE_CALL();
     if (!d_frame_xyz && n) return fail(KICP_ERR_ARG, "null frame");
     return run_registration(reg, map, d_frame_xyz, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
 }
 int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
                   const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
+    KICP_TRACE_CALL();
     if (!reg || !map || (!frame_xyz && n)) return fail(KICP_ERR_ARG, "null argument");
     if (!kicp_map_empty(map) && n) {
         if (int rc = set_device(reg->device)) return rc;
@@ -1279,6 +1309,7 @@ void kicp_pre_destroy(kicp_pre *p) {
 int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
                         const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range,
                         int deskew, int dst_buffer, size_t *out_n) {
+    KICP_TRACE_CALL();
     if (!p || (!frame_xyz && n) || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
         return fail(KICP_ERR_ARG, "bad argument");
     const bool do_deskew = deskew && n_timestamps != 0;  // Preprocessing.cpp: `if (deskew_ && !timestamps.empty())`
@@ -1295,6 +1326,7 @@ int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const do
 }
 int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
                     double *out_min_stamp, double *out_max_stamp) {
+    KICP_TRACE_CALL();
     if (!p || !layout || (!data && n_points)) return fail(KICP_ERR_ARG, "bad argument");
     const kicp_cloud_layout &L = *layout;
     const int st = L.stamp_datatype;
@@ -1345,6 +1377,7 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
 }
 int kicp_pre_preprocess_ingested(kicp_pre *p, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
                                  double min_range, int deskew, int dst_buffer, size_t *out_n) {
+    KICP_TRACE_CALL();
     if (!p || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
         return fail(KICP_ERR_ARG, "bad argument");
     if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
@@ -1364,6 +1397,7 @@ int kicp_pre_ingested(const kicp_pre *p, double *out_xyz, double *out_stamps, si
     return KICP_OK;
 }
 int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, size_t *out_n) {
+    KICP_TRACE_CALL();
     if (!p || src < 0 || src >= KICP_PRE_BUFFERS || dst < 0 || dst >= KICP_PRE_BUFFERS || src == dst || !(voxel_size > 0.0))
         return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
@@ -1388,6 +1422,7 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     return pre_compact(p, p->buf[src], n, dst, out_n);
 }
 int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
+    KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
     if (int rc = pre_ensure_buf(p, buffer, n ? n : 1)) return rc;
@@ -1397,6 +1432,7 @@ int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
     return KICP_OK;
 }
 int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap_points, size_t *out_n) {
+    KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
     const size_t n = p->buf_n[buffer], k = std::min(n, cap_points);

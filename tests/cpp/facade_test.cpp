@@ -93,6 +93,50 @@ int main(int argc, char **argv) {
                 printf("sizes %zu %zu %zu\n", deskewed.size(), source.size(), icp.LocalMap().size());
                 if (k == 0) printf("stamps %d %.17g %.17g\n", has_stamps ? 1 : 0, lo, hi);
             }
+        } else if (mode == "pipeline_steps") {  // RegisterFrame's backend calls one by one with a clock around each (diagnostics)
+            const auto h = read_doubles(f, 4);
+            const auto ext = read_doubles(f, 7);
+            kicp_pre *pre = nullptr;
+            kicp_map *map = nullptr;
+            kicp_reg *reg = nullptr;
+            kicp_reg_config rc{10, 1e-3, 1, 1, 0.0};
+            kicp_bridge::check(kicp_pre_create(0, &pre), "pre");
+            kicp_bridge::check(kicp_map_create(h[1], h[2], 20, &map), "map");
+            kicp_bridge::check(kicp_reg_create(&rc, 0, &reg), "reg");
+            double last[7] = {0, 0, 0, 1, 0, 0, 0};
+            const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+                const auto n = read_doubles(f, 1);
+                const size_t np = static_cast<size_t>(n[0]);
+                const auto xyz = read_doubles(f, np * 3), stamps = read_doubles(f, np);
+                const auto delta = read_doubles(f, 7);
+                double t[8];
+                auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+                size_t n_frame = 0, n_down = 0, n_src = 0;
+                t[0] = now();
+                kicp_bridge::check(kicp_pre_preprocess(pre, xyz.data(), np, stamps.data(), np, ident, ext.data(), h[2], 0.0, h[3] != 0.0, 0, &n_frame), "pp");
+                t[1] = now();
+                kicp_bridge::check(kicp_pre_voxel_downsample(pre, 0, h[1] * 0.5, 1, &n_down), "d1");
+                kicp_bridge::check(kicp_pre_voxel_downsample(pre, 1, h[1] * 1.5, 2, &n_src), "d2");
+                t[2] = now();
+                double pose[7];
+                kicp_stats st;
+                kicp_bridge::check(kicp_register_device(reg, map, kicp_pre_device_ptr(pre, 2, nullptr), n_src, last, delta.data(), 0.67 * h[1], pose, &st), "reg");
+                t[3] = now();
+                std::vector<double> a(3 * n_frame), b(3 * n_src);
+                t[4] = now();
+                kicp_bridge::check(kicp_pre_download(pre, 0, a.data(), n_frame, nullptr), "dl0");
+                kicp_bridge::check(kicp_pre_download(pre, 2, b.data(), n_src, nullptr), "dl2");
+                t[5] = now();
+                kicp_bridge::check(kicp_map_update_pose_device(map, 0, kicp_pre_device_ptr(pre, 1, nullptr), n_down, pose), "upd");
+                t[6] = now();
+                { std::vector<double>().swap(a); std::vector<double>().swap(b); }  // free the buffers the copies landed in
+                t[7] = now();
+                std::memcpy(last, pose, sizeof last);
+                printf("frame %d ms: preprocess+upload %.3f downsample %.3f register %.3f alloc %.3f download %.3f map_update %.3f free %.3f | total %.3f\n", k,
+                       t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[7] - t[0]);
+            }
+            kicp_reg_destroy(reg), kicp_map_destroy(map), kicp_pre_destroy(pre);
         } else if (mode == "pipeline_timed") {  // same input file; RegisterFrame alone inside the clock, no map download
             const auto h = read_doubles(f, 4);
             kinematic_icp::pipeline::Config cfg;
@@ -105,11 +149,17 @@ int main(int argc, char **argv) {
                 const auto stamps = read_doubles(f, static_cast<size_t>(n[0]));
                 const auto delta = read_doubles(f, 7);
                 const auto t0 = std::chrono::steady_clock::now();
-                const auto [deskewed, source] = icp.RegisterFrame(frame, stamps, kicp_bridge::from_params(ext.data()),
-                                                                  kicp_bridge::from_params(delta.data()));
-                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                printf("frame %d ms %.4f in %zu source %zu map_on_device %d\n", k, ms, deskewed.size(), source.size(),
-                       kicp_map_last_update_on_device(icp.VoxelMap().handle()));
+                double ms = 0.0;
+                size_t n_deskewed = 0, n_source = 0;
+                {
+                    const auto [deskewed, source] = icp.RegisterFrame(frame, stamps, kicp_bridge::from_params(ext.data()),
+                                                                      kicp_bridge::from_params(delta.data()));
+                    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    n_deskewed = deskewed.size(), n_source = source.size();
+                }  // the caller drops the returned clouds here
+                const double ms_with_free = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                printf("frame %d ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, ms, ms_with_free, n_deskewed,
+                       n_source, kicp_map_last_update_on_device(icp.VoxelMap().handle()));
                 print_pose("pose", icp.pose());
             }
             printf("map %zu\n", icp.LocalMap().size());
