@@ -130,6 +130,10 @@ struct DeviceMirror {
     double *d_world = nullptr;
     uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
     size_t upd_cap = 0;
+    // Pointcloud() from the device copy
+    double *d_pc = nullptr;
+    uint32_t *d_pc_blocks = nullptr;  // per-256-slot-block counts / offsets, then the total
+    size_t pc_points = 0, pc_blocks = 0;
 };
 }  // namespace
 
@@ -213,6 +217,17 @@ int set_device(int device) {
 }
 
 int ensure_host_current(kicp_map *map);
+// release every device buffer of a mirror (on its own device) and reset it
+void free_mirror(DeviceMirror &mr) {
+    if (mr.device >= 0) {
+        hipSetDevice(mr.device);
+        hipFree(mr.d_table), hipFree(mr.d_pool), hipFree(mr.d_pool32), hipFree(mr.d_stage), hipFree(mr.d_index);
+        hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
+        hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
+        hipFree(mr.d_pc), hipFree(mr.d_pc_blocks);
+    }
+    mr = DeviceMirror{};
+}
 
 // per-slot helper arrays, free list and counters of the device-side maintenance, rebuilt after every upload
 int sync_aux(kicp_map *map, hipStream_t stream) {
@@ -286,13 +301,7 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
     if (mr.device == device && mr.synced_epoch == h.epoch()) return KICP_OK;
     if (int rc = set_device(device)) return rc;
     if (mr.device != device && mr.device >= 0) {  // mirror lives on another GPU: drop it
-        hipSetDevice(mr.device);
-        if (mr.d_table) hipFree(mr.d_table);
-        if (mr.d_pool) hipFree(mr.d_pool);
-        if (mr.d_pool32) hipFree(mr.d_pool32);
-        if (mr.d_stage) hipFree(mr.d_stage);
-        if (mr.d_index) hipFree(mr.d_index);
-        mr = DeviceMirror{};
+        free_mirror(mr);
         hipSetDevice(device);
     }
     mr.device = device;
@@ -927,17 +936,7 @@ int kicp_map_create(double voxel_size, double max_distance, unsigned int max_poi
 }
 void kicp_map_destroy(kicp_map *map) {
     if (!map) return;
-    if (map->mirror.device >= 0) {
-        hipSetDevice(map->mirror.device);
-        if (map->mirror.d_table) hipFree(map->mirror.d_table);
-        if (map->mirror.d_pool) hipFree(map->mirror.d_pool);
-        if (map->mirror.d_pool32) hipFree(map->mirror.d_pool32);
-        if (map->mirror.d_stage) hipFree(map->mirror.d_stage);
-        if (map->mirror.d_index) hipFree(map->mirror.d_index);
-        DeviceMirror &mr = map->mirror;
-        hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
-        hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
-    }
+    free_mirror(map->mirror);
     delete map;
 }
 int kicp_map_clear(kicp_map *map) {
@@ -990,11 +989,48 @@ size_t kicp_map_num_voxels(const kicp_map *map) {
     if (!map) return 0;
     return map->device_ahead ? map->dev.n_voxels : map->host.num_voxels();
 }
-size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points) {
+size_t kicp_map_pointcloud(const kicp_map *cmap, double *out_xyz, size_t cap_points) {
     KICP_TRACE_CALL();
-    if (!map) return 0;
-    if (ensure_host_current(const_cast<kicp_map *>(map)) != KICP_OK) return 0;  // logically const: refreshes the host copy
-    return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
+    if (!cmap) return 0;
+    kicp_map *map = const_cast<kicp_map *>(cmap);  // logically const: only scratch buffers / the host copy are touched
+    if (!map->device_ahead) return map->host.Pointcloud(out_xyz, out_xyz ? cap_points : 0);
+    // the HBM copy is the current one: gather the points there (same table order) and download just them
+    const size_t total = static_cast<size_t>(map->dev.n_points);
+    const size_t want = out_xyz ? std::min(total, cap_points) : 0;
+    if (want == 0) return total;
+    DeviceMirror &mr = map->mirror;
+    auto gather = [&]() -> int {
+        if (int rc = set_device(mr.device)) return rc;
+        const size_t slots = mr.live_slots, blocks = (slots + 255) / 256;
+        if (blocks + 1 > mr.pc_blocks) {
+            hipFree(mr.d_pc_blocks);
+            mr.d_pc_blocks = nullptr, mr.pc_blocks = 0;
+            HIP_TRY(hipMalloc(&mr.d_pc_blocks, (blocks + 1) * 4));
+            mr.pc_blocks = blocks + 1;
+        }
+        if (total > mr.pc_points) {
+            hipFree(mr.d_pc);
+            mr.d_pc = nullptr, mr.pc_points = 0;
+            HIP_TRY(hipMalloc(&mr.d_pc, (total + total / 4 + 1024) * 24));
+            mr.pc_points = total + total / 4 + 1024;
+        }
+        hipStream_t st = nullptr;
+        hipLaunchKernelGGL(k_pc_count, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(slots), mr.d_pc_blocks);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, mr.d_pc_blocks, static_cast<uint32_t>(blocks), mr.d_pc_blocks + blocks);
+        hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(slots), mr.d_pool,
+                           map->host.cap(), mr.d_pc_blocks, mr.d_pc);
+        HIP_TRY(hipGetLastError());
+        uint32_t counted = 0;
+        HIP_TRY(hipMemcpy(&counted, mr.d_pc_blocks + blocks, 4, hipMemcpyDeviceToHost));
+        if (counted != total) return fail(KICP_ERR_HIP, "device map counters disagree with the table");
+        HIP_TRY(hipMemcpy(out_xyz, mr.d_pc, want * 24, hipMemcpyDeviceToHost));
+        return KICP_OK;
+    };
+    if (gather() != KICP_OK) {  // fall back to refreshing the host copy
+        if (ensure_host_current(map) != KICP_OK) return 0;
+        return map->host.Pointcloud(out_xyz, cap_points);
+    }
+    return total;
 }
 size_t kicp_map_check(const kicp_map *map) {
     if (!map || ensure_host_current(const_cast<kicp_map *>(map)) != KICP_OK) return 1;

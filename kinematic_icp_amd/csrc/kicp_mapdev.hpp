@@ -237,4 +237,40 @@ __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, do
     }
 }
 
+// ---- Pointcloud() from the device copy (KinematicICP.hpp:92, published by the ROS node when someone listens) ----------
+// All points, voxel by voxel in table order - the order HostMap::Pointcloud emits - without bringing the table and the
+// pools back to the host: count per 256-slot block, scan the block totals, then every slot copies its bucket's points.
+__global__ __launch_bounds__(256) void k_pc_count(const Slot *table, uint32_t slots, uint32_t *block_counts) {
+    __shared__ uint32_t s_sum[4];
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = 0;
+    if (h < slots && table[h].val != kEmptyVal) c = table[h].val & 0xffu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+__global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t slots, const double *pool, uint32_t cap,
+                                                   const uint32_t *block_offsets, double *out) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t c = 0, bucket = 0;
+    if (h < slots && table[h].val != kEmptyVal) c = table[h].val & 0xffu, bucket = table[h].val >> 8;
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t pos = block_offsets[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    const double *b = pool + static_cast<size_t>(bucket) * cap * 3;
+    double *o = out + static_cast<size_t>(pos) * 3;
+    for (uint32_t k = 0; k < 3 * c; ++k) o[k] = b[k];
+}
+
 }  // namespace kicp
