@@ -81,8 +81,8 @@ int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const doubl
 /* Update(points, pose) with the points already in HBM (e.g. a kicp_pre buffer): transform, AddPoints and
  * RemovePointsFarFromLocation run on the device - every touched voxel is processed by one thread in input order with the
  * reference's fp64 rule, so the accepted points and their order inside each voxel are exactly the sequential
- * reference's.  Falls back to the host map only when the hash table needs to grow (first frames); the host copy is
- * refreshed lazily when a host-side call (Pointcloud, AddPoints, ...) needs it. */
+ * reference's.  Table growth / clean-up (a device-side re-hash) and pool growth happen in HBM as well; the host copy is
+ * refreshed lazily when a host-side call (AddPoints, kicp_map_check, ...) needs it. */
 int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
 int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU */
 size_t kicp_map_num_points(const kicp_map *map);

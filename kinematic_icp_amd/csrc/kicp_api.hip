@@ -28,10 +28,13 @@ namespace {
 using namespace kicp;
 
 // KICP_TRACE=1 in the environment: every traced C-ABI call reports its wall time on stderr (debugging aid)
-const bool g_trace = [] {
-    const char *e = std::getenv("KICP_TRACE");
+// (plain function on purpose: hipcc gave two namespace-scope initialiser lambdas of this shape the same closure symbol and
+// ran the first one's body for both)
+bool env_flag(const char *name) {
+    const char *e = std::getenv(name);
     return e && *e && *e != '0';
-}();
+}
+const bool g_trace = env_flag("KICP_TRACE");
 struct TraceScope {
     const char *name;
     std::chrono::steady_clock::time_point t0;
@@ -107,6 +110,15 @@ struct CommApi {
 };
 CommApi g_comm;
 
+// pinned staging buffer for uploads of pageable caller memory (see staged_upload)
+struct HostStage {
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    void release() {
+        if (p) hipHostFree(p);
+        p = nullptr, cap = 0;
+    }
+};
 struct DeviceMirror {
     int device = -1;
     Slot *d_table = nullptr;
@@ -130,6 +142,7 @@ struct DeviceMirror {
     double *d_world = nullptr;
     uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
     size_t upd_cap = 0;
+    HostStage stage;  // pinned staging for transfers from / to caller memory (queries, Pointcloud)
     // Pointcloud() from the device copy
     double *d_pc = nullptr;
     uint32_t *d_pc_blocks = nullptr;  // per-256-slot-block counts / offsets, then the total
@@ -176,8 +189,9 @@ struct kicp_reg {
     size_t rows_groups = 0;
     uint32_t tag = 0;       // tag of the last pass (1..65535)
     int group_rows = 1;     // option "group_rows": 1 = mode 4 (default), 0 = the device folds everything (mode 2)
-    double *d_frame = nullptr;  // staging for host frames
+    double *d_frame = nullptr;  // device copy of host frames
     size_t frame_cap = 0;
+    HostStage stage;            // pinned staging for transfers from / to caller memory
     BinBuffers bin;
     // options
     int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather, 1 lds (given order), 2 binned by cell
@@ -216,6 +230,57 @@ int set_device(int device) {
     return KICP_OK;
 }
 
+// Transfers from / to caller memory never hand the caller's pointer to the HIP runtime.  The runtime pins a pageable
+// buffer for the DMA and remembers pinned ranges by address; with buffers that live at new or recycled addresses every
+// frame (a new message, a new std::vector) a 4 MB scan took 17-27 ms to upload instead of 0.16 ms in most processes we
+// measured (always in multiples of ~9 ms, and whether a process was hit depended on its allocation pattern only).  So
+// both directions go through a pinned staging buffer owned by the handle: CPU copy in 1 MB pieces (~0.03 ms each), each
+// followed by its asynchronous DMA - about 0.2 ms for that scan, every time.  KICP_DIRECT_UPLOAD=1 restores the direct
+// DMA for callers that pass pinned (hipHostMalloc / hipHostRegister) memory.  The caller drains `stream` before the staging
+// buffer is used again (every entry point here ends in a sync).
+const bool g_direct_upload = env_flag("KICP_DIRECT_UPLOAD");
+int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream) {
+    if (bytes <= hs.cap) return KICP_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    hs.release();
+    const size_t want = bytes + bytes / 2 + (1u << 20);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.p), want, hipHostMallocDefault));
+    hs.cap = want;
+    return KICP_OK;
+}
+constexpr size_t kStagePiece = 1u << 20;
+// `offset`: where in the staging buffer this transfer may start (several may be in flight within one call; reserve first)
+int staged_upload(HostStage &hs, size_t offset, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return KICP_OK;
+    if (g_direct_upload) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return KICP_OK;
+    }
+    if (offset == 0)
+        if (int rc = stage_reserve(hs, bytes, stream)) return rc;
+    if (offset + bytes > hs.cap) return fail(KICP_ERR_ARG, "staging buffer too small for a follow-up transfer");
+    for (size_t off = 0; off < bytes; off += kStagePiece) {
+        const size_t len = std::min(kStagePiece, bytes - off);
+        std::memcpy(hs.p + offset + off, static_cast<const unsigned char *>(src) + off, len);
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, hs.p + offset + off, len, hipMemcpyHostToDevice, stream));
+    }
+    return KICP_OK;
+}
+// device -> caller memory; returns with the data in place
+int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return KICP_OK;
+    if (g_direct_upload) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return KICP_OK;
+    }
+    if (int rc = stage_reserve(hs, bytes, stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(hs.p, src, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(dst, hs.p, bytes);
+    return KICP_OK;
+}
+
 int ensure_host_current(kicp_map *map);
 // release every device buffer of a mirror (on its own device) and reset it
 void free_mirror(DeviceMirror &mr) {
@@ -225,6 +290,7 @@ void free_mirror(DeviceMirror &mr) {
         hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
         hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
         hipFree(mr.d_pc), hipFree(mr.d_pc_blocks);
+        mr.stage.release();
     }
     mr = DeviceMirror{};
 }
@@ -425,9 +491,50 @@ int ensure_update_scratch(DeviceMirror &mr, size_t n) {
     return KICP_OK;
 }
 
-// VoxelHashMap::Update(points, pose) with the points already in HBM.  Runs on the device whenever the table and the
-// pools have room (the common case); otherwise - first frames, table growth - falls back to the host map, which also
-// re-hashes with generous head-room so that the following frames stay on the device.
+// Move the live entries of the device table into a fresh table with room for `extra_entries` more at a load factor of
+// at most 0.25 (the host map's ReserveEntries rule).  The HBM copy becomes the authoritative one.
+int device_rehash(kicp_map *map, size_t extra_entries) {
+    DeviceMirror &mr = map->mirror;
+    hipStream_t st = nullptr;
+    const size_t old_slots = mr.live_slots;
+    HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched (borrowed as the live counter) + error
+    const uint32_t grid_old = static_cast<uint32_t>(std::min<size_t>((old_slots + 255) / 256, 8192));
+    hipLaunchKernelGGL(k_rehash_count, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), &mr.d_ctr->touched);
+    uint32_t live = 0;
+    HIP_TRY(hipMemcpy(&live, &mr.d_ctr->touched, 4, hipMemcpyDeviceToHost));
+    size_t want = 1024;
+    while ((live + extra_entries) * 4 > want) want *= 2;
+    if (want > (1ull << 31)) return fail(KICP_ERR_CAPACITY, "voxel table would exceed 2^31 slots");
+    Slot *nt = nullptr;
+    unsigned long long *nk = nullptr;
+    uint32_t *nc = nullptr, *ns = nullptr;
+    HIP_TRY(hipMalloc(&nt, want * sizeof(Slot)));
+    HIP_TRY(hipMalloc(&nk, want * 8));
+    HIP_TRY(hipMalloc(&nc, want * 4));
+    HIP_TRY(hipMalloc(&ns, want * 4));
+    const uint32_t grid_new = static_cast<uint32_t>(std::min<size_t>((want + 255) / 256, 8192));
+    hipLaunchKernelGGL(k_table_clear, dim3(grid_new), dim3(256), 0, st, nt, static_cast<uint32_t>(want));
+    HIP_TRY(hipMemsetAsync(nk, 0xFF, want * 8, st));
+    HIP_TRY(hipMemsetAsync(nc, 0, want * 4, st));
+    hipLaunchKernelGGL(k_rehash_move, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), nt, nk,
+                       static_cast<uint32_t>(want - 1), &mr.d_ctr->error);
+    HIP_TRY(hipGetLastError());
+    map->dev.n_entries = live, map->dev.touched = 0;
+    HIP_TRY(hipMemcpyAsync(&mr.d_ctr->n_entries, &map->dev.n_entries, 4, hipMemcpyHostToDevice, st));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, &mr.d_ctr->error, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(mr.d_table), hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start);
+    mr.d_table = nt, mr.d_keys64 = nk, mr.d_cnt = nc, mr.d_seg_start = ns;
+    mr.table_slots = mr.live_slots = mr.aux_slots = want;
+    mr.view.table = nt, mr.view.mask = static_cast<uint32_t>(want - 1);
+    map->device_ahead = true;
+    if (err) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
+    return KICP_OK;
+}
+
+// VoxelHashMap::Update(points, pose) with the points already in HBM.  Runs on the device, table growth and pool growth
+// included; only degenerate calls (no points) take the host path.
 int map_update_device(kicp_map *map, int device, const double *d_points, size_t n, const Pose &pose) {
     DeviceMirror &mr = map->mirror;
     map->last_update_on_device = 0;
@@ -442,35 +549,39 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     if (int rc = set_device(device)) return rc;
     if (int rc = map_sync(map, device, nullptr)) return rc;
     const uint32_t cap = map->host.cap();
-    // room for the points' own voxels: <= n new buckets (the pools grow on the device) and <= n new table entries
-    // without leaving the probing regime (the table only grows on the host)
+    // room for the points' own voxels: <= n new buckets (the pools grow on the device) ...
+    if (map->dev.n_buckets_hi + n > 0xFFFFFEull) return fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
     if (int rc = grow_pools(map, map->dev.n_buckets_hi + n)) return rc;
-    const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
-    if ((map->dev.n_entries + n) * 2 > slots) return host_fallback();
     if (int rc = ensure_update_scratch(mr, n)) return rc;
-    UpdateParams up{};
-    up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, static_cast<uint32_t>(bucket_cap),
-                  map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
-    up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
-    up.touched = mr.d_touched;
     const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
     hipStream_t st = nullptr;
-    HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched + error
-    hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
+    UpdateParams up{};
     DevMapCounters c{};
-    HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries
-    if (c.error) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
-    // every newly occupied voxel may add up to 26 halo entries: only continue with head-room, else let the host grow
-    const size_t new_entries = c.n_entries - map->dev.n_entries;
-    map->dev = c;
-    if ((c.n_entries + 26 * new_entries) * 4 > slots * 3) {
-        // undo nothing: the extra entries are harmless halo entries; the per-slot counters must be cleared though
-        HIP_TRY(hipMemsetAsync(mr.d_cnt, 0, slots * 4, st));
+    for (int attempt = 0;; ++attempt) {
+        // ... and <= n new table entries without leaving the probing regime: re-hash (on the device) when the table is short
+        if ((map->dev.n_entries + n) * 2 > mr.live_slots)
+            if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
+        const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
+        up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, static_cast<uint32_t>(bucket_cap),
+                      map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
+        up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
+        up.touched = mr.d_touched;
+        HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched + error
+        hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
+        HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        return host_fallback();
+        map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries
+        if (c.error) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
+        // every newly occupied voxel may add up to 26 halo entries: only continue with head-room
+        const size_t new_entries = c.n_entries - map->dev.n_entries;
+        map->dev = c;
+        if ((c.n_entries + 26 * new_entries) * 4 <= slots * 3) break;
+        if (attempt) return fail(KICP_ERR_CAPACITY, "device-side map update found no room after a re-hash");
+        // Too tight.  The entries just claimed are still plain halo entries without an occupied neighbour, so a re-hash drops
+        // them together with the per-slot counters of this attempt; then claim again in the larger table.
+        if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
     }
+    const size_t slots = mr.live_slots;
     hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
     hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
     hipLaunchKernelGGL(k_up_apply, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
@@ -1023,7 +1134,7 @@ size_t kicp_map_pointcloud(const kicp_map *cmap, double *out_xyz, size_t cap_poi
         uint32_t counted = 0;
         HIP_TRY(hipMemcpy(&counted, mr.d_pc_blocks + blocks, 4, hipMemcpyDeviceToHost));
         if (counted != total) return fail(KICP_ERR_HIP, "device map counters disagree with the table");
-        HIP_TRY(hipMemcpy(out_xyz, mr.d_pc, want * 24, hipMemcpyDeviceToHost));
+        if (int rc = staged_download(mr.stage, out_xyz, mr.d_pc, want * 24, st)) return rc;
         return KICP_OK;
     };
     if (gather() != KICP_OK) {  // fall back to refreshing the host copy
@@ -1060,12 +1171,12 @@ int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_
     HIP_TRY(hipMalloc(&d_q, n * 24));
     HIP_TRY(hipMalloc(&d_nn, n * 24));
     HIP_TRY(hipMalloc(&d_d, n * 8));
-    HIP_TRY(hipMemcpy(d_q, queries_xyz, n * 24, hipMemcpyHostToDevice));
+    if (int rc = staged_upload(map->mirror.stage, 0, d_q, queries_xyz, n * 24, nullptr)) return rc;
     hipLaunchKernelGGL(k_closest, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, nullptr, d_q, static_cast<uint32_t>(n),
                        map->mirror.view, d_nn, d_d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out_nn_xyz, d_nn, n * 24, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_dist, d_d, n * 8, hipMemcpyDeviceToHost));
+    if (int rc = staged_download(map->mirror.stage, out_nn_xyz, d_nn, n * 24, nullptr)) return rc;
+    if (int rc = staged_download(map->mirror.stage, out_dist, d_d, n * 8, nullptr)) return rc;
     hipFree(d_q), hipFree(d_nn), hipFree(d_d);
     return KICP_OK;
 }
@@ -1113,6 +1224,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->d_state) hipFree(reg->d_state);
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->rows) hipHostFree(reg->rows);
+    reg->stage.release();
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
     free_bin(reg->bin);
@@ -1183,7 +1295,7 @@ int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t 
     if (!kicp_map_empty(map) && n) {
         if (int rc = set_device(reg->device)) return rc;
         if (int rc = ensure_frame(reg, n)) return rc;
-        HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
+        if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
     }
     return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
 }
@@ -1214,7 +1326,7 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     if (binned)
         if (int rc = ensure_bin(reg, n)) return rc;
     if (int rc = ensure_partials(reg, pass_grid(reg, n))) return rc;
-    HIP_TRY(hipMemcpyAsync(reg->d_frame, frame_xyz, n * 24, hipMemcpyHostToDevice, reg->stream));
+    if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
     const unsigned long long call_id = ++reg->call_id;
     PassParams pp{};
     pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
@@ -1247,6 +1359,7 @@ struct kicp_pre {
     // wire-format ingest: the raw message bytes, the stamps' extrema, what d_in / d_ts currently hold
     unsigned char *d_raw = nullptr;
     size_t raw_cap = 0;
+    mutable HostStage stage;  // pinned staging for transfers from / to caller memory
     unsigned long long *d_minmax = nullptr;
     size_t ingested_n = 0;
     bool ingested = false, ingested_stamps = false;
@@ -1339,6 +1452,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     for (double *b : p->buf) hipFree(b);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
     hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
+    p->stage.release();
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -1355,8 +1469,10 @@ int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const do
     if (n) {
         if (int rc = pre_ensure(p, n)) return rc;
         p->ingested = false;  // d_in / d_ts are overwritten
-        HIP_TRY(hipMemcpyAsync(p->d_in, frame_xyz, n * 24, hipMemcpyHostToDevice, p->stream));
-        if (do_deskew) HIP_TRY(hipMemcpyAsync(p->d_ts, timestamps, n * 8, hipMemcpyHostToDevice, p->stream));
+        if (int rc = stage_reserve(p->stage, n * 32, p->stream)) return rc;  // one buffer for both arrays
+        if (int rc = staged_upload(p->stage, 0, p->d_in, frame_xyz, n * 24, p->stream)) return rc;
+        if (do_deskew)
+            if (int rc = staged_upload(p->stage, n * 24, p->d_ts, timestamps, n * 8, p->stream)) return rc;
     }
     return pre_run_preprocess(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, dst_buffer, out_n);
 }
@@ -1389,7 +1505,7 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
     if (!p->d_minmax) HIP_TRY(hipMalloc(&p->d_minmax, 16));
     const unsigned long long init[2] = {~0ull, 0ull};
     HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_raw, data, bytes, hipMemcpyHostToDevice, p->stream));
+    if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, p->stream)) return rc;
     IngestParams ip{};
     ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
     ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
@@ -1426,8 +1542,10 @@ int kicp_pre_ingested(const kicp_pre *p, double *out_xyz, double *out_stamps, si
     if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
     if (int rc = set_device(p->device)) return rc;
     const size_t k = std::min(p->ingested_n, cap_points);
-    if (k && out_xyz) HIP_TRY(hipMemcpy(out_xyz, p->d_in, k * 24, hipMemcpyDeviceToHost));
-    if (k && out_stamps && p->ingested_stamps) HIP_TRY(hipMemcpy(out_stamps, p->d_ts, k * 8, hipMemcpyDeviceToHost));
+    if (k && out_xyz)
+        if (int rc = staged_download(p->stage, out_xyz, p->d_in, k * 24, p->stream)) return rc;
+    if (k && out_stamps && p->ingested_stamps)
+        if (int rc = staged_download(p->stage, out_stamps, p->d_ts, k * 8, p->stream)) return rc;
     if (out_n) *out_n = p->ingested_n;
     if (out_has_stamps) *out_has_stamps = p->ingested_stamps ? 1 : 0;
     return KICP_OK;
@@ -1462,7 +1580,8 @@ int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
     if (int rc = pre_ensure_buf(p, buffer, n ? n : 1)) return rc;
-    if (n) HIP_TRY(hipMemcpyAsync(p->buf[buffer], xyz, n * 24, hipMemcpyHostToDevice, p->stream));
+    if (n)
+        if (int rc = staged_upload(p->stage, 0, p->buf[buffer], xyz, n * 24, p->stream)) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->buf_n[buffer] = n;
     return KICP_OK;
@@ -1472,7 +1591,8 @@ int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
     const size_t n = p->buf_n[buffer], k = std::min(n, cap_points);
-    if (k && out_xyz) HIP_TRY(hipMemcpy(out_xyz, p->buf[buffer], k * 24, hipMemcpyDeviceToHost));
+    if (k && out_xyz)
+        if (int rc = staged_download(p->stage, out_xyz, p->buf[buffer], k * 24, p->stream)) return rc;
     if (out_n) *out_n = n;
     return KICP_OK;
 }

@@ -7,8 +7,8 @@
 // the reference's fp64 arithmetic: the accepted set and the order inside each bucket are exactly the sequential
 // reference's, while voxels proceed in parallel.  Table slots are claimed with a 64-bit CAS on a parallel array of
 // packed voxel keys (voxel coordinates must fit +-2^20); first-time occupation updates the 27 neighbour masks / bucket
-// records with atomics, creating halo entries on demand.  Only what the host map would do is done; table growth and
-// dead-entry cleanup stay host-side fallbacks (kicp_api.hip).
+// records with atomics, creating halo entries on demand.  Table growth and dead-entry cleanup are a device-side re-hash
+// (bottom of this file); the pools grow with device-to-device copies (kicp_api.hip).
 #pragma once
 #include "kicp_common.hpp"
 #include "kicp_se3.hpp"
@@ -271,6 +271,44 @@ __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t s
     const double *b = pool + static_cast<size_t>(bucket) * cap * 3;
     double *o = out + static_cast<size_t>(pos) * 3;
     for (uint32_t k = 0; k < 3 * c; ++k) o[k] = b[k];
+}
+
+// ---- re-hash on the device -------------------------------------------------------------------------------------------------
+// The table only ever gains entries between re-hashes (erased voxels turn into halo entries, halo entries nobody needs any
+// more stay behind as dead weight), so every now and then the live entries - occupied voxels and halo entries that still
+// see an occupied neighbour, the host map's rule - move into a fresh (possibly larger) table.  Entries refer to buckets,
+// never to slots, so they can move freely.
+__global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_t slots, uint32_t *live) {
+    uint32_t c = 0;
+    for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
+        const uint32_t val = table[h].val;
+        c += (val != kEmptyVal && ((val & 0xffu) != 0u || table[h].nbr != 0u)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(live, c);
+}
+__global__ __launch_bounds__(256) void k_table_clear(Slot *table, uint32_t slots) {
+    int4 *w = reinterpret_cast<int4 *>(table);
+    const size_t words = static_cast<size_t>(slots) * (sizeof(Slot) / 16);
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < words; i += gridDim.x * 256ull)
+        w[i] = (i % (sizeof(Slot) / 16) == 0) ? make_int4(0, 0, 0, static_cast<int>(kEmptyVal)) : make_int4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void k_rehash_move(const Slot *old_table, uint32_t old_slots, Slot *table, unsigned long long *keys64, uint32_t mask,
+                                                     uint32_t *error) {
+    for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < old_slots; o += gridDim.x * 256) {
+        const Slot &e = old_table[o];
+        if (e.val == kEmptyVal || ((e.val & 0xffu) == 0u && e.nbr == 0u)) continue;
+        bool ok;
+        const unsigned long long key = pack_key64(e.x, e.y, e.z, ok);
+        if (!ok) *error = 1u;
+        uint32_t h = voxel_hash(e.x, e.y, e.z) & mask;
+        while (atomicCAS(keys64 + h, kEmptyKey64, key) != kEmptyKey64) h = (h + 1) & mask;  // keys are unique: a taken slot is someone else's
+        const int4 *src = reinterpret_cast<const int4 *>(&e);
+        int4 *dst = reinterpret_cast<int4 *>(table + h);
+#pragma unroll
+        for (int u = 0; u < static_cast<int>(sizeof(Slot) / 16); ++u) dst[u] = src[u];
+    }
 }
 
 }  // namespace kicp
