@@ -68,4 +68,11 @@ constexpr uint64_t pack_axis(int axis) {
 constexpr uint64_t kShiftX = pack_axis(0), kShiftY = pack_axis(1), kShiftZ = pack_axis(2);
 KICP_HD int shift_component(uint64_t packed, int s) { return static_cast<int>((packed >> (2 * s)) & 3u) - 1; }
 
+// counters of the device-maintained map (kicp_mapdev.hpp), mirrored on the host after every device-side update
+struct DevMapCounters {
+    unsigned long long n_points;
+    uint32_t n_voxels, n_entries, n_buckets_hi, free_count;
+    uint32_t touched, error, pad0, pad1;
+};
+
 }  // namespace kicp

@@ -1,0 +1,116 @@
+// kicp_core.hip -- shared host-side plumbing of libkicp_amd.so: error state, tracing switch, the staging policy for caller
+// memory, version / device queries and the raw device-memory helpers of include/kicp.h.
+#include "kicp_internal.hpp"
+
+namespace kicp {
+namespace host {
+
+// (plain function on purpose: hipcc gave two namespace-scope initialiser lambdas of this shape the same closure symbol and
+// ran the first one's body for both)
+bool env_flag(const char *name) {
+    const char *e = std::getenv(name);
+    return e && *e && *e != '0';
+}
+const bool g_trace = env_flag("KICP_TRACE");
+
+std::string &last_error() {
+    thread_local std::string g_error;
+    return g_error;
+}
+int fail(int code, const std::string &msg) {
+    last_error() = msg;
+    return code;
+}
+
+// Transfers from / to caller memory never hand the caller's pointer to the HIP runtime.  The runtime pins a pageable
+// buffer for the DMA and remembers pinned ranges by address; with buffers that live at new or recycled addresses every
+// frame (a new message, a new std::vector) a 4 MB scan took 17-27 ms to upload instead of 0.16 ms in most processes we
+// measured (always in multiples of ~9 ms, and whether a process was hit depended on its allocation pattern only).  So
+// both directions go through a pinned staging buffer owned by the handle: CPU copy in 1 MB pieces (~0.03 ms each), each
+// followed by its asynchronous DMA - about 0.2 ms for that scan, every time.  KICP_DIRECT_UPLOAD=1 restores the direct
+// DMA for callers that pass pinned (hipHostMalloc / hipHostRegister) memory.  The caller drains `stream` before the staging
+// buffer is used again (every entry point here ends in a sync).
+const bool g_direct_upload = env_flag("KICP_DIRECT_UPLOAD");
+int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream) {
+    if (bytes <= hs.cap) return KICP_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    hs.release();
+    const size_t want = bytes + bytes / 2 + (1u << 20);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.p), want, hipHostMallocDefault));
+    hs.cap = want;
+    return KICP_OK;
+}
+constexpr size_t kStagePiece = 1u << 20;
+// `offset`: where in the staging buffer this transfer may start (several may be in flight within one call; reserve first)
+int staged_upload(HostStage &hs, size_t offset, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return KICP_OK;
+    if (g_direct_upload) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return KICP_OK;
+    }
+    if (offset == 0)
+        if (int rc = stage_reserve(hs, bytes, stream)) return rc;
+    if (offset + bytes > hs.cap) return fail(KICP_ERR_ARG, "staging buffer too small for a follow-up transfer");
+    for (size_t off = 0; off < bytes; off += kStagePiece) {
+        const size_t len = std::min(kStagePiece, bytes - off);
+        std::memcpy(hs.p + offset + off, static_cast<const unsigned char *>(src) + off, len);
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, hs.p + offset + off, len, hipMemcpyHostToDevice, stream));
+    }
+    return KICP_OK;
+}
+// device -> caller memory; returns with the data in place
+int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return KICP_OK;
+    if (g_direct_upload) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return KICP_OK;
+    }
+    if (int rc = stage_reserve(hs, bytes, stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(hs.p, src, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(dst, hs.p, bytes);
+    return KICP_OK;
+}
+
+}  // namespace host
+}  // namespace kicp
+
+using namespace kicp;
+using namespace kicp::host;
+
+extern "C" {
+
+
+const char *kicp_last_error(void) { return last_error().c_str(); }
+int kicp_version(void) { return KICP_VERSION; }
+int kicp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------------------
+int kicp_device_malloc(int device, size_t bytes, void **out_dptr) {
+    if (!out_dptr) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipMalloc(out_dptr, bytes ? bytes : 1));
+    return KICP_OK;
+}
+int kicp_device_free(int device, void *dptr) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipFree(dptr));
+    return KICP_OK;
+}
+int kicp_device_upload(int device, void *dst_dptr, const void *src_host, size_t bytes) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipMemcpy(dst_dptr, src_host, bytes, hipMemcpyHostToDevice));
+    return KICP_OK;
+}
+int kicp_device_synchronize(int device) {
+    if (int rc = set_device(device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return KICP_OK;
+}
+
+}  // extern "C"

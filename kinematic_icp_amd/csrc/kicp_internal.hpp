@@ -1,0 +1,122 @@
+// kicp_internal.hpp -- what the translation units behind include/kicp.h share: error handling, tracing, the staging
+// policy for caller memory, the HBM mirror of the voxel map and the handle behind kicp_map.  Host code only; the kernels
+// live in kicp_kernels.hpp (registration passes), kicp_mapdev.hpp (map maintenance) and kicp_pre.hpp (pre-steps), all with
+// internal linkage so that every translation unit may include what it launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kicp.h"
+#include "kicp_common.hpp"
+#include "kicp_host_map.hpp"
+#include "kicp_se3.hpp"
+
+namespace kicp {
+namespace host {
+
+// KICP_TRACE=1 in the environment: every traced C-ABI call reports its wall time on stderr (debugging aid)
+bool env_flag(const char *name);
+extern const bool g_trace;
+struct TraceScope {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit TraceScope(const char *n) : name(n) {
+        if (g_trace) t0 = std::chrono::steady_clock::now();
+    }
+    ~TraceScope() {
+        if (g_trace) std::fprintf(stderr, "[kicp] %-32s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+#define KICP_TRACE_CALL() ::kicp::host::TraceScope trace_scope_(__func__)
+
+// last error message of the calling thread (kicp_last_error) and the one way to report a failure
+std::string &last_error();
+int fail(int code, const std::string &msg);
+#define HIP_TRY(expr)                                                                                                        \
+    do {                                                                                                                     \
+        hipError_t e_ = (expr);                                                                                              \
+        if (e_ != hipSuccess)                                                                                                \
+            return ::kicp::host::fail(KICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                                        std::to_string(__LINE__) + ")");                                    \
+    } while (0)
+
+inline Pose pose_from(const double p[7]) { return Pose{p[0], p[1], p[2], p[3], p[4], p[5], p[6]}; }
+inline void pose_to(const Pose &T, double p[7]) { p[0] = T.qx, p[1] = T.qy, p[2] = T.qz, p[3] = T.qw, p[4] = T.tx, p[5] = T.ty, p[6] = T.tz; }
+inline int set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return KICP_OK;
+}
+
+// pinned staging buffer for uploads of pageable caller memory (see staged_upload)
+struct HostStage {
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    void release() {
+        if (p) hipHostFree(p);
+        p = nullptr, cap = 0;
+    }
+};
+// (policy and implementation: kicp_core.hip)
+int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream);
+int staged_upload(HostStage &hs, size_t offset, void *dst, const void *src, size_t bytes, hipStream_t stream);
+int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hipStream_t stream);
+
+struct DeviceMirror {
+    int device = -1;
+    Slot *d_table = nullptr;
+    double *d_pool = nullptr;
+    float4 *d_pool32 = nullptr;
+    size_t table_slots = 0, pool_doubles = 0;  // allocated sizes
+    size_t live_slots = 0;                     // table size the mirror currently represents
+    uint64_t synced_epoch = ~0ull, synced_generation = ~0ull;
+    // staging for delta uploads (device)
+    uint2 *d_stage = nullptr;
+    uint32_t *d_index = nullptr;
+    size_t stage_words = 0, index_cap = 0;
+    size_t last_upload_bytes = 0;
+    int last_upload_full = 1;
+    MapView view{};
+    // device-side maintenance (kicp_mapdev.hpp): per-slot and per-update scratch
+    unsigned long long *d_keys64 = nullptr;
+    uint32_t *d_cnt = nullptr, *d_seg_start = nullptr, *d_free_list = nullptr;
+    DevMapCounters *d_ctr = nullptr;
+    size_t aux_slots = 0, free_cap = 0;
+    double *d_world = nullptr;
+    uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
+    size_t upd_cap = 0;
+    HostStage stage;  // pinned staging for transfers from / to caller memory (queries, Pointcloud)
+    // Pointcloud() from the device copy
+    double *d_pc = nullptr;
+    uint32_t *d_pc_blocks = nullptr;  // per-256-slot-block counts / offsets, then the total
+    size_t pc_points = 0, pc_blocks = 0;
+};
+}  // namespace host
+}  // namespace kicp
+
+struct kicp_map {
+    kicp::HostMap host;
+    kicp::host::DeviceMirror mirror;
+    // set while the HBM copy is newer than the host copy (after a device-side Update); the host copy is refreshed on
+    // demand by ensure_host_current().  Counters of the device state for the cheap queries:
+    bool device_ahead = false;
+    kicp::DevMapCounters dev{};
+    int last_update_on_device = 0;
+    kicp_map(double vs, double md, uint32_t cap) : host(vs, md, cap) {}
+};
+
+namespace kicp {
+namespace host {
+// make the HBM mirror on `device` current / bring the host copy up to date after device-side updates (kicp_map.hip)
+int map_sync(kicp_map *map, int device, hipStream_t stream);
+int ensure_host_current(kicp_map *map);
+}  // namespace host
+}  // namespace kicp

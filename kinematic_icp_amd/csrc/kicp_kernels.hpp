@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void load_group_query(GroupQuery &g, const double *sr
 // ------------------------------------------------------------------------------------------------------------
 // variant 1: groups of 64 consecutive queries in the order given (persistent grid)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
+static __global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
     KICP_PASS_SHARED(64)
     __shared__ WaveLds L;
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
 constexpr int kCellShift = 1;  // cell = 2x2x2 voxels
 constexpr int kRunLen = 64;    // queries per work item
 
-__global__ __launch_bounds__(64, 3) void k_pass_binned(const PassParams p) {
+static __global__ __launch_bounds__(64, 3) void k_pass_binned(const PassParams p) {
     KICP_PASS_SHARED(64)
     __shared__ WaveLds L;
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
@@ -1131,7 +1131,7 @@ __device__ __forceinline__ uint32_t hash_cell(unsigned long long k) {
     return static_cast<uint32_t>(k);
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(const BinParams b) {
+static __global__ __launch_bounds__(256) void k_bin_count(const BinParams b) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < b.n;
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_bin_count(const BinParams b) {
 
 // single workgroup: exclusive scans over the occupied cells -> first query / first work item per cell; emits the
 // item list; leaves the cell table clean for the next scan
-__global__ __launch_bounds__(1024) void k_bin_scan(const BinParams b) {
+static __global__ __launch_bounds__(1024) void k_bin_scan(const BinParams b) {
     __shared__ uint32_t s_wave[16][2];
     __shared__ uint32_t s_carry[2];
     const uint32_t n_cells = b.counters[0];
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const BinParams b) {
     if (threadIdx.x == 0) b.counters[1] = s_carry[1], b.counters[2] = n_cells, b.counters[0] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(const BinParams b) {
+static __global__ __launch_bounds__(256) void k_bin_scatter(const BinParams b) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= b.n) return;
     const uint2 qi = b.qinfo[i];
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const BinParams b) {
 // ------------------------------------------------------------------------------------------------------------
 // solve step alone: multi-GPU (after the all-reduce of st->reduce)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f) {
+static __global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f) {
     if (threadIdx.x != 0) return;
     if (f.pass != 0 && st->done) return;
     long long limbs[kNumLimbs];
@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f)
 }
 
 // multi-GPU with host-side solve: hand the all-reduced limb totals to the host
-__global__ __launch_bounds__(64) void k_publish_words(IcpState *st, HostRecord *rec, unsigned long long call_id, int pass) {
+static __global__ __launch_bounds__(64) void k_publish_words(IcpState *st, HostRecord *rec, unsigned long long call_id, int pass) {
     const int lane = threadIdx.x;
     if (lane < kReduceWords) __hip_atomic_store(&rec->words[lane], st->reduce[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_publish_words(IcpState *st, HostRecord *
 }
 
 // publish the raw sums of the last pass (kicp_pass_sums)
-__global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *rec, unsigned long long call_id) {
+static __global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *rec, unsigned long long call_id) {
     if (threadIdx.x != 0) return;
     for (int i = 0; i < kNumSums; ++i)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&rec->sums[i]),
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(64) void k_publish_sums(IcpState *st, HostRecord *r
 // delta upload of the map mirror: scatter staged rows (8-byte words) to their places
 //   row r of `staged` (row_words uint2 each) goes to dst + index[r] * row_words
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter_rows(const uint2 *__restrict__ staged, const uint32_t *__restrict__ index, uint32_t rows,
+static __global__ __launch_bounds__(256) void k_scatter_rows(const uint2 *__restrict__ staged, const uint32_t *__restrict__ index, uint32_t rows,
                                                       uint32_t row_words, uint2 *__restrict__ dst) {
     const size_t total = static_cast<size_t>(rows) * row_words;
     for (size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<size_t>(gridDim.x) * 256) {
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const uint2 *__restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 // GetClosestNeighbor for a batch (API parity; same search code as the fused kernel, no acceptance bound)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_closest(const double *__restrict__ queries, uint32_t n, const MapView m,
+static __global__ __launch_bounds__(256) void k_closest(const double *__restrict__ queries, uint32_t n, const MapView m,
                                                  double *__restrict__ out_nn, double *__restrict__ out_dist) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

@@ -8,7 +8,7 @@
 // reference's, while voxels proceed in parallel.  Table slots are claimed with a 64-bit CAS on a parallel array of
 // packed voxel keys (voxel coordinates must fit +-2^20); first-time occupation updates the 27 neighbour masks / bucket
 // records with atomics, creating halo entries on demand.  Table growth and dead-entry cleanup are a device-side re-hash
-// (bottom of this file); the pools grow with device-to-device copies (kicp_api.hip).
+// (bottom of this file); the pools grow with device-to-device copies (kicp_map.hip).
 #pragma once
 #include "kicp_common.hpp"
 #include "kicp_se3.hpp"
@@ -16,12 +16,6 @@
 namespace kicp {
 
 constexpr unsigned long long kEmptyKey64 = ~0ull;
-
-struct DevMapCounters {
-    unsigned long long n_points;
-    uint32_t n_voxels, n_entries, n_buckets_hi, free_count;
-    uint32_t touched, error, pad0, pad1;
-};
 
 struct DevMap {
     Slot *table;
@@ -89,7 +83,7 @@ __device__ __forceinline__ uint32_t dev_find(const DevMap &m, int32_t x, int32_t
 }
 
 // keys64 from the table (after every host -> device upload)
-__global__ __launch_bounds__(256) void k_build_keys64(const Slot *table, uint32_t slots, unsigned long long *keys64) {
+static __global__ __launch_bounds__(256) void k_build_keys64(const Slot *table, uint32_t slots, unsigned long long *keys64) {
     for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
         bool ok;
         keys64[h] = table[h].val == kEmptyVal ? kEmptyKey64 : pack_key64(table[h].x, table[h].y, table[h].z, ok);
@@ -97,7 +91,7 @@ __global__ __launch_bounds__(256) void k_build_keys64(const Slot *table, uint32_
 }
 
 // 1. transform, find/claim the voxel's slot, count the voxel's new points
-__global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
+static __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     double rx, ry, rz;
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
 }
 
 // 2. exclusive scan of the touched voxels' counts -> group starts; counts are zeroed to serve as fill cursors
-__global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
+static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t n_touched = p.m.ctr->touched;
@@ -141,7 +135,7 @@ __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
 }
 
 // 3. scatter the point indices into their voxel's group (any order; the apply step walks a group by ascending index)
-__global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
+static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const uint32_t h = p.slot_of[i];
@@ -149,7 +143,7 @@ __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
 }
 
 // 4. one thread per touched voxel: the reference's AddPoints rule over the voxel's new points in input order
-__global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
+static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     const DevMap &m = p.m;
     if (t >= m.ctr->touched) return;
@@ -215,7 +209,7 @@ __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
 }
 
 // 5. RemovePointsFarFromLocation(origin): a voxel goes when its FIRST point is >= max_distance away
-__global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, double oy, double oz) {
+static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, double oy, double oz) {
     const uint32_t slots = m.mask + 1;
     const double max_distance2 = m.max_distance * m.max_distance;
     for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
@@ -240,7 +234,7 @@ __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, do
 // ---- Pointcloud() from the device copy (KinematicICP.hpp:92, published by the ROS node when someone listens) ----------
 // All points, voxel by voxel in table order - the order HostMap::Pointcloud emits - without bringing the table and the
 // pools back to the host: count per 256-slot block, scan the block totals, then every slot copies its bucket's points.
-__global__ __launch_bounds__(256) void k_pc_count(const Slot *table, uint32_t slots, uint32_t *block_counts) {
+static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, uint32_t slots, uint32_t *block_counts) {
     __shared__ uint32_t s_sum[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     uint32_t c = 0;
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, uint32_t sl
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
-__global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t slots, const double *pool, uint32_t cap,
+static __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t slots, const double *pool, uint32_t cap,
                                                    const uint32_t *block_offsets, double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
@@ -278,7 +272,7 @@ __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t s
 // more stay behind as dead weight), so every now and then the live entries - occupied voxels and halo entries that still
 // see an occupied neighbour, the host map's rule - move into a fresh (possibly larger) table.  Entries refer to buckets,
 // never to slots, so they can move freely.
-__global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_t slots, uint32_t *live) {
+static __global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_t slots, uint32_t *live) {
     uint32_t c = 0;
     for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
         const uint32_t val = table[h].val;
@@ -288,13 +282,13 @@ __global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(live, c);
 }
-__global__ __launch_bounds__(256) void k_table_clear(Slot *table, uint32_t slots) {
+static __global__ __launch_bounds__(256) void k_table_clear(Slot *table, uint32_t slots) {
     int4 *w = reinterpret_cast<int4 *>(table);
     const size_t words = static_cast<size_t>(slots) * (sizeof(Slot) / 16);
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < words; i += gridDim.x * 256ull)
         w[i] = (i % (sizeof(Slot) / 16) == 0) ? make_int4(0, 0, 0, static_cast<int>(kEmptyVal)) : make_int4(0, 0, 0, 0);
 }
-__global__ __launch_bounds__(256) void k_rehash_move(const Slot *old_table, uint32_t old_slots, Slot *table, unsigned long long *keys64, uint32_t mask,
+static __global__ __launch_bounds__(256) void k_rehash_move(const Slot *old_table, uint32_t old_slots, Slot *table, unsigned long long *keys64, uint32_t mask,
                                                      uint32_t *error) {
     for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < old_slots; o += gridDim.x * 256) {
         const Slot &e = old_table[o];

@@ -35,7 +35,7 @@ __device__ __forceinline__ void block_count_store(bool pred, uint32_t *block_cou
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-__global__ __launch_bounds__(256) void k_preprocess(const PreprocessParams p) {
+static __global__ __launch_bounds__(256) void k_preprocess(const PreprocessParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
     if (i < p.n) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const PreprocessParams p) {
 }
 
 // exclusive scan of the per-block counts (one workgroup; up to 1024 * 64 blocks = 16.7M points)
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *block_counts, uint32_t nblocks, uint32_t *total) {
+static __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *block_counts, uint32_t nblocks, uint32_t *total) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *block_counts, ui
 }
 
 // order-preserving compaction: survivor i goes to block_offset + (number of survivors before it in its block)
-__global__ __launch_bounds__(256) void k_compact(const double *staged, const uint32_t *flags, const uint32_t *block_offsets, uint32_t n,
+static __global__ __launch_bounds__(256) void k_compact(const double *staged, const uint32_t *flags, const uint32_t *block_offsets, uint32_t n,
                                                  double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -134,7 +134,7 @@ __device__ __forceinline__ uint32_t hash_u64(unsigned long long k) {
 }
 
 // pass 1: every point claims / finds its voxel's slot and lowers the slot's winner to its own index
-__global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
+static __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const double vs = p.voxel_size;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams
     p.slot_of[i] = slot;
 }
 // pass 2: the winners are the points whose index is their voxel's minimum
-__global__ __launch_bounds__(256) void k_downsample_flag(const DownsampleParams p) {
+static __global__ __launch_bounds__(256) void k_downsample_flag(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
     if (i < p.n) {
@@ -197,7 +197,7 @@ KICP_HD double ordered_value(unsigned long long k) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
+static __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
     __shared__ unsigned long long s_min[4], s_max[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long kmin = ~0ull, kmax = 0ull;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
     }
 }
 // TimeStampHandler.cpp:121-128: (t - min) / (max - min), the same two fp64 operations
-__global__ __launch_bounds__(256) void k_normalize_stamps(double *stamps, uint32_t n, const unsigned long long *minmax) {
+static __global__ __launch_bounds__(256) void k_normalize_stamps(double *stamps, uint32_t n, const unsigned long long *minmax) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double lo = ordered_value(minmax[0]), hi = ordered_value(minmax[1]);

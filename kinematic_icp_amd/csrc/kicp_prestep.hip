@@ -1,0 +1,265 @@
+// kicp_prestep.hip -- the pipeline's pre-steps behind include/kicp.h (kicp_pre_*): wire-format ingest, deskew + crop +
+// transform, voxel downsample (kernels: kicp_pre.hpp).
+#include "kicp_internal.hpp"
+#include "kicp_pre.hpp"
+
+using namespace kicp;
+using namespace kicp::host;
+
+struct kicp_pre {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    double *buf[KICP_PRE_BUFFERS] = {};
+    size_t buf_cap[KICP_PRE_BUFFERS] = {}, buf_n[KICP_PRE_BUFFERS] = {};
+    double *d_in = nullptr, *d_ts = nullptr, *d_staged = nullptr;
+    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_slot_of = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error
+    unsigned long long *d_keys = nullptr;
+    uint32_t *d_min_index = nullptr;
+    size_t cap_n = 0, table_slots = 0;
+    // wire-format ingest: the raw message bytes, the stamps' extrema, what d_in / d_ts currently hold
+    unsigned char *d_raw = nullptr;
+    size_t raw_cap = 0;
+    mutable HostStage stage;  // pinned staging for transfers from / to caller memory
+    unsigned long long *d_minmax = nullptr;
+    size_t ingested_n = 0;
+    bool ingested = false, ingested_stamps = false;
+};
+namespace {
+int pre_ensure(kicp_pre *p, size_t n) {
+    if (n <= p->cap_n) return KICP_OK;
+    const size_t cap = n + n / 4 + 1024;
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
+    hipFree(p->d_keys), hipFree(p->d_min_index);
+    HIP_TRY(hipMalloc(&p->d_in, cap * 24));
+    HIP_TRY(hipMalloc(&p->d_ts, cap * 8));
+    HIP_TRY(hipMalloc(&p->d_staged, cap * 24));
+    HIP_TRY(hipMalloc(&p->d_flags, cap * 4));
+    HIP_TRY(hipMalloc(&p->d_block_counts, (cap / 256 + 2) * 4));
+    HIP_TRY(hipMalloc(&p->d_slot_of, cap * 4));
+    size_t slots = 1024;
+    while (slots < 2 * cap) slots <<= 1;
+    HIP_TRY(hipMalloc(&p->d_keys, slots * 8));
+    HIP_TRY(hipMalloc(&p->d_min_index, slots * 4));
+    p->cap_n = cap, p->table_slots = slots;
+    return KICP_OK;
+}
+int pre_ensure_buf(kicp_pre *p, int b, size_t n) {
+    if (n <= p->buf_cap[b]) return KICP_OK;
+    if (p->buf[b]) HIP_TRY(hipFree(p->buf[b]));
+    p->buf[b] = nullptr;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc(&p->buf[b], cap * 24));
+    p->buf_cap[b] = cap;
+    return KICP_OK;
+}
+// flags + block counts are in place: scan, compact staged -> buffer dst, return the survivor count
+int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *out_n) {
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    if (int rc = pre_ensure_buf(p, dst, n)) return rc;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, p->d_flags, p->d_block_counts, static_cast<uint32_t>(n), p->buf[dst]);
+    HIP_TRY(hipGetLastError());
+    uint32_t misc[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (misc[1]) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
+    p->buf_n[dst] = misc[0];
+    if (out_n) *out_n = misc[0];
+    return KICP_OK;
+}
+// k_preprocess over what d_in / d_ts hold, then compaction into buffer dst
+int pre_run_preprocess(kicp_pre *p, size_t n, bool do_deskew, const double relative_motion_qt[7], const double lidar_to_base_qt[7],
+                       double max_range, double min_range, int dst_buffer, size_t *out_n) {
+    if (n == 0) {
+        p->buf_n[dst_buffer] = 0;
+        if (out_n) *out_n = 0;
+        return KICP_OK;
+    }
+    PreprocessParams pp{};
+    pp.in = p->d_in, pp.timestamps = p->d_ts, pp.n = static_cast<uint32_t>(n), pp.deskew = do_deskew ? 1 : 0;
+    const Pose rel = pose_from(relative_motion_qt);
+    pose_log(rel, pp.omega);
+    pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
+    pp.max_range = max_range, pp.min_range = min_range;
+    pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
+    hipLaunchKernelGGL(k_preprocess, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, p->stream, pp);
+    return pre_compact(p, p->d_staged, n, dst_buffer, out_n);
+}
+}  // namespace
+extern "C" {
+int kicp_pre_create(int device, kicp_pre **out) {
+    if (!out) return fail(KICP_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(KICP_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(KICP_ERR_ARG, "device index out of range");
+    if (int rc = set_device(device)) return rc;
+    kicp_pre *p = new kicp_pre;
+    p->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&p->d_misc, 16);
+    if (e == hipSuccess) e = hipMemset(p->d_misc, 0, 16);
+    if (e != hipSuccess) {
+        kicp_pre_destroy(p);
+        return fail(KICP_ERR_HIP, std::string("kicp_pre_create: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return KICP_OK;
+}
+void kicp_pre_destroy(kicp_pre *p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (double *b : p->buf) hipFree(b);
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
+    hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
+    p->stage.release();
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                        const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range,
+                        int deskew, int dst_buffer, size_t *out_n) {
+    KICP_TRACE_CALL();
+    if (!p || (!frame_xyz && n) || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
+        return fail(KICP_ERR_ARG, "bad argument");
+    const bool do_deskew = deskew && n_timestamps != 0;  // Preprocessing.cpp: `if (deskew_ && !timestamps.empty())`
+    if (do_deskew && (!timestamps || n_timestamps < n)) return fail(KICP_ERR_ARG, "one timestamp per point is required for deskewing");
+    if (int rc = set_device(p->device)) return rc;
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (n) {
+        if (int rc = pre_ensure(p, n)) return rc;
+        p->ingested = false;  // d_in / d_ts are overwritten
+        if (int rc = stage_reserve(p->stage, n * 32, p->stream)) return rc;  // one buffer for both arrays
+        if (int rc = staged_upload(p->stage, 0, p->d_in, frame_xyz, n * 24, p->stream)) return rc;
+        if (do_deskew)
+            if (int rc = staged_upload(p->stage, n * 24, p->d_ts, timestamps, n * 8, p->stream)) return rc;
+    }
+    return pre_run_preprocess(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, dst_buffer, out_n);
+}
+int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
+                    double *out_min_stamp, double *out_max_stamp) {
+    KICP_TRACE_CALL();
+    if (!p || !layout || (!data && n_points)) return fail(KICP_ERR_ARG, "bad argument");
+    const kicp_cloud_layout &L = *layout;
+    const int st = L.stamp_datatype;
+    if (st != 0 && st != KICP_FIELD_UINT32 && st != KICP_FIELD_FLOAT32 && st != KICP_FIELD_FLOAT64)
+        return fail(KICP_ERR_ARG, "timestamp field type not supported");  // TimeStampHandler.cpp:103
+    const uint32_t stamp_bytes = st == KICP_FIELD_FLOAT64 ? 8u : 4u;
+    if (L.point_step == 0 || L.offset_x + 4ull > L.point_step || L.offset_y + 4ull > L.point_step || L.offset_z + 4ull > L.point_step ||
+        (st != 0 && L.offset_stamp + static_cast<unsigned long long>(stamp_bytes) > L.point_step))
+        return fail(KICP_ERR_ARG, "field offsets do not fit inside point_step");
+    if (n_points > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "cloud too large");
+    if (int rc = set_device(p->device)) return rc;
+    p->ingested = true, p->ingested_n = n_points, p->ingested_stamps = st != 0 && n_points != 0;
+    if (out_min_stamp) *out_min_stamp = 0.0;
+    if (out_max_stamp) *out_max_stamp = 0.0;
+    if (n_points == 0) return KICP_OK;
+    if (int rc = pre_ensure(p, n_points)) return rc;
+    const size_t bytes = n_points * static_cast<size_t>(L.point_step);
+    if (bytes > p->raw_cap) {
+        hipFree(p->d_raw);
+        p->d_raw = nullptr, p->raw_cap = 0;
+        HIP_TRY(hipMalloc(&p->d_raw, bytes + bytes / 4 + 4096));
+        p->raw_cap = bytes + bytes / 4 + 4096;
+    }
+    if (!p->d_minmax) HIP_TRY(hipMalloc(&p->d_minmax, 16));
+    const unsigned long long init[2] = {~0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
+    if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, p->stream)) return rc;
+    IngestParams ip{};
+    ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
+    ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
+    ip.transform = sensor_pose_qt ? 1 : 0;
+    if (sensor_pose_qt) ip.T = pose_from(sensor_pose_qt);
+    ip.out_xyz = p->d_in, ip.out_stamps = p->d_ts, ip.minmax = p->d_minmax;
+    const uint32_t grid = static_cast<uint32_t>((n_points + 255) / 256);
+    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, p->stream, ip);
+    if (st != 0) {
+        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, p->stream, p->d_ts, ip.n, p->d_minmax);
+        unsigned long long mm[2];
+        HIP_TRY(hipMemcpyAsync(mm, p->d_minmax, 16, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (out_min_stamp) *out_min_stamp = ordered_value(mm[0]);
+        if (out_max_stamp) *out_max_stamp = ordered_value(mm[1]);
+    } else {
+        HIP_TRY(hipStreamSynchronize(p->stream));  // `data` is borrowed for the call only
+    }
+    HIP_TRY(hipGetLastError());
+    return KICP_OK;
+}
+int kicp_pre_preprocess_ingested(kicp_pre *p, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
+                                 double min_range, int deskew, int dst_buffer, size_t *out_n) {
+    KICP_TRACE_CALL();
+    if (!p || !relative_motion_qt || !lidar_to_base_qt || dst_buffer < 0 || dst_buffer >= KICP_PRE_BUFFERS)
+        return fail(KICP_ERR_ARG, "bad argument");
+    if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
+    if (int rc = set_device(p->device)) return rc;
+    return pre_run_preprocess(p, p->ingested_n, deskew && p->ingested_stamps, relative_motion_qt, lidar_to_base_qt, max_range, min_range,
+                              dst_buffer, out_n);
+}
+int kicp_pre_ingested(const kicp_pre *p, double *out_xyz, double *out_stamps, size_t cap_points, size_t *out_n, int *out_has_stamps) {
+    if (!p) return fail(KICP_ERR_ARG, "bad argument");
+    if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t k = std::min(p->ingested_n, cap_points);
+    if (k && out_xyz)
+        if (int rc = staged_download(p->stage, out_xyz, p->d_in, k * 24, p->stream)) return rc;
+    if (k && out_stamps && p->ingested_stamps)
+        if (int rc = staged_download(p->stage, out_stamps, p->d_ts, k * 8, p->stream)) return rc;
+    if (out_n) *out_n = p->ingested_n;
+    if (out_has_stamps) *out_has_stamps = p->ingested_stamps ? 1 : 0;
+    return KICP_OK;
+}
+int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, size_t *out_n) {
+    KICP_TRACE_CALL();
+    if (!p || src < 0 || src >= KICP_PRE_BUFFERS || dst < 0 || dst >= KICP_PRE_BUFFERS || src == dst || !(voxel_size > 0.0))
+        return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t n = p->buf_n[src];
+    if (n == 0) {
+        p->buf_n[dst] = 0;
+        if (out_n) *out_n = 0;
+        return KICP_OK;
+    }
+    if (int rc = pre_ensure(p, n)) return rc;
+    size_t slots = 1024;  // this call's table: the smallest power of two >= 2n keeps the memset small
+    while (slots < 2 * n) slots <<= 1;
+    HIP_TRY(hipMemsetAsync(p->d_keys, 0xFF, slots * 8, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_min_index, 0xFF, slots * 4, p->stream));
+    DownsampleParams dp{};
+    dp.in = p->buf[src], dp.n = static_cast<uint32_t>(n), dp.voxel_size = voxel_size, dp.keys = p->d_keys, dp.min_index = p->d_min_index;
+    dp.mask = static_cast<uint32_t>(slots - 1), dp.slot_of = p->d_slot_of, dp.flags = p->d_flags, dp.block_counts = p->d_block_counts;
+    dp.error = p->d_misc + 1;
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
+    hipLaunchKernelGGL(k_downsample_flag, dim3(grid), dim3(256), 0, p->stream, dp);
+    return pre_compact(p, p->buf[src], n, dst, out_n);
+}
+int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
+    KICP_TRACE_CALL();
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    if (int rc = pre_ensure_buf(p, buffer, n ? n : 1)) return rc;
+    if (n)
+        if (int rc = staged_upload(p->stage, 0, p->buf[buffer], xyz, n * 24, p->stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->buf_n[buffer] = n;
+    return KICP_OK;
+}
+int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap_points, size_t *out_n) {
+    KICP_TRACE_CALL();
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    const size_t n = p->buf_n[buffer], k = std::min(n, cap_points);
+    if (k && out_xyz)
+        if (int rc = staged_download(p->stage, out_xyz, p->buf[buffer], k * 24, p->stream)) return rc;
+    if (out_n) *out_n = n;
+    return KICP_OK;
+}
+const double *kicp_pre_device_ptr(const kicp_pre *p, int buffer, size_t *out_n) {
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return nullptr;
+    if (out_n) *out_n = p->buf_n[buffer];
+    return p->buf[buffer];
+}
+
+}  // extern "C"

@@ -1,0 +1,814 @@
+// kicp_reg.hip -- KinematicRegistration::ComputeRobotMotion behind include/kicp.h: the registration handle, the per-iteration
+// launch / hand-off / host-side solve loop (kicp_kernels.hpp), and the multi-GPU exchanges (host shared segment, RCCL bound
+// at run time, caller-supplied all-reduce).
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "kicp_internal.hpp"
+#include "kicp_kernels.hpp"
+
+using namespace kicp;
+using namespace kicp::host;
+
+namespace {
+// host twin of kicp::limbs_to_double (same operations, so host- and device-side solves see the same doubles)
+double host_limbs_to_double(const long long l[3]) {
+    unsigned __int128 t = static_cast<unsigned __int128>(static_cast<__int128>(l[0]));
+    t += static_cast<unsigned __int128>(static_cast<__int128>(l[1])) << 40;
+    t += static_cast<unsigned __int128>(static_cast<__int128>(l[2])) << 80;
+    const bool neg = static_cast<__int128>(t) < 0;
+    if (neg) t = ~t + 1;
+    const double mag = static_cast<double>(static_cast<unsigned long long>(t >> 64)) * 18446744073709551616.0 +
+                       static_cast<double>(static_cast<unsigned long long>(t));
+    return (neg ? -mag : mag) / kFixScale;
+}
+
+// ---- RCCL, bound lazily so that single-GPU users never load it ------------------------------------------------
+struct CommApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string &err) {
+        if (handle) return true;
+        // prefer an RCCL that is already in the process (e.g. the one torch.distributed loaded)
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names)
+            if ((handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!handle)
+            for (const char *nm : names)
+                if ((handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!handle) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+            err = "librccl lacks an expected symbol";
+            return false;
+        }
+        return true;
+    }
+};
+CommApi g_comm;
+
+}  // namespace
+
+struct BinBuffers {
+    unsigned long long *cell_keys = nullptr;
+    uint32_t *cell_count = nullptr, *cell_start = nullptr, *cell_list = nullptr, *counters = nullptr;
+    uint2 *qinfo = nullptr, *items = nullptr;
+    double *sorted_src = nullptr;
+    uint32_t mask = 0;
+    size_t cap_n = 0;
+};
+
+struct kicp_reg {
+    kicp_reg_config cfg{};
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evp[2 * KICP_MAX_LOG_PASSES] = {};  // per-pass events ("timing" == 2), created on first use
+    IcpState *d_state = nullptr;
+    HostRecord *rec = nullptr;    // host-mapped pinned result record (host view)
+    HostRecord *d_rec = nullptr;  // same memory, device view
+    unsigned long long call_id = 0;
+    unsigned long long *d_partials = nullptr;  // limb rows of the reduction tree
+    unsigned int *d_tickets = nullptr;
+    size_t partial_blocks = 0;
+    // mode 4 hand-off: tagged rows of the first-level groups in host-mapped pinned memory, added up by the host
+    unsigned long long *rows = nullptr, *d_rows = nullptr;  // host / device view
+    size_t rows_groups = 0;
+    uint32_t tag = 0;       // tag of the last pass (1..65535)
+    int group_rows = 1;     // option "group_rows": 1 = mode 4 (default), 0 = the device folds everything (mode 2)
+    double *d_frame = nullptr;  // device copy of host frames
+    size_t frame_cap = 0;
+    HostStage stage;            // pinned staging for transfers from / to caller memory
+    BinBuffers bin;
+    // options
+    int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather, 1 lds (given order), 2 binned by cell
+    int block = 128;      // workgroup size of variants 0/3
+    int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
+    int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
+    int waves_per_cu = 12; // persistent grid of variants 1/2
+    int timing = 0;       // record HIP events around the call -> stats.gpu_ms
+    int dbg = 0;
+    int query_every = 64;  // polls between hipStreamQuery calls while waiting
+    int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
+    int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
+    int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    kicp_allreduce_fn allreduce_fn = nullptr;
+    void *allreduce_user = nullptr;
+    // node-wide shared segment (multi-process, no device collective)
+    struct ShmSlot {
+        unsigned long long seq;
+        long long words[kReduceWords];
+        unsigned long long pad[7];  // 256 bytes
+    };
+    ShmSlot *shm = nullptr;    // host view: [2 buffers][nranks]
+    ShmSlot *d_shm = nullptr;  // device view of the same memory
+    size_t shm_bytes = 0;
+    unsigned long long shm_step = 0;  // hand-offs issued so far (same on every rank)
+    std::string shm_name;
+};
+
+namespace {
+
+template <int BLOCK>
+void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
+}
+int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
+// Sub-lanes per query of variant 3.  Small scans are latency bound (few waves, each lane's chain of dependent bucket
+// visits decides the kernel time): spreading a query's neighbour voxels over 2-4 lanes shortens that chain.  Large
+// scans already fill the machine and only pay for the extra waves.
+int lanes_for(const kicp_reg *r, size_t n) {
+    if (r->lanes_per_query > 0) return r->lanes_per_query;
+    return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
+}
+uint32_t pass_grid(const kicp_reg *r, size_t n) {
+    if (r->pass_kernel == 1 || r->pass_kernel == 2) {  // persistent one-wave workgroups
+        const size_t max_groups = (n + 63) / 64 + (r->pass_kernel == 2 ? n / 8 : 0);  // more workgroups than groups would only idle
+        const size_t want = static_cast<size_t>(r->num_cus) * r->waves_per_cu;
+        return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
+    }
+    const int block = normalized_block(r->block);
+    const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
+    return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
+}
+void launch_pass(const kicp_reg *r, const PassParams &p) {
+    const uint32_t grid = pass_grid(r, p.n);
+    if (r->pass_kernel == 2) {
+        hipLaunchKernelGGL(k_pass_binned, dim3(grid), dim3(64), 0, r->stream, p);
+        return;
+    }
+    if (r->pass_kernel == 1) {
+        hipLaunchKernelGGL(k_pass_lds, dim3(grid), dim3(64), 0, r->stream, p);
+        return;
+    }
+    if (r->pass_kernel == 3) {
+        const int b = normalized_block(r->block), g = lanes_for(r, p.n);
+#define KICP_G32(B, G) hipLaunchKernelGGL((k_pass_gather32<B, G>), dim3(grid), dim3(B), 0, r->stream, p)
+        if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
+        else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
+        else { if (b == 64) KICP_G32(64, 4); else if (b == 256) KICP_G32(256, 4); else KICP_G32(128, 4); }
+#undef KICP_G32
+        return;
+    }
+    switch (normalized_block(r->block)) {
+        case 64: launch_gather<64>(p, grid, r->stream); break;
+        case 256: launch_gather<256>(p, grid, r->stream); break;
+        default: launch_gather<128>(p, grid, r->stream); break;
+    }
+}
+
+int ensure_partials(kicp_reg *r, size_t blocks) {
+    if (blocks <= r->partial_blocks) return KICP_OK;
+    if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
+    if (r->d_tickets) HIP_TRY(hipFree(r->d_tickets));
+    r->d_partials = nullptr, r->d_tickets = nullptr;
+    const size_t want = blocks + blocks / 2 + 64, groups = want / kGroup + 2;
+    HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_partials, 0, (want + groups) * kReduceWords * sizeof(unsigned long long), r->stream));  // tag 0 = never valid
+    r->partial_blocks = want;
+    return KICP_OK;
+}
+// host-mapped rows of the first-level groups (mode 4)
+int ensure_rows(kicp_reg *r, size_t groups) {
+    if (groups <= r->rows_groups) return KICP_OK;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->rows) HIP_TRY(hipHostFree(r->rows));
+    r->rows = nullptr, r->d_rows = nullptr, r->rows_groups = 0;
+    const size_t want = groups + groups / 2 + 64;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->rows), want * kReduceWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(r->rows, 0, want * kReduceWords * sizeof(unsigned long long));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rows), r->rows, 0));
+    r->rows_groups = want;
+    return KICP_OK;
+}
+// next pass tag; when the 16-bit tag wraps, every buffer that holds tagged words is cleared so that a word left over
+// from 65535 passes ago can never be mistaken for a fresh one
+int next_tag(kicp_reg *r, uint32_t *tag) {
+    if (r->tag >= 0xFFFFu) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->rows) std::memset(r->rows, 0, r->rows_groups * kReduceWords * sizeof(unsigned long long));
+        if (r->d_partials) {
+            const size_t groups = r->partial_blocks / kGroup + 2;
+            HIP_TRY(hipMemsetAsync(r->d_partials, 0, (r->partial_blocks + groups) * kReduceWords * sizeof(unsigned long long), r->stream));
+        }
+        r->tag = 0;
+    }
+    *tag = ++r->tag;
+    return KICP_OK;
+}
+int ensure_frame(kicp_reg *r, size_t n) {
+    if (n <= r->frame_cap) return KICP_OK;
+    if (r->d_frame) HIP_TRY(hipFree(r->d_frame));
+    r->d_frame = nullptr;
+    const size_t want = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc(&r->d_frame, want * 3 * sizeof(double)));
+    r->frame_cap = want;
+    return KICP_OK;
+}
+void free_bin(BinBuffers &b) {
+    hipFree(b.cell_keys), hipFree(b.cell_count), hipFree(b.cell_start), hipFree(b.cell_list), hipFree(b.counters);
+    hipFree(b.qinfo), hipFree(b.items), hipFree(b.sorted_src);
+    b = BinBuffers{};
+}
+int ensure_bin(kicp_reg *r, size_t n) {
+    BinBuffers &b = r->bin;
+    if (n <= b.cap_n) return KICP_OK;
+    free_bin(b);
+    const size_t cap = n + n / 4 + 1024;
+    size_t slots = 1024;
+    while (slots < 2 * cap) slots <<= 1;  // load factor <= 0.5 even if every query had its own cell
+    HIP_TRY(hipMalloc(&b.cell_keys, slots * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&b.cell_count, slots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.cell_start, slots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.cell_list, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.counters, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.qinfo, cap * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&b.items, (cap / kRunLen + cap + 2) * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&b.sorted_src, cap * 3 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(b.cell_keys, 0xFF, slots * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(b.cell_count, 0, slots * sizeof(uint32_t), r->stream));
+    HIP_TRY(hipMemsetAsync(b.counters, 0, 16 * sizeof(uint32_t), r->stream));
+    b.mask = static_cast<uint32_t>(slots - 1), b.cap_n = cap;
+    return KICP_OK;
+}
+// counting sort of the scan by cell at the predicted pose: three launches, once per scan
+void launch_binning(kicp_reg *r, const double *d_frame, size_t n, const Pose &T0, double voxel_size) {
+    BinBuffers &b = r->bin;
+    BinParams bp{};
+    bp.src = d_frame, bp.n = static_cast<uint32_t>(n), bp.pose0 = T0, bp.voxel_size = voxel_size;
+    bp.cell_keys = b.cell_keys, bp.cell_count = b.cell_count, bp.cell_start = b.cell_start, bp.cell_list = b.cell_list;
+    bp.mask = b.mask, bp.counters = b.counters, bp.qinfo = b.qinfo, bp.sorted_src = b.sorted_src, bp.items = b.items;
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(256), 0, r->stream, bp);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, r->stream, bp);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid), dim3(256), 0, r->stream, bp);
+}
+
+// enqueue the collective between the limb reduction and the solve (multi-GPU only)
+int enqueue_allreduce(kicp_reg *r) {
+    long long *buf = r->d_state->reduce;
+    if (r->allreduce_fn) {
+        if (r->allreduce_fn(r->allreduce_user, buf, kReduceWords, static_cast<void *>(r->stream)) != 0)
+            return fail(KICP_ERR_COMM, "user all-reduce callback failed");
+        return KICP_OK;
+    }
+    const ncclResult_t rc = g_comm.AllReduce(buf, buf, kReduceWords, ncclInt64, ncclSum, r->comm, r->stream);
+    if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclAllReduce: ") + g_comm.GetErrorString(rc));
+    return KICP_OK;
+}
+
+// wait until the record carries `call_id` with at least `min_iter` completed iterations (or its done bit);
+// returns the observed seq.  Polls host-mapped memory; falls back to a stream sync when asked to or on a fault.
+int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool need_done, unsigned long long *seq_out) {
+    volatile unsigned long long *seq = &r->rec->seq;
+    auto ready = [&](unsigned long long s) {
+        return (s >> 16) == call_id && ((s & 0x8000ull) || (!need_done && (s & 0x7FFFull) >= min_iter));
+    };
+    if (r->wait_mode == 1) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+        if (!ready(s)) return fail(KICP_ERR_HIP, "result record not written after stream synchronisation");
+        *seq_out = s;
+        return KICP_OK;
+    }
+    // Poll the host-mapped record.  hipStreamQuery every `query_every` polls: it makes the runtime flush any command
+    // it still holds back (some HIP runtimes batch the tail of the queue) and reports device faults.
+    const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
+    unsigned drained = 0;
+    for (unsigned long long spins = 1;; ++spins) {
+        const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+        if (ready(s)) {
+            *seq_out = s;
+            return KICP_OK;
+        }
+        if (spins % query_every == 0) {
+            const hipError_t q = hipStreamQuery(r->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+            if (q == hipSuccess && ++drained > 4 && !ready(__atomic_load_n(seq, __ATOMIC_ACQUIRE)))
+                return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+        }
+    }
+}
+
+// mode 4: add the tagged rows of the `groups` first-level groups as they arrive (word = value << 16 | tag)
+int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kReduceWords]) {
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
+    unsigned drained = 0;
+    unsigned long long spins = 0;
+    for (size_t g = 0; g < groups; ++g) {
+        const unsigned long long *row = r->rows + g * kReduceWords;
+        long long v[kReduceWords];
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < kReduceWords; ++i) {
+                const unsigned long long w = __atomic_load_n(row + i, __ATOMIC_RELAXED);
+                ok = ok && (static_cast<uint32_t>(w) & 0xFFFFu) == tag;
+                v[i] = static_cast<long long>(w) >> 16;
+            }
+            if (ok) break;
+            if (r->wait_mode == 1 || ++spins % query_every == 0) {
+                // the query makes the runtime flush commands it may still hold back, and reports device faults
+                const hipError_t q = r->wait_mode == 1 ? hipStreamSynchronize(r->stream) : hipStreamQuery(r->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (q == hipSuccess && ++drained > 4) return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+            }
+        }
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] += v[i];
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return KICP_OK;
+}
+
+// wait until every rank's slot of the current buffer carries `value`, then add the limb words (exact, order independent)
+int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceWords]) {
+    const kicp_reg::ShmSlot *buf = r->shm + ((value - 1) & 1) * r->nranks;
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    for (int k = 0; k < r->nranks; ++k) {
+        const volatile unsigned long long *seq = &buf[k].seq;
+        for (unsigned long long spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != value; ++spins) {
+            if (spins % 4096 == 0) {
+                const hipError_t q = hipStreamQuery(r->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (spins > (1ull << 34)) return fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off");
+            }
+        }
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] += buf[k].words[i];
+    }
+    return KICP_OK;
+}
+
+int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
+                     const double rel_odom_qt[7], double tau, double out_pose_qt[7], kicp_stats *stats) {
+    if (!r || !map || !last_pose_qt || !rel_odom_qt || !out_pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    // current_estimate = last_robot_pose * relative_wheel_odometry   (Registration.cpp:156)
+    const Pose T0 = pose_mul(pose_from(last_pose_qt), pose_from(rel_odom_qt));
+    if (kicp_map_empty(map)) {  // Registration.cpp:157
+        pose_to(T0, out_pose_qt);
+        if (stats) stats->empty_map = 1;
+        return KICP_OK;
+    }
+    const int max_it = r->cfg.max_num_iterations;
+    if (max_it <= 0) {  // the reference's loop body never runs: the prediction is returned (Registration.cpp:179,189)
+        pose_to(T0, out_pose_qt);
+        return KICP_OK;
+    }
+    if (max_it > 0x7FFF) return fail(KICP_ERR_ARG, "max_num_iterations > 32767");
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (int rc = set_device(r->device)) return rc;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    const bool binned = r->pass_kernel == 2;
+    if (binned)
+        if (int rc = ensure_bin(r, n ? n : 1)) return rc;
+    if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
+    const bool shm = r->shm != nullptr;
+    const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
+    if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
+    const unsigned long long call_id = ++r->call_id;
+
+    PassParams pp{};
+    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.bin = BinView{r->bin.sorted_src, r->bin.items, r->bin.counters};
+    pp.partials = r->d_partials, pp.tickets = r->d_tickets;
+    pp.dbg = r->dbg;
+    SolveParams &sp = pp.sol;
+    sp.pose0 = T0, sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
+    sp.adaptive = r->cfg.use_adaptive_odometry_regularization, sp.fixed_regularization = r->cfg.fixed_regularization;
+    sp.mode = multi ? 1 : 0, sp.call_id = call_id, sp.rec = r->d_rec;
+
+    if (r->timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
+    if (binned) launch_binning(r, d_frame, n, T0, map->host.voxel_size());
+    const bool pass_events = r->timing == 2;
+    if (pass_events && !r->evp[0])
+        for (auto &e : r->evp) HIP_TRY(hipEventCreate(&e));
+    auto enqueue_iteration = [&](int it) -> int {
+        sp.pass = it;
+        const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
+        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
+        launch_pass(r, pp);
+        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
+        if (multi) {
+            if (int rc = enqueue_allreduce(r)) return rc;
+            hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, r->stream, r->d_state, sp);
+        }
+        return KICP_OK;
+    };
+    unsigned long long seq = 0;
+    if (r->host_solve) {
+        // ---- host-side solve: one launch per iteration, the pose travels as a kernel argument ----------------------
+        HostRecord *rec = r->rec;
+        Pose T = T0;
+        double beta = 0.0;
+        int iter = 0, converged = 0, nan_flag = 0;
+        for (int it = 0; it < max_it; ++it) {
+            const bool rows_mode = !multi && r->group_rows != 0;
+            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : (rows_mode ? 4 : 2);
+            long long words[kReduceWords];
+            unsigned long long shm_value = 0;
+            kicp_reg::ShmSlot *mine_host = nullptr;
+            if (shm) {  // this rank's slot of the shared segment, double-buffered by hand-off parity
+                const unsigned long long step = r->shm_step++;
+                kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
+                mine_host = r->shm + (step & 1) * r->nranks + r->rank;
+                sp.pub_words = mine->words, sp.pub_seq = &mine->seq, sp.pub_value = shm_value = step + 1;
+            } else {
+                sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
+                sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
+            }
+            const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
+            if (rows_mode) {
+                if (int rc = ensure_rows(r, groups)) return rc;
+                if (int rc = next_tag(r, &sp.tag)) return rc;
+                sp.pub_rows = r->d_rows;
+            }
+            const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
+            if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
+            launch_pass(r, pp);
+            if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
+            if (multi) {
+                if (int rc = enqueue_allreduce(r)) return rc;
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, r->stream, r->d_state, r->d_rec, call_id, it);
+            }
+            if (rows_mode) {
+                if (int rc = wait_rows(r, groups, sp.tag, words)) return rc;
+                if (shm) {  // this rank's totals go into its slot from the host side; then every rank adds all slots
+                    for (int i = 0; i < kReduceWords; ++i) mine_host->words[i] = words[i];
+                    __atomic_store_n(&mine_host->seq, shm_value, __ATOMIC_RELEASE);
+                    if (int rc = wait_shm(r, shm_value, words)) return rc;
+                }
+            } else if (shm) {
+                if (int rc = wait_shm(r, sp.pub_value, words)) return rc;
+            } else {
+                if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+                for (int i = 0; i < kReduceWords; ++i) words[i] = rec->words[i];
+            }
+            double sums[kNumSums];
+            for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(words + 3 * i);
+            const bool range_error = words[kNumLimbs] != 0;
+            const double n = sums[6];
+            if (it == 0)  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
+                beta = r->cfg.use_adaptive_odometry_regularization ? 1.0 / (sums[5] / n + DBL_MIN) : r->cfg.fixed_regularization;
+            double dx0, dx1;
+            solve_perturbation(sums, n, beta, dx0, dx1);    // Registration.cpp:119-125
+            T = pose_mul(T, motion_model(dx0, dx1));        // Registration.cpp:159-167,181-182
+            iter = it + 1;
+            if (stats && it < KICP_MAX_LOG_PASSES) {
+                stats->n_corr[it] = n;
+                for (int j = 0; j < 6; ++j) stats->sums[it][j] = sums[j];
+                stats->dx[it][0] = dx0, stats->dx[it][1] = dx1;
+            }
+            if (std::sqrt(dx0 * dx0 + dx1 * dx1) < r->cfg.convergence_criterion) {  // Registration.cpp:184
+                converged = 1;
+                break;
+            }
+            if (!(n > 0.0) || range_error) {  // 0/0: NaN pose from here on, exactly as in the reference
+                nan_flag = range_error ? 2 : 1;
+                break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+        pose_to(T, out_pose_qt);
+        if (stats) {
+            stats->iterations = iter, stats->converged = converged, stats->beta = beta;
+            if (r->timing) {
+                float ms = 0.f;
+                HIP_TRY(hipEventSynchronize(r->ev1));
+                HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+                stats->gpu_ms = ms;
+                for (int i = 0; pass_events && i < iter && i < KICP_MAX_LOG_PASSES; ++i) {
+                    HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
+                    stats->pass_ms[i] = ms;
+                }
+            }
+        }
+        if (nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
+        return nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+    }
+    if (r->loop_mode == 0) {
+        for (int it = 0; it < max_it; ++it)
+            if (int rc = enqueue_iteration(it)) return rc;
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+        if (int rc = wait_record(r, call_id, 0, true, &seq)) return rc;
+    } else {
+        // stepped: the host polls the stop flag after every iteration.  When the previous scan needed more than one
+        // iteration, iteration it+1 is queued before the flag of iteration it is known, so the GPU never idles on the
+        // host (at most one queued iteration turns out to be unnecessary and exits at once); when scans converge in
+        // one iteration - the usual case with good wheel odometry - nothing is queued speculatively.
+        int queued = 0;
+        if (int rc = enqueue_iteration(queued++)) return rc;
+        for (int it = 0;; ++it) {
+            if (r->speculate && queued < max_it && queued == it + 1)
+                if (int rc = enqueue_iteration(queued++)) return rc;
+            if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
+            if (seq & 0x8000ull) break;
+            if (queued == it + 1)
+                if (int rc = enqueue_iteration(queued++)) return rc;
+        }
+        r->speculate = (seq & 0x7FFFull) > 1 ? 1 : 0;
+        HIP_TRY(hipGetLastError());
+        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
+    }
+    const HostRecord *rec = r->rec;  // stable: after `done` no kernel writes the record again
+    pose_to(rec->T, out_pose_qt);
+    if (stats) {
+        stats->iterations = rec->iter, stats->converged = rec->converged, stats->beta = rec->beta;
+        const int k = rec->iter < KICP_MAX_LOG_PASSES ? rec->iter : KICP_MAX_LOG_PASSES;
+        for (int i = 0; i < k; ++i) {
+            stats->n_corr[i] = rec->log_ncorr[i];
+            for (int j = 0; j < 6; ++j) stats->sums[i][j] = rec->log_sums[i][j];
+            stats->dx[i][0] = rec->log_dx[i][0], stats->dx[i][1] = rec->log_dx[i][1];
+        }
+        if (r->timing) {
+            float ms = 0.f;
+            HIP_TRY(hipEventSynchronize(r->ev1));
+            HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+            stats->gpu_ms = ms;
+            for (int i = 0; pass_events && i < k; ++i) {
+                HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
+                stats->pass_ms[i] = ms;
+            }
+        }
+    }
+    if (rec->nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
+    return rec->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- registration ---------------------------------------------------------------------------------------------------
+int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
+    if (!config || !out) return fail(KICP_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KICP_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(KICP_ERR_ARG, "device index out of range");
+    if (int rc = set_device(device)) return rc;
+    kicp_reg *r = new kicp_reg;
+    r->cfg = *config, r->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+    if (e == hipSuccess) e = hipMalloc(&r->d_state, sizeof(IcpState));
+    if (e == hipSuccess) e = hipMemset(r->d_state, 0, sizeof(IcpState));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&r->rec), sizeof(HostRecord), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) std::memset(r->rec, 0, sizeof(HostRecord));
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rec), r->rec, 0);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) r->num_cus = prop.multiProcessorCount;
+    }
+    if (e != hipSuccess) {
+        kicp_reg_destroy(r);
+        return fail(KICP_ERR_HIP, std::string("kicp_reg_create: ") + hipGetErrorString(e));
+    }
+    if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env);
+    if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
+    if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
+    if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
+    if (const char *env = std::getenv("KICP_QUERY_EVERY")) r->query_every = std::atoi(env);
+    *out = r;
+    return KICP_OK;
+}
+void kicp_reg_destroy(kicp_reg *reg) {
+    if (!reg) return;
+    hipSetDevice(reg->device);
+    if (reg->comm) g_comm.CommDestroy(reg->comm);
+    if (reg->stream) hipStreamSynchronize(reg->stream);
+    if (reg->shm) kicp_reg_shm_destroy(reg);
+    if (reg->d_state) hipFree(reg->d_state);
+    if (reg->rec) hipHostFree(reg->rec);
+    if (reg->rows) hipHostFree(reg->rows);
+    reg->stage.release();
+    if (reg->d_partials) hipFree(reg->d_partials);
+    if (reg->d_tickets) hipFree(reg->d_tickets);
+    free_bin(reg->bin);
+    if (reg->d_frame) hipFree(reg->d_frame);
+    if (reg->ev0) hipEventDestroy(reg->ev0);
+    if (reg->ev1) hipEventDestroy(reg->ev1);
+    for (auto &e : reg->evp)
+        if (e) hipEventDestroy(e);
+    if (reg->stream) hipStreamDestroy(reg->stream);
+    delete reg;
+}
+int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out) {
+    if (!reg || !out) return fail(KICP_ERR_ARG, "null argument");
+    *out = reg->cfg;
+    return KICP_OK;
+}
+int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config) {
+    if (!reg || !config) return fail(KICP_ERR_ARG, "null argument");
+    reg->cfg = *config;
+    return KICP_OK;
+}
+int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
+    if (!reg || !name) return fail(KICP_ERR_ARG, "null argument");
+    const std::string k(name);
+    if (k == "pass_kernel") reg->pass_kernel = static_cast<int>(value);
+    else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
+    else if (k == "loop") reg->loop_mode = static_cast<int>(value);
+    else if (k == "wait") reg->wait_mode = static_cast<int>(value);
+    else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
+    else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
+    else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
+    else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
+    else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
+    else if (k == "timing") reg->timing = static_cast<int>(value);
+    else if (k == "dbg") reg->dbg = static_cast<int>(value);
+    else if (k == "query_every") reg->query_every = static_cast<int>(value);
+    else return fail(KICP_ERR_ARG, "unknown option " + k);
+    return KICP_OK;
+}
+double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
+    if (!reg || !name) return -1.0;
+    const std::string k(name);
+    if (k == "pass_kernel") return reg->pass_kernel;
+    if (k == "block") return reg->block;
+    if (k == "loop") return reg->loop_mode;
+    if (k == "wait") return reg->wait_mode;
+    if (k == "host_solve") return reg->host_solve;
+    if (k == "group_rows") return reg->group_rows;
+    if (k == "debug_tag") return reg->tag;
+    if (k == "lanes_per_query") return reg->lanes_per_query;
+    if (k == "waves_per_cu") return reg->waves_per_cu;
+    if (k == "timing") return reg->timing;
+    if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;
+    return -1.0;
+}
+
+int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
+                         const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
+                         kicp_stats *stats) {
+    KICP_TRACE_CALL();
+    if (!d_frame_xyz && n) return fail(KICP_ERR_ARG, "null frame");
+    return run_registration(reg, map, d_frame_xyz, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
+                  const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
+    KICP_TRACE_CALL();
+    if (!reg || !map || (!frame_xyz && n)) return fail(KICP_ERR_ARG, "null argument");
+    if (!kicp_map_empty(map) && n) {
+        if (int rc = set_device(reg->device)) return rc;
+        if (int rc = ensure_frame(reg, n)) return rc;
+        if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
+    }
+    return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                     double max_correspondence_distance, double out_sums[7], long long out_words[24]);
+int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                   double max_correspondence_distance, double out_sums[7]) {
+    if (!out_sums) return fail(KICP_ERR_ARG, "null argument");
+    return pass_once(reg, map, frame_xyz, n, pose_qt, max_correspondence_distance, out_sums, nullptr);
+}
+int kicp_pass_words(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                    double max_correspondence_distance, long long out_words[24]) {
+    if (!out_words) return fail(KICP_ERR_ARG, "null argument");
+    double sums[7];
+    return pass_once(reg, map, frame_xyz, n, pose_qt, max_correspondence_distance, sums, out_words);
+}
+static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                     double max_correspondence_distance, double out_sums[7], long long out_words[24]) {
+    if (!reg || !map || (!frame_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    for (int i = 0; i < 7; ++i) out_sums[i] = 0.0;
+    if (out_words)
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    if (kicp_map_empty(map) || n == 0) return KICP_OK;
+    if (int rc = set_device(reg->device)) return rc;
+    if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
+    if (int rc = ensure_frame(reg, n)) return rc;
+    const bool binned = reg->pass_kernel == 2;
+    if (binned)
+        if (int rc = ensure_bin(reg, n)) return rc;
+    if (int rc = ensure_partials(reg, pass_grid(reg, n))) return rc;
+    if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
+    const unsigned long long call_id = ++reg->call_id;
+    PassParams pp{};
+    pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
+    pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
+    pp.st = reg->d_state, pp.bin = BinView{reg->bin.sorted_src, reg->bin.items, reg->bin.counters};
+    pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
+    if (binned) launch_binning(reg, reg->d_frame, n, pp.sol.pose0, map->host.voxel_size());
+    launch_pass(reg, pp);
+    hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);
+    HIP_TRY(hipGetLastError());
+    unsigned long long seq = 0;
+    if (int rc = wait_record(reg, call_id, 1, true, &seq)) return rc;
+    for (int i = 0; i < 7; ++i) out_sums[i] = reg->rec->sums[i];
+    if (out_words) HIP_TRY(hipMemcpy(out_words, reg->d_state->reduce, sizeof(long long) * kReduceWords, hipMemcpyDeviceToHost));
+    return KICP_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------------------
+int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]) {
+    static_assert(KICP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    static_assert(KICP_REDUCE_WORDS == kReduceWords, "payload size");
+    if (!id) return fail(KICP_ERR_ARG, "null argument");
+    std::string err;
+    if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);
+    ncclUniqueId uid;
+    const ncclResult_t rc = g_comm.GetUniqueId(&uid);
+    if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclGetUniqueId: ") + g_comm.GetErrorString(rc));
+    std::memcpy(id, uid.internal, KICP_COMM_ID_BYTES);
+    return KICP_OK;
+}
+int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]) {
+    if (!reg || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad communicator arguments");
+    std::string err;
+    if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);
+    if (int rc = set_device(reg->device)) return rc;
+    if (reg->comm) g_comm.CommDestroy(reg->comm), reg->comm = nullptr;
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, KICP_COMM_ID_BYTES);
+    const ncclResult_t rc = g_comm.CommInitRank(&reg->comm, nranks, uid, rank);
+    if (rc != ncclSuccess) {
+        reg->comm = nullptr;
+        return fail(KICP_ERR_COMM, std::string("ncclCommInitRank: ") + g_comm.GetErrorString(rc));
+    }
+    reg->nranks = nranks, reg->rank = rank;
+    return KICP_OK;
+}
+int kicp_reg_comm_destroy(kicp_reg *reg) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    if (reg->comm) {
+        hipSetDevice(reg->device);
+        hipStreamSynchronize(reg->stream);
+        g_comm.CommDestroy(reg->comm);
+        reg->comm = nullptr;
+    }
+    reg->nranks = 1, reg->rank = 0;
+    return KICP_OK;
+}
+int kicp_reg_shm_destroy(kicp_reg *reg) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    if (reg->shm) {
+        hipSetDevice(reg->device);
+        hipStreamSynchronize(reg->stream);
+        hipHostUnregister(reg->shm);
+        munmap(reg->shm, reg->shm_bytes);
+        if (reg->rank == 0) shm_unlink(reg->shm_name.c_str());
+        reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_bytes = 0;
+    }
+    reg->nranks = 1, reg->rank = 0;
+    return KICP_OK;
+}
+int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
+    if (!reg || !name || nranks < 1 || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad shared-segment arguments");
+    if (reg->comm) return fail(KICP_ERR_ARG, "an RCCL communicator is already attached");
+    kicp_reg_shm_destroy(reg);
+    if (int rc = set_device(reg->device)) return rc;
+    const size_t bytes = 2 * static_cast<size_t>(nranks) * sizeof(kicp_reg::ShmSlot);
+    const std::string nm = std::string(name[0] == '/' ? "" : "/") + name;
+    const int fd = shm_open(nm.c_str(), rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) return fail(KICP_ERR_COMM, "shm_open(" + nm + ") failed (rank 0 must create it first)");
+    if (rank == 0 && ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+        close(fd);
+        return fail(KICP_ERR_COMM, "ftruncate on the shared segment failed");
+    }
+    void *ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
+    if (rank == 0) std::memset(ptr, 0, bytes);
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    void *dptr = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, ptr, 0);
+    if (e != hipSuccess) {
+        munmap(ptr, bytes);
+        return fail(KICP_ERR_HIP, std::string("registering the shared segment: ") + hipGetErrorString(e));
+    }
+    reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr), reg->d_shm = static_cast<kicp_reg::ShmSlot *>(dptr);
+    reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
+    return KICP_OK;
+}
+int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    reg->allreduce_fn = fn, reg->allreduce_user = user;
+    return KICP_OK;
+}
+
+}  // extern "C"
