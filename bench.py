@@ -176,6 +176,17 @@ def main():
     reg.set_option("timing", 0)
     poses = [step(i) for i in range(len(scans))]
     barrier()
+    # informational, never `value`: the same calls with the scan handed over as a HOST array (staged upload inside)
+    host_rate = None
+    if world == 1:
+        host_frames = [np.ascontiguousarray(s["frame"][lo:hi]) for s in scans]
+        for i in range(8):
+            reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
+        t1 = time.perf_counter()
+        k_host = min(args.steps, 200)
+        for i in range(k_host):
+            reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
+        host_rate = k_host / (time.perf_counter() - t1)
     if use_comm:  # all GPU work is done: tear the communicators down on every rank before rank 0's CPU-only epilogue
         if args.comm == "rccl":
             reg.comm_destroy()
@@ -248,7 +259,8 @@ def main():
                                "(mean %.2f per scan, reference %.2f)" % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(),
                                                                          cfg.voxel_size, tau, iters_gpu, float(np.mean(iters_ref))),
                    "points_per_gpu": hi - lo, "parallelism": ("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU",
-                   "pass_kernel": int(reg.get_option("pass_kernel")), "max_pose_abs_diff_vs_oracle": max_pose_err},
+                   "pass_kernel": int(reg.get_option("pass_kernel")), "max_pose_abs_diff_vs_oracle": max_pose_err,
+                   "scans_per_s_with_host_input_incl_pcie": None if host_rate is None else round(host_rate, 1)},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(world),
                      "kernel": "fused association+accumulation pass", "kernel_avg_us": round(kernel_us, 2),
