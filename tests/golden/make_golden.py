@@ -1,7 +1,8 @@
 """Generates tests/golden/*.npz.  The reference ships no fixtures and cannot be built or imported offline
 (SURVEY.md F5-F7), so these are REGRESSION vectors: inputs from the seeded synthetic generator, outputs from the
 CPU oracle (oracle/kicp_oracle.cpp) at the time of freezing, cross-checked against tests/ref_numpy.py by
-tests/test_oracle.py.  Re-run only deliberately:  python tests/golden/make_golden.py
+tests/test_oracle.py.  Re-run only deliberately:  python tests/golden/make_golden.py            (registration_small.npz)
+                                                 python tests/golden/make_golden.py pipeline   (pipeline_small.npz)
 """
 import os
 import sys
@@ -52,5 +53,69 @@ def main():
     print("wrote", os.path.join(HERE, "registration_small.npz"))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "pipeline" not in sys.argv[1:]:
     main()
+
+
+# ---- second fixture: the rows around the hot path ---------------------------------------------
+def first_seen_downsample(pts, vs):
+    """kiss_icp::VoxelDownsample with the output in first-seen order (what the device pre-steps emit; the reference's
+    order is its hash table's iteration order)."""
+    keys = np.floor(pts / vs).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    return pts[np.sort(first)]
+
+
+def pipeline_fixture():
+    rng = np.random.Generator(np.random.PCG64(404))
+    scene = syn.make_scene(rng, half=14.0, height=4.0, n_boxes=5, box_xy=(2.0, 5.0), box_z=(1.5, 3.5), keep_clear=2.5)
+    dirs = syn.beam_directions(6, 256, (-20.0, 8.0))
+    ext = np.concatenate([[0, 0, np.sin(0.04), np.cos(0.04)], [0.25, 0.0, 0.8]])  # lidar_to_base
+    voxel, max_range, min_range = 0.5, 25.0, 0.5
+    out = {"ext": ext, "voxel": np.array(voxel), "max_range": np.array(max_range), "min_range": np.array(min_range)}
+    # PointCloud2-like records: x y z f32 @0,4,8; intensity f32 @16; t u32 (ns since scan start) @20; 32-byte step
+    dt = np.dtype({"names": ["x", "y", "z", "intensity", "t"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u4"], "offsets": [0, 4, 8, 16, 20], "itemsize": 32})
+    out["layout"] = np.array([32, 0, 4, 8, 6, 20])  # point_step, offsets x y z, stamp datatype (UINT32), stamp offset
+    omap = okicp.VoxelHashMap(voxel, max_range, 20)
+    thr = okicp.CorrespondenceThreshold(voxel / np.sqrt(20), max_range, True, 1.0)
+    reg = okicp.KinematicRegistration()
+    pose = syn.planar_pose(0.0, 0.0, 0.1)
+    last = okicp.IDENTITY.copy()
+    n_frames = 4
+    for k in range(n_frames):
+        delta_true = syn.planar_pose(0.3, 0.0, np.deg2rad(2.0 + k))
+        pose = syn.pose_mul(pose, delta_true)
+        wl = syn.pose_mul(pose, ext)
+        t = scene.raycast(wl[4:], dirs @ syn.quat_to_matrix(wl[:4]).T) + rng.normal(0, 0.01, len(dirs))
+        rec = np.zeros(len(dirs), dtype=dt)
+        pts = dirs * t[:, None]
+        rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+        rec["intensity"] = rng.uniform(0, 1, len(dirs))
+        rec["t"] = np.round(np.linspace(0.0, 0.1, len(dirs)) * 1e9).astype(np.uint32)
+        raw = np.frombuffer(rec.tobytes(), dtype=np.uint8).copy()
+        delta = syn.pose_mul(delta_true, syn.planar_pose(0.01 * (-1) ** k, 0.0, np.deg2rad(0.15)))  # noisy wheel odometry
+        # the reference's RegisterFrame (pipeline/KinematicICP.cpp:48-85) with the oracle's pieces, deskew on
+        xyz, stamps, mm = okicp.ingest(raw.tobytes(), len(rec), 32, 0, 4, 8, 6, 20)
+        rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), delta), ext)
+        in_base = okicp.se3_act(ext, okicp.preprocess(xyz, stamps, rel_lidar, max_range, min_range, True))
+        down = first_seen_downsample(in_base, voxel * 0.5)
+        source = first_seen_downsample(down, voxel * 1.5)
+        new = reg.ComputeRobotMotion(source, omap, last, delta, thr.ComputeThreshold())
+        thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new))
+        omap.Update(down, new)
+        last = new
+        out.update({"raw%d" % k: raw, "delta%d" % k: delta, "minmax%d" % k: np.array(mm), "down%d" % k: down, "source%d" % k: source,
+                    "pose%d" % k: new, "n_in_base%d" % k: np.array(len(in_base)), "map_points%d" % k: np.array(omap.num_points()),
+                    "map_voxels%d" % k: np.array(omap.num_voxels())})
+        if k == 0:  # the decoded cloud and the preprocessed frame once (the later frames pin them through down / source)
+            out.update({"xyz0": xyz, "stamps0": stamps, "in_base0": in_base})
+        print("frame", k, "in", len(in_base), "down", len(down), "source", len(source), "map", omap.num_points(), "pose", new)
+    pc = omap.Pointcloud()
+    out["n_frames"] = np.array(n_frames)
+    out["final_map_sorted"] = pc[np.lexsort((pc[:, 2], pc[:, 1], pc[:, 0]))]
+    np.savez_compressed(os.path.join(HERE, "pipeline_small.npz"), **out)
+    print("wrote", os.path.join(HERE, "pipeline_small.npz"))
+
+
+if __name__ == "__main__" and "pipeline" in sys.argv[1:]:
+    pipeline_fixture()

@@ -1,0 +1,80 @@
+"""tests/golden/pipeline_small.npz: four PointCloud2-style frames through RegisterFrame (ingest -> deskew + crop ->
+two-level downsample -> registration -> map update), frozen from the oracle (tests/golden/make_golden.py pipeline).
+CPU: the oracle still reproduces the fixture (drift guard).  GPU: every device stage against the frozen values."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import sort_rows
+from oracle import okicp
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_small.npz"))
+STEP, OX, OY, OZ, STAMP_TYPE, OT = (int(v) for v in G["layout"])
+VOXEL, MAX_RANGE, MIN_RANGE = float(G["voxel"]), float(G["max_range"]), float(G["min_range"])
+N = int(G["n_frames"])
+
+
+def first_seen_downsample(pts, vs):
+    keys = np.floor(pts / vs).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    return pts[np.sort(first)]
+
+
+def test_oracle_reproduces_pipeline_fixture():
+    ext = G["ext"]
+    omap = okicp.VoxelHashMap(VOXEL, MAX_RANGE, 20)
+    thr = okicp.CorrespondenceThreshold(VOXEL / np.sqrt(20), MAX_RANGE, True, 1.0)
+    reg = okicp.KinematicRegistration()
+    last = okicp.IDENTITY.copy()
+    for k in range(N):
+        raw, delta = G["raw%d" % k], G["delta%d" % k]
+        xyz, stamps, mm = okicp.ingest(raw.tobytes(), len(raw) // STEP, STEP, OX, OY, OZ, STAMP_TYPE, OT)
+        assert np.array_equal(np.array(mm), G["minmax%d" % k])
+        rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), delta), ext)
+        in_base = okicp.se3_act(ext, okicp.preprocess(xyz, stamps, rel_lidar, MAX_RANGE, MIN_RANGE, True))
+        if k == 0:
+            assert np.array_equal(xyz, G["xyz0"]) and np.array_equal(stamps, G["stamps0"]) and np.array_equal(in_base, G["in_base0"])
+        down = first_seen_downsample(in_base, VOXEL * 0.5)
+        source = first_seen_downsample(down, VOXEL * 1.5)
+        assert np.array_equal(down, G["down%d" % k]) and np.array_equal(source, G["source%d" % k])
+        new = reg.ComputeRobotMotion(source, omap, last, delta, thr.ComputeThreshold())
+        np.testing.assert_allclose(new, G["pose%d" % k], rtol=0, atol=1e-12)
+        thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new))
+        omap.Update(down, new)
+        last = new
+        assert (omap.num_points(), omap.num_voxels()) == (int(G["map_points%d" % k]), int(G["map_voxels%d" % k]))
+    np.testing.assert_allclose(sort_rows(omap.Pointcloud()), G["final_map_sorted"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_device_pipeline_reproduces_pipeline_fixture():
+    import kinematic_icp_amd as K
+    ext = G["ext"]
+    pre, gmap, reg = K.PreSteps(), K.VoxelHashMap(VOXEL, MAX_RANGE, 20), K.KinematicRegistration()
+    thr = okicp.CorrespondenceThreshold(VOXEL / np.sqrt(20), MAX_RANGE, True, 1.0)  # host scalar bookkeeping (same in the drop-in header)
+    last = okicp.IDENTITY.copy()
+    for k in range(N):
+        raw, delta = G["raw%d" % k], G["delta%d" % k]
+        mm = pre.Ingest(raw.tobytes(), len(raw) // STEP, STEP, OX, OY, OZ, STAMP_TYPE, OT)
+        assert np.array_equal(np.array(mm), G["minmax%d" % k])
+        if k == 0:
+            xyz, stamps = pre.ingested()
+            assert np.array_equal(xyz, G["xyz0"]) and np.array_equal(stamps, G["stamps0"])
+        rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), delta), ext)
+        n_in = pre.PreprocessIngested(rel_lidar, ext, MAX_RANGE, MIN_RANGE, True, dst=0)
+        assert n_in == int(G["n_in_base%d" % k])
+        if k == 0:
+            np.testing.assert_allclose(pre.download(0), G["in_base0"], rtol=0, atol=1e-11)
+        n_down, n_src = pre.VoxelDownsample(0, VOXEL * 0.5, 1), pre.VoxelDownsample(1, VOXEL * 1.5, 2)
+        assert (n_down, n_src) == (len(G["down%d" % k]), len(G["source%d" % k]))
+        np.testing.assert_allclose(pre.download(1), G["down%d" % k], rtol=0, atol=1e-11)    # same survivors, same order
+        np.testing.assert_allclose(pre.download(2), G["source%d" % k], rtol=0, atol=1e-11)
+        new = reg.ComputeRobotMotion(pre.frame(2), gmap, last, delta, thr.ComputeThreshold())
+        np.testing.assert_allclose(new, G["pose%d" % k], rtol=0, atol=1e-9)
+        thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new))
+        assert gmap.UpdateDevice(pre.frame(1), new)
+        last = new
+        assert (gmap.num_points(), gmap.num_voxels()) == (int(G["map_points%d" % k]), int(G["map_voxels%d" % k]))
+    np.testing.assert_allclose(sort_rows(gmap.Pointcloud()), G["final_map_sorted"], rtol=0, atol=1e-9)
+    assert gmap.check() == 0
