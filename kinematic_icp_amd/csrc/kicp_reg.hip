@@ -430,9 +430,13 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
             kicp_reg::ShmSlot *mine_host = nullptr;
             if (shm) {  // this rank's slot of the shared segment, double-buffered by hand-off parity
                 const unsigned long long step = r->shm_step++;
-                kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
                 mine_host = r->shm + (step & 1) * r->nranks + r->rank;
-                sp.pub_words = mine->words, sp.pub_seq = &mine->seq, sp.pub_value = shm_value = step + 1;
+                sp.pub_value = shm_value = step + 1;
+                if (!rows_mode) {  // the GPU writes the slot itself
+                    if (!r->d_shm) return fail(KICP_ERR_HIP, "the shared segment has no device view (hipHostRegister failed): keep group_rows = 1");
+                    kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
+                    sp.pub_words = mine->words, sp.pub_seq = &mine->seq;
+                }
             } else {
                 sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
                 sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
@@ -769,7 +773,7 @@ int kicp_reg_shm_destroy(kicp_reg *reg) {
     if (reg->shm) {
         hipSetDevice(reg->device);
         hipStreamSynchronize(reg->stream);
-        hipHostUnregister(reg->shm);
+        if (reg->d_shm) (void)hipHostUnregister(reg->shm);
         munmap(reg->shm, reg->shm_bytes);
         if (reg->rank == 0) shm_unlink(reg->shm_name.c_str());
         reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_bytes = 0;
@@ -794,12 +798,14 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     close(fd);
     if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
     if (rank == 0) std::memset(ptr, 0, bytes);
+    // The device view is only needed when the GPU itself writes the slot ("group_rows" = 0); by default the rank's host adds
+    // its GPU's tagged rows and stores the totals, so a failed registration is not fatal.
     hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     void *dptr = nullptr;
     if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, ptr, 0);
     if (e != hipSuccess) {
-        munmap(ptr, bytes);
-        return fail(KICP_ERR_HIP, std::string("registering the shared segment: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        dptr = nullptr;
     }
     reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr), reg->d_shm = static_cast<kicp_reg::ShmSlot *>(dptr);
     reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
