@@ -45,3 +45,28 @@ def pack(totals):
 def unpack(words):
     """int64[24] (after the all-reduce) -> seven float64 sums."""
     return np.array([from_limbs(words[3 * i:3 * i + 3]) / float(1 << FIX_BITS) for i in range(NUM_SUMS)], dtype=np.float64)
+
+
+# ---- tagged rows of the hand-off (kicp_kernels.hpp finish_pass, mode 4; kicp_reg.hip wait_rows) ----------------------
+# Every word of a workgroup's / group's row carries the 16-bit tag of its pass in the low bits: word = value << 16 | tag.
+# A reader knows a row has landed when all its words carry the current tag - no store acknowledgement, no fence.
+TAG_BITS = 16
+TAG_MASK = (1 << TAG_BITS) - 1
+GROUP = 32  # workgroups per first-level group (kGroup)
+
+
+def tag_row(words, tag):
+    """int64[24] limb row -> uint64[24] tagged row (two's complement, like the device's `value << 16 | tag`)."""
+    assert 1 <= tag <= TAG_MASK
+    return np.array([((int(w) << TAG_BITS) | tag) & 0xFFFFFFFFFFFFFFFF for w in words], dtype=np.uint64)
+
+
+def untag_row(row, tag):
+    """uint64[24] -> (int64[24] values, landed?) : arithmetic shift, as the host and the group's reader do."""
+    vals, ok = [], True
+    for w in row:
+        w = int(w)
+        ok = ok and (w & TAG_MASK) == tag
+        s = w - (1 << 64) if w >> 63 else w  # reinterpret as signed
+        vals.append(s >> TAG_BITS)
+    return np.array(vals, dtype=np.int64), ok

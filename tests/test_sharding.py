@@ -137,3 +137,34 @@ def test_gloo_world_size_2(tmp_path):
     expect = ref.ComputeRobotMotion(frame, omap, last, rel, cfg.first_frame_tau())
     assert int(p0[7]) == ref.last_stats.iterations
     np.testing.assert_allclose(p0[:7], expect, atol=1e-9)
+
+
+def test_tagged_rows_carry_group_sums_exactly():
+    """The hand-off's word format (value << 16 | tag): a workgroup's limbs, the sum of a group's 32 rows and the top limb's
+    sign all survive the round trip; a row with a stale tag is recognised; the tag never collides with value bits."""
+    from kinematic_icp_amd import sharding as sh
+    rng = np.random.Generator(np.random.PCG64(3))
+    tag = 0xBEEF
+    rows = []
+    for _ in range(sh.GROUP):
+        # 128 per-lane terms of either sign, each below 2^23 in magnitude (the documented range), 7 sums
+        totals = [int(sum(sh.quantize(x) for x in rng.uniform(-8.3e6, 8.3e6, 128))) for _ in range(sh.NUM_SUMS)]
+        rows.append(sh.pack(totals))
+    # worst case of the unsigned limbs: all ones
+    rows[0][:2] = sh.LIMB_MASK
+    group = np.sum(np.stack(rows), axis=0)
+    assert int(group[:21].max()) < (1 << 47) and int(group[:21].min()) > -(1 << 47)
+    for words in rows + [group]:
+        back, ok = sh.untag_row(sh.tag_row(words, tag), tag)
+        assert ok and np.array_equal(back, words)
+    # stale or half-written rows are not accepted
+    stale = sh.tag_row(rows[1], tag - 1)
+    assert not sh.untag_row(stale, tag)[1]
+    mixed = sh.tag_row(rows[1], tag)
+    mixed[5] = stale[5]
+    assert not sh.untag_row(mixed, tag)[1]
+    # the host's sum of untagged group rows equals the plain sum of all workgroup rows (what the old device tree produced)
+    groups = [np.sum(np.stack(rows[i:i + 8]), axis=0) for i in range(0, sh.GROUP, 8)]
+    host_total = sum(sh.untag_row(sh.tag_row(g, tag), tag)[0] for g in groups)
+    assert np.array_equal(host_total, group)
+    np.testing.assert_array_equal(sh.unpack(host_total), sh.unpack(group))
