@@ -69,3 +69,30 @@ def test_keys_order_like_floats_and_carry_the_position():
     tie = order[np.isin(order, np.arange(100, 120))]
     assert np.array_equal(pos[tie], np.sort(pos[tie]))                      # among equals the lower position comes first
     assert np.all((key & np.uint32(31)) == pos)
+
+
+@pytest.mark.parametrize("vs", [1.0, 0.1, 0.37])
+def test_face_bounds_never_exceed_the_true_distance_to_a_neighbour_voxel(vs):
+    """Culling visits neighbour voxel c only if box_c <= current minimum + margin, with box_c built from the (rounded-down)
+    squared distances to the own voxel's faces.  Sound iff box_c never exceeds the squared distance of ANY point of voxel c."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    n = 300_000
+    base = rng.integers(-2000, 2000, (n, 3)).astype(np.float64)
+    q = (base + rng.uniform(0, 1, (n, 3))) * vs
+    # queries hugging faces, edges and corners are the critical ones
+    hug = rng.random((n, 3)) < 0.3
+    q = np.where(hug, (base + rng.choice([1e-7, 1 - 1e-7, 1e-3, 1 - 1e-3], (n, 3))) * vs, q)
+    shift = rng.integers(-1, 2, (n, 3))
+    p = (np.floor(q / vs) + shift + rng.uniform(0, 1, (n, 3))) * vs
+    same = np.all(np.floor(p / vs) == np.floor(q / vs) + shift, axis=1)
+    q, p, shift = q[same], p[same], shift[same]
+    fvs = np.float32(vs)
+    B = min((0.6708 * vs) ** 2, 12.0 * vs * vs)
+    margin = np.float32(max(8e-6 * vs * vs, 2.2 * (1.25e-6 * np.sqrt(B) * vs + 4.2e-6 * B)))
+    l = f32(q - np.floor(q / vs) * vs)
+    lo = (l * l).astype(np.float32) * np.float32(0.99999) - margin          # face[a][0]
+    hi = ((fvs - l) * (fvs - l)).astype(np.float32) * np.float32(0.99999) - margin  # face[a][2]
+    comp = np.where(shift < 0, lo, np.where(shift > 0, hi, np.float32(0.0))).astype(np.float32)
+    box = (comp[:, 0] + comp[:, 1]).astype(np.float32) + comp[:, 2]
+    D = np.sum((p - q) ** 2, axis=1)
+    assert np.all(box.astype(np.float64) <= D)
