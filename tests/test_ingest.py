@@ -142,3 +142,24 @@ def test_gpu_pipeline_from_raw_bytes_equals_pipeline_from_host_arrays(deskew):
     np.testing.assert_array_equal(a.download(0), b.download(0))
     ref = okicp.se3_act(ext, okicp.preprocess(xyz, st, rel, 60.0, 1.0, deskew))
     np.testing.assert_allclose(a.download(0), ref, rtol=0, atol=1e-11)
+
+
+def test_ordered_integer_keys_of_doubles_are_monotone():
+    """k_ingest merges the stamps' extrema with integer atomics on an order-preserving map double -> uint64
+    (kicp_pre.hpp ordered_key / ordered_value); re-enacted here: monotone over negatives, zeros, subnormals and infinities,
+    and invertible."""
+    def ordered_key(v):
+        b = np.asarray(v, dtype=np.float64).view(np.uint64)
+        return np.where(b >> np.uint64(63), ~b, b | np.uint64(1 << 63))
+
+    def ordered_value(k):
+        b = np.where(k >> np.uint64(63), k & np.uint64((1 << 63) - 1), ~k)
+        return b.view(np.float64)
+
+    rng = np.random.Generator(np.random.PCG64(21))
+    v = np.concatenate([rng.normal(0, 1e9, 5000), rng.normal(0, 1e-300, 100), [0.0, -0.0, 5e-324, -5e-324, np.inf, -np.inf, 1.7e9, 1.7e18]])
+    k = ordered_key(v)
+    order = np.argsort(k, kind="stable")
+    assert np.all(np.diff(v[order]) >= 0)
+    assert np.array_equal(ordered_value(k).view(np.uint64), v.view(np.uint64))
+    assert ordered_value(np.array([k.min()]))[0] == v.min() and ordered_value(np.array([k.max()]))[0] == v.max()
