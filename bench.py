@@ -14,6 +14,8 @@ iteration sums 24 int64 words per rank (the exact limb sums of the 2x2 normal eq
 bit-identical pose.  The exchange is selectable (--comm): "shm" (default) - every GPU writes its words into its slot of a
 node-wide host shared segment and every rank's host adds them: no device collective at all; "rccl" - the built-in RCCL
 all-reduce over xGMI; "torch" - torch.distributed all-reduce.  Total work is fixed -> "scaling": "strong".
+(--mode replicas, not the default: every rank registers whole scans on its own - one robot per GPU - no exchange,
+value = all ranks' scans per second, "scaling": "weak".)
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
   "roofline"     the dominant kernel (fused association+accumulation pass): algorithmic bytes per launch / live
@@ -49,6 +51,9 @@ def main():
                     help="N>1 exchange of the per-iteration sums: host shared segment written by every GPU (default, no device "
                          "collective), built-in RCCL all-reduce, or torch.distributed all-reduce callback")
     ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for barriers/timing")
+    ap.add_argument("--mode", default="shard", choices=["shard", "replicas"],
+                    help="N>1: 'shard' (default, the north star) splits every scan's points across the ranks and exchanges the sums each "
+                         "iteration; 'replicas' lets every rank register whole scans on its own (one robot per GPU, no exchange; weak scaling)")
     ap.add_argument("--force-comm", action="store_true", help="exercise the multi-GPU code path (all-reduce + separate solve) even with one rank")
     args = ap.parse_args()
 
@@ -81,7 +86,9 @@ def main():
     if "KICP_BENCH_DEVICE" in os.environ:  # testing aid: several ranks on one GPU (works with --comm shm --pg-backend gloo)
         device = int(os.environ["KICP_BENCH_DEVICE"])
     torch.cuda.set_device(device)
-    use_comm = world > 1 or args.force_comm
+    replicas = args.mode == "replicas" and world > 1
+    use_comm = world > 1 or args.force_comm      # a process group exists (barriers, timing)
+    exchange = use_comm and not replicas          # the registration itself exchanges sums
     if use_comm:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -102,11 +109,13 @@ def main():
     gmap.sync(device)
     n_total = scans[0]["frame"].shape[0]
     lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world  # contiguous shard of this rank
+    if replicas:
+        lo, hi = 0, n_total
     frames = [K.DeviceFrame(s["frame"][lo:hi], device=device) for s in scans]
 
     reg = K.KinematicRegistration(device=device)  # reference defaults (KinematicICP.hpp:51-56)
     keep = []
-    if use_comm:
+    if exchange:
         if args.comm == "shm":
             name = "kicp_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
             if rank == 0:
@@ -188,10 +197,10 @@ def main():
             reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
         host_rate = k_host / (time.perf_counter() - t1)
     if use_comm:  # all GPU work is done: tear the communicators down on every rank before rank 0's CPU-only epilogue
-        if args.comm == "rccl":
+        if exchange and args.comm == "rccl":
             reg.comm_destroy()
         dist.barrier()
-        if args.comm == "shm":
+        if exchange and args.comm == "shm":
             reg.shm_destroy()
         dist.destroy_process_group()
     if rank != 0:
@@ -211,7 +220,7 @@ def main():
             # B_algo(pass) = 12 N_q + 16 P + 12 S  (fp32 xyz per point, 16 B per probed slot)
             balgo_pass.append(12 * n_total + 16 * int(st.probes[k]) + 12 * int(st.points_scanned[k]))
         max_pose_err = max(max_pose_err, float(np.max(np.abs(pose - ref))))
-    bytes_per_launch = float(np.mean(balgo_pass)) / world  # each rank's launch covers its shard
+    bytes_per_launch = float(np.mean(balgo_pass)) / (1 if replicas else world)  # each rank's launch covers its shard
     pass_ms = np.array([ms for _, lst, _ in per_call for ms in lst], dtype=np.float64)
     kernel_us = float(pass_ms.mean() * 1e3) if pass_ms.size else float("nan")
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if pass_ms.size else None
@@ -241,7 +250,7 @@ def main():
                "sample": "%d calls of the same %d scans over %.0f s, OpenMP on all host cores" % (done, len(scans), args.cpu_seconds),
                "single_thread_value": round(cpu_one, 3), "cpu_model": _cpu_model()}
 
-    value = args.steps / elapsed
+    value = (world if replicas else 1) * args.steps / elapsed  # replicas: every rank completed `steps` scans of its own
     out = {
         "metric": "scans/sec (ICP registration only), 128k-pt scan vs 1M-pt map",
         "value": round(value, 2),
@@ -251,14 +260,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 5),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if replicas else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
                                "(mean %.2f per scan, reference %.2f)" % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(),
                                                                          cfg.voxel_size, tau, iters_gpu, float(np.mean(iters_ref))),
-                   "points_per_gpu": hi - lo, "parallelism": ("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU",
+                   "points_per_gpu": hi - lo, "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
+                                  (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
                    "pass_kernel": int(reg.get_option("pass_kernel")), "max_pose_abs_diff_vs_oracle": max_pose_err,
                    "scans_per_s_with_host_input_incl_pcie": None if host_rate is None else round(host_rate, 1)},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
