@@ -2,16 +2,21 @@
 //
 //   k_pass_*    : fused DataAssociation + ComputePerturbation reduction (+ the pass-0 sum of
 //                 ComputeOdometryRegularization): registration/Registration.cpp:62-81, 83-118, 48-55, with
-//                 kiss_icp::VoxelHashMap::GetClosestNeighbor (kiss-icp v1.2.0) inlined as the
-//                 27-voxel probe + bucket scan.  No correspondence list is materialised.  The LAST workgroup to
-//                 finish also runs Registration.cpp:119-125 (2x2 solve), :159-167 (motion model) and :181-184
-//                 (pose update + stop test) on one lane, so one launch = one ICP iteration.
-//       k_pass_binned  variant 2 (default): queries were binned by 2x2x2-voxel cell (k_bin_*); one wave per run of
-//                      <= 64 queries of a cell stages the cell's voxel neighbourhood in LDS and every lane scans it.
-//       k_pass_lds     variant 1: same staging, but over consecutive queries in their given order.
-//       k_pass_gather  variant 0: thread-per-query straight from HBM/L2 (baseline / fallback).
-//   k_bin_*     : counting sort of the scan by cell at the predicted pose (once per scan).
-//   k_solve     : the solve/update step alone (multi-GPU: runs after the all-reduce).
+//                 kiss_icp::VoxelHashMap::GetClosestNeighbor (kiss-icp v1.2.0) inlined as ONE table
+//                 probe + the scan of the neighbour buckets that can matter.  No correspondence list is materialised.
+//                 One launch = one ICP iteration; every variant ends in finish_pass (exact reduction + hand-off).
+//       k_pass_gather32 variant 3 (default): thread (or 2 / 4 sub-lanes) per query; fp32 mirror pre-selects with an
+//                      integer-key tournament, the winner and anything within the fp32 margin are resolved in fp64.
+//       k_pass_gather   variant 0: thread-per-query, plain fp64 (baseline of the ablation).
+//       k_pass_lds      variant 1 (experimental): one wave per <= 64 consecutive queries stages their voxel neighbourhood
+//                      in LDS and every lane scans it.
+//       k_pass_binned   variant 2 (experimental): the same after binning the scan by 2x2x2-voxel cell (k_bin_*).
+//   finish_pass : wave / workgroup reduction of the exact sums, then either tagged rows for the host (default: the host
+//                 adds the rows of the first-level groups and solves, Registration.cpp:119-125,159-167,181-184) or the
+//                 full device-side tree whose last workgroup solves on one lane (host_solve = 0) / leaves the totals
+//                 for an all-reduce (RCCL and callback modes).
+//   k_bin_*     : counting sort of the scan by cell at the predicted pose (variant 2, once per scan).
+//   k_solve     : the solve/update step alone (multi-GPU with device-side solve: runs after the all-reduce).
 //   k_closest   : GetClosestNeighbor for a batch of queries (API parity / tests).
 //
 // Roofline: gather + reduction, ~0.02 flop/B -> memory bound, no MFMA.
@@ -335,10 +340,12 @@ __device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams
     }
 }
 
-// Workgroup epilogue of every pass kernel: exact workgroup sum -> two-level last-arriver tree -> the last workgroup
-// finishes the iteration.  Inter-workgroup traffic follows cdna_hip_programming.md Guideline 16 (form R1): payload
-// as 8-byte write-through (sc1) stores, `s_waitcnt vmcnt(0)`, ONE relaxed agent-scope ticket atomic per workgroup;
-// readers use sc1 loads.  No fences, no same-line atomic fan-in (tickets live on separate 128-B lines).
+// Workgroup epilogue of every pass kernel: exact workgroup sum, then a last-arriver tree.  Default (mode 4): ONE level -
+// the last workgroup of every group of kGroup sends the group's row, tagged, to the host.  Other modes: two levels, the
+// last workgroup of the launch finishes the iteration.  Inter-workgroup traffic follows cdna_hip_programming.md
+// Guideline 16 (form R1): payload as 8-byte write-through (sc1) stores, ONE relaxed agent-scope ticket atomic per
+// workgroup, readers use sc1 loads; no fences, no same-line atomic fan-in (tickets live on separate 128-B lines).  The
+// two-level modes order payload before ticket with `s_waitcnt vmcnt(0)`; mode 4 needs no ordering (tags).
 constexpr int kGroup = 32;        // workgroups per first-level group
 constexpr int kTicketStride = 32; // uint32 words between group tickets (128 B)
 
