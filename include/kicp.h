@@ -4,7 +4,11 @@
  *   kinematic_icp::KinematicRegistration      (cpp/kinematic_icp/registration/Registration.hpp:32-50)
  *   kiss_icp::VoxelHashMap (kiss-icp v1.2.0)  (used at registration/Registration.cpp:63,74,152,157,
  *                                              pipeline/KinematicICP.hpp:79,88,92 and KinematicICP.cpp:79)
- * need from a backend, as plain C: opaque handles, pointers and sizes, no C++/torch types.
+ * need from a backend, as plain C: opaque handles, pointers and sizes, no C++/torch types - plus, further down, the
+ * steps either side of that path in KinematicICP::RegisterFrame: kicp_pre_* for the wire-format
+ * ingest, deskew + crop + downsample (pipeline/KinematicICP.cpp:31-62, ros/.../RosUtils.cpp:30-39,
+ * TimeStampHandler.cpp:57-128) and kicp_map_update_pose_device / kicp_map_pointcloud for the map side (KinematicICP.cpp:79,
+ * KinematicICP.hpp:92).
  *
  * Conventions
  *   points : contiguous AoS float64 xyz (the memory layout of std::vector<Eigen::Vector3d>, so
