@@ -35,6 +35,7 @@ public:
     SE3d inverse() const {
         SE3d r;
         r.q_ = {-q_[0], -q_[1], -q_[2], q_[3]};
+        r.normalize();  // Sophus: SO3::inverse() passes the conjugate through the normalising constructor
         r.t_ = r.rotate(t_ * -1.0);
         return r;
     }

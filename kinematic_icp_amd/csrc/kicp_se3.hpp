@@ -93,7 +93,8 @@ KICP_HD Pose pose_exp(const double xi[6]) {
         double W2[9];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + (a * W[i] + b * W2[i]);
+        // Eigen evaluates `I + a * Omega + b * Omega_sq` coefficient-wise, left to right
+        for (int i = 0; i < 9; ++i) V[i] = (((i % 4 == 0) ? 1.0 : 0.0) + a * W[i]) + b * W2[i];
     }
     T.tx = V[0] * xi[0] + V[1] * xi[1] + V[2] * xi[2];
     T.ty = V[3] * xi[0] + V[4] * xi[1] + V[5] * xi[2];
@@ -102,21 +103,25 @@ KICP_HD Pose pose_exp(const double xi[6]) {
 }
 
 KICP_HD Pose pose_inverse(const Pose &a) {
+    // Sophus: SE3(so3().inverse(), so3().inverse() * (translation() * -1)); SO3::inverse() hands the conjugate to the
+    // normalising quaternion constructor
+    const double n = sqrt(a.qx * a.qx + a.qy * a.qy + a.qz * a.qz + a.qw * a.qw);
     Pose r;
-    r.qx = -a.qx, r.qy = -a.qy, r.qz = -a.qz, r.qw = a.qw;
+    r.qx = -a.qx / n, r.qy = -a.qy / n, r.qz = -a.qz / n, r.qw = a.qw / n;
     double x, y, z;
-    quat_rotate(r, -a.tx, -a.ty, -a.tz, x, y, z);
+    quat_rotate(r, a.tx * -1.0, a.ty * -1.0, a.tz * -1.0, x, y, z);
     r.tx = x, r.ty = y, r.tz = z;
     return r;
 }
 
 // SE3 logarithm -> twist (v, w), Sophus' formulas (used once per frame for the deskewing velocity; kiss-icp v1.2.0
-// core/Preprocessing.cpp)
+// core/Preprocessing.cpp): V^-1 = I - 1/2 W + c W^2 as a matrix (coefficient-wise, left to right),
+// then V^-1 t
 KICP_HD void pose_log(const Pose &T, double xi[6]) {
     const double sn = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz, w = T.qw;
     double k, theta;
     if (sn < 1e-20) {
-        k = 2.0 / w - (2.0 / 3.0) * sn / (w * w * w);
+        k = 2.0 / w - (2.0 / 3.0) * sn / (w * (w * w));
         theta = 2.0 * sn / w;
     } else {
         const double n = sqrt(sn);
@@ -125,9 +130,6 @@ KICP_HD void pose_log(const Pose &T, double xi[6]) {
         theta = k * n;
     }
     const double ox = k * T.qx, oy = k * T.qy, oz = k * T.qz;
-    // V^-1 t = t - 1/2 w x t + c w x (w x t)
-    const double ax = oy * T.tz - oz * T.ty, ay = oz * T.tx - ox * T.tz, az = ox * T.ty - oy * T.tx;
-    const double bx = oy * az - oz * ay, by = oz * ax - ox * az, bz = ox * ay - oy * ax;
     double c;
     if (fabs(theta) < 1e-10) {
         c = 1.0 / 12.0;
@@ -135,7 +137,16 @@ KICP_HD void pose_log(const Pose &T, double xi[6]) {
         const double h = 0.5 * theta;
         c = (1.0 - theta * cos(h) / (2.0 * sin(h))) / (theta * theta);
     }
-    xi[0] = T.tx - 0.5 * ax + c * bx, xi[1] = T.ty - 0.5 * ay + c * by, xi[2] = T.tz - 0.5 * az + c * bz;
+    const double W[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    double Vi[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double w2 = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+            Vi[3 * i + j] = (((i == j) ? 1.0 : 0.0) - 0.5 * W[3 * i + j]) + c * w2;
+        }
+    xi[0] = Vi[0] * T.tx + Vi[1] * T.ty + Vi[2] * T.tz;
+    xi[1] = Vi[3] * T.tx + Vi[4] * T.ty + Vi[5] * T.tz;
+    xi[2] = Vi[6] * T.tx + Vi[7] * T.ty + Vi[8] * T.tz;
     xi[3] = ox, xi[4] = oy, xi[5] = oz;
 }
 

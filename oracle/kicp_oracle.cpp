@@ -33,7 +33,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <numeric>
 #include <utility>
 #include <vector>
 #ifdef _OPENMP
@@ -117,7 +119,8 @@ inline V3 so3_act(const Quat &q, const V3 &p) {
     uv = uv + uv;
     return p + q.w * uv + cross(qv, uv);
 }
-inline Quat so3_inverse(const Quat &q) { return {-q.x, -q.y, -q.z, q.w}; }
+// Sophus SO3Base::inverse(): SO3(unit_quaternion().conjugate()) - through the normalising constructor
+inline Quat so3_inverse(const Quat &q) { return so3_from_quat({-q.x, -q.y, -q.z, q.w}); }
 // Sophus SO3Base::matrix() == Eigen::Quaternion::toRotationMatrix()
 inline M3 so3_matrix(const Quat &q) {
     const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
@@ -179,8 +182,9 @@ inline SE3 se3_exp(const double a[6]) {
         V = so3_matrix(so3);
     } else {
         const double theta_sq = theta * theta;
-        V = m3_add(m3_identity(), m3_add(m3_scale((1.0 - std::cos(theta)) / theta_sq, Omega),
-                                         m3_scale((theta - std::sin(theta)) / (theta_sq * theta), Omega_sq)));
+        // Eigen evaluates `I + a * Omega + b * Omega_sq` coefficient-wise, left to right
+        V = m3_add(m3_add(m3_identity(), m3_scale((1.0 - std::cos(theta)) / theta_sq, Omega)),
+                   m3_scale((theta - std::sin(theta)) / (theta_sq * theta), Omega_sq));
     }
     return {so3, m3_apply(V, upsilon)};
 }
@@ -193,12 +197,11 @@ inline void se3_log(const SE3 &T, double out[6]) {
     const M3 Omega_sq = m3_mul(Omega, Omega);
     M3 V_inv;
     if (std::abs(theta) < kSophusEps) {
-        V_inv = m3_add(m3_identity(), m3_add(m3_scale(-0.5, Omega), m3_scale(1.0 / 12.0, Omega_sq)));
+        V_inv = m3_add(m3_add(m3_identity(), m3_scale(-0.5, Omega)), m3_scale(1.0 / 12.0, Omega_sq));
     } else {
         const double half_theta = 0.5 * theta;
-        V_inv = m3_add(m3_identity(),
-                       m3_add(m3_scale(-0.5, Omega),
-                              m3_scale((1.0 - theta * std::cos(half_theta) / (2.0 * std::sin(half_theta))) / (theta * theta), Omega_sq)));
+        V_inv = m3_add(m3_add(m3_identity(), m3_scale(-0.5, Omega)),
+                       m3_scale((1.0 - theta * std::cos(half_theta) / (2.0 * std::sin(half_theta))) / (theta * theta), Omega_sq));
     }
     const V3 u = m3_apply(V_inv, T.t);
     out[0] = u.x, out[1] = u.y, out[2] = u.z, out[3] = omega.x, out[4] = omega.y, out[5] = omega.z;
@@ -413,17 +416,55 @@ struct VoxelMap {
     }
 };
 
-// kiss-icp v1.2.0 core/VoxelUtils.cpp : VoxelDownsample (App. A.7).  Output order = table order here.
-std::vector<V3> voxel_downsample(const V3 *frame, size_t n, double voxel_size) {
-    VoxelTable<V3> grid;
+// kiss-icp v1.2.0 core/VoxelUtils.cpp : VoxelDownsample (App. A.7): the first point of every voxel, emitted in the
+// iteration order of the reference's `tsl::robin_map<Voxel, Vector3d> grid` after `grid.reserve(frame.size())`
+// [RECALLED: robin-map 1.x semantics, see oracle/ref_shim/tsl/robin_map.h, which implements the general container;
+// tests/test_ref.py checks this specialised restatement against it]:
+//   * reserve(n) gives B = pow2ceil(ceil(n / 0.5)) buckets, so the table never re-hashes while <= n voxels go in;
+//   * a voxel seen for the first time walks from its ideal bucket h = hash & (B-1) past every resident that is at
+//     least as far from ITS ideal bucket, takes the first bucket whose resident is closer to home (or empty), and the
+//     evicted resident walks on under the same rule - so an evicted element also passes the residents that share its
+//     ideal bucket (the order inside such a group is a function of the whole insertion history, not of first-seen time);
+//   * the output is the table read in ascending bucket order.
+// `first_index_out` (optional) receives the input index of every emitted point.
+std::vector<V3> voxel_downsample(const V3 *frame, size_t n, double voxel_size, std::vector<uint32_t> *first_index_out = nullptr) {
+    size_t buckets = 0;
+    const size_t want = static_cast<size_t>(std::ceil(static_cast<float>(n) / 0.5f));
+    if (want > 0) {
+        buckets = 1;
+        while (buckets < want) buckets <<= 1;
+    }
+    constexpr uint32_t kFree = 0xFFFFFFFFu;
+    std::vector<uint32_t> point_at(buckets, kFree);  // input index of the point stored in a bucket
+    std::vector<int32_t> dist_at(buckets, -1);       // its distance from the ideal bucket (-1 = free)
+    const size_t mask = buckets - 1;
     for (size_t i = 0; i < n; ++i) {
         const Voxel voxel = point_to_voxel(frame[i], voxel_size);
-        if (grid.find(voxel) == nullptr) grid.insert(voxel, V3(frame[i]));
+        size_t b = voxel_hash(voxel) & mask;
+        int32_t dist = 0;
+        bool present = false;
+        while (dist <= dist_at[b]) {  // look-up: stop at the first bucket whose resident is closer to home than we are
+            if (point_to_voxel(frame[point_at[b]], voxel_size) == voxel) {
+                present = true;
+                break;
+            }
+            b = (b + 1) & mask, ++dist;
+        }
+        if (present) continue;  // not the first point of its voxel
+        uint32_t carry = static_cast<uint32_t>(i);
+        while (dist_at[b] >= 0) {  // evict the closer-to-home resident and carry it on
+            if (dist > dist_at[b]) std::swap(carry, point_at[b]), std::swap(dist, dist_at[b]);
+            b = (b + 1) & mask, ++dist;
+        }
+        point_at[b] = carry, dist_at[b] = dist;
     }
     std::vector<V3> out;
-    out.reserve(grid.size());
-    for (const auto &s : grid.slots())
-        if (s.used) out.emplace_back(s.value);
+    if (first_index_out) first_index_out->clear();
+    for (size_t b = 0; b < buckets; ++b)
+        if (dist_at[b] >= 0) {
+            out.emplace_back(frame[point_at[b]]);
+            if (first_index_out) first_index_out->push_back(point_at[b]);
+        }
     return out;
 }
 
@@ -461,12 +502,16 @@ struct LinearSystem {                                           // Registration.
     double JTr[2] = {0, 0};
 };
 
-// Registration.cpp:48-60
+// Registration.cpp:48-60.  The reference sums with std::transform_reduce (no execution policy); libstdc++ evaluates that
+// over random-access iterators four elements at a time - init + ((u0 + u1) + (u2 + u3)) - so calling the same
+// algorithm here reproduces the reference's (libstdc++) summation order bit for bit (checked against oracle/_ref).
 double compute_odometry_regularization(const Correspondences &associations, const SE3 &odometry_initial_guess,
                                        double *sum_sq_out = nullptr) {
-    double sum_of_squared_residuals = 0.0;
-    for (const auto &[source, target] : associations)
-        sum_of_squared_residuals += squared_norm(se3_act(odometry_initial_guess, source) - target);
+    const double sum_of_squared_residuals =
+        std::transform_reduce(associations.cbegin(), associations.cend(), 0.0, std::plus<double>(), [&](const auto &association) {
+            const auto &[source, target] = association;
+            return squared_norm(se3_act(odometry_initial_guess, source) - target);
+        });
     const double N = static_cast<double>(associations.size());
     const double mean_squared_residual = sum_of_squared_residuals / N;
     const double beta = 1.0 / (mean_squared_residual + epsilon);
@@ -514,38 +559,45 @@ Correspondences data_association(const V3 *points, size_t n, const VoxelMap &vox
 }
 
 // Registration.cpp:86-93 + :108-113 : one correspondence's (J^T J, J^T r)
-inline void accumulate_one(const std::pair<V3, V3> &correspondence, const SE3 &current_estimate, LinearSystem &a) {
+inline LinearSystem linear_system_of(const std::pair<V3, V3> &correspondence, const SE3 &current_estimate) {
     const auto &[source, target] = correspondence;
     const V3 residual = se3_act(current_estimate, source) - target;
     const V3 J0 = so3_act(current_estimate.q, V3{1.0, 0.0, 0.0});
     const V3 J1 = so3_act(current_estimate.q, V3{-source.y, source.x, 0.0});
-    a.JTJ[0][0] += dot(J0, J0), a.JTJ[0][1] += dot(J0, J1);
-    a.JTJ[1][0] += dot(J1, J0), a.JTJ[1][1] += dot(J1, J1);
-    a.JTr[0] += dot(J0, residual), a.JTr[1] += dot(J1, residual);
+    LinearSystem a;
+    a.JTJ[0][0] = dot(J0, J0), a.JTJ[0][1] = dot(J0, J1);
+    a.JTJ[1][0] = dot(J1, J0), a.JTJ[1][1] = dot(J1, J1);
+    a.JTr[0] = dot(J0, residual), a.JTr[1] = dot(J1, residual);
+    return a;
 }
-// Registration.cpp:102-118 : the (un-normalised) reduction
+// Registration.cpp:95-99
+inline LinearSystem sum_linear_systems(LinearSystem a, const LinearSystem &b) {
+    a.JTJ[0][0] += b.JTJ[0][0], a.JTJ[0][1] += b.JTJ[0][1], a.JTJ[1][0] += b.JTJ[1][0], a.JTJ[1][1] += b.JTJ[1][1];
+    a.JTr[0] += b.JTr[0], a.JTr[1] += b.JTr[1];
+    return a;
+}
+// Registration.cpp:102-118 : the (un-normalised) reduction.  One thread = one tbb::blocked_range covering everything,
+// folded by std::transform_reduce (libstdc++: four elements at a time, see compute_odometry_regularization); several
+// threads = equal contiguous chunks folded the same way from the identity and joined in chunk order.
 LinearSystem reduce_linear_system(const Correspondences &correspondences, const SE3 &current_estimate, int num_threads) {
-    LinearSystem sys;
+    const auto fold = [&](size_t lo, size_t hi) {
+        return std::transform_reduce(correspondences.cbegin() + static_cast<std::ptrdiff_t>(lo), correspondences.cbegin() + static_cast<std::ptrdiff_t>(hi),
+                                     LinearSystem{}, sum_linear_systems,
+                                     [&](const auto &correspondence) { return linear_system_of(correspondence, current_estimate); });
+    };
+    const size_t n = correspondences.size();
 #ifdef _OPENMP
-    if (num_threads > 1) {
+    if (num_threads > 1 && n >= 2 * static_cast<size_t>(num_threads)) {
         std::vector<LinearSystem> part(num_threads);
-#pragma omp parallel num_threads(num_threads)
-        {
-            LinearSystem mine;
-#pragma omp for schedule(static)
-            for (long i = 0; i < static_cast<long>(correspondences.size()); ++i) accumulate_one(correspondences[i], current_estimate, mine);
-            part[omp_get_thread_num()] = mine;
-        }
-        for (const auto &p : part) {  // sum_linear_systems, Registration.cpp:95-99
-            sys.JTJ[0][0] += p.JTJ[0][0], sys.JTJ[0][1] += p.JTJ[0][1], sys.JTJ[1][0] += p.JTJ[1][0], sys.JTJ[1][1] += p.JTJ[1][1];
-            sys.JTr[0] += p.JTr[0], sys.JTr[1] += p.JTr[1];
-        }
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+        for (int c = 0; c < num_threads; ++c) part[c] = fold(n * c / num_threads, n * (c + 1) / num_threads);
+        LinearSystem sys = part[0];
+        for (int c = 1; c < num_threads; ++c) sys = sum_linear_systems(sys, part[c]);
         return sys;
     }
 #endif
     (void)num_threads;
-    for (const auto &c : correspondences) accumulate_one(c, current_estimate, sys);
-    return sys;
+    return fold(0, n);
 }
 // Registration.cpp:119-125 : normalise, regularise, closed-form 2x2 solve (Eigen Matrix2d::inverse())
 inline void solve_perturbation(LinearSystem sys, double num_correspondences, double beta, double dx[2]) {
