@@ -114,9 +114,8 @@ int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
 int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
 /* Backend tuning knobs (not part of the reference API):
  *   "pass_kernel"  3 (default) thread-per-query gather over the fp32 mirror with exact fp64 resolution; 0 plain fp64
- *                  gather; 1 LDS staging over the queries in their given order; 2 queries binned by 2x2x2-voxel cell +
- *                  LDS staging (1 and 2 are experimental)
- *   "block"        workgroup size of variants 0/3 (64|128|256);  "waves_per_cu" persistent grid of variants 1/2
+ *                  gather (baseline of the ablation)
+ *   "block"        workgroup size (64|128|256)
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device

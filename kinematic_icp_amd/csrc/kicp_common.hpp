@@ -72,7 +72,7 @@ KICP_HD int shift_component(uint64_t packed, int s) { return static_cast<int>((p
 struct DevMapCounters {
     unsigned long long n_points;
     uint32_t n_voxels, n_entries, n_buckets_hi, free_count;
-    uint32_t touched, error, pad0, pad1;
+    uint32_t touched, error, may_occupy, pad1;  // may_occupy: touched voxels without points (k_up_scan)
 };
 
 }  // namespace kicp

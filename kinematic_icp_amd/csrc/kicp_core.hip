@@ -28,9 +28,17 @@ int fail(int code, const std::string &msg) {
 // measured (always in multiples of ~9 ms, and whether a process was hit depended on its allocation pattern only).  So
 // both directions go through a pinned staging buffer owned by the handle: CPU copy in 1 MB pieces (~0.03 ms each), each
 // followed by its asynchronous DMA - about 0.2 ms for that scan, every time.  KICP_DIRECT_UPLOAD=1 restores the direct
-// DMA for callers that pass pinned (hipHostMalloc / hipHostRegister) memory.  The caller drains `stream` before the staging
-// buffer is used again (every entry point here ends in a sync).
+// DMA for callers that pass pinned (hipHostMalloc / hipHostRegister) memory.  An event recorded behind the last copy of an
+// upload guards the buffer: the next transfer through it waits for that event first, so an entry point that returns early
+// (error, max_num_iterations <= 0) cannot have its copy overtaken by the next call's CPU writes.
 const bool g_direct_upload = env_flag("KICP_DIRECT_UPLOAD");
+static int stage_wait(HostStage &hs) {
+    if (hs.pending) {
+        HIP_TRY(hipEventSynchronize(hs.done));
+        hs.pending = false;
+    }
+    return KICP_OK;
+}
 int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream) {
     if (bytes <= hs.cap) return KICP_OK;
     HIP_TRY(hipStreamSynchronize(stream));
@@ -48,14 +56,19 @@ int staged_upload(HostStage &hs, size_t offset, void *dst, const void *src, size
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
         return KICP_OK;
     }
-    if (offset == 0)
+    if (offset == 0) {
+        if (int rc = stage_wait(hs)) return rc;  // a copy of the previous call may still be reading the buffer
         if (int rc = stage_reserve(hs, bytes, stream)) return rc;
+    }
     if (offset + bytes > hs.cap) return fail(KICP_ERR_ARG, "staging buffer too small for a follow-up transfer");
     for (size_t off = 0; off < bytes; off += kStagePiece) {
         const size_t len = std::min(kStagePiece, bytes - off);
         std::memcpy(hs.p + offset + off, static_cast<const unsigned char *>(src) + off, len);
         HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, hs.p + offset + off, len, hipMemcpyHostToDevice, stream));
     }
+    if (!hs.done) HIP_TRY(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(hs.done, stream));
+    hs.pending = true;
     return KICP_OK;
 }
 // device -> caller memory; returns with the data in place
@@ -66,6 +79,7 @@ int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hip
         HIP_TRY(hipStreamSynchronize(stream));
         return KICP_OK;
     }
+    if (int rc = stage_wait(hs)) return rc;
     if (int rc = stage_reserve(hs, bytes, stream)) return rc;
     HIP_TRY(hipMemcpyAsync(hs.p, src, bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

@@ -60,9 +60,12 @@ inline int set_device(int device) {
 struct HostStage {
     unsigned char *p = nullptr;
     size_t cap = 0;
+    hipEvent_t done = nullptr;  // recorded behind the last asynchronous copy that reads the buffer
+    bool pending = false;       // such a copy may still be in flight: wait on `done` before writing the buffer again
     void release() {
+        if (done) hipEventSynchronize(done), hipEventDestroy(done);
         if (p) hipHostFree(p);
-        p = nullptr, cap = 0;
+        p = nullptr, cap = 0, done = nullptr, pending = false;
     }
 };
 // (policy and implementation: kicp_core.hip)

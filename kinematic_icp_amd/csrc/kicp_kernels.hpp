@@ -8,14 +8,12 @@
 //       k_pass_gather32 variant 3 (default): thread (or 2 / 4 sub-lanes) per query; fp32 mirror pre-selects with an
 //                      integer-key tournament, the winner and anything within the fp32 margin are resolved in fp64.
 //       k_pass_gather   variant 0: thread-per-query, plain fp64 (baseline of the ablation).
-//       k_pass_lds      variant 1 (experimental): one wave per <= 64 consecutive queries stages their voxel neighbourhood
-//                      in LDS and every lane scans it.
-//       k_pass_binned   variant 2 (experimental): the same after binning the scan by 2x2x2-voxel cell (k_bin_*).
+//                      (Variants 1/2 of round 1 - neighbourhoods staged in LDS per wave, optionally after binning the scan
+//                      by cell - were slower than variant 3 on every BASELINE config and spilled registers; removed.)
 //   finish_pass : wave / workgroup reduction of the exact sums, then either tagged rows for the host (default: the host
 //                 adds the rows of the first-level groups and solves, Registration.cpp:119-125,159-167,181-184) or the
 //                 full device-side tree whose last workgroup solves on one lane (host_solve = 0) / leaves the totals
 //                 for an all-reduce (RCCL and callback modes).
-//   k_bin_*     : counting sort of the scan by cell at the predicted pose (variant 2, once per scan).
 //   k_solve     : the solve/update step alone (multi-GPU with device-side solve: runs after the all-reduce).
 //   k_closest   : GetClosestNeighbor for a batch of queries (API parity / tests).
 //
@@ -50,7 +48,7 @@ struct HostRecord {
     double log_sums[kMaxLog][6];
     double log_dx[kMaxLog][2];
     double sums[kNumSums];  // last pass, for kicp_pass_sums
-    uint32_t n_cells, n_items, not_staged, reserved;
+    uint32_t reserved[4];
     long long words[kReduceWords];  // limb totals of the last pass (host-side solve / kicp_pass_words)
 };
 
@@ -59,7 +57,7 @@ struct IcpState {
     Pose T;  // current_estimate
     double beta;
     int32_t done, iter, converged, nan_flag;
-    unsigned int not_staged;             // diagnostics: workgroups that fell back to the HBM search
+    unsigned int reserved_;
     long long reduce[kReduceWords];      // limb sums of the running pass (multi-GPU: all-reduced in place)
     unsigned int pad_[32];
     unsigned int ticket;                 // second-level arrival counter (own cache line)
@@ -93,12 +91,6 @@ struct SolveParams {
     uint32_t tag;                  // 1..65535, unique per pass within an epoch (the buffers are cleared when it wraps)
 };
 
-struct BinView {
-    const double *sorted_src;  // scan points permuted by cell (AoS xyz fp64)
-    const uint2 *items;        // (first query, count <= 64) per work item
-    const uint32_t *counters;  // [0] n_cells, [1] n_items
-};
-
 struct PassParams {
     const double *src;  // scan points, base frame, AoS xyz fp64 (device)
     uint32_t n;
@@ -107,7 +99,6 @@ struct PassParams {
     IcpState *st;
     unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
-    BinView bin;
     SolveParams sol;
     int32_t dbg;  // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
@@ -333,7 +324,6 @@ __device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams
         put_d(&rec->T.qx, T.qx), put_d(&rec->T.qy, T.qy), put_d(&rec->T.qz, T.qz), put_d(&rec->T.qw, T.qw);
         put_d(&rec->T.tx, T.tx), put_d(&rec->T.ty, T.ty), put_d(&rec->T.tz, T.tz), put_d(&rec->beta, beta);
         put_i(&rec->done, done), put_i(&rec->iter, f.pass + 1), put_i(&rec->converged, converged), put_i(&rec->nan_flag, nan_flag);
-        put_i(reinterpret_cast<int32_t *>(&rec->not_staged), static_cast<int32_t>(st->not_staged));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&rec->seq, (f.call_id << 16) | (done ? 0x8000ull : 0ull) | static_cast<unsigned long long>(f.pass + 1),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -598,26 +588,6 @@ __device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, ui
     t.o1 = lt1 ? ord : t.o1;
 }
 
-// minimum of N register-resident values and the (first) position attaining it, as a balanced tournament
-template <int N>
-__device__ __forceinline__ void tree_min_index(const float (&v)[N], float &m, int &k) {
-    float a[N];
-    int ia[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) a[u] = v[u], ia[u] = u;
-#pragma unroll
-    for (int width = N; width > 1; width = (width + 1) / 2) {
-#pragma unroll
-        for (int u = 0; u < width / 2; ++u) {
-            const int r = width - 1 - u;  // pair u with its mirror; the lower position wins ties
-            const bool take = a[r] < a[u];
-            a[u] = take ? a[r] : a[u];
-            ia[u] = take ? ia[r] : ia[u];
-        }
-    }
-    m = a[0], k = ia[0];
-}
-
 // minimum of N register-resident unsigned keys (v_min3_u32 friendly reduction)
 constexpr uint32_t kFarKey = 0x7F000000u;  // 1.7e38 as a float: beyond every real squared distance
 template <int N>
@@ -790,448 +760,6 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) 
     }
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Wave-level staged matching, shared by variants 1 and 2.  One wave handles a group of <= 64 queries:
-//   1. bounding box of the group's query voxels (+1 voxel halo) = the "region";
-//   2. one table probe per region voxel, all first probes in flight together;
-//   3. the occupied buckets are copied to LDS as fp32 offsets from the region origin (every load of the copy in
-//      flight together), each staged point tagged with its index in the HBM pool;
-//   4. every lane scans its 27 neighbour voxels out of LDS in fp32, tracking the smallest and second smallest
-//      squared distance; voxels that cannot contain a closer point are culled per lane;
-//   5. the winner is re-evaluated in fp64 from HBM.  fp32 only PRE-SELECTS: when the runner-up is within the fp32
-//      error margin of the winner the lane repeats the scan, evaluating every near-minimal candidate in fp64 in
-//      the reference's visiting order - so the chosen neighbour and its distance are exactly the fp64 reference's.
-// If the region exceeds the LDS budget the group is split in halves (down to single queries, whose region is 27
-// voxels), so any input order is handled; order only costs time.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kSlots = 256;    // region voxels per staging (6x6x6 = 216 fits)
-constexpr int kPoints = 640;   // staged map points per staging
-constexpr int kCopyRounds = kPoints / 64;
-constexpr int kCopyBatch = 5;  // point loads in flight per lane during the copy
-constexpr uint32_t kNotStaged = 0xFFFFu;
-constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
-
-struct WaveLds {
-    uint32_t val[kSlots];        // table value (bucket<<8 | count) of each region voxel, or kEmptyVal
-    uint16_t off[kSlots];        // first staged point of that voxel, or kNotStaged
-    uint16_t owner[kPoints];     // region slot a staged point belongs to
-    float4 pts[kPoints];         // (x,y,z) relative to the region origin, w = bit pattern of the HBM pool index
-};
-
-struct GroupQuery {
-    double sx, sy;  // source point (x,y) in the base frame (the Jacobian needs them)
-    Query q;
-    bool valid;
-};
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-// Steps 1-5 for the lanes with `active` set.  On return best/best_idx hold the exact fp64 result per lane
-// (best_idx == kNoIndex: no candidate below the bound).  Returns false (nothing done) if the region does not fit.
-__device__ __forceinline__ bool stage_and_match(WaveLds &L, const MapView &m, const Query &q, bool active, double bound_d2, double &best,
-                                                uint32_t &best_idx) {
-    const int lane = threadIdx.x & 63;
-    // ---- 1. region ---------------------------------------------------------------------------------------------
-    const int lox = uniform_i(wave_min_i(active ? q.vx : INT_MAX)), loy = uniform_i(wave_min_i(active ? q.vy : INT_MAX)),
-              loz = uniform_i(wave_min_i(active ? q.vz : INT_MAX));
-    const int hix = uniform_i(wave_max_i(active ? q.vx : INT_MIN)), hiy = uniform_i(wave_max_i(active ? q.vy : INT_MIN)),
-              hiz = uniform_i(wave_max_i(active ? q.vz : INT_MIN));
-    if (hix < lox) return true;  // no active lane
-    const long long ex = static_cast<long long>(hix) - lox + 3, ey = static_cast<long long>(hiy) - loy + 3, ez = static_cast<long long>(hiz) - loz + 3;
-    if (ex * ey * ez > kSlots) return false;
-    const int bx = lox - 1, by = loy - 1, bz = loz - 1, iex = static_cast<int>(ex), iey = static_cast<int>(ey);
-    const int nslots = static_cast<int>(ex * ey * ez);
-    const double vs = m.voxel_size;
-    const double ox = bx * vs, oy = by * vs, oz = bz * vs;  // region origin (world)
-    __syncthreads();  // previous staging fully consumed
-    // ---- 2. probes ---------------------------------------------------------------------------------------------
-    constexpr int kRounds = kSlots / 64;
-    int4 e[kRounds];
-    int kx[kRounds], ky[kRounds], kz[kRounds];
-    uint32_t h[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int s = lane + r * 64;
-        if (s < nslots) {
-            kx[r] = bx + s % iex, ky[r] = by + (s / iex) % iey, kz[r] = bz + s / (iex * iey);
-            h[r] = voxel_hash(kx[r], ky[r], kz[r]) & m.mask;
-            e[r] = *reinterpret_cast<const int4 *>(m.table + h[r]);
-        }
-    }
-    uint32_t used = 0, npts = 0;  // wave-uniform: running allocation; end of the densely staged prefix
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int s = lane + r * 64;
-        uint32_t val = kEmptyVal;
-        if (s < nslots) {
-            for (;;) {  // collision chain (rare: load factor <= 0.25)
-                if (static_cast<uint32_t>(e[r].w) == kEmptyVal) break;
-                if (e[r].x == kx[r] && e[r].y == ky[r] && e[r].z == kz[r]) {
-                    if (e[r].w & 0xff) val = static_cast<uint32_t>(e[r].w);  // halo entries hold no points
-                    break;
-                }
-                h[r] = (h[r] + 1) & m.mask;
-                e[r] = *reinterpret_cast<const int4 *>(m.table + h[r]);
-            }
-        }
-        const uint32_t cnt = (val != kEmptyVal) ? (val & 0xffu) : 0u;
-        uint32_t incl = cnt;  // inclusive wave scan of the point counts
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        const uint32_t first = used + incl - cnt;
-        used += static_cast<uint32_t>(uniform_i(static_cast<int>(__shfl(incl, 63, 64))));
-        uint32_t my_end = 0;
-        if (s < nslots) {
-            uint32_t o = kNotStaged;
-            if (cnt && first + cnt <= kPoints) {
-                o = first, my_end = first + cnt;
-                for (uint32_t k = 0; k < cnt; ++k) L.owner[first + k] = static_cast<uint16_t>(s);
-            }
-            L.val[s] = val, L.off[s] = static_cast<uint16_t>(o);
-        }
-        // allocation is in prefix order, so the staged buckets form the dense range [0, max end)
-        npts = max(npts, static_cast<uint32_t>(uniform_i(wave_max_i(static_cast<int>(my_end)))));
-        if (r * 64 + 64 >= nslots) break;  // wave-uniform
-    }
-    __syncthreads();
-    // ---- 3. copy: lane handles points lane, lane+64, ...; all loads issued before the first LDS store ---------------
-#pragma unroll
-    for (int batch = 0; batch < kCopyRounds; batch += kCopyBatch) {
-        if (static_cast<uint32_t>(batch * 64) >= npts) break;  // wave-uniform
-        double cx[kCopyBatch], cy[kCopyBatch], cz[kCopyBatch];
-        uint32_t gi[kCopyBatch];
-#pragma unroll
-        for (int r = 0; r < kCopyBatch; ++r) {
-            const uint32_t pt = lane + (batch + r) * 64;
-            gi[r] = kNoIndex;
-            if (pt < npts) {
-                const uint32_t s = L.owner[pt];
-                gi[r] = (L.val[s] >> 8) * m.cap + (pt - L.off[s]);
-                const double *src = m.pool + static_cast<size_t>(gi[r]) * 3;
-                cx[r] = src[0], cy[r] = src[1], cz[r] = src[2];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kCopyBatch; ++r) {
-            const uint32_t pt = lane + (batch + r) * 64;
-            if (gi[r] != kNoIndex)
-                L.pts[pt] = make_float4(static_cast<float>(cx[r] - ox), static_cast<float>(cy[r] - oy), static_cast<float>(cz[r] - oz),
-                                        __uint_as_float(gi[r]));
-        }
-    }
-    __syncthreads();
-    // ---- 4. fp32 scan -------------------------------------------------------------------------------------------
-    // fp32 error model: coordinates relative to the region origin are < 8 voxels, so each rounded coordinate is off
-    // by <= 2^-24 * 8 vs; a squared distance below (1.2 vs)^2 is then off by < 3e-6 vs^2.  kMargin covers twice that.
-    const float vs2 = static_cast<float>(vs * vs);
-    const float margin = 8e-6f * vs2;
-    const float bound32 = static_cast<float>(bound_d2) * 1.00001f + margin;
-    const float qx = static_cast<float>(q.x - ox), qy = static_cast<float>(q.y - oy), qz = static_cast<float>(q.z - oz);
-    // conservative (rounded-down) squared distances to the faces of the own voxel
-    float fm[3], fp[3];
-    {
-        const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
-        const float fvs = static_cast<float>(vs);
-        fm[0] = lx * lx, fm[1] = ly * ly, fm[2] = lz * lz;
-        fp[0] = (fvs - lx) * (fvs - lx), fp[1] = (fvs - ly) * (fvs - ly), fp[2] = (fvs - lz) * (fvs - lz);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) fm[a] = fm[a] * 0.99999f - margin, fp[a] = fp[a] * 0.99999f - margin;
-    }
-    const int cx0 = q.vx - bx, cy0 = q.vy - by, cz0 = q.vz - bz;
-    float b1 = bound32, b2 = bound32;
-    uint32_t i1 = kNoIndex;
-    bool overflow = false;
-    if (active) {
-#pragma unroll 1
-        for (int s = 0; s < 27; ++s) {
-            const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-            const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
-                              (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
-            if (box > b1 + margin) continue;  // nothing in there can come within the margin of the current minimum
-            const int slot = ((cz0 + dz) * iey + (cy0 + dy)) * iex + (cx0 + dx);
-            const uint32_t val = L.val[slot];
-            if (val == kEmptyVal) continue;
-            const uint32_t o = L.off[slot], cnt = val & 0xffu;
-            if (o == kNotStaged) {
-                overflow = true;  // bucket did not fit into LDS: this lane is resolved from HBM below
-                continue;
-            }
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4 c = L.pts[o + k];
-                const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
-                const float d = ddx * ddx + ddy * ddy + ddz * ddz;
-                const bool lt = d < b1;
-                b2 = lt ? b1 : fminf(b2, d);
-                i1 = lt ? __float_as_uint(c.w) : i1;
-                b1 = lt ? d : b1;
-            }
-        }
-    }
-    // ---- 5. exact resolution ---------------------------------------------------------------------------------------
-    best = bound_d2, best_idx = kNoIndex;
-    const bool found = active && !overflow && i1 != kNoIndex;
-    const bool ambiguous = found && (b2 - b1 <= margin);
-    if (found && !ambiguous) {
-        const double d2 = exact_d2(m, i1, q);
-        if (d2 < bound_d2) best = d2, best_idx = i1;
-    }
-    if (__any(ambiguous)) {
-        if (ambiguous) {  // repeat the scan; every candidate within the margin of the fp32 minimum is evaluated exactly, in order
-            const float lim = b1 + margin;
-#pragma unroll 1
-            for (int s = 0; s < 27; ++s) {
-                const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-                const float box = (dx > 0 ? fp[0] : (dx < 0 ? fm[0] : 0.f)) + (dy > 0 ? fp[1] : (dy < 0 ? fm[1] : 0.f)) +
-                                  (dz > 0 ? fp[2] : (dz < 0 ? fm[2] : 0.f));
-                if (box > lim) continue;
-                const int slot = ((cz0 + dz) * iey + (cy0 + dy)) * iex + (cx0 + dx);
-                const uint32_t val = L.val[slot];
-                if (val == kEmptyVal) continue;
-                const uint32_t o = L.off[slot], cnt = val & 0xffu;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4 c = L.pts[o + k];
-                    const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
-                    const float d = ddx * ddx + ddy * ddy + ddz * ddz;
-                    if (d <= lim) {
-                        const uint32_t gi = __float_as_uint(c.w);
-                        const double d2 = exact_d2(m, gi, q);
-                        if (d2 < best) best = d2, best_idx = gi;
-                    }
-                }
-            }
-        }
-    }
-    if (__any(active && overflow)) {
-        if (active && overflow) search_global(m, q, best, best_idx);  // exact fp64 search straight from HBM
-    }
-    return true;
-}
-
-// Match a group of up to 64 queries (one per lane), splitting it while its region does not fit; accepted
-// correspondences are accumulated.  Returns the number of splits (diagnostics).
-__device__ __forceinline__ uint32_t match_group(WaveLds &L, Acc &acc, const PassParams &p, const Pose &T, const GroupQuery &g) {
-    const int lane = threadIdx.x & 63;
-    const double bound = p.tau * p.tau * (1.0 + 9.1e-13);
-    uint32_t splits = 0;
-    // stackless binary subdivision of the lane range [lo, lo+len); wave-uniform control flow
-    int lo = 0, len = 64;
-    while (lo < 64) {
-        const bool active = g.valid && lane >= lo && lane < lo + len;
-        double best;
-        uint32_t best_idx;
-        if (!stage_and_match(L, p.map, g.q, active, bound, best, best_idx)) {
-            len >>= 1;  // len >= 2 here: a single query's region is 27 voxels and always fits
-            ++splits;
-            continue;
-        }
-        if (active && best_idx != kNoIndex && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
-            const double *t = p.map.pool + static_cast<size_t>(best_idx) * 3;
-            accumulate(acc, T, g.sx, g.sy, g.q.x, g.q.y, g.q.z, t[0], t[1], t[2]);
-        }
-        lo += len;
-        len = lo ? (lo & -lo) : 64;  // largest aligned block that starts at lo
-    }
-    return splits;
-}
-
-__device__ __forceinline__ void load_group_query(GroupQuery &g, const double *src, uint32_t i, bool valid, const Pose &T, double vs) {
-    double sx = 0, sy = 0, sz = 0;
-    if (valid) sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-    double rx, ry, rz;
-    quat_rotate(T, sx, sy, sz, rx, ry, rz);
-    make_query(g.q, rx + T.tx, ry + T.ty, rz + T.tz, vs);
-    g.sx = sx, g.sy = sy, g.valid = valid;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// variant 1: groups of 64 consecutive queries in the order given (persistent grid)
-// ------------------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(64, 3) void k_pass_lds(const PassParams p) {
-    KICP_PASS_SHARED(64)
-    __shared__ WaveLds L;
-    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
-    const Pose T = load_pose(p);
-    const uint32_t n_groups = (p.n + 63) / 64;
-    Acc acc{};
-    uint32_t splits = 0;
-    for (uint32_t w = blockIdx.x; w < n_groups; w += gridDim.x) {
-        const uint32_t i = w * 64 + threadIdx.x;
-        GroupQuery g;
-        load_group_query(g, p.src, i, i < p.n, T, p.map.voxel_size);
-        if (p.dbg == 0) splits += match_group(L, acc, p, T, g);
-    }
-    if (splits && threadIdx.x == 0) atomicAdd(&p.st->not_staged, splits);
-    finish_pass<64>(acc, p, s_red, &s_flag);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// variant 2: one wave per work item (<= 64 queries of one 2x2x2-voxel cell), persistent over the item list
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kCellShift = 1;  // cell = 2x2x2 voxels
-constexpr int kRunLen = 64;    // queries per work item
-
-static __global__ __launch_bounds__(64, 3) void k_pass_binned(const PassParams p) {
-    KICP_PASS_SHARED(64)
-    __shared__ WaveLds L;
-    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
-    const Pose T = load_pose(p);
-    const uint32_t n_items = p.bin.counters[1];
-    Acc acc{};
-    uint32_t splits = 0;
-    for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
-        const uint2 item = p.bin.items[w];
-        GroupQuery g;
-        load_group_query(g, p.bin.sorted_src, item.x + threadIdx.x, threadIdx.x < item.y, T, p.map.voxel_size);
-        if (p.dbg == 0) splits += match_group(L, acc, p, T, g);
-    }
-    if (splits && threadIdx.x == 0) atomicAdd(&p.st->not_staged, splits);
-    finish_pass<64>(acc, p, s_red, &s_flag);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// binning: counting sort of the scan by cell at the predicted pose (count -> scan -> scatter)
-// ------------------------------------------------------------------------------------------------------------
-constexpr unsigned long long kEmptyCell = ~0ull;
-
-struct BinParams {
-    const double *src;
-    uint32_t n;
-    Pose pose0;
-    double voxel_size;
-    unsigned long long *cell_keys;  // [mask+1], kEmptyCell when free
-    uint32_t *cell_count;           // [mask+1]
-    uint32_t *cell_start;           // [mask+1]
-    uint32_t *cell_list;            // occupied slots in arrival order
-    uint32_t mask;
-    uint32_t *counters;             // [0] n_cells, [1] n_items
-    uint2 *qinfo;                   // (slot, rank) per query
-    double *sorted_src;
-    uint2 *items;
-};
-
-__device__ __forceinline__ unsigned long long pack_cell(int32_t vx, int32_t vy, int32_t vz) {
-    const unsigned long long cx = static_cast<unsigned long long>((vx >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
-    const unsigned long long cy = static_cast<unsigned long long>((vy >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
-    const unsigned long long cz = static_cast<unsigned long long>((vz >> kCellShift) + (1 << 20)) & 0x1FFFFFull;
-    return (cz << 42) | (cy << 21) | cx;
-}
-__device__ __forceinline__ uint32_t hash_cell(unsigned long long k) {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return static_cast<uint32_t>(k);
-}
-
-static __global__ __launch_bounds__(256) void k_bin_count(const BinParams b) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = i < b.n;
-    unsigned long long key = kEmptyCell;
-    if (valid) {
-        const double sx = b.src[3 * i], sy = b.src[3 * i + 1], sz = b.src[3 * i + 2];
-        double rx, ry, rz;
-        quat_rotate(b.pose0, sx, sy, sz, rx, ry, rz);
-        const double vs = b.voxel_size;
-        key = pack_cell(static_cast<int32_t>(floor((rx + b.pose0.tx) / vs)), static_cast<int32_t>(floor((ry + b.pose0.ty) / vs)),
-                        static_cast<int32_t>(floor((rz + b.pose0.tz) / vs)));
-    }
-    // runs of equal keys among consecutive lanes share one table insertion and one counter update
-    const unsigned long long prev = __shfl_up(key, 1, 64);
-    const bool head = (lane == 0) || (prev != key);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes <= mine
-    const int leader = 63 - __clzll(below);
-    const unsigned long long above = heads & ~((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes > mine
-    const int run_end = above ? (__ffsll(static_cast<long long>(above)) - 1) : 64;
-    __shared__ uint32_t s_new, s_base;
-    if (threadIdx.x == 0) s_new = 0;
-    __syncthreads();
-    uint32_t slot = 0, base = 0, my_new = 0xFFFFFFFFu;
-    if (head && valid) {
-        const uint32_t run = static_cast<uint32_t>(run_end - lane);
-        slot = hash_cell(key) & b.mask;
-        for (;;) {
-            const unsigned long long seen = atomicCAS(b.cell_keys + slot, kEmptyCell, key);
-            if (seen == kEmptyCell) {  // claimed a fresh cell: its list position is assigned per workgroup below
-                my_new = atomicAdd(&s_new, 1u);
-                break;
-            }
-            if (seen == key) break;
-            slot = (slot + 1) & b.mask;
-        }
-        base = atomicAdd(b.cell_count + slot, run);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_new) s_base = atomicAdd(b.counters, s_new);  // one same-address atomic per workgroup
-    __syncthreads();
-    if (my_new != 0xFFFFFFFFu) b.cell_list[s_base + my_new] = slot;
-    slot = __shfl(slot, leader, 64), base = __shfl(base, leader, 64);
-    if (valid) b.qinfo[i] = make_uint2(slot, base + static_cast<uint32_t>(lane - leader));
-}
-
-// single workgroup: exclusive scans over the occupied cells -> first query / first work item per cell; emits the
-// item list; leaves the cell table clean for the next scan
-static __global__ __launch_bounds__(1024) void k_bin_scan(const BinParams b) {
-    __shared__ uint32_t s_wave[16][2];
-    __shared__ uint32_t s_carry[2];
-    const uint32_t n_cells = b.counters[0];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry[0] = s_carry[1] = 0;
-    __syncthreads();
-    for (uint32_t j0 = 0; j0 < n_cells; j0 += 1024) {
-        const uint32_t j = j0 + threadIdx.x;
-        uint32_t slot = 0, c = 0;
-        if (j < n_cells) {
-            slot = b.cell_list[j];
-            c = b.cell_count[slot];
-            b.cell_count[slot] = 0, b.cell_keys[slot] = kEmptyCell;  // self-cleaning table
-        }
-        const uint32_t it = (c + kRunLen - 1) / kRunLen;
-        uint32_t pc = c, pi = it;  // inclusive wave scans
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t tc = __shfl_up(pc, off, 64), ti = __shfl_up(pi, off, 64);
-            if (lane >= off) pc += tc, pi += ti;
-        }
-        if (lane == 63) s_wave[wave][0] = pc, s_wave[wave][1] = pi;
-        __syncthreads();
-        uint32_t wc = 0, wi = 0;
-        for (int w = 0; w < wave; ++w) wc += s_wave[w][0], wi += s_wave[w][1];
-        const uint32_t start = s_carry[0] + wc + pc - c, first_item = s_carry[1] + wi + pi - it;
-        if (j < n_cells) {
-            b.cell_start[slot] = start;
-            for (uint32_t t = 0; t < it; ++t)
-                b.items[first_item + t] = make_uint2(start + t * kRunLen, min(static_cast<uint32_t>(kRunLen), c - t * kRunLen));
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry[0] += wc + pc, s_carry[1] += wi + pi;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) b.counters[1] = s_carry[1], b.counters[2] = n_cells, b.counters[0] = 0;
-}
-
-static __global__ __launch_bounds__(256) void k_bin_scatter(const BinParams b) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= b.n) return;
-    const uint2 qi = b.qinfo[i];
-    const uint32_t dst = b.cell_start[qi.x] + qi.y;
-    b.sorted_src[3 * dst] = b.src[3 * i], b.sorted_src[3 * dst + 1] = b.src[3 * i + 1], b.sorted_src[3 * dst + 2] = b.src[3 * i + 2];
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -304,23 +304,25 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
                       map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
         up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
         up.touched = mr.d_touched;
-        HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched + error
+        HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
         hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
+        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
         HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries
+        if (c.error == 3) return fail(KICP_ERR_CAPACITY, "device-side map update: voxel table full");
         if (c.error) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
-        // every newly occupied voxel may add up to 26 halo entries: only continue with head-room
-        const size_t new_entries = c.n_entries - map->dev.n_entries;
+        // Every touched voxel that holds no point yet - a fresh entry or a halo entry that existed before - may become
+        // occupied in k_up_apply and then adds up to 26 halo entries of its own: only continue with that head-room
+        // (load factor <= 0.75 in the worst case, so that no probe sequence can run away).
         map->dev = c;
-        if ((c.n_entries + 26 * new_entries) * 4 <= slots * 3) break;
+        if ((c.n_entries + 26ull * c.may_occupy) * 4 <= slots * 3) break;
         if (attempt) return fail(KICP_ERR_CAPACITY, "device-side map update found no room after a re-hash");
         // Too tight.  The entries just claimed are still plain halo entries without an occupied neighbour, so a re-hash drops
         // them together with the per-slot counters of this attempt; then claim again in the larger table.
         if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
     }
     const size_t slots = mr.live_slots;
-    hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
     hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
     hipLaunchKernelGGL(k_up_apply, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
     hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((slots + 255) / 256, 8192))), dim3(256), 0, st, up.m, pose.tx,
@@ -328,7 +330,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
+    if (c.error) return fail(KICP_ERR_CAPACITY, c.error == 3 ? "device-side map update: voxel table full" : "device-side map update ran out of room");
     map->dev = c;
     map->last_update_on_device = 1;
     return KICP_OK;

@@ -52,12 +52,20 @@ __device__ __forceinline__ unsigned long long pack_key64(int32_t x, int32_t y, i
 }
 
 // slot of voxel (x,y,z); creates a halo entry when absent.  Same probe sequence as the host map (voxel_hash, linear).
+// The host keeps the table below a load factor of 0.75 (head-room check in map_update_device), so a probe sequence is
+// short; should the table ever be full all the same, the walk stops after one lap, raises ctr->error = 3 and returns
+// kNoSlot (callers skip their writes; the host reports KICP_ERR_CAPACITY) instead of spinning for ever.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t dev_find_or_insert(const DevMap &m, int32_t x, int32_t y, int32_t z) {
     bool ok;
     const unsigned long long key = pack_key64(x, y, z, ok);
     if (!ok) m.ctr->error = 1u;
     uint32_t h = voxel_hash(x, y, z) & m.mask;
-    for (;;) {
+    for (uint32_t probes = 0;; ++probes) {
+        if (probes > m.mask) {
+            m.ctr->error = 3u;
+            return kNoSlot;
+        }
         const unsigned long long seen = atomicCAS(m.keys64 + h, kEmptyKey64, key);
         if (seen == kEmptyKey64) {  // this thread owns the new entry: key fields and the halo marker (nbr is already 0)
             m.table[h].x = x, m.table[h].y = y, m.table[h].z = z;
@@ -74,12 +82,13 @@ __device__ __forceinline__ uint32_t dev_find(const DevMap &m, int32_t x, int32_t
     bool ok;
     const unsigned long long key = pack_key64(x, y, z, ok);
     uint32_t h = voxel_hash(x, y, z) & m.mask;
-    for (;;) {
+    for (uint32_t probes = 0; probes <= m.mask; ++probes) {
         const unsigned long long seen = m.keys64[h];
-        if (seen == kEmptyKey64) return 0xFFFFFFFFu;
+        if (seen == kEmptyKey64) return kNoSlot;
         if (seen == key) return h;
         h = (h + 1) & m.mask;
     }
+    return kNoSlot;
 }
 
 // keys64 from the table (after every host -> device upload)
@@ -102,21 +111,25 @@ static __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
     const uint32_t h = dev_find_or_insert(p.m, static_cast<int32_t>(floor(wx / vs)), static_cast<int32_t>(floor(wy / vs)),
                                           static_cast<int32_t>(floor(wz / vs)));
     p.slot_of[i] = h;
+    if (h == kNoSlot) return;  // table full (error raised): the host aborts the update
     if (atomicAdd(p.m.cnt + h, 1u) == 0u) p.touched[atomicAdd(&p.m.ctr->touched, 1u)] = h;
 }
 
-// 2. exclusive scan of the touched voxels' counts -> group starts; counts are zeroed to serve as fill cursors
+// 2. exclusive scan of the touched voxels' counts -> group starts; counts are zeroed to serve as fill cursors.  Also counts
+//    the touched voxels that hold no point yet (fresh entries and halo entries alike): each of them may become occupied
+//    in step 4 and then insert up to 26 halo entries of its own - the head-room the host checks before going on.
 static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t n_touched = p.m.ctr->touched;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
+    uint32_t may_become_occupied = 0;
     __syncthreads();
     for (uint32_t j0 = 0; j0 < n_touched; j0 += 1024) {
         const uint32_t j = j0 + threadIdx.x;
         uint32_t h = 0, c = 0;
-        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h];
+        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h], may_become_occupied += (p.m.table[h].val & 0xffu) == 0u ? 1u : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -132,6 +145,9 @@ static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
         if (threadIdx.x == 1023) s_carry = before + incl;
         __syncthreads();
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) may_become_occupied += __shfl_down(may_become_occupied, off, 64);
+    if (lane == 0 && may_become_occupied) atomicAdd(&p.m.ctr->may_occupy, may_become_occupied);
 }
 
 // 3. scatter the point indices into their voxel's group (any order; the apply step walks a group by ascending index)
@@ -139,6 +155,7 @@ static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const uint32_t h = p.slot_of[i];
+    if (h == kNoSlot) return;
     p.order[p.m.seg_start[h] + atomicAdd(p.m.cnt + h, 1u)] = i;
 }
 
@@ -202,6 +219,7 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
         atomicAdd(&m.ctr->n_voxels, 1u);
         for (int s = 0; s < 27; ++s) {
             const uint32_t u = dev_find_or_insert(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
+            if (u == kNoSlot) continue;  // table full (error raised)
             m.table[u].nb[s] = bucket;
             atomicOr(&m.table[u].nbr, 1u << s);
         }
@@ -226,7 +244,7 @@ static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double
         atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val & 0xffu) + 1ull);
         for (int s = 0; s < 27; ++s) {
             const uint32_t u = dev_find(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
-            if (u != 0xFFFFFFFFu) atomicAnd(&m.table[u].nbr, ~(1u << s));
+            if (u != kNoSlot) atomicAnd(&m.table[u].nbr, ~(1u << s));
         }
     }
 }

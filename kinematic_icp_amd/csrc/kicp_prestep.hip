@@ -62,7 +62,10 @@ int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *ou
     uint32_t misc[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (misc[1]) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
+    if (misc[1]) {  // report once: the flag must not poison the calls that follow on this handle
+        HIP_TRY(hipMemsetAsync(p->d_misc + 1, 0, 4, p->stream));
+        return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
+    }
     p->buf_n[dst] = misc[0];
     if (out_n) *out_n = misc[0];
     return KICP_OK;

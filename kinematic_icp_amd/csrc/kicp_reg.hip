@@ -64,15 +64,6 @@ CommApi g_comm;
 
 }  // namespace
 
-struct BinBuffers {
-    unsigned long long *cell_keys = nullptr;
-    uint32_t *cell_count = nullptr, *cell_start = nullptr, *cell_list = nullptr, *counters = nullptr;
-    uint2 *qinfo = nullptr, *items = nullptr;
-    double *sorted_src = nullptr;
-    uint32_t mask = 0;
-    size_t cap_n = 0;
-};
-
 struct kicp_reg {
     kicp_reg_config cfg{};
     int device = 0;
@@ -95,13 +86,11 @@ struct kicp_reg {
     double *d_frame = nullptr;  // device copy of host frames
     size_t frame_cap = 0;
     HostStage stage;            // pinned staging for transfers from / to caller memory
-    BinBuffers bin;
     // options
-    int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather, 1 lds (given order), 2 binned by cell
+    int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather
     int block = 128;      // workgroup size of variants 0/3
     int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
     int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
-    int waves_per_cu = 12; // persistent grid of variants 1/2
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
     int dbg = 0;
     int query_every = 64;  // polls between hipStreamQuery calls while waiting
@@ -119,6 +108,7 @@ struct kicp_reg {
         long long words[kReduceWords];
         unsigned long long pad[7];  // 256 bytes
     };
+    void *shm_base = nullptr;  // start of the mapping (header slot first)
     ShmSlot *shm = nullptr;    // host view: [2 buffers][nranks]
     ShmSlot *d_shm = nullptr;  // device view of the same memory
     size_t shm_bytes = 0;
@@ -141,25 +131,12 @@ int lanes_for(const kicp_reg *r, size_t n) {
     return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
 }
 uint32_t pass_grid(const kicp_reg *r, size_t n) {
-    if (r->pass_kernel == 1 || r->pass_kernel == 2) {  // persistent one-wave workgroups
-        const size_t max_groups = (n + 63) / 64 + (r->pass_kernel == 2 ? n / 8 : 0);  // more workgroups than groups would only idle
-        const size_t want = static_cast<size_t>(r->num_cus) * r->waves_per_cu;
-        return static_cast<uint32_t>(std::max<size_t>(1, std::min(want, max_groups)));
-    }
     const int block = normalized_block(r->block);
     const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
     return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
 }
 void launch_pass(const kicp_reg *r, const PassParams &p) {
     const uint32_t grid = pass_grid(r, p.n);
-    if (r->pass_kernel == 2) {
-        hipLaunchKernelGGL(k_pass_binned, dim3(grid), dim3(64), 0, r->stream, p);
-        return;
-    }
-    if (r->pass_kernel == 1) {
-        hipLaunchKernelGGL(k_pass_lds, dim3(grid), dim3(64), 0, r->stream, p);
-        return;
-    }
     if (r->pass_kernel == 3) {
         const int b = normalized_block(r->block), g = lanes_for(r, p.n);
 #define KICP_G32(B, G) hipLaunchKernelGGL((k_pass_gather32<B, G>), dim3(grid), dim3(B), 0, r->stream, p)
@@ -226,45 +203,6 @@ int ensure_frame(kicp_reg *r, size_t n) {
     r->frame_cap = want;
     return KICP_OK;
 }
-void free_bin(BinBuffers &b) {
-    hipFree(b.cell_keys), hipFree(b.cell_count), hipFree(b.cell_start), hipFree(b.cell_list), hipFree(b.counters);
-    hipFree(b.qinfo), hipFree(b.items), hipFree(b.sorted_src);
-    b = BinBuffers{};
-}
-int ensure_bin(kicp_reg *r, size_t n) {
-    BinBuffers &b = r->bin;
-    if (n <= b.cap_n) return KICP_OK;
-    free_bin(b);
-    const size_t cap = n + n / 4 + 1024;
-    size_t slots = 1024;
-    while (slots < 2 * cap) slots <<= 1;  // load factor <= 0.5 even if every query had its own cell
-    HIP_TRY(hipMalloc(&b.cell_keys, slots * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&b.cell_count, slots * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&b.cell_start, slots * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&b.cell_list, cap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&b.counters, 16 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&b.qinfo, cap * sizeof(uint2)));
-    HIP_TRY(hipMalloc(&b.items, (cap / kRunLen + cap + 2) * sizeof(uint2)));
-    HIP_TRY(hipMalloc(&b.sorted_src, cap * 3 * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(b.cell_keys, 0xFF, slots * sizeof(unsigned long long), r->stream));
-    HIP_TRY(hipMemsetAsync(b.cell_count, 0, slots * sizeof(uint32_t), r->stream));
-    HIP_TRY(hipMemsetAsync(b.counters, 0, 16 * sizeof(uint32_t), r->stream));
-    b.mask = static_cast<uint32_t>(slots - 1), b.cap_n = cap;
-    return KICP_OK;
-}
-// counting sort of the scan by cell at the predicted pose: three launches, once per scan
-void launch_binning(kicp_reg *r, const double *d_frame, size_t n, const Pose &T0, double voxel_size) {
-    BinBuffers &b = r->bin;
-    BinParams bp{};
-    bp.src = d_frame, bp.n = static_cast<uint32_t>(n), bp.pose0 = T0, bp.voxel_size = voxel_size;
-    bp.cell_keys = b.cell_keys, bp.cell_count = b.cell_count, bp.cell_start = b.cell_start, bp.cell_list = b.cell_list;
-    bp.mask = b.mask, bp.counters = b.counters, bp.qinfo = b.qinfo, bp.sorted_src = b.sorted_src, bp.items = b.items;
-    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
-    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(256), 0, r->stream, bp);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, r->stream, bp);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid), dim3(256), 0, r->stream, bp);
-}
-
 // enqueue the collective between the limb reduction and the solve (multi-GPU only)
 int enqueue_allreduce(kicp_reg *r) {
     long long *buf = r->d_state->reduce;
@@ -277,6 +215,21 @@ int enqueue_allreduce(kicp_reg *r) {
     if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclAllReduce: ") + g_comm.GetErrorString(rc));
     return KICP_OK;
 }
+
+// Every spin-wait below is bounded by wall-clock time (default 20 s, KICP_WAIT_TIMEOUT_S): a wedged kernel or a dead peer
+// rank turns into KICP_ERR_HIP / KICP_ERR_COMM instead of a hung caller.
+double wait_timeout_s() {
+    static const double t = [] {
+        const char *e = std::getenv("KICP_WAIT_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 20.0;
+    }();
+    return t;
+}
+struct Deadline {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool passed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_s(); }
+};
 
 // wait until the record carries `call_id` with at least `min_iter` completed iterations (or its done bit);
 // returns the observed seq.  Polls host-mapped memory; falls back to a stream sync when asked to or on a fault.
@@ -296,6 +249,7 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
     // it still holds back (some HIP runtimes batch the tail of the queue) and reports device faults.
     const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
     unsigned drained = 0;
+    const Deadline deadline;
     for (unsigned long long spins = 1;; ++spins) {
         const unsigned long long s = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
         if (ready(s)) {
@@ -307,6 +261,7 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
             if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
             if (q == hipSuccess && ++drained > 4 && !ready(__atomic_load_n(seq, __ATOMIC_ACQUIRE)))
                 return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+            if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the registration kernels (KICP_WAIT_TIMEOUT_S)");
         }
     }
 }
@@ -317,6 +272,7 @@ int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kRed
     const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
     unsigned drained = 0;
     unsigned long long spins = 0;
+    const Deadline deadline;
     for (size_t g = 0; g < groups; ++g) {
         const unsigned long long *row = r->rows + g * kReduceWords;
         long long v[kReduceWords];
@@ -333,6 +289,7 @@ int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kRed
                 const hipError_t q = r->wait_mode == 1 ? hipStreamSynchronize(r->stream) : hipStreamQuery(r->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
                 if (q == hipSuccess && ++drained > 4) return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+                if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
             }
         }
         for (int i = 0; i < kReduceWords; ++i) out_words[i] += v[i];
@@ -345,13 +302,14 @@ int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kRed
 int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceWords]) {
     const kicp_reg::ShmSlot *buf = r->shm + ((value - 1) & 1) * r->nranks;
     for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    const Deadline deadline;
     for (int k = 0; k < r->nranks; ++k) {
         const volatile unsigned long long *seq = &buf[k].seq;
         for (unsigned long long spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != value; ++spins) {
             if (spins % 4096 == 0) {
                 const hipError_t q = hipStreamQuery(r->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
-                if (spins > (1ull << 34)) return fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off");
+                if (deadline.passed()) return fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off (KICP_WAIT_TIMEOUT_S)");
             }
         }
         for (int i = 0; i < kReduceWords; ++i) out_words[i] += buf[k].words[i];
@@ -379,9 +337,6 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
     if (int rc = set_device(r->device)) return rc;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
-    const bool binned = r->pass_kernel == 2;
-    if (binned)
-        if (int rc = ensure_bin(r, n ? n : 1)) return rc;
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
@@ -390,7 +345,6 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
 
     PassParams pp{};
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
-    pp.bin = BinView{r->bin.sorted_src, r->bin.items, r->bin.counters};
     pp.partials = r->d_partials, pp.tickets = r->d_tickets;
     pp.dbg = r->dbg;
     SolveParams &sp = pp.sol;
@@ -399,7 +353,6 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     sp.mode = multi ? 1 : 0, sp.call_id = call_id, sp.rec = r->d_rec;
 
     if (r->timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
-    if (binned) launch_binning(r, d_frame, n, T0, map->host.voxel_size());
     const bool pass_events = r->timing == 2;
     if (pass_events && !r->evp[0])
         for (auto &e : r->evp) HIP_TRY(hipEventCreate(&e));
@@ -591,7 +544,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
         kicp_reg_destroy(r);
         return fail(KICP_ERR_HIP, std::string("kicp_reg_create: ") + hipGetErrorString(e));
     }
-    if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env);
+    if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env) == 0 ? 0 : 3;
     if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
     if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
@@ -611,7 +564,6 @@ void kicp_reg_destroy(kicp_reg *reg) {
     reg->stage.release();
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
-    free_bin(reg->bin);
     if (reg->d_frame) hipFree(reg->d_frame);
     if (reg->ev0) hipEventDestroy(reg->ev0);
     if (reg->ev1) hipEventDestroy(reg->ev1);
@@ -633,7 +585,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config) {
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     if (!reg || !name) return fail(KICP_ERR_ARG, "null argument");
     const std::string k(name);
-    if (k == "pass_kernel") reg->pass_kernel = static_cast<int>(value);
+    if (k == "pass_kernel") {
+        if (value != 0.0 && value != 3.0) return fail(KICP_ERR_ARG, "pass_kernel must be 3 (default) or 0");
+        reg->pass_kernel = static_cast<int>(value);
+    }
     else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
     else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
@@ -641,7 +596,6 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
-    else if (k == "waves_per_cu") reg->waves_per_cu = std::max(1, static_cast<int>(value));
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
@@ -659,9 +613,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "group_rows") return reg->group_rows;
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
-    if (k == "waves_per_cu") return reg->waves_per_cu;
     if (k == "timing") return reg->timing;
-    if (k == "last_not_staged") return reg->rec ? reg->rec->not_staged : -1.0;
     return -1.0;
 }
 
@@ -706,18 +658,14 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     if (int rc = set_device(reg->device)) return rc;
     if (int rc = map_sync(map, reg->device, reg->stream)) return rc;
     if (int rc = ensure_frame(reg, n)) return rc;
-    const bool binned = reg->pass_kernel == 2;
-    if (binned)
-        if (int rc = ensure_bin(reg, n)) return rc;
     if (int rc = ensure_partials(reg, pass_grid(reg, n))) return rc;
     if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
     const unsigned long long call_id = ++reg->call_id;
     PassParams pp{};
     pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
     pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
-    pp.st = reg->d_state, pp.bin = BinView{reg->bin.sorted_src, reg->bin.items, reg->bin.counters};
+    pp.st = reg->d_state;
     pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
-    if (binned) launch_binning(reg, reg->d_frame, n, pp.sol.pose0, map->host.voxel_size());
     launch_pass(reg, pp);
     hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);
     HIP_TRY(hipGetLastError());
@@ -768,15 +716,18 @@ int kicp_reg_comm_destroy(kicp_reg *reg) {
     reg->nranks = 1, reg->rank = 0;
     return KICP_OK;
 }
+// Shared segment layout: one header slot (magic word written LAST by rank 0, then the rank count) followed by the
+// [2 buffers][nranks] hand-off slots.
+constexpr unsigned long long kShmMagic = 0x4B49435053484D31ull;  // "KICPSHM1"
 int kicp_reg_shm_destroy(kicp_reg *reg) {
     if (!reg) return fail(KICP_ERR_ARG, "null argument");
     if (reg->shm) {
         hipSetDevice(reg->device);
         hipStreamSynchronize(reg->stream);
-        if (reg->d_shm) (void)hipHostUnregister(reg->shm);
-        munmap(reg->shm, reg->shm_bytes);
+        if (reg->d_shm) (void)hipHostUnregister(reg->shm_base);
+        munmap(reg->shm_base, reg->shm_bytes);
         if (reg->rank == 0) shm_unlink(reg->shm_name.c_str());
-        reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_bytes = 0;
+        reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_base = nullptr, reg->shm_bytes = 0;
     }
     reg->nranks = 1, reg->rank = 0;
     return KICP_OK;
@@ -786,18 +737,57 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     if (reg->comm) return fail(KICP_ERR_ARG, "an RCCL communicator is already attached");
     kicp_reg_shm_destroy(reg);
     if (int rc = set_device(reg->device)) return rc;
-    const size_t bytes = 2 * static_cast<size_t>(nranks) * sizeof(kicp_reg::ShmSlot);
+    const size_t bytes = (1 + 2 * static_cast<size_t>(nranks)) * sizeof(kicp_reg::ShmSlot);
     const std::string nm = std::string(name[0] == '/' ? "" : "/") + name;
-    const int fd = shm_open(nm.c_str(), rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
-    if (fd < 0) return fail(KICP_ERR_COMM, "shm_open(" + nm + ") failed (rank 0 must create it first)");
-    if (rank == 0 && ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+    void *ptr = MAP_FAILED;
+    if (rank == 0) {
+        // a segment of this name left behind by a crashed run must not be adopted: remove it, then create exclusively
+        shm_unlink(nm.c_str());
+        const int fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(KICP_ERR_COMM, "shm_open(" + nm + ", O_CREAT | O_EXCL) failed");
+        if (ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+            close(fd);
+            shm_unlink(nm.c_str());
+            return fail(KICP_ERR_COMM, "ftruncate on the shared segment failed");
+        }
+        ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
-        return fail(KICP_ERR_COMM, "ftruncate on the shared segment failed");
+        if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
+        std::memset(ptr, 0, bytes);
+        auto *hdr = static_cast<kicp_reg::ShmSlot *>(ptr);
+        hdr->words[0] = nranks;
+        __atomic_store_n(&hdr->seq, kShmMagic, __ATOMIC_RELEASE);  // published last: the other ranks wait for it
+    } else {
+        // wait (bounded) until rank 0 has created, sized, zeroed and published the segment
+        const Deadline deadline;
+        for (;;) {
+            const int fd = shm_open(nm.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st {};
+                if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) == bytes) {
+                    ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                    close(fd);
+                    if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
+                    auto *hdr = static_cast<kicp_reg::ShmSlot *>(ptr);
+                    while (__atomic_load_n(&hdr->seq, __ATOMIC_ACQUIRE) != kShmMagic) {
+                        if (deadline.passed()) {
+                            munmap(ptr, bytes);
+                            return fail(KICP_ERR_COMM, "timed out waiting for rank 0 to publish the shared segment");
+                        }
+                        usleep(50);
+                    }
+                    if (hdr->words[0] != nranks) {
+                        munmap(ptr, bytes);
+                        return fail(KICP_ERR_COMM, "the shared segment was created for a different number of ranks");
+                    }
+                    break;
+                }
+                close(fd);
+            }
+            if (deadline.passed()) return fail(KICP_ERR_COMM, "timed out waiting for rank 0 to create shared segment " + nm);
+            usleep(200);
+        }
     }
-    void *ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
-    if (rank == 0) std::memset(ptr, 0, bytes);
     // The device view is only needed when the GPU itself writes the slot ("group_rows" = 0); by default the rank's host adds
     // its GPU's tagged rows and stores the totals, so a failed registration is not fatal.
     hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
@@ -807,7 +797,9 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
         (void)hipGetLastError();
         dptr = nullptr;
     }
-    reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr), reg->d_shm = static_cast<kicp_reg::ShmSlot *>(dptr);
+    reg->shm_base = ptr;
+    reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr) + 1;
+    reg->d_shm = dptr ? static_cast<kicp_reg::ShmSlot *>(dptr) + 1 : nullptr;
     reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
     return KICP_OK;
 }
