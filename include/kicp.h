@@ -115,8 +115,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
 /* Backend tuning knobs (not part of the reference API):
  *   "pass_kernel"  3 (default) thread-per-query gather over the fp32 mirror with exact fp64 resolution; 0 plain fp64
  *                  gather (baseline of the ablation)
- *   "block"        workgroup size (64|128|256)
+ *   "block"        workgroup size (64|128|256; default 256)
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
+ *   "xcds"         variant 3: 8 (default) workgroup b serves the (b % 8)-th contiguous eighth of the scan, so that each XCD's
+ *                  L2 only holds one part of the scan's neighbourhood; 1 = workgroup b serves block b
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the

@@ -12,7 +12,7 @@ namespace kicp {
 //   val : (bucket_index << 8) | point_count ; kEmptyVal marks a free slot; kHaloVal an entry without points.
 //   nbr : bit s set <=> voxel key + shift[s] holds points (s in the reference's visiting order, bit 0 = this voxel).
 //   nb  : bucket index of voxel key + shift[s] for every set bit of nbr (that bucket's point count sits in the
-//         bucket itself, see MapView::pool32).
+//         bucket itself, see MapView::pool16).
 // Besides the occupied voxels the table holds "halo" entries for every empty voxel that has an occupied neighbour,
 // so ONE probe at a query's own voxel yields the buckets of all 27 neighbours: empty space is never probed, and
 // neighbour voxels need no probe of their own.
@@ -42,16 +42,38 @@ KICP_HD uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
     return h;
 }
 
+// One point of the compact mirror the pre-selection pass reads: the offset from the voxel corner, per axis, in units of
+// voxel_size / 65536 (so the quantisation error is <= 1 unit = 1.5e-5 voxel sizes wherever the map is), 8 bytes:
+//   x = qx | qy << 16,  y = qz | aux << 16;  aux of point 0 = the bucket's point count, 0 elsewhere.
+// It only PRE-SELECTS: the winner, and anything within the error margin of it, is re-evaluated from the fp64 pool.
+using MirrorPoint = uint2;
+KICP_HD uint32_t mirror_quant(double offset, double units_per_metre) {  // round to nearest unit, clamped into 16 bits
+    const double q = floor(offset * units_per_metre + 0.5);
+    return q <= 0.0 ? 0u : (q >= 65535.0 ? 65535u : static_cast<uint32_t>(q));
+}
+KICP_HD MirrorPoint mirror_point(double ox, double oy, double oz, double units_per_metre, uint32_t aux) {
+    MirrorPoint m;
+    m.x = mirror_quant(ox, units_per_metre) | (mirror_quant(oy, units_per_metre) << 16);
+    m.y = mirror_quant(oz, units_per_metre) | (aux << 16);
+    return m;
+}
+KICP_HD double mirror_units_per_metre(double voxel_size) { return 65536.0 / voxel_size; }
+
 // Device view of a voxel map mirror (all pointers in HBM).
 struct MapView {
     const Slot *table;    // capacity = mask + 1 (power of two), linear probing, no tombstones
     uint32_t mask;
     const double *pool;   // bucket b holds <= cap points at pool + b * cap * 3 (AoS xyz, insertion order)
-    const float4 *pool32; // fp32 mirror: point k of bucket b at pool32[b * cap + k] = offset from the voxel corner in
-                          // xyz; the w of point 0 carries the bucket's point count (integer bits)
-    uint32_t cap;         // max_points_per_voxel
+    const MirrorPoint *pool16; // 16-bit mirror: point k of bucket b at pool16[b * cap + k] (see MirrorPoint); the aux field of
+                               // point 0 carries the bucket's point count
+    uint32_t cap;         // max_points_per_voxel = bucket stride of `pool` in points
+    uint32_t cap16;       // bucket stride of `pool16` in points: cap rounded up to a multiple of kMirrorTrip (mirror_stride)
     double voxel_size;
 };
+// The pass kernel reads a mirror bucket kMirrorTrip points (= kMirrorTrip / 2 16-byte loads at immediate offsets) at a time
+// without ever looking at the count first; the stride is padded so that such a trip never leaves the bucket.
+constexpr uint32_t kMirrorTrip = 20;
+KICP_HD uint32_t mirror_stride(uint32_t cap) { return (cap + kMirrorTrip - 1u) / kMirrorTrip * kMirrorTrip; }
 
 // The reference's neighbour visiting order (kiss-icp v1.2.0 core/VoxelHashMap.cpp `voxel_shifts`; App. A.3),
 // packed 2 bits per axis (value+1) so it lives in three 64-bit immediates instead of a constant-memory table.

@@ -23,20 +23,21 @@ namespace kicp {
 class HostMap {
 public:
     HostMap(double voxel_size, double max_distance, uint32_t max_points_per_voxel)
-        : voxel_size_(voxel_size), max_distance_(max_distance), cap_(max_points_per_voxel) {
+        : voxel_size_(voxel_size), max_distance_(max_distance), cap_(max_points_per_voxel), cap16_(mirror_stride(max_points_per_voxel)) {
         Clear();
     }
 
     double voxel_size() const { return voxel_size_; }
     double max_distance() const { return max_distance_; }
     uint32_t cap() const { return cap_; }
+    uint32_t cap16() const { return cap16_; }  // bucket stride of the 16-bit mirror (kicp_common.hpp::mirror_stride)
     size_t num_voxels() const { return n_voxels_; }
     size_t num_points() const { return n_points_; }
     uint64_t epoch() const { return epoch_; }
     bool Empty() const { return n_voxels_ == 0; }
     const std::vector<Slot> &table() const { return table_; }
     const std::vector<double> &pool() const { return pool_; }
-    const std::vector<float> &pool32() const { return pool32_; }  // (x,y,z,0) offsets from the voxel corner, stride cap*4
+    const std::vector<MirrorPoint> &pool16() const { return pool16_; }  // 16-bit offsets from the voxel corner, stride cap
     size_t buckets_in_use_hi() const { return n_buckets_hi_; }  // pool prefix that may hold live buckets
 
     // ---- hand-over with the device-side maintenance (kicp_mapdev.hpp) ---------------------------------------------------
@@ -49,9 +50,9 @@ public:
         if (want != table_.size()) rebuild(want), ++epoch_;
     }
     // take over the state the device produced (same layouts): table, pools, free list; counters are recounted
-    void Adopt(std::vector<Slot> &&table, std::vector<double> &&pool, std::vector<float> &&pool32, size_t n_buckets_hi,
+    void Adopt(std::vector<Slot> &&table, std::vector<double> &&pool, std::vector<MirrorPoint> &&pool16, size_t n_buckets_hi,
                std::vector<uint32_t> &&free_list) {
-        table_ = std::move(table), pool_ = std::move(pool), pool32_ = std::move(pool32), free_ = std::move(free_list);
+        table_ = std::move(table), pool_ = std::move(pool), pool16_ = std::move(pool16), free_ = std::move(free_list);
         n_buckets_hi_ = n_buckets_hi;
         n_voxels_ = n_points_ = n_entries_ = n_dead_ = 0;
         for (const Slot &e : table_) {
@@ -88,7 +89,7 @@ public:
         slot_flag_.assign(kMinTable, 0), bucket_flag_.clear(), dirty_slots_.clear(), dirty_buckets_.clear();
         ++generation_;
         pool_.clear();
-        pool32_.clear();
+        pool16_.clear();
         free_.clear();
         n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
         ++epoch_;
@@ -197,16 +198,19 @@ public:
                 ++occupied, points += count;
                 const uint32_t b = e.val >> 8;
                 if (b >= n_buckets_hi_ || count > cap_) ++bad;
-                uint32_t hdr;
-                std::memcpy(&hdr, &pool32_[static_cast<size_t>(b) * cap_ * 4 + 3], 4);
-                if (hdr != count) ++bad;
+                if ((pool16_[static_cast<size_t>(b) * cap16_].y >> 16) != count) ++bad;
+                const double upm = mirror_units_per_metre(voxel_size_);
                 for (uint32_t k = 0; k < count; ++k) {
                     const double *p = &pool_[(static_cast<size_t>(b) * cap_ + k) * 3];
-                    const float *f = &pool32_[(static_cast<size_t>(b) * cap_ + k) * 4];
+                    const MirrorPoint f = pool16_[static_cast<size_t>(b) * cap16_ + k];
                     if (to_voxel(p[0]) != e.x || to_voxel(p[1]) != e.y || to_voxel(p[2]) != e.z) ++bad;
-                    if (f[0] != static_cast<float>(p[0] - e.x * voxel_size_) || f[1] != static_cast<float>(p[1] - e.y * voxel_size_) ||
-                        f[2] != static_cast<float>(p[2] - e.z * voxel_size_))
-                        ++bad;
+                    const MirrorPoint want = mirror_point(p[0] - e.x * voxel_size_, p[1] - e.y * voxel_size_, p[2] - e.z * voxel_size_, upm, k == 0 ? count : 0u);
+                    if (f.x != want.x || f.y != want.y) ++bad;
+                    // the decoded offset is within one unit of the true one on every axis (what the kernel's margin assumes)
+                    const double o[3] = {p[0] - e.x * voxel_size_, p[1] - e.y * voxel_size_, p[2] - e.z * voxel_size_};
+                    const uint32_t q[3] = {f.x & 0xffffu, f.x >> 16, f.y & 0xffffu};
+                    for (int a = 0; a < 3; ++a)
+                        if (std::fabs(q[a] / upm - o[a]) > 1.0 / upm) ++bad;
                 }
             } else if (e.val != kHaloVal) {
                 ++bad;
@@ -227,14 +231,17 @@ private:
     static constexpr size_t kMinTable = 1024;
     int32_t to_voxel(double c) const { return static_cast<int32_t>(std::floor(c / voxel_size_)); }  // PointToVoxel, App. A.1
 
-    // fp32 mirror used by the pre-selection pass: offset from the voxel corner (|offset| <~ voxel_size, so the rounding
-    // error is <= 2^-24 * voxel_size regardless of how far the map is from the origin)
+    // compact mirror used by the pre-selection pass (kicp_common.hpp::MirrorPoint): 16-bit offsets from the voxel corner,
+    // so the error is <= voxel_size / 65536 per axis regardless of how far the map is from the origin
     void store32(uint32_t bucket, uint32_t k, double px, double py, double pz, int32_t vx, int32_t vy, int32_t vz) {
-        float *f = &pool32_[(static_cast<size_t>(bucket) * cap_ + k) * 4];
-        f[0] = static_cast<float>(px - vx * voxel_size_), f[1] = static_cast<float>(py - vy * voxel_size_);
-        f[2] = static_cast<float>(pz - vz * voxel_size_), f[3] = 0.f;
+        MirrorPoint &f = pool16_[static_cast<size_t>(bucket) * cap16_ + k];
+        const uint32_t aux = k == 0 ? (f.y >> 16) : 0u;  // point 0 keeps the count
+        f = mirror_point(px - vx * voxel_size_, py - vy * voxel_size_, pz - vz * voxel_size_, mirror_units_per_metre(voxel_size_), aux);
     }
-    void set_count32(uint32_t bucket, uint32_t count) { std::memcpy(&pool32_[static_cast<size_t>(bucket) * cap_ * 4 + 3], &count, 4); }
+    void set_count32(uint32_t bucket, uint32_t count) {
+        MirrorPoint &f = pool16_[static_cast<size_t>(bucket) * cap16_];
+        f.y = (f.y & 0xffffu) | (count << 16);
+    }
     int64_t find(int32_t x, int32_t y, int32_t z) const {
         const size_t mask = table_.size() - 1;
         for (size_t i = voxel_hash(x, y, z) & mask;; i = (i + 1) & mask) {
@@ -321,15 +328,15 @@ private:
         if (pool_.size() < n_buckets_hi_ * cap_ * 3) {
             const size_t buckets = std::max<size_t>(pool_.size() / (cap_ * 3) * 2, n_buckets_hi_ + 1024);
             pool_.resize(buckets * cap_ * 3);
-            pool32_.resize(buckets * cap_ * 4);
+            pool16_.resize(buckets * cap16_);
         }
         return b;
     }
     double voxel_size_, max_distance_;
-    uint32_t cap_;
+    uint32_t cap_, cap16_;
     std::vector<Slot> table_;
     std::vector<double> pool_;
-    std::vector<float> pool32_;
+    std::vector<MirrorPoint> pool16_;
     std::vector<uint32_t> free_;
     size_t n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
     size_t n_entries_ = 0, n_dead_ = 0;  // table entries (occupied + halo); halo entries with no occupied neighbour left

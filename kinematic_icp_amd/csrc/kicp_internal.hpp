@@ -77,7 +77,7 @@ struct DeviceMirror {
     int device = -1;
     Slot *d_table = nullptr;
     double *d_pool = nullptr;
-    float4 *d_pool32 = nullptr;
+    MirrorPoint *d_pool16 = nullptr;
     size_t table_slots = 0, pool_doubles = 0;  // allocated sizes
     size_t live_slots = 0;                     // table size the mirror currently represents
     uint64_t synced_epoch = ~0ull, synced_generation = ~0ull;

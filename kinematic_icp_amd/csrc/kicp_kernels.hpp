@@ -5,8 +5,9 @@
 //                 kiss_icp::VoxelHashMap::GetClosestNeighbor (kiss-icp v1.2.0) inlined as ONE table
 //                 probe + the scan of the neighbour buckets that can matter.  No correspondence list is materialised.
 //                 One launch = one ICP iteration; every variant ends in finish_pass (exact reduction + hand-off).
-//       k_pass_gather32 variant 3 (default): thread (or 2 / 4 sub-lanes) per query; fp32 mirror pre-selects with an
-//                      integer-key tournament, the winner and anything within the fp32 margin are resolved in fp64.
+//       k_pass_gather32 variant 3 (default): thread (or 2 / 4 sub-lanes) per query; the 16-bit mirror pre-selects (packed
+//                      fp32 arithmetic, integer-key tournament), the winner and anything within the error margin of it
+//                      are resolved in fp64.
 //       k_pass_gather   variant 0: thread-per-query, plain fp64 (baseline of the ablation).
 //                      (Variants 1/2 of round 1 - neighbourhoods staged in LDS per wave, optionally after binning the scan
 //                      by cell - were slower than variant 3 on every BASELINE config and spilled registers; removed.)
@@ -91,16 +92,40 @@ struct SolveParams {
     uint32_t tag;                  // 1..65535, unique per pass within an epoch (the buffers are cleared when it wraps)
 };
 
+// Wave-uniform numbers of the pre-selection over the 16-bit mirror, computed once per call on the host (search_params()).
+struct SearchParams {
+    double bound;    // tau^2 (1 + 9.1e-13): acceptance bound on exact squared distances
+    double upm;      // mirror units per metre = 65536 / voxel_size
+    double inv_vs;   // 1 / voxel_size (voxel_coord's fast path)
+    float bound_u;   // the bound in units^2, widened by the margin
+    float margin_u;  // error margin of one decision between two mirror distances, units^2
+};
+KICP_HD SearchParams search_params(double tau, double vs) {
+    SearchParams sp;
+    sp.bound = tau * tau * (1.0 + 9.1e-13);
+    sp.upm = mirror_units_per_metre(vs);
+    sp.inv_vs = 1.0 / vs;
+    // error model in metres (k_pass_gather32): |delta| <= sqrt(3) * 1.05 units = 2.78e-5 vs; D off by <= 2 sqrt(D) |delta| +
+    // |delta|^2 + 4.2e-6 D; both candidates of a decision, 10 % spare; D <= min(bound, 12 vs^2)
+    const double bcap = fmin(sp.bound, 12.0 * vs * vs);
+    const double margin = 2.2 * (5.55e-5 * sqrt(bcap) * vs + 4.2e-6 * bcap + 7.7e-10 * vs * vs);
+    sp.margin_u = static_cast<float>(margin * sp.upm * sp.upm) * 1.00001f;
+    sp.bound_u = static_cast<float>(sp.bound * sp.upm * sp.upm) * 1.00001f + sp.margin_u;
+    return sp;
+}
+
 struct PassParams {
     const double *src;  // scan points, base frame, AoS xyz fp64 (device)
     uint32_t n;
     MapView map;
     double tau;
+    SearchParams search;  // = search_params(tau, map.voxel_size)
     IcpState *st;
     unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     SolveParams sol;
-    int32_t dbg;  // ablation switches for tools/gpu_dbg.py (0 = normal operation)
+    uint32_t xcds;  // XCD-aware block -> scan slice mapping (xcd_slice_block): 8 on MI355X, 1 = identity
+    int32_t dbg;    // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -387,8 +412,22 @@ __device__ __forceinline__ long long sum_rows_tagged(const unsigned long long *r
     return v + __shfl_down(v, kReduceWords, 64);
 }
 
+// Sum of a 32-bit value over the wave with DPP adds only (no LDS crossbar): inclusive scan inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of row 0 / 2 is added to every lane of
+// row 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).  LANE 63 holds the wave total.
+__device__ __forceinline__ int wave_sum_to_lane63(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return v;
+}
+constexpr int kWaveLimbs = 3 * kNumSums;  // per sum three 21-bit limbs (the top one signed): a wave's 64 values add up in int32
+
 template <int BLOCK>
-__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*s_red)[kNumSums], int *s_flag) {
+__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
     if (p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
@@ -402,34 +441,38 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         }
         return;
     }
+    // Every lane contributes at most ONE correspondence per pass, so its seven sums are single terms |t| < 2^63 (the
+    // accumulation range, i128_add_fixed): three limbs of 21 bits each, and a wave's 64 values of a limb add up in int32.
+    int range_error = a.range_error;
+    int limb[kWaveLimbs];
 #pragma unroll
     for (int i = 0; i < kNumSums; ++i) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            I128 o;
-            o.lo = __shfl_down(a.v[i].lo, off, 64);
-            o.hi = __shfl_down(a.v[i].hi, off, 64);
-            i128_add(a.v[i], o);
-        }
+        const long long t = static_cast<long long>(a.v[i].lo);
+        if (a.v[i].hi != (t >> 63)) range_error = 1;  // more than one term in a lane: not this kernel family's contract
+        limb[3 * i] = static_cast<int>(t & 0x1FFFFF), limb[3 * i + 1] = static_cast<int>((t >> 21) & 0x1FFFFF), limb[3 * i + 2] = static_cast<int>(t >> 42);
     }
-    int range_error = __any(a.range_error) ? 1 : 0;
-    if (BLOCK > 64) {
-        if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < kNumSums; ++i) s_red[wave][i] = a.v[i];
-            if (range_error) atomicOr(s_flag, 2);
-        }
-        __syncthreads();
-        if (wave != 0) return;
-        range_error = (*s_flag & 2) ? 1 : 0;
+    for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(limb[k]);
+    range_error = __any(range_error) ? 1 : 0;
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < kWaveLimbs; ++k) s_red[wave][k] = limb[k];
+        if (range_error) atomicOr(s_flag, 2);
     }
-    // wave 0 only from here.  Lane i < 7 takes the workgroup total of sum i and publishes its three limbs.
+    __syncthreads();
+    if (wave != 0) return;
+    range_error = (*s_flag & 2) ? 1 : 0;
+    // wave 0 only from here.  Lane i < 7 takes the workgroup total of sum i (as a 128-bit integer) and publishes its three
+    // 40-bit limbs.
     I128 t{0ull, 0ll};
-#pragma unroll
-    for (int i = 0; i < kNumSums; ++i) {
-        I128 o;
-        o.lo = __shfl(a.v[i].lo, 0, 64), o.hi = __shfl(a.v[i].hi, 0, 64);
-        if (lane == i) t = o;
+    if (lane < kNumSums) {
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            const long long s0 = s_red[w][3 * lane], s1 = s_red[w][3 * lane + 1], s2 = s_red[w][3 * lane + 2];
+            const long long low = s0 + (s1 << 21);                                           // < 2^49
+            I128 part{static_cast<unsigned long long>(s2) << 42, s2 >> 22};                     // s2 * 2^42 as a 128-bit integer
+            I128 lowpart{static_cast<unsigned long long>(low), low >> 63};
+            i128_add(t, part), i128_add(t, lowpart);
+        }
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
@@ -439,10 +482,6 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         // within the documented range), so value << 16 | tag fits a word, and so does the sum of a group's 32 rows.
         const unsigned long long tag = p.sol.tag;
         if (lane < kNumSums) {
-            if (BLOCK > 64) {
-                t = s_red[0][lane];
-                for (int w = 1; w < BLOCK / 64; ++w) i128_add(t, s_red[w][lane]);
-            }
             long long l[3];
             i128_to_limbs(t, l);
 #pragma unroll
@@ -467,10 +506,6 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
         return;
     }
     if (lane < kNumSums) {
-        if (BLOCK > 64) {
-            t = s_red[0][lane];
-            for (int w = 1; w < BLOCK / 64; ++w) i128_add(t, s_red[w][lane]);
-        }
         long long l[3];
         i128_to_limbs(t, l);
 #pragma unroll
@@ -514,6 +549,18 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, I128 (*
     solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
 }
 
+// Which slice of the scan a workgroup serves.  Workgroups are handed to the 8 XCDs round-robin (b % 8, the dispatcher's
+// observed habit - a performance assumption only, nothing depends on it for correctness) and every XCD has its own 4 MiB
+// L2, so the 8 workgroups of a "row" land on 8 different L2s.  With the identity mapping every L2 therefore sees queries
+// from ALL over the scan and must hold the whole touched part of the map (table slots + buckets: more than 4 MiB on the
+// headline scan - 40 % of the L2 requests missed).  Mapped this way, XCD x serves ONE contiguous eighth of the scan - for
+// an organised LiDAR cloud a few neighbouring rings - and its L2 only has to hold that part's neighbourhood.
+__device__ __forceinline__ uint32_t xcd_slice_block(uint32_t b, uint32_t nblocks, uint32_t xcds) {
+    if (xcds <= 1u) return b;
+    const uint32_t x = b % xcds, per = nblocks / xcds, extra = nblocks % xcds;
+    return x * per + min(x, extra) + b / xcds;  // XCD x owns blocks x, x + xcds, ...: (per or per + 1) of them, laid end to end
+}
+
 // wave-uniform values belong in SGPRs: tell the compiler explicitly
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uniform_d(double v) {
@@ -528,7 +575,7 @@ __device__ __forceinline__ Pose load_pose(const PassParams &p) {
 }
 
 #define KICP_PASS_SHARED(BLOCK)                       \
-    __shared__ I128 s_red[(BLOCK) / 64][kNumSums];    \
+    __shared__ int s_red[(BLOCK) / 64][kWaveLimbs];   \
     __shared__ int s_flag;                            \
     if (threadIdx.x == 0) s_flag = 0;
 
@@ -561,18 +608,20 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// variant 3: thread-per-query gather over the fp32 mirror, per-lane work lists
-//   * candidates are read from the fp32 mirror (one 16-byte load per point, offsets from the voxel corner) and
-//     compared in fp32; the three smallest squared distances are tracked with the indices/visiting order of the two
-//     smallest.  fp32 only PRE-SELECTS: the winner (and the runner-up when it lies within the fp32 error margin) is
-//     re-evaluated in fp64 from the fp64 pool, ties resolved by the reference's visiting order; if even the third
-//     smallest is within the margin the lane falls back to the exact fp64 search.  The chosen neighbour and its
-//     distance are therefore exactly the fp64 reference's.
-//   * each lane walks ITS OWN list of neighbour voxels (bit mask over the 27 shifts, in the reference's order):
-//     culled voxels cost ALU only, so a wave iterates max-over-lanes(#voxels actually visited) times instead of
-//     over the union of the lanes' shifts; every bucket is scanned five points per trip (five loads in flight).
+// variant 3: thread-per-query gather over the 16-bit mirror, per-lane work lists
+//   * candidates are read from the compact mirror (kicp_common.hpp::MirrorPoint: 8 bytes per point, offsets from the voxel
+//     corner in units of voxel_size / 65536; two points per 16-byte load) and compared in fp32 IN THOSE UNITS with packed
+//     fp32 arithmetic (two points per instruction); the three smallest squared distances are tracked with the
+//     indices / visiting order of the two smallest.  The mirror only PRE-SELECTS: the winner (and the runner-up when it
+//     lies within the error margin) is re-evaluated in fp64 from the fp64 pool, ties resolved by the reference's visiting
+//     order; if even the third smallest is within the margin the lane falls back to the exact fp64 search.  The chosen
+//     neighbour and its distance are therefore exactly the fp64 reference's.
+//   * each lane walks ITS OWN list of neighbour voxels (bit mask over the 27 shifts, in the reference's order): culled
+//     voxels cost ALU only, so a wave iterates max-over-lanes(#voxels actually visited) times instead of over the union
+//     of the lanes' shifts; a bucket is scanned 20 points per trip (ten 16-byte loads in flight).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kTrip = 20;  // bucket points in flight per lane and trip
+constexpr int kTrip = kMirrorTrip;  // bucket points in flight per lane and trip (even: two points per load)
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct Best3 {
     float b1, b2, b3;
     uint32_t i1, i2, o1, o2;  // pool index and visiting order (shift * 256 + k) of the two smallest
@@ -613,120 +662,210 @@ __device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
     t.b3 = fminf(t.b3, o.b3);  // o.b3 can never undercut the runner-up of a set that already holds o.b1 <= o.b2
 }
 
+// which of the 27 neighbour voxels (bit s = shift s of the reference's order) may hold a point within `lim` (units^2) of
+// the query: lower bound = sum of the squared distances to the faces crossed.  lo[a] / hi[a] = conservative squared
+// distance to the -/+ face of the own voxel on axis a.  Own voxel: always; 6 face neighbours: one term; 12 edge
+// neighbours: two; 8 corner neighbours: three (an edge sum plus one term).
+__device__ __forceinline__ uint32_t alive_mask(const float (&lo)[3], const float (&hi)[3], float lim) {
+    // reference order (kShiftTable): 0 own | 1 +x 2 -x 3 +y 4 -y 5 +z 6 -z | 7 ++0 8 +-0 9 -+0 10 --0 | 11 +0+ 12 +0- 13 -0+ 14 -0-
+    // | 15 0++ 16 0+- 17 0-+ 18 0-- | 19 +++ 20 ++- 21 +-+ 22 +-- 23 -++ 24 -+- 25 --+ 26 ---
+    const float px = hi[0], mx = lo[0], py = hi[1], my = lo[1], pz = hi[2], mz = lo[2];
+    uint32_t a = 1u;
+    a |= (px <= lim ? 1u << 1 : 0u) | (mx <= lim ? 1u << 2 : 0u) | (py <= lim ? 1u << 3 : 0u) | (my <= lim ? 1u << 4 : 0u) |
+         (pz <= lim ? 1u << 5 : 0u) | (mz <= lim ? 1u << 6 : 0u);
+    const float pp = px + py, pm = px + my, mp = mx + py, mm = mx + my;  // xy edges
+    a |= (pp <= lim ? 1u << 7 : 0u) | (pm <= lim ? 1u << 8 : 0u) | (mp <= lim ? 1u << 9 : 0u) | (mm <= lim ? 1u << 10 : 0u);
+    a |= (px + pz <= lim ? 1u << 11 : 0u) | (px + mz <= lim ? 1u << 12 : 0u) | (mx + pz <= lim ? 1u << 13 : 0u) | (mx + mz <= lim ? 1u << 14 : 0u);
+    a |= (py + pz <= lim ? 1u << 15 : 0u) | (py + mz <= lim ? 1u << 16 : 0u) | (my + pz <= lim ? 1u << 17 : 0u) | (my + mz <= lim ? 1u << 18 : 0u);
+    a |= (pp + pz <= lim ? 1u << 19 : 0u) | (pp + mz <= lim ? 1u << 20 : 0u) | (pm + pz <= lim ? 1u << 21 : 0u) | (pm + mz <= lim ? 1u << 22 : 0u);
+    a |= (mp + pz <= lim ? 1u << 23 : 0u) | (mp + mz <= lim ? 1u << 24 : 0u) | (mm + pz <= lim ? 1u << 25 : 0u) | (mm + mz <= lim ? 1u << 26 : 0u);
+    return a;
+}
+
+// PointToVoxel component: static_cast<int>(floor(c / vs)) as the reference evaluates it (kiss-icp v1.2.0 core/VoxelUtils.hpp),
+// without paying an fp64 division for every coordinate: t = c * (1 / vs) agrees with fl(c / vs) to a few ulps, so the two
+// floors can only differ when t lies within that distance of an integer - and only then is the division carried out.
+__device__ __forceinline__ int32_t voxel_coord(double c, double vs, double inv_vs) {
+    const double t = c * inv_vs;
+    const double f = floor(t);
+    const double frac = t - f;
+    const double guard = 4.0e-16 * fabs(t) + 1.0e-300;
+    if (__builtin_expect(frac < guard || 1.0 - frac < guard, 0)) return static_cast<int32_t>(floor(c / vs));
+    return static_cast<int32_t>(f);
+}
+
+// One query's search state.
+struct Lane {
+    uint32_t i;        // query index, kNoIndex32 = none
+    float lx, ly, lz;  // the query's offset inside its own voxel, mirror units
+    uint32_t slot0;    // table slot of the own voxel's entry (its record lists the 27 neighbours' buckets)
+    uint32_t todo;     // neighbour voxels still to visit (bit s = shift s of the reference's order)
+    Best3 t;
+};
+constexpr float kCell = 65536.f;  // one voxel in mirror units
+
+// the transformed point T * source[i] and its voxel (PointToVoxel); recomputed where needed rather than kept in registers
+__device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const Pose &T, uint32_t i) {
+    const double sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
+    double rx, ry, rz;
+    quat_rotate(T, sx, sy, sz, rx, ry, rz);
+    q.x = rx + T.tx, q.y = ry + T.ty, q.z = rz + T.tz;
+    const double vs = p.map.voxel_size;
+    q.vx = voxel_coord(q.x, vs, p.search.inv_vs), q.vy = voxel_coord(q.y, vs, p.search.inv_vs), q.vz = voxel_coord(q.z, vs, p.search.inv_vs);
+}
+// Everything the search does is in MIRROR UNITS (voxel_size / 65536) until the exact phase.  Error model (units): a mirror
+// coordinate is within 1.0 of the true offset (rounding 0.5; 1.0 where the top of the range is clamped), the query offset and
+// the difference add < 0.05 (fp32 roundings of numbers < 2^18), so a squared distance D is off by <= 2 sqrt(3 D) 1.05 + 3.3,
+// plus 4.2e-6 D for the fp32 squares / sums and the 5 mantissa bits dropped for the integer tournament.  sp.margin_u covers
+// the errors of BOTH candidates of a decision with 10 % to spare, for D up to the acceptance bound (and never farther than
+// the 27-voxel neighbourhood reaches, D <= 12 voxel sizes^2): computed on the host (search_params()).
+__device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const Pose &T, uint32_t i, bool valid) {
+    const SearchParams &sp = p.search;
+    L.i = valid ? i : kNoIndex32;
+    L.slot0 = 0u, L.todo = 0u;
+    L.t = Best3{sp.bound_u, sp.bound_u, sp.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
+    Query q;
+    make_query_of(q, p, T, valid ? i : 0u);
+    const double vs = p.map.voxel_size;
+    L.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
+    L.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
+    // ONE probe at the own voxel: the occupancy mask of the 27 neighbours (bit s = shift s of the reference's order) and
+    // the record of their buckets.  Only voxels that hold points are ever visited; empty space costs nothing.
+    if (valid && p.dbg != 2) table_lookup_entry(p.map, q.vx, q.vy, q.vz, L.slot0, L.todo);
+    if (p.dbg == 3) L.todo &= 1u;     // experiments: own voxel only
+    if (p.dbg == 5) L.todo &= 0x7Fu;  // own + faces
+    if (p.dbg == 4) L.todo = 0u;      // probe only, no bucket visit
+}
+// drop the neighbour voxels that cannot hold anything within the margin of `best` (units^2)
+__device__ __forceinline__ uint32_t cull_todo(const Lane &L, float best, float margin) {
+    // conservative (rounded-down) squared distances to the faces of the own voxel
+    const float lo[3] = {L.lx * L.lx * 0.99999f - margin, L.ly * L.ly * 0.99999f - margin, L.lz * L.lz * 0.99999f - margin};
+    const float hi[3] = {(kCell - L.lx) * (kCell - L.lx) * 0.99999f - margin, (kCell - L.ly) * (kCell - L.ly) * 0.99999f - margin,
+                         (kCell - L.lz) * (kCell - L.lz) * 0.99999f - margin};
+    return L.todo & alive_mask(lo, hi, best + margin);
+}
+// scan the bucket of neighbour voxel `s` of the lane's query and merge what it finds into L.t
+__device__ __forceinline__ void visit_bucket(Lane &L, const MapView &m, int s, float margin) {
+    const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
+    // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
+    const uint32_t bucket = m.table[L.slot0].nb[s];
+    const uint32_t base = bucket * m.cap;  // index into the fp64 pool
+    const uint32_t stride16 = m.cap16;
+    const uint4 *b = reinterpret_cast<const uint4 *>(m.pool16 + static_cast<size_t>(bucket) * stride16);
+    // the query as seen from that voxel's corner, both lanes of the packed arithmetic
+    const v2f qx = {L.lx - dx * kCell, L.lx - dx * kCell}, qy = {L.ly - dy * kCell, L.ly - dy * kCell}, qz = {L.lz - dz * kCell, L.lz - dz * kCell};
+    // Branch-free loads at immediate offsets so that the compiler keeps a whole trip in flight: kTrip points = kTrip / 2
+    // 16-byte loads per trip; the count arrives with point 0 (its aux field).
+    uint32_t cnt = kTrip;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += kTrip) {
+        uint4 c[kTrip / 2];
+        const uint4 *bt = b + k0 / 2;  // the mirror's bucket stride is a multiple of kTrip: a trip never leaves the bucket
+#pragma unroll
+        for (int u = 0; u < kTrip / 2; ++u) c[u] = bt[u];
+        if (k0 == 0) cnt = c[0].y >> 16;
+        // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
+        // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
+        // and yields value and position at once (unique keys: the lower position wins a tie, like the
+        // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
+        uint32_t key[kTrip];
+#pragma unroll
+        for (int u = 0; u < kTrip / 2; ++u) {
+            const v2f px = {static_cast<float>(c[u].x & 0xffffu), static_cast<float>(c[u].z & 0xffffu)};
+            const v2f py = {static_cast<float>(c[u].x >> 16), static_cast<float>(c[u].z >> 16)};
+            const v2f pz = {static_cast<float>(c[u].y & 0xffffu), static_cast<float>(c[u].w & 0xffffu)};
+            const v2f ddx = px - qx, ddy = py - qy, ddz = pz - qz;
+            const v2f d = __builtin_elementwise_fma(ddz, ddz, __builtin_elementwise_fma(ddy, ddy, ddx * ddx));
+            // (select the bits first, then and-or the position in: ONE shared far constant and inline position literals,
+            // instead of twenty distinct far keys parked in registers)
+            const uint32_t bits0 = (k0 + 2 * u < cnt) ? __float_as_uint(d.x) : kFarKey;
+            const uint32_t bits1 = (k0 + 2 * u + 1 < cnt) ? __float_as_uint(d.y) : kFarKey;
+            key[2 * u] = (bits0 & ~31u) | static_cast<uint32_t>(2 * u);
+            key[2 * u + 1] = (bits1 & ~31u) | static_cast<uint32_t>(2 * u + 1);
+        }
+        const uint32_t key1 = tree_min_u32<kTrip>(key);
+        const float m1 = __uint_as_float(key1 & ~31u);
+        if (m1 <= L.t.b1 + margin) {  // something here can come within the margin of the running minimum
+            uint32_t rest[kTrip];
+#pragma unroll
+            for (int u = 0; u < kTrip; ++u) rest[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
+            const uint32_t key2 = tree_min_u32<kTrip>(rest);
+#pragma unroll
+            for (int u = 0; u < kTrip; ++u) rest[u] = (rest[u] == key2) ? 0xFFFFFFFFu : rest[u];
+            const uint32_t key3 = tree_min_u32<kTrip>(rest);
+            const uint32_t k1 = key1 & 31u, k2 = key2 & 31u;
+            // with fewer than three points the far key stands in (finite, beyond every real distance)
+            Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k0 + k1,
+                    base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1, static_cast<uint32_t>(s) * 256u + k0 + k2};
+            best3_merge(L.t, o);
+        }
+    }
+}
+// exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
+// reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
+__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t) {
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || p.dbg != 0) return;
+    const MapView &m = p.map;
+    const float margin = p.search.margin_u;
+    Query q;
+    make_query_of(q, p, T, i);
+    const double bound = p.search.bound;
+    double best = bound;
+    uint32_t best_idx = kNoIndex32;
+    if (t.b3 - t.b1 <= margin) {  // three near-equal candidates: leave it to the exact fp64 search
+        search_global(m, q, best, best_idx);
+    } else {
+        const double d1 = exact_d2(m, t.i1, q);
+        if (d1 < best) best = d1, best_idx = t.i1;
+        if (t.b2 - t.b1 <= margin) {
+            const double d2 = exact_d2(m, t.i2, q);
+            // the reference keeps the FIRST candidate (in visiting order) that attains the strict minimum
+            if (d2 < bound && (best_idx == kNoIndex32 || d2 < best || (d2 == best && t.o2 < t.o1))) best = d2, best_idx = t.i2;
+        }
+    }
+    if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+        const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
+        // the untransformed source point again (L1 / L2 hit): cheaper than registers kept live through the search
+        accumulate(acc, T, p.src[3 * i], p.src[3 * i + 1], q.x, q.y, q.z, tp[0], tp[1], tp[2]);
+    }
+}
+
 // G consecutive lanes serve one query: the occupied neighbour voxels are dealt round-robin to the G sub-lanes, which
 // halves/quarters each lane's dependent chain and multiplies the resident waves; the sub-lanes share their running
-// minimum for culling and merge their records with shuffles at the end.
+// minimum for culling and merge their records with shuffles at the end.  (Small scans: few waves, latency bound.)
 template <int BLOCK, int G>
-__global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) {
+__global__ __launch_bounds__(BLOCK, 4) void k_pass_gather32(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const MapView &m = p.map;
-    const uint32_t gt = blockIdx.x * BLOCK + threadIdx.x;
+    const float margin = p.search.margin_u;
+    const uint32_t gt = xcd_slice_block(blockIdx.x, gridDim.x, p.xcds) * BLOCK + threadIdx.x;
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
     const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
-    Acc acc{};
-    double sx = 0, sy = 0, sz = 0;
-    if (valid) sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
-    double rx, ry, rz;
-    quat_rotate(T, sx, sy, sz, rx, ry, rz);
-    Query q;
-    make_query(q, rx + T.tx, ry + T.ty, rz + T.tz, m.voxel_size);
-    const double vs = m.voxel_size;
-    const double bound = p.tau * p.tau * (1.0 + 9.1e-13);
-    const float fvs = static_cast<float>(vs);
-    // fp32 error model.  Mirror offsets (< vs) and the query offset seen from a neighbour's corner (< 2 vs) are rounded
-    // once each and so is their difference (< 3 vs): per axis the difference is off by <= 3.6e-7 vs, which moves a squared
-    // distance D by <= 2 sqrt(3 D) * 3.6e-7 vs; the squares and sums add 1.8e-7 D and the 5 mantissa bits dropped for the
-    // integer tournament 3.9e-6 D.  Decisions compare two candidates no farther than the acceptance bound (and never
-    // farther than the 27-voxel neighbourhood reaches, D <= 12 vs^2): the margin covers both errors, with 10 % to spare.
-    const double bcap = fmin(bound, 12.0 * vs * vs);
-    const float margin = fmaxf(8e-6f * fvs * fvs, static_cast<float>(2.2 * (1.25e-6 * sqrt(bcap) * vs + 4.2e-6 * bcap)));
-    const float bound32 = static_cast<float>(bound) * 1.00001f + margin;
-    const float lx = static_cast<float>(q.x - q.vx * vs), ly = static_cast<float>(q.y - q.vy * vs), lz = static_cast<float>(q.z - q.vz * vs);
-    // conservative (rounded-down) squared distances to the faces of the own voxel, indexed by shift component + 1
-    float face[3][3] = {{lx * lx, 0.f, (fvs - lx) * (fvs - lx)}, {ly * ly, 0.f, (fvs - ly) * (fvs - ly)}, {lz * lz, 0.f, (fvs - lz) * (fvs - lz)}};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) face[a][0] = face[a][0] * 0.99999f - margin, face[a][2] = face[a][2] * 0.99999f - margin;
-
-    Best3 t{bound32, bound32, bound32, kNoIndex32, kNoIndex32, 0u, 0u};
-    // ONE probe at the own voxel: the occupancy mask of the 27 neighbours (bit s = shift s of the reference's order) and
-    // the record of their buckets.  Only voxels that hold points are ever visited; empty space costs nothing.
-    uint32_t slot0 = 0u, nbr = 0u;
-    if (valid && p.dbg != 2) table_lookup_entry(m, q.vx, q.vy, q.vz, slot0, nbr);
-    if (p.dbg == 3) nbr &= 1u;     // experiments: own voxel only
-    if (p.dbg == 5) nbr &= 0x7Fu;  // own + faces
-    if (p.dbg == 4) nbr = 0u;      // probe only, no bucket visit
-    uint32_t todo = nbr;
+    Lane L;
+    start_lane(L, p, T, i, valid);
     if (G > 1) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
-        todo = 0u;
-        uint32_t rest = nbr;
+        uint32_t rest = L.todo, mine = 0u;
         for (int r = 0; rest; ++r) {
             const uint32_t low = rest & (0u - rest);
             rest ^= low;
-            if (r % G == sub) todo |= low;
+            if (r % G == sub) mine |= low;
         }
+        L.todo = mine;
     }
-    float cull = bound32;  // running minimum shared by the G sub-lanes (culling only)
-    while (__any(todo != 0u)) {
-        // which of the 27 neighbours could still hold something within the margin of the current minimum (branch-free)
-        const float lim = cull + margin;
-        uint32_t alive = 0u;
-#pragma unroll
-        for (int c = 0; c < 27; ++c) {
-            const float box = face[0][kShiftTable[c][0] + 1] + face[1][kShiftTable[c][1] + 1] + face[2][kShiftTable[c][2] + 1];
-            alive |= (box <= lim) ? (1u << c) : 0u;
+    float cull = L.t.b1;      // running minimum shared by the G sub-lanes (culling only)
+    float culled_at = -1.0f;  // the minimum the work list was last culled with (the first round always culls)
+    while (__any(L.todo != 0u)) {
+        // which of the 27 neighbours could still hold something within the margin of the current minimum; only re-evaluated
+        // when some lane's minimum moved (the mask can only lose bits as the limit shrinks)
+        if (__any(cull != culled_at)) L.todo = cull_todo(L, cull, margin), culled_at = cull;
+        if (L.todo) {
+            const int s = __ffs(L.todo) - 1;
+            L.todo &= L.todo - 1u;
+            visit_bucket(L, m, s, margin);
         }
-        todo &= alive;
-        if (todo) {
-            const int s = __ffs(todo) - 1;
-            todo &= todo - 1u;
-            const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-            // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
-            const uint32_t base = m.table[slot0].nb[s] * m.cap;
-            const float4 *b = m.pool32 + base;
-            // the query as seen from that voxel's corner
-            const float qx = lx - dx * fvs, qy = ly - dy * fvs, qz = lz - dz * fvs;
-            // Branch-free loads (indices clamped into the bucket) so that the compiler keeps a whole trip in flight:
-            // kTrip points per trip; the count arrives with point 0 (its w).
-            uint32_t cnt = kTrip;
-            const uint32_t last = m.cap - 1;
-            for (uint32_t k0 = 0; k0 < cnt; k0 += kTrip) {
-                float4 c[kTrip];
-#pragma unroll
-                for (int u = 0; u < kTrip; ++u) c[u] = b[min(k0 + u, last)];
-                if (k0 == 0) cnt = __float_as_uint(c[0].w);
-                // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
-                // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
-                // and yields value and position at once (unique keys: the lower position wins a tie, like the
-                // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
-                uint32_t key[kTrip];
-#pragma unroll
-                for (int u = 0; u < kTrip; ++u) {
-                    const float ddx = c[u].x - qx, ddy = c[u].y - qy, ddz = c[u].z - qz;
-                    const float d = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
-                    key[u] = (k0 + u < cnt) ? ((__float_as_uint(d) & ~31u) | static_cast<uint32_t>(u)) : (kFarKey | static_cast<uint32_t>(u));
-                }
-                const uint32_t key1 = tree_min_u32<kTrip>(key);
-                const float m1 = __uint_as_float(key1 & ~31u);
-                if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
-                    uint32_t rest[kTrip];
-#pragma unroll
-                    for (int u = 0; u < kTrip; ++u) rest[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
-                    const uint32_t key2 = tree_min_u32<kTrip>(rest);
-#pragma unroll
-                    for (int u = 0; u < kTrip; ++u) rest[u] = (rest[u] == key2) ? 0xFFFFFFFFu : rest[u];
-                    const uint32_t key3 = tree_min_u32<kTrip>(rest);
-                    const uint32_t k1 = key1 & 31u, k2 = key2 & 31u;
-                    // with fewer than three points the far key stands in (finite, beyond every real distance)
-                    Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k0 + k1,
-                            base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1, static_cast<uint32_t>(s) * 256u + k0 + k2};
-                    best3_merge(t, o);
-                }
-            }
-        }
-        cull = t.b1;
+        cull = L.t.b1;
 #pragma unroll
         for (int off = 1; off < G; off <<= 1) cull = fminf(cull, __shfl_xor(cull, off, 64));
     }
@@ -734,30 +873,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pass_gather32(const PassParams p) 
 #pragma unroll
     for (int off = 1; off < G; off <<= 1) {
         Best3 o;
-        o.b1 = __shfl_xor(t.b1, off, 64), o.b2 = __shfl_xor(t.b2, off, 64), o.b3 = __shfl_xor(t.b3, off, 64);
-        o.i1 = __shfl_xor(t.i1, off, 64), o.i2 = __shfl_xor(t.i2, off, 64), o.o1 = __shfl_xor(t.o1, off, 64), o.o2 = __shfl_xor(t.o2, off, 64);
-        best3_merge(t, o);
+        o.b1 = __shfl_xor(L.t.b1, off, 64), o.b2 = __shfl_xor(L.t.b2, off, 64), o.b3 = __shfl_xor(L.t.b3, off, 64);
+        o.i1 = __shfl_xor(L.t.i1, off, 64), o.i2 = __shfl_xor(L.t.i2, off, 64), o.o1 = __shfl_xor(L.t.o1, off, 64), o.o2 = __shfl_xor(L.t.o2, off, 64);
+        best3_merge(L.t, o);
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
-    if (valid && sub == 0 && t.i1 != kNoIndex32 && p.dbg == 0) {
-        double best = bound;
-        uint32_t best_idx = kNoIndex32;
-        if (t.b3 - t.b1 <= margin) {  // three near-equal candidates: leave it to the exact fp64 search
-            search_global(m, q, best, best_idx);
-        } else {
-            const double d1 = exact_d2(m, t.i1, q);
-            if (d1 < best) best = d1, best_idx = t.i1;
-            if (t.b2 - t.b1 <= margin) {
-                const double d2 = exact_d2(m, t.i2, q);
-                // the reference keeps the FIRST candidate (in visiting order) that attains the strict minimum
-                if (d2 < bound && (best_idx == kNoIndex32 || d2 < best || (d2 == best && t.o2 < t.o1))) best = d2, best_idx = t.i2;
-            }
-        }
-        if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
-            const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
-            accumulate(acc, T, sx, sy, q.x, q.y, q.z, tp[0], tp[1], tp[2]);
-        }
-    }
+    Acc acc{};  // (declared here, not at the top: 28 registers that would otherwise stay live through the search)
+    if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag);
 }

@@ -10,11 +10,13 @@ using namespace kicp;
 using namespace kicp::host;
 
 namespace {
+// points of the 16-bit mirror that go with `pool_doubles` doubles of the fp64 pool (bucket strides cap / cap16)
+size_t mirror_points(size_t pool_doubles, uint32_t cap) { return pool_doubles / (static_cast<size_t>(cap) * 3) * mirror_stride(cap); }
 // release every device buffer of a mirror (on its own device) and reset it
 void free_mirror(DeviceMirror &mr) {
     if (mr.device >= 0) {
         hipSetDevice(mr.device);
-        hipFree(mr.d_table), hipFree(mr.d_pool), hipFree(mr.d_pool32), hipFree(mr.d_stage), hipFree(mr.d_index);
+        hipFree(mr.d_table), hipFree(mr.d_pool), hipFree(mr.d_pool16), hipFree(mr.d_stage), hipFree(mr.d_index);
         hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
         hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
         hipFree(mr.d_pc), hipFree(mr.d_pc_blocks);
@@ -118,17 +120,17 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
     if (pool_doubles > mr.pool_doubles) {  // grow the pools, keeping what is already there (device-side copy)
         const size_t want = pool_doubles + pool_doubles / 2 + 3 * 1024;
         double *np = nullptr;
-        float4 *np32 = nullptr;
+        MirrorPoint *np32 = nullptr;
         HIP_TRY(hipMalloc(&np, want * sizeof(double)));
-        HIP_TRY(hipMalloc(&np32, want / 3 * sizeof(float4)));
+        HIP_TRY(hipMalloc(&np32, mirror_points(want, cap) * sizeof(MirrorPoint)));
         if (mr.d_pool && !full) {
             HIP_TRY(hipMemcpyAsync(np, mr.d_pool, mr.pool_doubles * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(np32, mr.d_pool32, mr.pool_doubles / 3 * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(np32, mr.d_pool16, mirror_points(mr.pool_doubles, cap) * sizeof(MirrorPoint), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
         if (mr.d_pool) HIP_TRY(hipFree(mr.d_pool));
-        if (mr.d_pool32) HIP_TRY(hipFree(mr.d_pool32));
-        mr.d_pool = np, mr.d_pool32 = np32, mr.pool_doubles = want;
+        if (mr.d_pool16) HIP_TRY(hipFree(mr.d_pool16));
+        mr.d_pool = np, mr.d_pool16 = np32, mr.pool_doubles = want;
     }
     mr.last_upload_bytes = 0;
     // delta only pays off while the changed part is small
@@ -136,9 +138,9 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
     if (full) {
         HIP_TRY(hipMemcpyAsync(mr.d_table, h.table().data(), slots * sizeof(Slot), hipMemcpyHostToDevice, stream));
         if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool, h.pool().data(), pool_doubles * sizeof(double), hipMemcpyHostToDevice, stream));
-        if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool32, h.pool32().data(), pool_doubles / 3 * sizeof(float4), hipMemcpyHostToDevice, stream));
+        if (pool_doubles) HIP_TRY(hipMemcpyAsync(mr.d_pool16, h.pool16().data(), mirror_points(pool_doubles, cap) * sizeof(MirrorPoint), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mr.last_upload_bytes = slots * sizeof(Slot) + pool_doubles * sizeof(double) + pool_doubles / 3 * sizeof(float4);
+        mr.last_upload_bytes = slots * sizeof(Slot) + pool_doubles * sizeof(double) + mirror_points(pool_doubles, cap) * sizeof(MirrorPoint);
     } else {
         // gather the changed rows on the host, ship them with their indices, scatter on the device
         std::vector<uint2> staged;
@@ -150,15 +152,16 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
         for (size_t i = 0; i < db.size(); ++i)
             std::memcpy(&staged[i * static_cast<size_t>(cap) * 3], &h.pool()[static_cast<size_t>(db[i]) * cap * 3], static_cast<size_t>(cap) * 24);
         if (int rc = upload_rows(mr, staged, db, cap * 3, mr.d_pool, stream)) return rc;
-        staged.resize(db.size() * static_cast<size_t>(cap) * 2);
+        const size_t cap16 = h.cap16();
+        staged.resize(db.size() * cap16);  // one 8-byte word per mirror point
         for (size_t i = 0; i < db.size(); ++i)
-            std::memcpy(&staged[i * static_cast<size_t>(cap) * 2], &h.pool32()[static_cast<size_t>(db[i]) * cap * 4], static_cast<size_t>(cap) * 16);
-        if (int rc = upload_rows(mr, staged, db, cap * 2, mr.d_pool32, stream)) return rc;
+            std::memcpy(&staged[i * cap16], &h.pool16()[static_cast<size_t>(db[i]) * cap16], cap16 * sizeof(MirrorPoint));
+        if (int rc = upload_rows(mr, staged, db, static_cast<uint32_t>(cap16), mr.d_pool16, stream)) return rc;
     }
     mr.last_upload_full = full ? 1 : 0;
     if (int rc = sync_aux(map, stream)) return rc;
     h.mark_synced(full);
-    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, h.voxel_size()};
+    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, h.cap16(), h.voxel_size()};
     mr.synced_epoch = h.epoch(), mr.synced_generation = h.generation(), mr.live_slots = slots;
     return KICP_OK;
 }
@@ -175,13 +178,13 @@ int ensure_host_current(kicp_map *map) {
     const uint32_t cap = map->host.cap();
     std::vector<Slot> table(mr.live_slots);
     std::vector<double> pool(static_cast<size_t>(c.n_buckets_hi) * cap * 3);
-    std::vector<float> pool32(static_cast<size_t>(c.n_buckets_hi) * cap * 4);
+    std::vector<MirrorPoint> pool16(static_cast<size_t>(c.n_buckets_hi) * map->host.cap16());
     std::vector<uint32_t> free_list(c.free_count);
     HIP_TRY(hipMemcpy(table.data(), mr.d_table, table.size() * sizeof(Slot), hipMemcpyDeviceToHost));
     if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), mr.d_pool, pool.size() * 8, hipMemcpyDeviceToHost));
-    if (!pool32.empty()) HIP_TRY(hipMemcpy(pool32.data(), mr.d_pool32, pool32.size() * 4, hipMemcpyDeviceToHost));
+    if (!pool16.empty()) HIP_TRY(hipMemcpy(pool16.data(), mr.d_pool16, pool16.size() * sizeof(MirrorPoint), hipMemcpyDeviceToHost));
     if (!free_list.empty()) HIP_TRY(hipMemcpy(free_list.data(), mr.d_free_list, free_list.size() * 4, hipMemcpyDeviceToHost));
-    map->host.Adopt(std::move(table), std::move(pool), std::move(pool32), c.n_buckets_hi, std::move(free_list));
+    map->host.Adopt(std::move(table), std::move(pool), std::move(pool16), c.n_buckets_hi, std::move(free_list));
     map->host.mark_synced(true);
     mr.synced_epoch = map->host.epoch(), mr.synced_generation = map->host.generation();  // the mirror already holds this state
     map->device_ahead = false;
@@ -202,17 +205,17 @@ int grow_pools(kicp_map *map, size_t want_buckets) {
     const size_t buckets = std::max(want_buckets + want_buckets / 2 + 1024, have);
     const size_t doubles = buckets * cap * 3;
     double *np = nullptr;
-    float4 *np32 = nullptr;
+    MirrorPoint *np32 = nullptr;
     uint32_t *nf = nullptr;
     HIP_TRY(hipMalloc(&np, doubles * sizeof(double)));
-    HIP_TRY(hipMalloc(&np32, doubles / 3 * sizeof(float4)));
+    HIP_TRY(hipMalloc(&np32, mirror_points(doubles, cap) * sizeof(MirrorPoint)));
     HIP_TRY(hipMalloc(&nf, (buckets + 1) * 4));
     if (mr.d_pool) HIP_TRY(hipMemcpy(np, mr.d_pool, mr.pool_doubles * sizeof(double), hipMemcpyDeviceToDevice));
-    if (mr.d_pool32) HIP_TRY(hipMemcpy(np32, mr.d_pool32, mr.pool_doubles / 3 * sizeof(float4), hipMemcpyDeviceToDevice));
+    if (mr.d_pool16) HIP_TRY(hipMemcpy(np32, mr.d_pool16, mirror_points(mr.pool_doubles, cap) * sizeof(MirrorPoint), hipMemcpyDeviceToDevice));
     if (mr.d_free_list && mr.free_cap) HIP_TRY(hipMemcpy(nf, mr.d_free_list, std::min(mr.free_cap, buckets) * 4, hipMemcpyDeviceToDevice));
-    hipFree(mr.d_pool), hipFree(mr.d_pool32), hipFree(mr.d_free_list);
-    mr.d_pool = np, mr.d_pool32 = np32, mr.d_free_list = nf, mr.pool_doubles = doubles, mr.free_cap = buckets;
-    mr.view.pool = mr.d_pool, mr.view.pool32 = mr.d_pool32;
+    hipFree(mr.d_pool), hipFree(mr.d_pool16), hipFree(mr.d_free_list);
+    mr.d_pool = np, mr.d_pool16 = np32, mr.d_free_list = nf, mr.pool_doubles = doubles, mr.free_cap = buckets;
+    mr.view.pool = mr.d_pool, mr.view.pool16 = mr.d_pool16;
     return KICP_OK;
 }
 
@@ -300,7 +303,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         if ((map->dev.n_entries + n) * 2 > mr.live_slots)
             if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
         const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
-        up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool32, cap, static_cast<uint32_t>(bucket_cap),
+        up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, static_cast<uint32_t>(bucket_cap),
                       map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
         up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
         up.touched = mr.d_touched;

@@ -22,7 +22,7 @@ struct DevMap {
     unsigned long long *keys64;  // packed key of every live entry, kEmptyKey64 otherwise (find-or-insert by CAS)
     uint32_t mask;
     double *pool;
-    float4 *pool32;
+    MirrorPoint *pool16;
     uint32_t cap;
     uint32_t bucket_capacity;    // buckets the pools can hold
     double voxel_size, max_distance;
@@ -186,7 +186,8 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
     const double vs = m.voxel_size;
     const double map_resolution = sqrt(vs * vs / m.cap);
     double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
-    float4 *b32 = m.pool32 + static_cast<size_t>(bucket) * m.cap;
+    MirrorPoint *b16 = m.pool16 + static_cast<size_t>(bucket) * mirror_stride(m.cap);
+    const double upm = mirror_units_per_metre(vs);
     // walk the group in ascending input index (selection; groups are small: the pipeline feeds <= 8 points per voxel)
     uint32_t last = 0;
     bool first = true;
@@ -208,11 +209,11 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
         }
         if (too_close) continue;
         b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
-        b32[count] = make_float4(static_cast<float>(px - e.x * vs), static_cast<float>(py - e.y * vs), static_cast<float>(pz - e.z * vs), 0.f);
+        b16[count] = mirror_point(px - e.x * vs, py - e.y * vs, pz - e.z * vs, upm, 0u);
         ++count;
     }
     if (count == old_count) return;
-    reinterpret_cast<uint32_t *>(b32)[3] = count;  // the bucket's count travels in the w of point 0
+    b16[0].y = (b16[0].y & 0xffffu) | (count << 16);  // the bucket's count travels in the aux field of point 0
     e.val = (bucket << 8) | count;
     atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
     if (old_count == 0) {  // newly occupied: tell the 27 voxels that see this one (U + shift[s] == this  <=>  U = this - shift[s])

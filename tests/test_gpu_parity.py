@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-9
 SUM_RTOL = 1e-10
-VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256)]
+# (pass kernel, workgroup size[, lanes per query, xcds]): variant 0 = plain fp64 gather; variant 3 = 16-bit mirror
+# pre-selection with the scan-size defaults (2 sub-lanes per query on this 16k scan), with one lane per query (what large
+# scans run), with four, and with / without the XCD-aware block -> scan slice mapping
+VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 128, 1, 8), (3, 256, 1, 8), (3, 256, 1, 1), (3, 256, 1, 3), (3, 64, 4, 8)]
 
 
 @pytest.fixture(scope="module")
@@ -40,10 +43,14 @@ def test_reference_build_is_present():
     ref()
 
 
-def _reg(kernel, block, **kw):
+def _reg(kernel, block, lanes=None, xcds=None, **kw):
     reg = K.KinematicRegistration(**kw)
     reg.set_option("pass_kernel", kernel)
     reg.set_option("block", block)
+    if lanes is not None:
+        reg.set_option("lanes_per_query", lanes)
+    if xcds is not None:
+        reg.set_option("xcds", xcds)
     return reg
 
 
@@ -62,10 +69,10 @@ def test_closest_neighbor_matches_oracle(case1):
     assert (d_o == np.finfo(np.float64).max).any()  # some queries have no candidate
 
 
-@pytest.mark.parametrize("kernel,block", VARIANTS)
-def test_pass_sums_match_oracle(case1, kernel, block):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_pass_sums_match_oracle(case1, variant):
     cfg, scans, gmap, omap = case1
-    reg = _reg(kernel, block)
+    reg = _reg(*variant)
     for s in scans:
         guess = syn.pose_mul(s["last_pose"], s["rel_odom"])
         for tau in (cfg.first_frame_tau(), 0.2):
@@ -75,11 +82,11 @@ def test_pass_sums_match_oracle(case1, kernel, block):
             np.testing.assert_allclose(g, o, rtol=SUM_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("kernel,block", VARIANTS)
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("loop", [0, 1, 2])
-def test_registration_matches_oracle(case1, case1_ref, kernel, block, loop):
+def test_registration_matches_oracle(case1, case1_ref, variant, loop):
     cfg, scans, gmap, omap = case1
-    reg = _reg(kernel, block)
+    reg = _reg(*variant)
     reg.set_option("host_solve", 1 if loop == 2 else 0)  # 2 = default mode: host-side solve
     reg.set_option("loop", min(loop, 1))
     oreg = okicp.KinematicRegistration()
@@ -153,10 +160,10 @@ def test_all_variants_bit_identical(case1):
     by_mode = {}
     for host_solve in (1, 0):
         poses = []
-        for kernel, block in VARIANTS:
+        for variant in VARIANTS:
             for loop in (0, 1):
                 for wait in (0, 1):
-                    reg = _reg(kernel, block)
+                    reg = _reg(*variant)
                     reg.set_option("host_solve", host_solve)
                     reg.set_option("loop", loop)
                     reg.set_option("wait", wait)

@@ -14,19 +14,22 @@ pytestmark = pytest.mark.gpu
 POSE_TOL = 1e-9
 
 
-def world(seed, voxel, cap, n_beams=16, n_az=512, map_pts=60_000, half=18.0, max_range=60.0):
+def world(seed, voxel, cap, n_beams=16, n_az=512, map_pts=60_000, scale=1.0):
+    """a closed room of half-width 18 m x scale with boxes in it, a map of ~map_pts points and two 8k-point scans"""
     rng = np.random.Generator(np.random.PCG64(seed))
-    scene = syn.make_scene(rng, half=half, height=5.0, n_boxes=8, box_xy=(2.0, 6.0), box_z=(1.5, 4.0), keep_clear=2.5)
-    cfg = syn.Config("ranges", n_beams, n_az, map_pts, voxel_size=voxel, max_points_per_voxel=cap, max_range=max_range, sensor_height=1.2)
+    half, max_range = 18.0 * scale, 60.0 * scale
+    scene = syn.make_scene(rng, half=half, height=5.0 * scale, n_boxes=8, box_xy=(2.0 * scale, 6.0 * scale), box_z=(1.5 * scale, 4.0 * scale),
+                           keep_clear=2.5 * scale)
+    cfg = syn.Config("ranges", n_beams, n_az, map_pts, voxel_size=voxel, max_points_per_voxel=cap, max_range=max_range, sensor_height=1.2 * scale)
     omap = okicp.VoxelHashMap(voxel, max_range, cap)
     syn.build_map_points(scene, cfg, omap.AddPoints, omap.num_points, rng, batch=30_000, max_rounds=60)
     dirs = syn.beam_directions(n_beams, n_az, cfg.elev_deg)
     scans = []
     for k in range(2):
-        true_pose = syn.planar_pose(rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-np.pi, np.pi))
+        true_pose = syn.planar_pose(rng.uniform(-2, 2) * scale, rng.uniform(-2, 2) * scale, rng.uniform(-np.pi, np.pi))
         frame = syn.make_scan(scene, true_pose, dirs, cfg.sensor_height, rng)
         guess = syn.pose_mul(true_pose, syn.planar_pose(0.15 * voxel * (-1) ** k, 0.0, np.deg2rad(0.8)))
-        rel = syn.planar_pose(0.4, 0.0, np.deg2rad(2.0))
+        rel = syn.planar_pose(0.4 * scale, 0.0, np.deg2rad(2.0))
         scans.append((frame, syn.pose_mul(guess, syn.pose_inverse(rel)), rel))
     return cfg, omap.Pointcloud(), scans
 
@@ -78,8 +81,8 @@ def test_far_from_the_origin(shift):
 @pytest.mark.parametrize("voxel", [0.1, 0.25, 2.0])
 @pytest.mark.parametrize("tau_in_voxels", [0.05, 0.3, 0.67, 1.5, 3.0])
 def test_voxel_sizes_and_thresholds(voxel, tau_in_voxels):
-    scale = {0.1: 0.25, 0.25: 0.5, 2.0: 2.0}[voxel]  # keep the point count per voxel sensible
-    cfg, pts, scans = world(11, voxel, 20, half=18.0 * scale, max_range=60.0 * scale, map_pts=60_000)
+    scale = {0.1: 0.25, 0.25: 0.5, 2.0: 2.0}[voxel]  # shrink / grow the room with the voxel size: similar point counts per voxel
+    cfg, pts, scans = world(11, voxel, 20, scale=scale, map_pts=60_000)
     g, o, r = maps_of(pts, voxel, cfg.max_range, 20)
     for frame, last, rel in scans:
         compare(frame, g, o, r, last, rel, tau_in_voxels * voxel)
@@ -88,10 +91,10 @@ def test_voxel_sizes_and_thresholds(voxel, tau_in_voxels):
 
 @pytest.mark.parametrize("cap", [1, 5, 20, 255])
 def test_max_points_per_voxel(cap):
-    cfg, pts, scans = world(13, 1.0, cap, map_pts=min(60_000, 4_000 * max(cap, 2)))
+    cfg, pts, scans = world(13, 1.0, cap, map_pts={1: 3_000, 5: 15_000, 20: 60_000, 255: 250_000}[cap])
     g, o, r = maps_of(pts, 1.0, cfg.max_range, cap)
     if cap == 255:
-        assert g.num_points() / g.num_voxels() > 20  # buckets beyond one 20-point trip are exercised
+        assert g.num_points() / g.num_voxels() > 40  # buckets far beyond one 20-point trip are exercised
     for frame, last, rel in scans:
         for tau in (cfg.first_frame_tau(), 0.8):
             compare(frame, g, o, r, last, rel, tau)
