@@ -1,0 +1,157 @@
+"""The multi-rank code paths of the registration with MORE THAN ONE rank:
+
+  * callback all-reduce (kicp_reg_set_allreduce): 2 and 3 processes share device 0; every iteration the pass kernel leaves its
+    24 limb words in HBM, the callback sums them across the processes (through torch.distributed / gloo on the host - what
+    matters here is the DEVICE side: totals left for a collective, all-reduce on the registration's stream, k_publish_words
+    / the separate solve kernel afterwards), and every rank must return the single-process bits;
+  * built-in RCCL communicator (kicp_reg_comm_init) with two ranks on two GPUs - RCCL refuses two ranks on one device, so this
+    one needs a box with >= 2 GPUs and is skipped elsewhere;
+  * bench.py itself launched by torch.distributed.run with two ranks (host shared segment, gloo process group, both ranks on
+    device 0): the launch path the driver uses for its scaling runs must at least work end to end.
+"""
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden", "registration_small.npz")
+CASES = ("a", "b", "c")
+
+
+def _single_process_results():
+    import kinematic_icp_amd as K
+    g = np.load(GOLD)
+    single, out = K.KinematicRegistration(), []
+    for case in CASES:
+        m = K.VoxelHashMap(float(g[case + "_voxel"]), float(g[case + "_maxrange"]), 20)
+        m.AddPoints(g[case + "_map"])
+        pose = single.ComputeRobotMotion(g[case + "_frame"], m, g[case + "_last"], g[case + "_rel"], float(g[case + "_tau"]))
+        assert single.last_stats.iterations == int(g[case + "_iters"])
+        out.append((pose, single.last_stats.iterations))
+    return out
+
+
+def _run_cases(reg, world, rank):
+    import kinematic_icp_amd as K
+    from kinematic_icp_amd import sharding as sh
+    g = np.load(GOLD)
+    out = []
+    for case in CASES:
+        m = K.VoxelHashMap(float(g[case + "_voxel"]), float(g[case + "_maxrange"]), 20)
+        m.AddPoints(g[case + "_map"])
+        frame = g[case + "_frame"]
+        lo, hi = sh.shard_bounds(len(frame), world, rank)
+        pose = reg.ComputeRobotMotion(K.DeviceFrame(frame[lo:hi], device=reg.device), m, g[case + "_last"], g[case + "_rel"], float(g[case + "_tau"]))
+        out.append((pose, reg.last_stats.iterations))
+    return out
+
+
+def _callback_worker(rank, world, port, host_solve, q):
+    sys.path.insert(0, ROOT)
+    try:
+        import torch
+        import torch.distributed as dist
+        import kinematic_icp_amd as K
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group(backend="gloo")
+        torch.cuda.set_device(0)
+        reg = K.KinematicRegistration(device=0)
+        reg.set_option("host_solve", host_solve)
+        calls = []
+
+        def allreduce(ptr, count, stream):
+            class _Arr:
+                __cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+            ext = torch.cuda.ExternalStream(stream)
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_Arr(), device="cuda")
+                host = t.cpu()                       # ordered behind the pass kernel on the registration's stream
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                t.copy_(host)                        # and back, before the publish / solve kernel that follows
+                ext.synchronize()
+            calls.append(count)
+
+        reg.set_allreduce(allreduce)
+        out = _run_cases(reg, world, rank)
+        assert calls and all(c == 24 for c in calls)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, out, None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, [], repr(e) + "\n" + traceback.format_exc()))
+
+
+def _spawn(target, world, extra):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world) + extra + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, out, err = q.get(timeout=300)
+        assert err is None, "rank %d: %s" % (rank, err)
+        results[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("world,host_solve", [(2, 1), (3, 1), (2, 0)])
+def test_callback_allreduce_across_processes(world, host_solve):
+    results = _spawn(_callback_worker, world, (29600 + world * 7 + host_solve, host_solve))
+    ref = _single_process_results()
+    for r in range(world):
+        for (pose, iters), (pose1, iters1) in zip(results[r], ref):
+            assert iters == iters1
+            if host_solve:
+                assert np.array_equal(pose, pose1)  # exact integer sums, the same host-side solve: the same bits
+            else:                                   # device-side solve: libm vs device sin / cos in the last place
+                np.testing.assert_allclose(pose, pose1, rtol=0, atol=1e-13)
+
+
+def _rccl_worker(rank, world, uid, q):
+    sys.path.insert(0, ROOT)
+    try:
+        import kinematic_icp_amd as K
+        reg = K.KinematicRegistration(device=rank)
+        reg.comm_init(world, rank, uid)
+        out = _run_cases(reg, world, rank)
+        reg.comm_destroy()
+        q.put((rank, out, None))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, [], repr(e)))
+
+
+def test_rccl_allreduce_two_gpus():
+    import kinematic_icp_amd as K
+    if K.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL does not accept two ranks on one device")
+    results = _spawn(_rccl_worker, 2, (K.comm_unique_id(),))
+    ref = _single_process_results()
+    for r in range(2):
+        for (pose, iters), (pose1, iters1) in zip(results[r], ref):
+            assert iters == iters1 and np.array_equal(pose, pose1)
+
+
+def test_bench_launch_path_with_two_ranks_on_one_gpu():
+    env = dict(os.environ, KICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans-per-step", "4",
+           "--workload", "cfg1", "--comm", "shm", "--pg-backend", "gloo", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["max_pose_abs_diff_vs_oracle"] < 1e-9
+    assert out["roofline"]["kernel_avg_us"] > 0
