@@ -89,6 +89,11 @@ int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const doubl
  * refreshed lazily when a host-side call (AddPoints, kicp_map_check, ...) needs it. */
 int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
 int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU */
+/* Preferred device for BULK host-side insertions (not part of the reference API): with device >= 0, kicp_map_add_points /
+ * kicp_map_update_origin / kicp_map_update_pose calls of 4096 points or more stage their points into HBM and insert them
+ * there (the same map as the sequential host insertion builds, an order of magnitude faster); -1 (default) = always on the
+ * host.  Small calls stay on the host either way. */
+int kicp_map_set_device(kicp_map *map, int device);
 size_t kicp_map_num_points(const kicp_map *map);
 size_t kicp_map_num_voxels(const kicp_map *map);
 /* Pointcloud() -- KinematicICP.hpp:92.  Writes min(cap_points, total) points, returns total. */
@@ -117,8 +122,6 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  gather (baseline of the ablation)
  *   "block"        workgroup size (64|128|256; default 256)
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
- *   "xcds"         variant 3: 8 (default) workgroup b serves the (b % 8)-th contiguous eighth of the scan, so that each XCD's
- *                  L2 only holds one part of the scan's neighbourhood; 1 = workgroup b serves block b
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the

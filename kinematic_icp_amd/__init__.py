@@ -64,6 +64,7 @@ _SIGNATURES = {
     "kicp_map_update_pose": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
     "kicp_map_update_pose_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _dp]),
     "kicp_map_last_update_on_device": (C.c_int, [C.c_void_p]),
+    "kicp_map_set_device": (C.c_int, [C.c_void_p, C.c_int]),
     "kicp_map_num_points": (C.c_size_t, [C.c_void_p]),
     "kicp_map_num_voxels": (C.c_size_t, [C.c_void_p]),
     "kicp_map_pointcloud": (C.c_size_t, [C.c_void_p, _dp, C.c_size_t]),
@@ -139,11 +140,17 @@ def device_count():
 class VoxelHashMap:
     """kiss_icp::VoxelHashMap: host-authoritative voxel map with an HBM mirror (SURVEY.md App. A.2)."""
 
-    def __init__(self, voxel_size, max_distance, max_points_per_voxel):
+    def __init__(self, voxel_size, max_distance, max_points_per_voxel, device=None):
+        """device: preferred GPU for bulk insertions (AddPoints / Update with >= 4096 points run there); None = on the host."""
         self.voxel_size_, self.max_distance_, self.max_points_per_voxel_ = voxel_size, max_distance, max_points_per_voxel
         h = C.c_void_p()
         _check(lib().kicp_map_create(voxel_size, max_distance, max_points_per_voxel, C.byref(h)))
         self._h = h
+        if device is not None:
+            self.set_device(device)
+
+    def set_device(self, device):
+        _check(lib().kicp_map_set_device(self._h, -1 if device is None else int(device)))
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

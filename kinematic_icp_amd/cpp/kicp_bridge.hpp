@@ -33,6 +33,15 @@ inline const double *xyz(const std::vector<Eigen::Vector3d> &v) {
     static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d must be 3 packed doubles");
     return v.empty() ? nullptr : v.front().data();
 }
+// Which GPU the drop-in classes use: the reference API has no notion of a device, so the choice travels out of band -
+// KICP_DEVICE in the environment (default 0), read once per process.
+inline int default_device() {
+    static const int device = [] {
+        const char *e = std::getenv("KICP_DEVICE");
+        return e && *e ? std::atoi(e) : 0;
+    }();
+    return device;
+}
 // The reference's core throws nothing; a backend failure must not return garbage silently.
 inline void check(int rc, const char *what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + kicp_last_error());

@@ -56,7 +56,7 @@ public:
           preprocessor_(config.max_range, config.min_range, config.deskew, config.max_num_threads),
           local_map_(config.voxel_size, config.max_range, config.max_points_per_voxel) {
 #ifndef KICP_HOST_PRESTEPS
-        kicp_bridge::check(kicp_pre_create(0, &pre_), "KinematicICP");
+        kicp_bridge::check(kicp_pre_create(kicp_bridge::default_device(), &pre_), "KinematicICP");
 #endif
     }
     ~KinematicICP() { kicp_pre_destroy(pre_); }

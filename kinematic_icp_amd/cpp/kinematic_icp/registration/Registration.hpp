@@ -69,7 +69,7 @@ private:
         return kicp_reg_config{max_num_iterations_, convergence_criterion_, max_num_threads_, use_adaptive_odometry_regularization_ ? 1 : 0,
                                fixed_regularization_};
     }
-    int device_ = 0;
+    int device_ = kicp_bridge::default_device();  // KICP_DEVICE
     kicp_reg *handle_ = nullptr;
     kicp_stats last_stats_{};
 };

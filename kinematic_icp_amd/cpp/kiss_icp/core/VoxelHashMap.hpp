@@ -18,12 +18,14 @@ struct VoxelHashMap {
     explicit VoxelHashMap(double voxel_size, double max_distance, unsigned int max_points_per_voxel)
         : voxel_size_(voxel_size), max_distance_(max_distance), max_points_per_voxel_(max_points_per_voxel) {
         kicp_bridge::check(kicp_map_create(voxel_size, max_distance, max_points_per_voxel, &handle_), "VoxelHashMap");
+        kicp_map_set_device(handle_, device_);  // bulk AddPoints / Update calls from host vectors insert on the GPU
     }
     ~VoxelHashMap() { kicp_map_destroy(handle_); }
     VoxelHashMap(const VoxelHashMap &) = delete;
     VoxelHashMap &operator=(const VoxelHashMap &) = delete;
     VoxelHashMap(VoxelHashMap &&o) noexcept
-        : voxel_size_(o.voxel_size_), max_distance_(o.max_distance_), max_points_per_voxel_(o.max_points_per_voxel_), handle_(o.handle_) {
+        : voxel_size_(o.voxel_size_), max_distance_(o.max_distance_), max_points_per_voxel_(o.max_points_per_voxel_), device_(o.device_),
+          handle_(o.handle_) {
         o.handle_ = nullptr;
     }
 
@@ -66,7 +68,7 @@ struct VoxelHashMap {
 
     // backend access (not part of the reference API)
     kicp_map *handle() const { return handle_; }
-    int device_ = 0;
+    int device_ = kicp_bridge::default_device();  // KICP_DEVICE
 
 private:
     kicp_map *handle_ = nullptr;

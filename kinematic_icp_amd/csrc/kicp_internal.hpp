@@ -113,6 +113,10 @@ struct kicp_map {
     bool device_ahead = false;
     kicp::DevMapCounters dev{};
     int last_update_on_device = 0;
+    // preferred device for bulk host-side insertions (kicp_map_set_device; -1 = none: host insertion) and their staging
+    int bulk_device = -1;
+    double *d_bulk = nullptr;
+    size_t bulk_cap = 0;
     kicp_map(double vs, double md, uint32_t cap) : host(vs, md, cap) {}
 };
 

@@ -124,8 +124,7 @@ struct PassParams {
     unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     SolveParams sol;
-    uint32_t xcds;  // XCD-aware block -> scan slice mapping (xcd_slice_block): 8 on MI355X, 1 = identity
-    int32_t dbg;    // ablation switches for tools/gpu_dbg.py (0 = normal operation)
+    int32_t dbg;  // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -549,18 +548,6 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
 }
 
-// Which slice of the scan a workgroup serves.  Workgroups are handed to the 8 XCDs round-robin (b % 8, the dispatcher's
-// observed habit - a performance assumption only, nothing depends on it for correctness) and every XCD has its own 4 MiB
-// L2, so the 8 workgroups of a "row" land on 8 different L2s.  With the identity mapping every L2 therefore sees queries
-// from ALL over the scan and must hold the whole touched part of the map (table slots + buckets: more than 4 MiB on the
-// headline scan - 40 % of the L2 requests missed).  Mapped this way, XCD x serves ONE contiguous eighth of the scan - for
-// an organised LiDAR cloud a few neighbouring rings - and its L2 only has to hold that part's neighbourhood.
-__device__ __forceinline__ uint32_t xcd_slice_block(uint32_t b, uint32_t nblocks, uint32_t xcds) {
-    if (xcds <= 1u) return b;
-    const uint32_t x = b % xcds, per = nblocks / xcds, extra = nblocks % xcds;
-    return x * per + min(x, extra) + b / xcds;  // XCD x owns blocks x, x + xcds, ...: (per or per + 1) of them, laid end to end
-}
-
 // wave-uniform values belong in SGPRs: tell the compiler explicitly
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uniform_d(double v) {
@@ -839,7 +826,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_pass_gather32(const PassParams p) 
     const Pose T = load_pose(p);
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
-    const uint32_t gt = xcd_slice_block(blockIdx.x, gridDim.x, p.xcds) * BLOCK + threadIdx.x;
+    const uint32_t gt = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
     const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;

@@ -96,7 +96,6 @@ struct kicp_reg {
     int query_every = 512; // polls between hipStreamQuery calls while waiting (a call costs ~1 us of host time)
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
-    int xcds = 1;             // variant 3: XCD-aware block -> scan slice mapping (kicp_kernels.hpp::xcd_slice_block); 1 = identity
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -348,7 +347,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.partials = r->d_partials, pp.tickets = r->d_tickets;
-    pp.dbg = r->dbg, pp.xcds = static_cast<uint32_t>(r->xcds);
+    pp.dbg = r->dbg;
     SolveParams &sp = pp.sol;
     sp.pose0 = T0, sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
     sp.adaptive = r->cfg.use_adaptive_odometry_regularization, sp.fixed_regularization = r->cfg.fixed_regularization;
@@ -598,7 +597,6 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
-    else if (k == "xcds") reg->xcds = value >= 1.0 ? static_cast<int>(value) : 1;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
@@ -616,7 +614,6 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "group_rows") return reg->group_rows;
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
-    if (k == "xcds") return reg->xcds;
     if (k == "timing") return reg->timing;
     return -1.0;
 }
@@ -669,7 +666,6 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
     pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
     pp.st = reg->d_state, pp.search = search_params(max_correspondence_distance, map->mirror.view.voxel_size);
-    pp.xcds = static_cast<uint32_t>(reg->xcds);
     pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
     launch_pass(reg, pp);
     hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);

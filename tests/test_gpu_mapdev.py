@@ -79,3 +79,31 @@ def test_mixed_host_and_device_updates():
     assert g.UpdateDevice(K.DeviceFrame(pts[:100]), syn.IDENTITY) in (True, False)
     o.Clear(), o.Update(pts[:100], syn.IDENTITY)
     np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+
+
+def test_bulk_host_calls_insert_on_the_device():
+    """kicp_map_set_device: AddPoints / Update(points, origin) / Update(points, pose) from host arrays with many points go
+    through HBM; the map must equal the sequential reference's point by point (per voxel, in order), small calls stay on
+    the host, and host / bulk calls mix freely."""
+    rng = np.random.default_rng(11)
+    pts = rng.normal(0, 9, (60000, 3)) * np.array([1, 1, 0.15])
+    g, h, o = K.VoxelHashMap(1.0, 30.0, 20, device=0), K.VoxelHashMap(1.0, 30.0, 20), okicp.VoxelHashMap(1.0, 30.0, 20)
+    g.AddPoints(pts[:30000]), h.AddPoints(pts[:30000]), o.AddPoints(pts[:30000])      # bulk / host / oracle
+    assert lib_last_on_device(g) and not lib_last_on_device(h)
+    g.AddPoints(pts[30000:30100]), h.AddPoints(pts[30000:30100]), o.AddPoints(pts[30000:30100])  # small: host path (after a download)
+    g.Update(pts[30100:45000], np.array([4.0, -3.0, 0.0])), h.Update(pts[30100:45000], np.array([4.0, -3.0, 0.0]))
+    o.Update(pts[30100:45000], np.array([4.0, -3.0, 0.0]))                              # AddPoints + pruning around an origin
+    pose = syn.planar_pose(2.0, 1.0, 0.3)
+    g.Update(pts[45000:], pose), h.Update(pts[45000:], pose), o.Update(pts[45000:], pose)
+    for m in (g, h):
+        assert (m.num_points(), m.num_voxels()) == (o.num_points(), o.num_voxels())
+        assert m.check() == 0
+        np.testing.assert_array_equal(sort_rows(m.Pointcloud()), sort_rows(o.Pointcloud()))
+    q = pts[::37] + rng.normal(0, 0.2, (len(pts[::37]), 3))
+    nn_g, d_g = g.GetClosestNeighbor(q)
+    nn_o, d_o = o.GetClosestNeighbor(q)
+    assert np.array_equal(d_g, d_o) and np.array_equal(nn_g, nn_o)                      # incl. the order inside every bucket
+
+
+def lib_last_on_device(m):
+    return bool(K.lib().kicp_map_last_update_on_device(m._h))

@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-9
 SUM_RTOL = 1e-10
-# (pass kernel, workgroup size[, lanes per query, xcds]): variant 0 = plain fp64 gather; variant 3 = 16-bit mirror
-# pre-selection with the scan-size defaults (2 sub-lanes per query on this 16k scan), with one lane per query (what large
-# scans run), with four, and with / without the XCD-aware block -> scan slice mapping
-VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 128, 1, 8), (3, 256, 1, 8), (3, 256, 1, 1), (3, 256, 1, 3), (3, 64, 4, 8)]
+# (pass kernel, workgroup size[, lanes per query]): variant 0 = plain fp64 gather; variant 3 = 16-bit mirror pre-selection
+# with the scan-size default (2 sub-lanes per query on this 16k scan), with one lane per query (what large scans run) and
+# with four (what very small scans run)
+VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 64, 1), (3, 128, 1), (3, 256, 1), (3, 64, 4), (3, 256, 4)]
 
 
 @pytest.fixture(scope="module")
@@ -43,14 +43,12 @@ def test_reference_build_is_present():
     ref()
 
 
-def _reg(kernel, block, lanes=None, xcds=None, **kw):
+def _reg(kernel, block, lanes=None, **kw):
     reg = K.KinematicRegistration(**kw)
     reg.set_option("pass_kernel", kernel)
     reg.set_option("block", block)
     if lanes is not None:
         reg.set_option("lanes_per_query", lanes)
-    if xcds is not None:
-        reg.set_option("xcds", xcds)
     return reg
 
 
