@@ -2,6 +2,7 @@
 // With the real Eigen/Sophus the same code compiles: only the two param-conversion helpers differ.
 #pragma once
 #include <Eigen/Core>
+#include <Eigen/Geometry>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,21 +14,16 @@
 #include "kicp.h"
 
 namespace kicp_bridge {
+// Sophus::SE3d <-> the C-ABI's 7 parameters [qx qy qz qw tx ty tz] (Sophus' own parameter order; Eigen::Quaterniond's
+// constructor takes w first).  The same code for the real Sophus and for cpp/compat.  from_params goes through Sophus'
+// normalising quaternion constructor, like any SE3d a caller builds from a quaternion.
 inline void to_params(const Sophus::SE3d &T, double p[7]) {
-#ifdef KICP_COMPAT_SOPHUS
-    T.toParams(p);
-#else
     const auto &q = T.unit_quaternion();
     p[0] = q.x(), p[1] = q.y(), p[2] = q.z(), p[3] = q.w();
     p[4] = T.translation().x(), p[5] = T.translation().y(), p[6] = T.translation().z();
-#endif
 }
 inline Sophus::SE3d from_params(const double p[7]) {
-#ifdef KICP_COMPAT_SOPHUS
-    return Sophus::SE3d::fromParams(p);
-#else
     return Sophus::SE3d(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]));
-#endif
 }
 inline const double *xyz(const std::vector<Eigen::Vector3d> &v) {
     static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d must be 3 packed doubles");

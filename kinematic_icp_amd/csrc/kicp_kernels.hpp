@@ -819,8 +819,10 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // G consecutive lanes serve one query: the occupied neighbour voxels are dealt round-robin to the G sub-lanes, which
 // halves/quarters each lane's dependent chain and multiplies the resident waves; the sub-lanes share their running
 // minimum for culling and merge their records with shuffles at the end.  (Small scans: few waves, latency bound.)
-template <int BLOCK, int G>
-__global__ __launch_bounds__(BLOCK, 4) void k_pass_gather32(const PassParams p) {
+// OCC = waves per SIMD the register allocation aims for: 4 (<= 128 VGPRs; what scans larger than the machine want) or 3
+// (<= 168: the compiler keeps more values instead of recomputing them; for scans that do not fill three waves per SIMD).
+template <int BLOCK, int G, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);

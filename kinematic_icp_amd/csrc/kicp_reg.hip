@@ -96,6 +96,7 @@ struct kicp_reg {
     int query_every = 512; // polls between hipStreamQuery calls while waiting (a call costs ~1 us of host time)
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
+    int occupancy = 0;        // variant 3: waves per SIMD the kernel is compiled for (3 | 4); 0 = by scan size
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -139,7 +140,14 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
     const uint32_t grid = pass_grid(r, p.n);
     if (r->pass_kernel == 3) {
         const int b = normalized_block(r->block), g = lanes_for(r, p.n);
-#define KICP_G32(B, G) hipLaunchKernelGGL((k_pass_gather32<B, G>), dim3(grid), dim3(B), 0, r->stream, p)
+#define KICP_G32(B, G)                                                                                      \
+    do {                                                                                                    \
+        if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3>), dim3(grid), dim3(B), 0, r->stream, p); \
+        else hipLaunchKernelGGL((k_pass_gather32<B, G, 4>), dim3(grid), dim3(B), 0, r->stream, p);          \
+    } while (0)
+        // register budget: scans that fit the machine at three waves per SIMD (256 CUs x 4 SIMDs x 3 waves) take the roomier one
+        const size_t waves = (p.n * static_cast<size_t>(g) + 63) / 64;
+        const int occ = r->occupancy ? r->occupancy : (waves <= static_cast<size_t>(r->num_cus) * 4 * 3 ? 3 : 4);
         if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
         else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
         else { if (b == 64) KICP_G32(64, 4); else if (b == 256) KICP_G32(256, 4); else KICP_G32(128, 4); }
@@ -597,6 +605,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
+    else if (k == "occupancy") reg->occupancy = (value == 3.0 || value == 4.0) ? static_cast<int>(value) : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
@@ -614,6 +623,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "group_rows") return reg->group_rows;
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
+    if (k == "occupancy") return reg->occupancy;
     if (k == "timing") return reg->timing;
     return -1.0;
 }

@@ -1,16 +1,30 @@
+# Round-2 collection run (one gpurun call): GPU tests, the bench line, kernel trace of the same command, PMC passes of the
+# pass kernel for cfg2 and cfg5, the other BASELINE workloads, pre-steps / pipeline timings.  Everything lands under
+# gpurun_out/r02/; the summaries that are meant to be judged are copied into profiles/ by hand (profiles/README.md).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/final; mkdir -p $O
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 200 --warmup 40 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/kt.err
-python tools/prof_summary.py $(ls $O/kt/*.db | head -1) > $O/kernel_trace_stats.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  n=$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c -d $O/pmc_$n -o pmc -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/pmc_$n.err
-  python tools/prof_counters.py $(ls $O/pmc_$n/*.db | head -1) > $O/pmc_$n.txt 2>&1
+O=gpurun_out/r02; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+for w in cfg2 cfg5 cfg4; do for occ in 3 4; do
+  echo "$w occupancy=$occ"; timeout 300 python tools/prof_target.py --workload $w --calls 2000 --option occupancy=$occ 2>> $O/target.err | tee -a $O/targets.txt
+done; done
+timeout 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 1500 $O/bench_n1.json
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python bench.py --steps 10 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/kt_bench.err
+python tools/prof_summary.py $(find $O/kt_bench -name "*.db" | head -1) > $O/kernel_trace_stats.txt 2>&1; head -5 $O/kernel_trace_stats.txt
+for w in cfg2 cfg5; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$w -o kt -- python tools/prof_target.py --workload $w --calls 300 > $O/kt_$w.json 2> $O/kt_$w.err
+  python tools/prof_summary.py $(find $O/kt_$w -name "*.db" | head -1) > $O/kernel_trace_$w.txt 2>&1; grep k_pass $O/kernel_trace_$w.txt
+  i=0
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" "VALUBusy" "MeanOccupancyPerCU"; do
+    i=$((i+1))
+    timeout 120 rocprofv3 --pmc $c -d $O/pmc_${w}_$i -o pmc -- python tools/prof_target.py --workload $w --calls 200 > /dev/null 2> $O/pmc_${w}_$i.err || echo "pmc pass $i ($c) failed for $w"
+  done
+  avg=$(grep k_pass_gather32 $O/kernel_trace_$w.txt | head -1 | awk '{print $(NF-3)}')
+  python tools/prof_counters_json.py $O/r02_counters_$w.json k_pass_gather32 ${avg:-0} $(find $O/pmc_${w}_* -name "*.db") > $O/counters_$w.txt 2>&1; cat $O/counters_$w.txt
 done
-python tools/prof_traffic.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) k_pass $O/pmc_traffic.json > /dev/null 2>&1
-for w in cfg1 cfg4 cfg5; do python bench.py --workload $w --steps 200 --warmup 20 --cpu-seconds 6 > $O/bench_$w.json 2> $O/bench_$w.err; done
-python tools/bench_presteps.py > $O/presteps.txt 2>&1
-python tools/bench_pipeline.py --frames 40 --dump /tmp/pipe.bin > /dev/null 2>&1 && tests/cpp/facade_test pipeline_timed /tmp/pipe.bin > /tmp/pipe.txt && python tools/bench_pipeline.py --frames 40 --check /tmp/pipe.txt --oracle-frames 40 2>&1 | grep -v "^frame [0-9]* ms" > $O/pipeline.txt
-rm -rf $O/kt/*.db $O/pmc_*/  # keep the text summaries only
-tail -c 600 $O/bench_n1.json; cat $O/kernel_trace_stats.txt | head -8; cat $O/pmc_traffic.json; tail -3 $O/pipeline.txt
+for w in cfg1 cfg4 cfg5; do timeout 400 python bench.py --workload $w --cpu-seconds 6 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; done
+timeout 300 python tools/bench_presteps.py > $O/presteps.txt 2>&1; tail -4 $O/presteps.txt
+(timeout 300 python tools/bench_pipeline.py --frames 40 --dump /tmp/pipe.bin > /dev/null 2>&1 && timeout 300 tests/cpp/facade_test pipeline_timed /tmp/pipe.bin > /tmp/pipe.txt && timeout 600 python tools/bench_pipeline.py --frames 40 --check /tmp/pipe.txt --oracle-frames 40 2>&1 | grep -v "^frame [0-9]* ms" > $O/pipeline.txt); tail -3 $O/pipeline.txt
+find $O -name "*.db" -delete
+du -sh $O
