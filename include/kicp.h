@@ -122,7 +122,7 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  gather (baseline of the ablation)
  *   "block"        workgroup size (64|128|256; default 256)
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
- *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (3|4; 0 = chosen from the scan size)
+ *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (4 default | 3)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the

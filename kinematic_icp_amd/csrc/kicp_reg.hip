@@ -96,7 +96,7 @@ struct kicp_reg {
     int query_every = 512; // polls between hipStreamQuery calls while waiting (a call costs ~1 us of host time)
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
-    int occupancy = 0;        // variant 3: waves per SIMD the kernel is compiled for (3 | 4); 0 = by scan size
+    int occupancy = 4;        // variant 3: waves per SIMD the kernel is compiled for (4 default | 3)
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -145,9 +145,9 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
         if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3>), dim3(grid), dim3(B), 0, r->stream, p); \
         else hipLaunchKernelGGL((k_pass_gather32<B, G, 4>), dim3(grid), dim3(B), 0, r->stream, p);          \
     } while (0)
-        // register budget: scans that fit the machine at three waves per SIMD (256 CUs x 4 SIMDs x 3 waves) take the roomier one
-        const size_t waves = (p.n * static_cast<size_t>(g) + 63) / 64;
-        const int occ = r->occupancy ? r->occupancy : (waves <= static_cast<size_t>(r->num_cus) * 4 * 3 ? 3 : 4);
+        // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
+        // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
+        const int occ = r->occupancy == 3 ? 3 : 4;
         if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
         else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
         else { if (b == 64) KICP_G32(64, 4); else if (b == 256) KICP_G32(256, 4); else KICP_G32(128, 4); }
@@ -605,7 +605,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
-    else if (k == "occupancy") reg->occupancy = (value == 3.0 || value == 4.0) ? static_cast<int>(value) : 0;
+    else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
