@@ -133,6 +133,26 @@ def _d(a):
     return a, C.cast(a.ctypes.data, _dp)
 
 
+# Small arrays that come back call after call (poses): their ctypes pointer is built once.  The cache holds a reference
+# to the array, so its address - and the id() used as the key - stays valid; it is only used for arrays of at most 16
+# doubles and is bounded.
+_PTR_CACHE = {}
+
+
+def _pose_ptr(a):
+    hit = _PTR_CACHE.get(id(a))
+    if hit is not None and hit[0] is a:
+        return hit[1]
+    arr, ptr = _d(a)
+    if arr is a and arr.size <= 16:
+        if len(_PTR_CACHE) >= 256:
+            _PTR_CACHE.clear()
+        _PTR_CACHE[id(a)] = (a, ptr)
+    elif arr is not a:
+        ptr._keep = arr  # a converted temporary must outlive the call
+    return ptr
+
+
 def device_count():
     return lib().kicp_device_count()
 
@@ -288,8 +308,7 @@ class KinematicRegistration:
 
     def ComputeRobotMotion(self, frame, voxel_map, last_robot_pose, relative_wheel_odometry, max_correspondence_distance):
         """frame: (N,3) float64 host array, or a DeviceFrame already resident in HBM."""
-        a1, lp = _d(last_robot_pose)
-        a2, ro = _d(relative_wheel_odometry)
+        lp, ro = _pose_ptr(last_robot_pose), _pose_ptr(relative_wheel_odometry)
         if isinstance(frame, DeviceFrame):
             rc = _lib.kicp_register_device(self._h, voxel_map._h, frame.ptr, frame.n, lp, ro, max_correspondence_distance,
                                            self._out_p, self._stats_ref)
