@@ -171,10 +171,19 @@ __device__ __forceinline__ double limbs_to_double(const long long l[3]) {
     return (neg ? -mag : mag) / kFixScale;
 }
 
+// A lane's contribution to the seven sums of one pass: every lane serves at most ONE correspondence per pass, so each sum is
+// a single fixed-point term |t| < 2^63 (x * 2^40 with |x| < 2^23).
 struct Acc {
-    I128 v[kNumSums];
+    long long v[kNumSums];
     int range_error;
 };
+__device__ __forceinline__ long long to_fixed(double x, int &range_error) {
+    if (!(fabs(x) < kFixLimit)) {
+        range_error = 1;
+        return 0;
+    }
+    return __double2ll_rn(x * kFixScale);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // nearest-neighbour search helpers
@@ -294,13 +303,13 @@ __device__ __forceinline__ void accumulate(Acc &a, const Pose &T, double sx, dou
     double j0x, j0y, j0z, j1x, j1y, j1z;
     quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
     quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)
-    i128_add_fixed(a.v[0], j0x * j0x + j0y * j0y + j0z * j0z, a.range_error);
-    i128_add_fixed(a.v[1], j0x * j1x + j0y * j1y + j0z * j1z, a.range_error);
-    i128_add_fixed(a.v[2], j1x * j1x + j1y * j1y + j1z * j1z, a.range_error);
-    i128_add_fixed(a.v[3], j0x * rx + j0y * ry + j0z * rz, a.range_error);
-    i128_add_fixed(a.v[4], j1x * rx + j1y * ry + j1z * rz, a.range_error);
-    i128_add_fixed(a.v[5], rx * rx + ry * ry + rz * rz, a.range_error);
-    a.v[6].lo += static_cast<unsigned long long>(kFixScale);  // 1.0; cannot carry for < 2^24 points per lane
+    a.v[0] = to_fixed(j0x * j0x + j0y * j0y + j0z * j0z, a.range_error);
+    a.v[1] = to_fixed(j0x * j1x + j0y * j1y + j0z * j1z, a.range_error);
+    a.v[2] = to_fixed(j1x * j1x + j1y * j1y + j1z * j1z, a.range_error);
+    a.v[3] = to_fixed(j0x * rx + j0y * ry + j0z * rz, a.range_error);
+    a.v[4] = to_fixed(j1x * rx + j1y * ry + j1z * rz, a.range_error);
+    a.v[5] = to_fixed(rx * rx + ry * ry + rz * rz, a.range_error);
+    a.v[6] = static_cast<long long>(kFixScale);  // the count: 1.0
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -441,13 +450,12 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         return;
     }
     // Every lane contributes at most ONE correspondence per pass, so its seven sums are single terms |t| < 2^63 (the
-    // accumulation range, i128_add_fixed): three limbs of 21 bits each, and a wave's 64 values of a limb add up in int32.
+    // accumulation range, to_fixed): three limbs of 21 bits each, and a wave's 64 values of a limb add up in int32.
     int range_error = a.range_error;
     int limb[kWaveLimbs];
 #pragma unroll
     for (int i = 0; i < kNumSums; ++i) {
-        const long long t = static_cast<long long>(a.v[i].lo);
-        if (a.v[i].hi != (t >> 63)) range_error = 1;  // more than one term in a lane: not this kernel family's contract
+        const long long t = a.v[i];
         limb[3 * i] = static_cast<int>(t & 0x1FFFFF), limb[3 * i + 1] = static_cast<int>((t >> 21) & 0x1FFFFF), limb[3 * i + 2] = static_cast<int>(t >> 42);
     }
 #pragma unroll
@@ -772,13 +780,13 @@ __device__ __forceinline__ void visit_bucket(Lane &L, const MapView &m, int s, f
         const uint32_t key1 = tree_min_u32<kTrip>(key);
         const float m1 = __uint_as_float(key1 & ~31u);
         if (m1 <= L.t.b1 + margin) {  // something here can come within the margin of the running minimum
-            uint32_t rest[kTrip];
+            // (in place: the keys are not needed again)
 #pragma unroll
-            for (int u = 0; u < kTrip; ++u) rest[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
-            const uint32_t key2 = tree_min_u32<kTrip>(rest);
+            for (int u = 0; u < kTrip; ++u) key[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
+            const uint32_t key2 = tree_min_u32<kTrip>(key);
 #pragma unroll
-            for (int u = 0; u < kTrip; ++u) rest[u] = (rest[u] == key2) ? 0xFFFFFFFFu : rest[u];
-            const uint32_t key3 = tree_min_u32<kTrip>(rest);
+            for (int u = 0; u < kTrip; ++u) key[u] = (key[u] == key2) ? 0xFFFFFFFFu : key[u];
+            const uint32_t key3 = tree_min_u32<kTrip>(key);
             const uint32_t k1 = key1 & 31u, k2 = key2 & 31u;
             // with fewer than three points the far key stands in (finite, beyond every real distance)
             Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k0 + k1,
@@ -843,12 +851,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
         }
         L.todo = mine;
     }
-    float cull = L.t.b1;      // running minimum shared by the G sub-lanes (culling only)
-    float culled_at = -1.0f;  // the minimum the work list was last culled with (the first round always culls)
+    float cull = L.t.b1;  // running minimum shared by the G sub-lanes (culling only)
     while (__any(L.todo != 0u)) {
-        // which of the 27 neighbours could still hold something within the margin of the current minimum; only re-evaluated
-        // when some lane's minimum moved (the mask can only lose bits as the limit shrinks)
-        if (__any(cull != culled_at)) L.todo = cull_todo(L, cull, margin), culled_at = cull;
+        // which of the 27 neighbours could still hold something within the margin of the current minimum
+        L.todo = cull_todo(L, cull, margin);
         if (L.todo) {
             const int s = __ffs(L.todo) - 1;
             L.todo &= L.todo - 1u;

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
-for w in cfg2 cfg5 cfg4; do for occ in 3 4; do
+for w in cfg2; do for occ in 4; do
   echo "$w occupancy=$occ"; timeout 300 python tools/prof_target.py --workload $w --calls 2000 --option occupancy=$occ 2>> $O/target.err | tee -a $O/targets.txt
 done; done
 timeout 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 1500 $O/bench_n1.json
