@@ -5,15 +5,15 @@
 // `cpu_baseline` leg can check / time the HIP path against the reference arithmetic.
 // Nothing under kinematic_icp_amd/ may include, link or call this file.
 //
-// PARITY UNPINNED: the reference (PRBonn/kinematic-icp @ /root/reference) ships no tests,
-// golden vectors or fixtures and cannot be compiled in this
-// image (no Eigen / Sophus / oneTBB headers / tsl::robin_map / kiss-icp v1.2.0 source, no
-// network - SURVEY.md F7).  The in-tree parts are restated from the cited lines; the
-// third-party parts (kiss-icp v1.2.0 VoxelHashMap/VoxelUtils, Sophus SE3/SO3, Eigen 2x2
-// inverse) are restated from their published algorithms and each
-// is isolated in a named function below.  The pins available offline are (i) analytic
-// known-answer tests, (ii) an independent numpy/scipy restatement (tests/ref_numpy.py)
-// and (iii) frozen regression vectors under tests/golden/.
+// PINNING: the reference ships no tests, golden vectors or fixtures, so the pin is the
+// reference itself: `make -C oracle ref` compiles the reference's own Registration.cpp / CorrespondenceThreshold.cpp /
+// KinematicICP.cpp, unmodified, against stand-in headers for the dependencies this image lacks (oracle/ref_shim/) into
+// oracle/_ref/libkicp_ref.so, and tests/test_ref.py requires this file to equal that build BIT FOR BIT (registrations,
+// thresholds, pre-steps, whole RegisterFrame sequences); its outputs are frozen in tests/golden/ref_outputs.npz.  What
+// stays recalled rather than verified: the third-party parts both builds share by construction (kiss-icp v1.2.0
+// VoxelHashMap / VoxelUtils / Preprocessing, Sophus SE3/SO3, tsl::robin_map's iteration order), restated from their
+// published algorithms, pinned by analytic known-answer tests, scipy, and an independent
+// numpy restatement (tests/ref_numpy.py).
 //
 // Reference map (all under /root/reference/cpp/kinematic_icp/):
 //   registration/Registration.cpp:42-46    LinearSystem, Correspondences, epsilon

@@ -4,9 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
-for w in cfg2; do for occ in 4; do
-  echo "$w occupancy=$occ"; timeout 300 python tools/prof_target.py --workload $w --calls 2000 --option occupancy=$occ 2>> $O/target.err | tee -a $O/targets.txt
-done; done
+timeout 300 python tools/prof_target.py --workload cfg2 --calls 2000 2>> $O/target.err | tee -a $O/targets.txt
 timeout 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 1500 $O/bench_n1.json
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python bench.py --steps 10 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/kt_bench.err
 python tools/prof_summary.py $(find $O/kt_bench -name "*.db" | head -1) > $O/kernel_trace_stats.txt 2>&1; head -5 $O/kernel_trace_stats.txt
