@@ -122,7 +122,14 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  gather (baseline of the ablation)
  *   "block"        workgroup size (64|128|256; default 256)
  *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
+ *   "split_buckets" variant 3 with two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing
+ *                  the neighbour voxels between them (1 default | 0)
  *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (4 default | 3)
+ *   "split_buckets" variant 3 with two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing
+ *                  the neighbour voxels between them (1 default | 0)
+ *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (4 default | 3)
+ *   "pool_visits"  variant 3: after a wave's first round of bucket visits, deal the remaining ones evenly over its lanes
+ *                  instead of letting every lane walk its own list (1 | 0 | -1 = for scans of 262144 points and more, default)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the

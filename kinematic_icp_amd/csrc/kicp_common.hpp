@@ -44,17 +44,25 @@ KICP_HD uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
 
 // One point of the compact mirror the pre-selection pass reads: the offset from the voxel corner, per axis, in units of
 // voxel_size / 65536 (so the quantisation error is <= 1 unit = 1.5e-5 voxel sizes wherever the map is), 8 bytes:
-//   x = qx | qy << 16,  y = qz | aux << 16;  aux of point 0 = the bucket's point count, 0 elsewhere.
+//   x = qx | qy << 16,  y = qz | aux << 16;  aux = 0 for a point, 0xFFFF for an empty slot of the bucket.
+// The pass kernel converts the whole second word to float: a point yields its z offset exactly, an empty slot 4.3e9 units -
+// farther than anything real, so empty slots lose every comparison without being tested for.  A bucket's mirror is reset to
+// empty slots (mirror_empty) when the bucket receives its first point.
 // It only PRE-SELECTS: the winner, and anything within the error margin of it, is re-evaluated from the fp64 pool.
 using MirrorPoint = uint2;
+KICP_HD MirrorPoint mirror_empty() {
+    MirrorPoint m;
+    m.x = 0u, m.y = 0xFFFF0000u;
+    return m;
+}
 KICP_HD uint32_t mirror_quant(double offset, double units_per_metre) {  // round to nearest unit, clamped into 16 bits
     const double q = floor(offset * units_per_metre + 0.5);
     return q <= 0.0 ? 0u : (q >= 65535.0 ? 65535u : static_cast<uint32_t>(q));
 }
-KICP_HD MirrorPoint mirror_point(double ox, double oy, double oz, double units_per_metre, uint32_t aux) {
+KICP_HD MirrorPoint mirror_point(double ox, double oy, double oz, double units_per_metre) {
     MirrorPoint m;
     m.x = mirror_quant(ox, units_per_metre) | (mirror_quant(oy, units_per_metre) << 16);
-    m.y = mirror_quant(oz, units_per_metre) | (aux << 16);
+    m.y = mirror_quant(oz, units_per_metre);
     return m;
 }
 KICP_HD double mirror_units_per_metre(double voxel_size) { return 65536.0 / voxel_size; }
@@ -64,8 +72,8 @@ struct MapView {
     const Slot *table;    // capacity = mask + 1 (power of two), linear probing, no tombstones
     uint32_t mask;
     const double *pool;   // bucket b holds <= cap points at pool + b * cap * 3 (AoS xyz, insertion order)
-    const MirrorPoint *pool16; // 16-bit mirror: point k of bucket b at pool16[b * cap + k] (see MirrorPoint); the aux field of
-                               // point 0 carries the bucket's point count
+    const MirrorPoint *pool16; // 16-bit mirror: point k of bucket b at pool16[b * cap16 + k] (see MirrorPoint); slots beyond
+                               // the bucket's point count are marked empty
     uint32_t cap;         // max_points_per_voxel = bucket stride of `pool` in points
     uint32_t cap16;       // bucket stride of `pool16` in points: cap rounded up to a multiple of kMirrorTrip (mirror_stride)
     double voxel_size;

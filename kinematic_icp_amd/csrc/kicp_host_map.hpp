@@ -118,7 +118,6 @@ public:
                 if (too_close) continue;
                 b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
                 store32(bucket, count, px, py, pz, vx, vy, vz);
-                set_count32(bucket, count + 1);
                 slot.val = (bucket << 8) | (count + 1);
                 touch_slot(static_cast<size_t>(s)), touch_bucket(bucket);
             } else {
@@ -127,7 +126,6 @@ public:
                 double *b = &pool_[static_cast<size_t>(bucket) * cap_ * 3];
                 b[0] = px, b[1] = py, b[2] = pz;
                 store32(bucket, 0, px, py, pz, vx, vy, vz);
-                set_count32(bucket, 1);
                 touch_bucket(bucket);
                 occupy(vx, vy, vz, (bucket << 8) | 1u);
             }
@@ -198,13 +196,14 @@ public:
                 ++occupied, points += count;
                 const uint32_t b = e.val >> 8;
                 if (b >= n_buckets_hi_ || count > cap_) ++bad;
-                if ((pool16_[static_cast<size_t>(b) * cap16_].y >> 16) != count) ++bad;
+                for (uint32_t k = count; k < cap16_; ++k)  // empty slots are marked (what lets the kernel skip testing for them)
+                    if ((pool16_[static_cast<size_t>(b) * cap16_ + k].y >> 16) != 0xFFFFu) ++bad;
                 const double upm = mirror_units_per_metre(voxel_size_);
                 for (uint32_t k = 0; k < count; ++k) {
                     const double *p = &pool_[(static_cast<size_t>(b) * cap_ + k) * 3];
                     const MirrorPoint f = pool16_[static_cast<size_t>(b) * cap16_ + k];
                     if (to_voxel(p[0]) != e.x || to_voxel(p[1]) != e.y || to_voxel(p[2]) != e.z) ++bad;
-                    const MirrorPoint want = mirror_point(p[0] - e.x * voxel_size_, p[1] - e.y * voxel_size_, p[2] - e.z * voxel_size_, upm, k == 0 ? count : 0u);
+                    const MirrorPoint want = mirror_point(p[0] - e.x * voxel_size_, p[1] - e.y * voxel_size_, p[2] - e.z * voxel_size_, upm);
                     if (f.x != want.x || f.y != want.y) ++bad;
                     // the decoded offset is within one unit of the true one on every axis (what the kernel's margin assumes)
                     const double o[3] = {p[0] - e.x * voxel_size_, p[1] - e.y * voxel_size_, p[2] - e.z * voxel_size_};
@@ -234,13 +233,10 @@ private:
     // compact mirror used by the pre-selection pass (kicp_common.hpp::MirrorPoint): 16-bit offsets from the voxel corner,
     // so the error is <= voxel_size / 65536 per axis regardless of how far the map is from the origin
     void store32(uint32_t bucket, uint32_t k, double px, double py, double pz, int32_t vx, int32_t vy, int32_t vz) {
-        MirrorPoint &f = pool16_[static_cast<size_t>(bucket) * cap16_ + k];
-        const uint32_t aux = k == 0 ? (f.y >> 16) : 0u;  // point 0 keeps the count
-        f = mirror_point(px - vx * voxel_size_, py - vy * voxel_size_, pz - vz * voxel_size_, mirror_units_per_metre(voxel_size_), aux);
-    }
-    void set_count32(uint32_t bucket, uint32_t count) {
-        MirrorPoint &f = pool16_[static_cast<size_t>(bucket) * cap16_];
-        f.y = (f.y & 0xffffu) | (count << 16);
+        MirrorPoint *row = &pool16_[static_cast<size_t>(bucket) * cap16_];
+        if (k == 0)  // first point of a (possibly re-used) bucket: every other slot is empty from now on
+            for (uint32_t j = 1; j < cap16_; ++j) row[j] = mirror_empty();
+        row[k] = mirror_point(px - vx * voxel_size_, py - vy * voxel_size_, pz - vz * voxel_size_, mirror_units_per_metre(voxel_size_));
     }
     int64_t find(int32_t x, int32_t y, int32_t z) const {
         const size_t mask = table_.size() - 1;

@@ -124,7 +124,7 @@ struct PassParams {
     unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     SolveParams sol;
-    int32_t dbg;  // ablation switches for tools/gpu_dbg.py (0 = normal operation)
+    int32_t dbg;          // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -689,12 +689,16 @@ __device__ __forceinline__ int32_t voxel_coord(double c, double vs, double inv_v
     return static_cast<int32_t>(f);
 }
 
-// One query's search state.
-struct Lane {
-    uint32_t i;        // query index, kNoIndex32 = none
+// What a bucket visit needs to know about the query it serves (a lane may visit on behalf of another lane's query).
+struct Probe {
     float lx, ly, lz;  // the query's offset inside its own voxel, mirror units
     uint32_t slot0;    // table slot of the own voxel's entry (its record lists the 27 neighbours' buckets)
-    uint32_t todo;     // neighbour voxels still to visit (bit s = shift s of the reference's order)
+};
+// One query's search state.
+struct Lane {
+    uint32_t i;  // query index, kNoIndex32 = none
+    Probe q;
+    uint32_t todo;  // neighbour voxels still to visit (bit s = shift s of the reference's order)
     Best3 t;
 };
 constexpr float kCell = 65536.f;  // one voxel in mirror units
@@ -717,16 +721,16 @@ __device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, con
 __device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const Pose &T, uint32_t i, bool valid) {
     const SearchParams &sp = p.search;
     L.i = valid ? i : kNoIndex32;
-    L.slot0 = 0u, L.todo = 0u;
+    L.q.slot0 = 0u, L.todo = 0u;
     L.t = Best3{sp.bound_u, sp.bound_u, sp.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
     Query q;
     make_query_of(q, p, T, valid ? i : 0u);
     const double vs = p.map.voxel_size;
-    L.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
-    L.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
+    L.q.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
+    L.q.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
     // ONE probe at the own voxel: the occupancy mask of the 27 neighbours (bit s = shift s of the reference's order) and
     // the record of their buckets.  Only voxels that hold points are ever visited; empty space costs nothing.
-    if (valid && p.dbg != 2) table_lookup_entry(p.map, q.vx, q.vy, q.vz, L.slot0, L.todo);
+    if (valid && p.dbg != 2) table_lookup_entry(p.map, q.vx, q.vy, q.vz, L.q.slot0, L.todo);
     if (p.dbg == 3) L.todo &= 1u;     // experiments: own voxel only
     if (p.dbg == 5) L.todo &= 0x7Fu;  // own + faces
     if (p.dbg == 4) L.todo = 0u;      // probe only, no bucket visit
@@ -734,67 +738,83 @@ __device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const P
 // drop the neighbour voxels that cannot hold anything within the margin of `best` (units^2)
 __device__ __forceinline__ uint32_t cull_todo(const Lane &L, float best, float margin) {
     // conservative (rounded-down) squared distances to the faces of the own voxel
-    const float lo[3] = {L.lx * L.lx * 0.99999f - margin, L.ly * L.ly * 0.99999f - margin, L.lz * L.lz * 0.99999f - margin};
-    const float hi[3] = {(kCell - L.lx) * (kCell - L.lx) * 0.99999f - margin, (kCell - L.ly) * (kCell - L.ly) * 0.99999f - margin,
-                         (kCell - L.lz) * (kCell - L.lz) * 0.99999f - margin};
+    const Probe &P = L.q;
+    const float lo[3] = {P.lx * P.lx * 0.99999f - margin, P.ly * P.ly * 0.99999f - margin, P.lz * P.lz * 0.99999f - margin};
+    const float hi[3] = {(kCell - P.lx) * (kCell - P.lx) * 0.99999f - margin, (kCell - P.ly) * (kCell - P.ly) * 0.99999f - margin,
+                         (kCell - P.lz) * (kCell - P.lz) * 0.99999f - margin};
     return L.todo & alive_mask(lo, hi, best + margin);
 }
-// scan the bucket of neighbour voxel `s` of the lane's query and merge what it finds into L.t
-__device__ __forceinline__ void visit_bucket(Lane &L, const MapView &m, int s, float margin) {
+// scan the bucket of neighbour voxel `s` of query P and merge what it finds into t.  PARTS = 2: two neighbouring lanes serve the same query and share every bucket - this lane
+// takes points [10 part, 10 part + 10) of each 20-point trip (five 16-byte loads), the records are merged by the caller.
+template <int PARTS>
+__device__ __forceinline__ void visit_bucket(const Probe &P, Best3 &t, const MapView &m, int s, float margin, int part = 0) {
+    static_assert(PARTS == 1 || PARTS == 2, "a trip is dealt to one lane or to two");
+    constexpr int kMine = kTrip / PARTS;  // points of a trip this lane looks at
     const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
     // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
-    const uint32_t bucket = m.table[L.slot0].nb[s];
+    const uint32_t bucket = m.table[P.slot0].nb[s];
     const uint32_t base = bucket * m.cap;  // index into the fp64 pool
     const uint32_t stride16 = m.cap16;
     const uint4 *b = reinterpret_cast<const uint4 *>(m.pool16 + static_cast<size_t>(bucket) * stride16);
     // the query as seen from that voxel's corner, both lanes of the packed arithmetic
-    const v2f qx = {L.lx - dx * kCell, L.lx - dx * kCell}, qy = {L.ly - dy * kCell, L.ly - dy * kCell}, qz = {L.lz - dz * kCell, L.lz - dz * kCell};
+    const v2f qx = {P.lx - dx * kCell, P.lx - dx * kCell}, qy = {P.ly - dy * kCell, P.ly - dy * kCell}, qz = {P.lz - dz * kCell, P.lz - dz * kCell};
     // Branch-free loads at immediate offsets so that the compiler keeps a whole trip in flight: kTrip points = kTrip / 2
-    // 16-byte loads per trip; the count arrives with point 0 (its aux field).
-    uint32_t cnt = kTrip;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += kTrip) {
-        uint4 c[kTrip / 2];
-        const uint4 *bt = b + k0 / 2;  // the mirror's bucket stride is a multiple of kTrip: a trip never leaves the bucket
+    // 16-byte loads per trip.  Empty slots need no test: their second word converts to 4.3e9 units (kicp_common.hpp).
+    const uint32_t first = static_cast<uint32_t>(part) * kMine;  // this lane's first point within a trip
+    for (uint32_t k0 = 0; k0 < stride16; k0 += kTrip) {
+        uint4 c[kMine / 2];
+        const uint4 *bt = b + (k0 + first) / 2;  // the mirror's bucket stride is a multiple of kTrip: a trip never leaves the bucket
 #pragma unroll
-        for (int u = 0; u < kTrip / 2; ++u) c[u] = bt[u];
-        if (k0 == 0) cnt = c[0].y >> 16;
+        for (int u = 0; u < kMine / 2; ++u) c[u] = bt[u];
         // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
         // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
         // and yields value and position at once (unique keys: the lower position wins a tie, like the
         // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
-        uint32_t key[kTrip];
+        uint32_t key[kMine];
 #pragma unroll
-        for (int u = 0; u < kTrip / 2; ++u) {
+        for (int u = 0; u < kMine / 2; ++u) {
             const v2f px = {static_cast<float>(c[u].x & 0xffffu), static_cast<float>(c[u].z & 0xffffu)};
             const v2f py = {static_cast<float>(c[u].x >> 16), static_cast<float>(c[u].z >> 16)};
-            const v2f pz = {static_cast<float>(c[u].y & 0xffffu), static_cast<float>(c[u].w & 0xffffu)};
+            const v2f pz = {static_cast<float>(c[u].y), static_cast<float>(c[u].w)};  // (the whole word: z, or far away for an empty slot)
             const v2f ddx = px - qx, ddy = py - qy, ddz = pz - qz;
             const v2f d = __builtin_elementwise_fma(ddz, ddz, __builtin_elementwise_fma(ddy, ddy, ddx * ddx));
-            // (select the bits first, then and-or the position in: ONE shared far constant and inline position literals,
-            // instead of twenty distinct far keys parked in registers)
-            const uint32_t bits0 = (k0 + 2 * u < cnt) ? __float_as_uint(d.x) : kFarKey;
-            const uint32_t bits1 = (k0 + 2 * u + 1 < cnt) ? __float_as_uint(d.y) : kFarKey;
-            key[2 * u] = (bits0 & ~31u) | static_cast<uint32_t>(2 * u);
-            key[2 * u + 1] = (bits1 & ~31u) | static_cast<uint32_t>(2 * u + 1);
+            key[2 * u] = (__float_as_uint(d.x) & ~31u) | static_cast<uint32_t>(2 * u);
+            key[2 * u + 1] = (__float_as_uint(d.y) & ~31u) | static_cast<uint32_t>(2 * u + 1);
         }
-        const uint32_t key1 = tree_min_u32<kTrip>(key);
+        // the bucket ends where a trip's last slot is empty (the pair of lanes of a shared bucket must agree: the odd lane
+        // holds that slot - quad_perm [1, 1, 3, 3])
+        uint32_t last_word = c[kMine / 2 - 1].w;
+        if (PARTS == 2) last_word = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(last_word), 0xF5, 0xf, 0xf, false));
+        const bool more = (last_word >> 16) == 0u;
+        const uint32_t key1 = tree_min_u32<kMine>(key);
         const float m1 = __uint_as_float(key1 & ~31u);
-        if (m1 <= L.t.b1 + margin) {  // something here can come within the margin of the running minimum
-            // (in place: the keys are not needed again)
+        if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
+            // Runner-up: the keys are unique, so key - (key1 + 1) wraps to the top of the range for the winner alone and
+            // keeps the order of all the others (one subtraction per key instead of compare + select).  The third place is
+            // only worth a tournament when the runner-up lies within the margin of the winner; otherwise the runner-up's
+            // value stands in for it (a lower bound that can never look like a near tie).
+            const uint32_t after1 = key1 + 1u;
 #pragma unroll
-            for (int u = 0; u < kTrip; ++u) key[u] = (key[u] == key1) ? 0xFFFFFFFFu : key[u];
-            const uint32_t key2 = tree_min_u32<kTrip>(key);
+            for (int u = 0; u < kMine; ++u) key[u] -= after1;
+            const uint32_t rest2 = tree_min_u32<kMine>(key);
+            const uint32_t key2 = after1 + rest2;
+            uint32_t key3 = key2;
+            if (__uint_as_float(min(key2, kFarKey) & ~31u) - m1 <= margin) {
+                const uint32_t after2 = rest2 + 1u;  // (= key2 + 1 in the shifted keys; the winner stays at the top: it wrapped)
 #pragma unroll
-            for (int u = 0; u < kTrip; ++u) key[u] = (key[u] == key2) ? 0xFFFFFFFFu : key[u];
-            const uint32_t key3 = tree_min_u32<kTrip>(key);
-            const uint32_t k1 = key1 & 31u, k2 = key2 & 31u;
+                for (int u = 0; u < kMine; ++u) key[u] -= after2;
+                key3 = key2 + 1u + tree_min_u32<kMine>(key);
+            }
+            const uint32_t k1 = k0 + first + (key1 & 31u), k2 = k0 + first + (key2 & 31u);  // positions within the bucket
             // with fewer than three points the far key stands in (finite, beyond every real distance)
-            Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k0 + k1,
-                    base + k0 + k2, static_cast<uint32_t>(s) * 256u + k0 + k1, static_cast<uint32_t>(s) * 256u + k0 + k2};
-            best3_merge(L.t, o);
+            Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k1,
+                    base + k2, static_cast<uint32_t>(s) * 256u + k1, static_cast<uint32_t>(s) * 256u + k2};
+            best3_merge(t, o);
         }
+        if (!more) break;
     }
 }
+
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t) {
@@ -829,8 +849,11 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // minimum for culling and merge their records with shuffles at the end.  (Small scans: few waves, latency bound.)
 // OCC = waves per SIMD the register allocation aims for: 4 (<= 128 VGPRs; what scans larger than the machine want) or 3
 // (<= 168: the compiler keeps more values instead of recomputing them; for scans that do not fill three waves per SIMD).
-template <int BLOCK, int G, int OCC>
+// SPLIT (G == 2): the two sub-lanes of a query do not deal the neighbour voxels between them but share every bucket, ten
+// points each.
+template <int BLOCK, int G, int OCC, bool SPLIT>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
+    static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
@@ -842,7 +865,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
     Lane L;
     start_lane(L, p, T, i, valid);
-    if (G > 1) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
+    if (G > 1 && !SPLIT) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
         uint32_t rest = L.todo, mine = 0u;
         for (int r = 0; rest; ++r) {
             const uint32_t low = rest & (0u - rest);
@@ -858,7 +881,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
         if (L.todo) {
             const int s = __ffs(L.todo) - 1;
             L.todo &= L.todo - 1u;
-            visit_bucket(L, m, s, margin);
+            visit_bucket<SPLIT ? 2 : 1>(L.q, L.t, m, s, margin, SPLIT ? sub : 0);
         }
         cull = L.t.b1;
 #pragma unroll

@@ -188,6 +188,8 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
     double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
     MirrorPoint *b16 = m.pool16 + static_cast<size_t>(bucket) * mirror_stride(m.cap);
     const double upm = mirror_units_per_metre(vs);
+    if (old_count == 0)  // a fresh or re-used bucket: every slot of its mirror is empty until a point is stored there
+        for (uint32_t k = 0; k < mirror_stride(m.cap); ++k) b16[k] = mirror_empty();
     // walk the group in ascending input index (selection; groups are small: the pipeline feeds <= 8 points per voxel)
     uint32_t last = 0;
     bool first = true;
@@ -209,11 +211,10 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
         }
         if (too_close) continue;
         b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
-        b16[count] = mirror_point(px - e.x * vs, py - e.y * vs, pz - e.z * vs, upm, 0u);
+        b16[count] = mirror_point(px - e.x * vs, py - e.y * vs, pz - e.z * vs, upm);
         ++count;
     }
     if (count == old_count) return;
-    b16[0].y = (b16[0].y & 0xffffu) | (count << 16);  // the bucket's count travels in the aux field of point 0
     e.val = (bucket << 8) | count;
     atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
     if (old_count == 0) {  // newly occupied: tell the 27 voxels that see this one (U + shift[s] == this  <=>  U = this - shift[s])

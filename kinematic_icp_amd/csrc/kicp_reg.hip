@@ -97,6 +97,7 @@ struct kicp_reg {
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
     int occupancy = 4;        // variant 3: waves per SIMD the kernel is compiled for (4 default | 3)
+    int split_buckets = 1;    // variant 3 with two sub-lanes per query: the pair shares every bucket (1 default) | deals the voxels (0)
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -140,17 +141,25 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
     const uint32_t grid = pass_grid(r, p.n);
     if (r->pass_kernel == 3) {
         const int b = normalized_block(r->block), g = lanes_for(r, p.n);
-#define KICP_G32(B, G)                                                                                      \
-    do {                                                                                                    \
-        if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3>), dim3(grid), dim3(B), 0, r->stream, p); \
-        else hipLaunchKernelGGL((k_pass_gather32<B, G, 4>), dim3(grid), dim3(B), 0, r->stream, p);          \
+#define KICP_G32(B, G, SPLIT)                                                                                     \
+    do {                                                                                                          \
+        if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3, SPLIT>), dim3(grid), dim3(B), 0, r->stream, p); \
+        else hipLaunchKernelGGL((k_pass_gather32<B, G, 4, SPLIT>), dim3(grid), dim3(B), 0, r->stream, p);          \
+    } while (0)
+#define KICP_G32_BLOCKS(G, SPLIT)                   \
+    do {                                            \
+        if (b == 64) KICP_G32(64, G, SPLIT);        \
+        else if (b == 256) KICP_G32(256, G, SPLIT); \
+        else KICP_G32(128, G, SPLIT);               \
     } while (0)
         // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
         // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
         const int occ = r->occupancy == 3 ? 3 : 4;
-        if (g == 1) { if (b == 64) KICP_G32(64, 1); else if (b == 256) KICP_G32(256, 1); else KICP_G32(128, 1); }
-        else if (g == 2) { if (b == 64) KICP_G32(64, 2); else if (b == 256) KICP_G32(256, 2); else KICP_G32(128, 2); }
-        else { if (b == 64) KICP_G32(64, 4); else if (b == 256) KICP_G32(256, 4); else KICP_G32(128, 4); }
+        if (g == 1) KICP_G32_BLOCKS(1, false);
+        else if (g == 2 && r->split_buckets) KICP_G32_BLOCKS(2, true);
+        else if (g == 2) KICP_G32_BLOCKS(2, false);
+        else KICP_G32_BLOCKS(4, false);
+#undef KICP_G32_BLOCKS
 #undef KICP_G32
         return;
     }
@@ -606,6 +615,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
+    else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
@@ -624,6 +634,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "occupancy") return reg->occupancy;
+    if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
     return -1.0;
 }

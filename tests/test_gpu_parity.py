@@ -19,7 +19,9 @@ SUM_RTOL = 1e-10
 # (pass kernel, workgroup size[, lanes per query]): variant 0 = plain fp64 gather; variant 3 = 16-bit mirror pre-selection
 # with the scan-size default (2 sub-lanes per query on this 16k scan), with one lane per query (what large scans run) and
 # with four (what very small scans run)
-VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 64, 1), (3, 128, 1), (3, 256, 1), (3, 64, 4), (3, 256, 4)]
+# (pass kernel, workgroup size[, sub-lanes per query[, bucket sharing]])
+VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 64, 1), (3, 128, 1), (3, 256, 1), (3, 64, 4), (3, 256, 4),
+            (3, 64, 2, 1), (3, 128, 2, 1), (3, 256, 2, 1), (3, 64, 2, 0), (3, 256, 2, 0)]
 
 
 @pytest.fixture(scope="module")
@@ -43,12 +45,14 @@ def test_reference_build_is_present():
     ref()
 
 
-def _reg(kernel, block, lanes=None, **kw):
+def _reg(kernel, block, lanes=None, split=None, **kw):
     reg = K.KinematicRegistration(**kw)
     reg.set_option("pass_kernel", kernel)
     reg.set_option("block", block)
     if lanes is not None:
         reg.set_option("lanes_per_query", lanes)
+    if split is not None:
+        reg.set_option("split_buckets", split)
     return reg
 
 

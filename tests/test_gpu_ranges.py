@@ -54,6 +54,16 @@ def compare(frame, g, o, r, last, rel, tau, atol=POSE_TOL, **kw):
     assert k == oreg.last_stats.iterations and reg.last_stats.converged == oreg.last_stats.converged
     np.testing.assert_array_equal(np.array(reg.last_stats.n_corr[:k]), np.array(oreg.last_stats.n_corr[:k]))  # same decisions
     np.testing.assert_allclose(a, b, rtol=0, atol=atol, equal_nan=True)
+    # the other ways of walking the neighbourhood (one lane per query, lane pairs sharing the buckets or dealing the voxels,
+    # four lanes dealing the voxels): the sums are exact integers, so every one of them must give the identical pose
+    for lanes, split in ((1, 0), (2, 1), (2, 0), (4, 0)):
+        alt = K.KinematicRegistration(**kw)
+        alt.set_option("lanes_per_query", lanes)
+        alt.set_option("split_buckets", split)
+        a2 = alt.ComputeRobotMotion(frame, g, last, rel, tau)
+        assert alt.last_stats.iterations == k
+        np.testing.assert_array_equal(np.array(alt.last_stats.n_corr[:k]), np.array(reg.last_stats.n_corr[:k]))
+        np.testing.assert_array_equal(a2, a)
     if r is not None:
         c = rkicp.KinematicRegistration(**kw).ComputeRobotMotion(frame, r, last, rel, tau)
         np.testing.assert_allclose(a, c, rtol=0, atol=atol, equal_nan=True)

@@ -14,6 +14,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kinematic_icp_amd as K  # noqa: E402
+if os.environ.get("KICP_AB_LIB"):  # A/B runs against another build of the library (tools/ab/)
+    K.LIB_PATH = os.environ["KICP_AB_LIB"]
 from kinematic_icp_amd import synthetic as syn  # noqa: E402
 
 ap = argparse.ArgumentParser()
