@@ -1,14 +1,16 @@
 // kicp_pre.hpp -- the pipeline's pre-steps on the GPU (reference call sites
 // pipeline/KinematicICP.cpp:54-62): kiss_icp::Preprocessor::Preprocess (constant-velocity deskew + range crop, kiss-icp
 // v1.2.0 core/Preprocessing.cpp) fused with transform_points (KinematicICP.cpp:31-36), and kiss_icp::VoxelDownsample
-// (core/VoxelUtils.cpp: first point of every voxel wins).  All of them are order-sensitive on the CPU; here the order is
-// made explicit - survivors keep their input order, and "first" means lowest input index (atomicMin) - so the results
-// are deterministic and equal to the sequential reference up to the order of VoxelDownsample's output (the reference's
-// is its hash table's iteration order; ours is first-seen order).
+// (core/VoxelUtils.cpp: first point of every voxel wins, output in the hash table's iteration order).  All of them are
+// order-sensitive on the CPU; here the order is made explicit - the crop keeps input order, "first" means lowest input
+// index (atomicMin), and the downsample's output order is the reference table's, replayed per cluster - so the results
+// are deterministic and equal to the sequential reference's, order included.
 // HBM bound streaming kernels: 24-32 B read + <= 24 B written per point, fp64 throughout.
 #pragma once
+#include <cmath>
 #include "kicp_common.hpp"
 #include "kicp_se3.hpp"
+#include "kicp_table_order.hpp"
 
 namespace kicp {
 
@@ -103,17 +105,31 @@ static __global__ __launch_bounds__(256) void k_compact(const double *staged, co
 }
 
 // ---- VoxelDownsample ----------------------------------------------------------------------------------------------------
+// kiss_icp::VoxelDownsample (kiss-icp v1.2.0 core/VoxelUtils.cpp; call sites
+// pipeline/KinematicICP.cpp:40,42) keeps the first point of every voxel and returns the survivors in the ITERATION ORDER of
+// its tsl::robin_map<Voxel, Vector3d> after reserve(frame.size()).  That order decides which point of a coarser voxel the
+// second downsample keeps and the order in which local_map_.Update inserts, so it is reproduced here, in parallel:
+//   1. the device table has the reference's bucket count and the reference's ideal bucket (std::hash<Voxel> & mask).
+//      Linear probing and robin-hood probing occupy the SAME set of buckets (an insertion always ends in the first free
+//      bucket at or after the ideal one), so after k_downsample_claim the occupied slots are the reference's occupied
+//      buckets, and every maximal run of occupied slots ("cluster") holds exactly the keys the reference holds there -
+//      only their arrangement inside the run differs;
+//   2. "first" = lowest input index (atomicMin per slot), which is also the order in which the reference inserted;
+//   3. k_downsample_replay: the thread at the head of a run replays the reference's robin-hood insertions of that
+//      run's keys, in insertion order, inside the run (insertions never leave their final cluster, so clusters are
+//      independent).  Runs are short (load factor <= 0.5 by construction, typically < 0.2);
+//   4. the survivors are gathered in ascending bucket index = the reference's iteration order.
 constexpr unsigned long long kEmptyVoxelKey = ~0ull;
 struct DownsampleParams {
     const double *in;
     uint32_t n;
     double voxel_size;
-    unsigned long long *keys;  // [mask+1], kEmptyVoxelKey when free
-    uint32_t *min_index;       // [mask+1], 0xFFFFFFFF initially
-    uint32_t mask;
-    uint32_t *slot_of;         // table slot of every input point
-    uint32_t *flags;
-    uint32_t *block_counts;
+    unsigned long long *keys;  // [mask+1] packed voxel of the slot, kEmptyVoxelKey when free
+    uint32_t *min_index;       // [mask+1] lowest input index seen for the slot's voxel, 0xFFFFFFFF initially
+    uint32_t *order;           // [mask+1] after the replay: input index of the point the reference keeps in this bucket
+    uint32_t *home_at;         // [mask+1] scratch of the replay: ideal bucket of order[]'s resident
+    uint32_t mask;             // the reference's bucket count - 1
+    uint32_t *block_counts;    // occupied buckets per 256-slot block
     uint32_t *error;           // set when a voxel coordinate leaves the 21-bit packable range
 };
 
@@ -124,42 +140,57 @@ __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y,
            (static_cast<unsigned long long>(static_cast<uint32_t>(y + lim) & 0x1FFFFFu) << 21) |
            static_cast<unsigned long long>(static_cast<uint32_t>(x + lim) & 0x1FFFFFu);
 }
-__device__ __forceinline__ uint32_t hash_u64(unsigned long long k) {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return static_cast<uint32_t>(k);
-}
-
-// pass 1: every point claims / finds its voxel's slot and lowers the slot's winner to its own index
+// pass 1: every point claims / finds its voxel's slot (linear probing from the reference's ideal bucket) and lowers the
+// slot's winner to its own index
 static __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const double vs = p.voxel_size;
+    const int32_t vx = static_cast<int32_t>(floor(p.in[3 * i] / vs)), vy = static_cast<int32_t>(floor(p.in[3 * i + 1] / vs)),
+                  vz = static_cast<int32_t>(floor(p.in[3 * i + 2] / vs));
     bool ok;
-    const unsigned long long key = pack_voxel21(static_cast<int32_t>(floor(p.in[3 * i] / vs)), static_cast<int32_t>(floor(p.in[3 * i + 1] / vs)),
-                                                static_cast<int32_t>(floor(p.in[3 * i + 2] / vs)), ok);
-    if (!ok) *p.error = 1u;
-    uint32_t slot = hash_u64(key) & p.mask;
+    const unsigned long long key = pack_voxel21(vx, vy, vz, ok);
+    if (!ok) {
+        *p.error = 1u;
+        return;
+    }
+    uint32_t slot = reference_voxel_hash(vx, vy, vz) & p.mask;
     for (;;) {
         const unsigned long long seen = atomicCAS(p.keys + slot, kEmptyVoxelKey, key);
         if (seen == kEmptyVoxelKey || seen == key) break;
         slot = (slot + 1) & p.mask;
     }
     atomicMin(p.min_index + slot, i);
-    p.slot_of[i] = slot;
 }
-// pass 2: the winners are the points whose index is their voxel's minimum
-static __global__ __launch_bounds__(256) void k_downsample_flag(const DownsampleParams p) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
-    if (i < p.n) {
-        keep = p.min_index[p.slot_of[i]] == i;
-        p.flags[i] = keep ? 1u : 0u;
+
+// pass 2: one thread per bucket; heads of clusters replay them; every thread counts its bucket for the compaction
+static __global__ __launch_bounds__(256) void k_downsample_replay(const DownsampleParams p) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    bool occupied = false;
+    if (s <= p.mask) {
+        occupied = p.keys[s] != kEmptyVoxelKey;
+        if (occupied && p.keys[(s - 1u) & p.mask] == kEmptyVoxelKey) {
+            uint32_t len = 1u;
+            while (p.keys[(s + len) & p.mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
+            replay_cluster(p.keys, p.min_index, p.order, p.home_at, p.mask, s, len);
+        }
     }
-    block_count_store(keep, p.block_counts);
+    block_count_store(occupied, p.block_counts);
+}
+// pass 3: survivors in ascending bucket index (the reference's iteration order)
+static __global__ __launch_bounds__(256) void k_downsample_gather(const DownsampleParams p, const uint32_t *block_offsets, double *out) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool occupied = s <= p.mask && p.keys[s] != kEmptyVoxelKey;
+    const unsigned long long ballot = __ballot(occupied);
+    if (lane == 0) s_wave[wave] = static_cast<uint32_t>(__popcll(ballot));
+    __syncthreads();
+    if (!occupied) return;
+    uint32_t pos = block_offsets[blockIdx.x] + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    const uint32_t i = p.order[s];
+    out[3 * pos] = p.in[3 * i], out[3 * pos + 1] = p.in[3 * i + 1], out[3 * pos + 2] = p.in[3 * i + 2];
 }
 
 // ---- PointCloud2 wire-format ingest ----------------------------------------------------

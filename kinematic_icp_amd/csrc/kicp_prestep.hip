@@ -12,9 +12,8 @@ struct kicp_pre {
     double *buf[KICP_PRE_BUFFERS] = {};
     size_t buf_cap[KICP_PRE_BUFFERS] = {}, buf_n[KICP_PRE_BUFFERS] = {};
     double *d_in = nullptr, *d_ts = nullptr, *d_staged = nullptr;
-    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_slot_of = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error
-    unsigned long long *d_keys = nullptr;
-    uint32_t *d_min_index = nullptr;
+    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error
+    unsigned char *d_table = nullptr;  // downsampling table: keys | min_index | order | home_at, 20 B per bucket (kicp_pre.hpp)
     size_t cap_n = 0, table_slots = 0;
     // wire-format ingest: the raw message bytes, the stamps' extrema, what d_in / d_ts currently hold
     unsigned char *d_raw = nullptr;
@@ -28,18 +27,15 @@ namespace {
 int pre_ensure(kicp_pre *p, size_t n) {
     if (n <= p->cap_n) return KICP_OK;
     const size_t cap = n + n / 4 + 1024;
-    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
-    hipFree(p->d_keys), hipFree(p->d_min_index);
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
+    p->d_in = p->d_ts = p->d_staged = nullptr, p->d_flags = p->d_block_counts = nullptr, p->d_table = nullptr, p->cap_n = 0;
+    const size_t slots = reference_bucket_count(cap);  // >= the reference's bucket count for every frame of <= cap points
     HIP_TRY(hipMalloc(&p->d_in, cap * 24));
     HIP_TRY(hipMalloc(&p->d_ts, cap * 8));
     HIP_TRY(hipMalloc(&p->d_staged, cap * 24));
     HIP_TRY(hipMalloc(&p->d_flags, cap * 4));
-    HIP_TRY(hipMalloc(&p->d_block_counts, (cap / 256 + 2) * 4));
-    HIP_TRY(hipMalloc(&p->d_slot_of, cap * 4));
-    size_t slots = 1024;
-    while (slots < 2 * cap) slots <<= 1;
-    HIP_TRY(hipMalloc(&p->d_keys, slots * 8));
-    HIP_TRY(hipMalloc(&p->d_min_index, slots * 4));
+    HIP_TRY(hipMalloc(&p->d_block_counts, (std::max(cap, slots) / 256 + 2) * 4));
+    HIP_TRY(hipMalloc(&p->d_table, slots * 20));
     p->cap_n = cap, p->table_slots = slots;
     return KICP_OK;
 }
@@ -52,13 +48,8 @@ int pre_ensure_buf(kicp_pre *p, int b, size_t n) {
     p->buf_cap[b] = cap;
     return KICP_OK;
 }
-// flags + block counts are in place: scan, compact staged -> buffer dst, return the survivor count
-int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *out_n) {
-    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
-    if (int rc = pre_ensure_buf(p, dst, n)) return rc;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, p->d_flags, p->d_block_counts, static_cast<uint32_t>(n), p->buf[dst]);
-    HIP_TRY(hipGetLastError());
+// the survivor count (misc[0]) and the range flag (misc[1]) of the kernels queued so far -> buf_n[dst]
+int pre_finish(kicp_pre *p, int dst, size_t *out_n) {
     uint32_t misc[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -69,6 +60,15 @@ int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *ou
     p->buf_n[dst] = misc[0];
     if (out_n) *out_n = misc[0];
     return KICP_OK;
+}
+// flags + block counts are in place: scan, compact staged -> buffer dst, return the survivor count
+int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *out_n) {
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    if (int rc = pre_ensure_buf(p, dst, n)) return rc;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, p->d_flags, p->d_block_counts, static_cast<uint32_t>(n), p->buf[dst]);
+    HIP_TRY(hipGetLastError());
+    return pre_finish(p, dst, out_n);
 }
 // k_preprocess over what d_in / d_ts hold, then compaction into buffer dst
 int pre_run_preprocess(kicp_pre *p, size_t n, bool do_deskew, const double relative_motion_qt[7], const double lidar_to_base_qt[7],
@@ -113,8 +113,8 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
-    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_slot_of);
-    hipFree(p->d_keys), hipFree(p->d_min_index), hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
+    hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
     p->stage.release();
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
@@ -225,18 +225,25 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
         return KICP_OK;
     }
     if (int rc = pre_ensure(p, n)) return rc;
-    size_t slots = 1024;  // this call's table: the smallest power of two >= 2n keeps the memset small
-    while (slots < 2 * n) slots <<= 1;
-    HIP_TRY(hipMemsetAsync(p->d_keys, 0xFF, slots * 8, p->stream));
-    HIP_TRY(hipMemsetAsync(p->d_min_index, 0xFF, slots * 4, p->stream));
+    if (int rc = pre_ensure_buf(p, dst, n)) return rc;
+    // the reference's table: tsl::robin_map::reserve(frame.size()) buckets, ideal bucket = std::hash<Voxel> & mask (kicp_pre.hpp)
+    const size_t slots = reference_bucket_count(n);
+    if (slots > p->table_slots || slots > 0x80000000ull || n > slots / 2)  // n > 2^24: float rounding in reserve() lets the reference re-hash mid-way
+        return fail(KICP_ERR_CAPACITY, "frame too large for the downsampling table");
     DownsampleParams dp{};
-    dp.in = p->buf[src], dp.n = static_cast<uint32_t>(n), dp.voxel_size = voxel_size, dp.keys = p->d_keys, dp.min_index = p->d_min_index;
-    dp.mask = static_cast<uint32_t>(slots - 1), dp.slot_of = p->d_slot_of, dp.flags = p->d_flags, dp.block_counts = p->d_block_counts;
-    dp.error = p->d_misc + 1;
-    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
+    dp.in = p->buf[src], dp.n = static_cast<uint32_t>(n), dp.voxel_size = voxel_size, dp.mask = static_cast<uint32_t>(slots - 1);
+    dp.keys = reinterpret_cast<unsigned long long *>(p->d_table);
+    dp.min_index = reinterpret_cast<uint32_t *>(p->d_table + slots * 8);
+    dp.order = dp.min_index + slots, dp.home_at = dp.order + slots;
+    dp.block_counts = p->d_block_counts, dp.error = p->d_misc + 1;
+    HIP_TRY(hipMemsetAsync(p->d_table, 0xFF, slots * 16, p->stream));  // keys free, no winner yet, buckets of the replay free
+    const uint32_t grid = static_cast<uint32_t>((n + 255) / 256), sgrid = static_cast<uint32_t>((slots + 255) / 256);
     hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
-    hipLaunchKernelGGL(k_downsample_flag, dim3(grid), dim3(256), 0, p->stream, dp);
-    return pre_compact(p, p->buf[src], n, dst, out_n);
+    hipLaunchKernelGGL(k_downsample_replay, dim3(sgrid), dim3(256), 0, p->stream, dp);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, p->d_misc);
+    hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, p->d_block_counts, p->buf[dst]);
+    HIP_TRY(hipGetLastError());
+    return pre_finish(p, dst, out_n);
 }
 int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
     KICP_TRACE_CALL();

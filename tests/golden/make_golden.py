@@ -58,14 +58,6 @@ if __name__ == "__main__" and "pipeline" not in sys.argv[1:]:
 
 
 # ---- second fixture: the rows around the hot path ---------------------------------------------
-def first_seen_downsample(pts, vs):
-    """kiss_icp::VoxelDownsample with the output in first-seen order (what the device pre-steps emit; the reference's
-    order is its hash table's iteration order)."""
-    keys = np.floor(pts / vs).astype(np.int64)
-    _, first = np.unique(keys, axis=0, return_index=True)
-    return pts[np.sort(first)]
-
-
 def pipeline_fixture():
     rng = np.random.Generator(np.random.PCG64(404))
     scene = syn.make_scene(rng, half=14.0, height=4.0, n_boxes=5, box_xy=(2.0, 5.0), box_z=(1.5, 3.5), keep_clear=2.5)
@@ -98,8 +90,8 @@ def pipeline_fixture():
         xyz, stamps, mm = okicp.ingest(raw.tobytes(), len(rec), 32, 0, 4, 8, 6, 20)
         rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), delta), ext)
         in_base = okicp.se3_act(ext, okicp.preprocess(xyz, stamps, rel_lidar, max_range, min_range, True))
-        down = first_seen_downsample(in_base, voxel * 0.5)
-        source = first_seen_downsample(down, voxel * 1.5)
+        down = okicp.voxel_downsample(in_base, voxel * 0.5)   # the reference's order: its hash table's iteration order
+        source = okicp.voxel_downsample(down, voxel * 1.5)
         new = reg.ComputeRobotMotion(source, omap, last, delta, thr.ComputeThreshold())
         thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new))
         omap.Update(down, new)

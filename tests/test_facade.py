@@ -1,6 +1,6 @@
 """The drop-in C++ headers (kinematic_icp_amd/cpp): compiled here on CPU against the Eigen/Sophus stand-ins, run on
-the GPU box against the golden registration vector and against a python re-enactment of RegisterFrame built from the
-oracle's pieces (pipeline/KinematicICP.cpp:48-85)."""
+the GPU box against the golden registration vector, against a python re-enactment of RegisterFrame built from the
+oracle's pieces (pipeline/KinematicICP.cpp:48-85) and against the reference build's own RegisterFrame (oracle/_ref)."""
 import os
 import subprocess
 
@@ -9,7 +9,7 @@ import pytest
 
 from conftest import ROOT
 from kinematic_icp_amd import synthetic as syn
-from oracle import okicp
+from oracle import okicp, rkicp
 
 CPP = os.path.join(ROOT, "kinematic_icp_amd", "cpp")
 BIN = os.path.join(ROOT, "tests", "cpp", "facade_test")
@@ -34,12 +34,6 @@ def test_facade_compiles_and_links():
                 "kinematic_icp/correspondence_threshold/CorrespondenceThreshold.hpp", "kiss_icp/core/VoxelHashMap.hpp",
                 "kiss_icp/core/Preprocessing.hpp"):
         assert os.path.exists(os.path.join(CPP, inc))
-
-
-def _first_seen_downsample(pts, vs):
-    keys = np.floor(pts / vs).astype(np.int64)
-    _, first = np.unique(keys, axis=0, return_index=True)
-    return pts[np.sort(first)]
 
 
 @pytest.mark.gpu
@@ -92,21 +86,27 @@ def test_facade_pipeline_matches_oracle_pipeline(tmp_path, deskew):
     thr = okicp.CorrespondenceThreshold(voxel / np.sqrt(20), max_range, True, 1.0)
     reg = okicp.KinematicRegistration()
     last = okicp.IDENTITY.copy()
+    # ... and the reference's own KinematicICP.cpp (oracle/_ref), where the build is present
+    ref_icp = rkicp.KinematicICP(max_range=max_range, min_range=0.0, voxel_size=voxel, deskew=bool(deskew)) if rkicp.available() else None
     for k, (fr, st, dl) in enumerate(zip(frames, stamps, deltas)):
         rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), dl), ext)
         pre = okicp.preprocess(fr, st, rel_lidar, max_range, 0.0, bool(deskew))
         in_base = okicp.se3_act(ext, pre)
-        down = _first_seen_downsample(in_base, voxel * 0.5)
-        source = _first_seen_downsample(down, voxel * 1.5)
+        down = okicp.voxel_downsample(in_base, voxel * 0.5)
+        source = okicp.voxel_downsample(down, voxel * 1.5)
         tau = thr.ComputeThreshold()
         new = reg.ComputeRobotMotion(source, omap, last, dl, tau)
         thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, dl)), new))
         omap.Update(down, new)
         last = new
         pose = np.array([float(x) for x in out[2 * k].split()[1:]])
-        np.testing.assert_allclose(pose, new, rtol=0, atol=1e-8, err_msg="frame %d" % k)
+        np.testing.assert_allclose(pose, new, rtol=0, atol=1e-9, err_msg="frame %d" % k)
         sizes = [int(x) for x in out[2 * k + 1].split()[1:]]
         assert sizes == [len(in_base), len(source), omap.num_points()], "frame %d" % k
+        if ref_icp is not None:  # the drop-in pipeline against the reference's RegisterFrame, frame by frame
+            ref_frame, ref_source = ref_icp.RegisterFrame(fr, st, ext, dl)
+            np.testing.assert_allclose(pose, ref_icp.pose(), rtol=0, atol=1e-9, err_msg="frame %d vs reference build" % k)
+            assert sizes == [len(ref_frame), len(ref_source), len(ref_icp.LocalMap())], "frame %d vs reference build" % k
     assert out[-1] == "after_setpose 0 1"
 
 

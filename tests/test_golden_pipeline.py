@@ -1,6 +1,9 @@
 """tests/golden/pipeline_small.npz: four PointCloud2-style frames through RegisterFrame (ingest -> deskew + crop ->
-two-level downsample -> registration -> map update), frozen from the oracle (tests/golden/make_golden.py pipeline).
-CPU: the oracle still reproduces the fixture (drift guard).  GPU: every device stage against the frozen values."""
+two-level downsample in the reference's table order -> registration -> map update), frozen from the oracle
+(tests/golden/make_golden.py pipeline) and equal, bit for bit, to what the reference build's own KinematicICP::RegisterFrame
+returned on the same frames (tests/golden/ref_outputs.npz, frozen from oracle/_ref).
+CPU: the oracle still reproduces the fixture (drift guard) and the fixture still equals the reference build's outputs.
+GPU: every device stage against the frozen values - the device pipeline equals the reference's frame by frame."""
 import os
 
 import numpy as np
@@ -13,12 +16,6 @@ G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 STEP, OX, OY, OZ, STAMP_TYPE, OT = (int(v) for v in G["layout"])
 VOXEL, MAX_RANGE, MIN_RANGE = float(G["voxel"]), float(G["max_range"]), float(G["min_range"])
 N = int(G["n_frames"])
-
-
-def first_seen_downsample(pts, vs):
-    keys = np.floor(pts / vs).astype(np.int64)
-    _, first = np.unique(keys, axis=0, return_index=True)
-    return pts[np.sort(first)]
 
 
 def test_oracle_reproduces_pipeline_fixture():
@@ -35,8 +32,8 @@ def test_oracle_reproduces_pipeline_fixture():
         in_base = okicp.se3_act(ext, okicp.preprocess(xyz, stamps, rel_lidar, MAX_RANGE, MIN_RANGE, True))
         if k == 0:
             assert np.array_equal(xyz, G["xyz0"]) and np.array_equal(stamps, G["stamps0"]) and np.array_equal(in_base, G["in_base0"])
-        down = first_seen_downsample(in_base, VOXEL * 0.5)
-        source = first_seen_downsample(down, VOXEL * 1.5)
+        down = okicp.voxel_downsample(in_base, VOXEL * 0.5)
+        source = okicp.voxel_downsample(down, VOXEL * 1.5)
         assert np.array_equal(down, G["down%d" % k]) and np.array_equal(source, G["source%d" % k])
         new = reg.ComputeRobotMotion(source, omap, last, delta, thr.ComputeThreshold())
         np.testing.assert_allclose(new, G["pose%d" % k], rtol=0, atol=1e-12)
@@ -45,6 +42,14 @@ def test_oracle_reproduces_pipeline_fixture():
         last = new
         assert (omap.num_points(), omap.num_voxels()) == (int(G["map_points%d" % k]), int(G["map_voxels%d" % k]))
     np.testing.assert_allclose(sort_rows(omap.Pointcloud()), G["final_map_sorted"], rtol=0, atol=1e-12)
+
+
+def test_pipeline_fixture_is_the_reference_builds_output():
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_outputs.npz"))
+    for k in range(N):
+        assert np.array_equal(G["pose%d" % k], R["pipe1_%d_pose" % k]) and np.array_equal(G["source%d" % k], R["pipe1_%d_source" % k])
+        assert int(G["n_in_base%d" % k]) == int(R["pipe1_%d_nframe" % k]) and int(G["map_points%d" % k]) == int(R["pipe1_%d_nmap" % k])
+    assert np.array_equal(G["final_map_sorted"], R["pipe1_final_map_sorted"])
 
 
 @pytest.mark.gpu
@@ -68,7 +73,7 @@ def test_device_pipeline_reproduces_pipeline_fixture():
             np.testing.assert_allclose(pre.download(0), G["in_base0"], rtol=0, atol=1e-11)
         n_down, n_src = pre.VoxelDownsample(0, VOXEL * 0.5, 1), pre.VoxelDownsample(1, VOXEL * 1.5, 2)
         assert (n_down, n_src) == (len(G["down%d" % k]), len(G["source%d" % k]))
-        np.testing.assert_allclose(pre.download(1), G["down%d" % k], rtol=0, atol=1e-11)    # same survivors, same order
+        np.testing.assert_allclose(pre.download(1), G["down%d" % k], rtol=0, atol=1e-11)    # same survivors, in the reference's order
         np.testing.assert_allclose(pre.download(2), G["source%d" % k], rtol=0, atol=1e-11)
         new = reg.ComputeRobotMotion(pre.frame(2), gmap, last, delta, thr.ComputeThreshold())
         np.testing.assert_allclose(new, G["pose%d" % k], rtol=0, atol=1e-9)

@@ -1,20 +1,15 @@
 """The pipeline's pre-steps on the GPU against the oracle's restatements of kiss-icp v1.2.0
 Preprocessor::Preprocess / VoxelDownsample and pipeline/KinematicICP.cpp:31-44,54-62.
-fp64 throughout: points agree to 1e-12 (device vs host sin/cos), survivor sets and counts are identical."""
+fp64 throughout: points agree to 1e-12 (device vs host sin/cos); VoxelDownsample returns the very same points in the
+reference's order (its hash table's iteration order)."""
 import numpy as np
 import pytest
 
 import kinematic_icp_amd as K
 from kinematic_icp_amd import synthetic as syn
-from oracle import okicp
+from oracle import okicp, rkicp
 
 pytestmark = pytest.mark.gpu
-
-
-def first_seen_downsample(pts, vs):
-    keys = np.floor(pts / vs).astype(np.int64)
-    _, first = np.unique(keys, axis=0, return_index=True)
-    return pts[np.sort(first)]
 
 
 @pytest.fixture(scope="module")
@@ -51,15 +46,20 @@ def test_voxel_downsample_matches_oracle(raw):
         n = pre.VoxelDownsample(src, vs, dst)
         got = pre.download(dst)
         inp = pre.download(src)
-        ref = first_seen_downsample(inp, vs)
+        ref = okicp.voxel_downsample(inp, vs)
         assert n == len(ref)
-        np.testing.assert_array_equal(got, ref)  # the very same points, in first-seen order
-        from conftest import sort_rows
-        np.testing.assert_array_equal(sort_rows(got), sort_rows(okicp.voxel_downsample(inp, vs)))  # the oracle's set
+        np.testing.assert_array_equal(got, ref)  # the very same points in the reference's (hash table iteration) order
+        if rkicp.available():
+            np.testing.assert_array_equal(got, rkicp.voxel_downsample(inp, vs))
     # determinism and the all-in-one-voxel / all-distinct edge cases
     assert pre.VoxelDownsample(0, 1e6, 3) == len(np.unique(np.floor(frame / 1e6), axis=0)) <= 8  # one voxel per octant
-    assert np.array_equal(pre.download(3)[0], frame[0])
-    assert pre.VoxelDownsample(0, 1e-3, 3) == len(np.unique(np.floor(frame / 1e-3), axis=0))
+    np.testing.assert_array_equal(pre.download(3), okicp.voxel_downsample(frame, 1e6))
+    assert pre.VoxelDownsample(0, 1e-3, 3) == len(np.unique(np.floor(frame / 1e-3), axis=0))  # (almost) all distinct: load 0.5
+    np.testing.assert_array_equal(pre.download(3), okicp.voxel_downsample(frame, 1e-3))
+    for m in (1, 2, 3, 5, 64, 1000):  # tiny tables (2 .. 2048 buckets), incl. clusters that wrap around the table's end
+        pre.upload(1, frame[:m])
+        assert pre.VoxelDownsample(1, 0.7, 3) == len(okicp.voxel_downsample(frame[:m], 0.7))
+        np.testing.assert_array_equal(pre.download(3), okicp.voxel_downsample(frame[:m], 0.7))
     with pytest.raises(K.KicpError) as e:  # documented limit: voxel coordinates must fit +-2^20
         pre.VoxelDownsample(0, 1e-6, 3)
     assert e.value.code == K.KICP_ERR_CAPACITY
@@ -81,6 +81,6 @@ def test_presteps_feed_registration_without_leaving_the_gpu(raw):
     assert np.array_equal(a, b)
     omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
     omap.AddPoints(gmap.Pointcloud())
-    src = first_seen_downsample(first_seen_downsample(okicp.se3_act(ext, frame), 0.5), 1.5)
+    src = okicp.voxel_downsample(okicp.voxel_downsample(okicp.se3_act(ext, frame), 0.5), 1.5)
     ref = okicp.KinematicRegistration().ComputeRobotMotion(src, omap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
     np.testing.assert_allclose(a, ref, rtol=0, atol=1e-9)

@@ -1,0 +1,60 @@
+"""Table-order VoxelDownsample (kiss-icp v1.2.0 core/VoxelUtils.cpp): the survivors come out in the
+iteration order of the reference's robin-hood table.  CPU side of it:
+  * the integer core of the device kernels (csrc/kicp_table_order.hpp: claim in any order + per-cluster replay) against a
+    sequential robin-hood table (tests/cpp/downsample_order_test.cpp, compiled with g++ from the very header the kernels use);
+  * the drop-in HOST VoxelDownsample against the oracle and, where present, the reference build.
+The kernels themselves: tests/test_gpu_presteps.py, tests/test_golden_pipeline.py, tests/test_facade.py (GPU)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from kinematic_icp_amd import synthetic as syn
+from oracle import okicp
+
+CPP = os.path.join(ROOT, "kinematic_icp_amd", "cpp")
+
+
+def test_cluster_replay_equals_sequential_robin_hood(tmp_path):
+    exe = str(tmp_path / "downsample_order_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "downsample_order_test.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True).strip()
+    assert out.startswith("ok "), out
+    assert int(out.split()[1]) > 80
+
+
+def _clouds():
+    rng = np.random.Generator(np.random.PCG64(5))
+    cfg, scene, scans, _ = syn.make_case("cfg1", n_scans=1)
+    yield "scan", scans[0]["frame"], 0.5
+    yield "scan_coarse", scans[0]["frame"], 1.5
+    yield "dense_duplicates", rng.uniform(-3, 3, (5000, 3)), 1.0
+    yield "all_distinct", rng.uniform(-200, 200, (4096, 3)), 0.05  # load factor 0.5: long clusters
+    yield "negative_side", rng.uniform(-50, -49, (300, 3)), 0.1
+    yield "single", np.array([[0.1, -0.2, 0.3]]), 1.0
+
+
+def test_host_drop_in_downsample_has_the_reference_order(tmp_path):
+    exe = str(tmp_path / "host_downsample_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", CPP, "-I", os.path.join(CPP, "compat"),
+                           os.path.join(ROOT, "tests", "cpp", "host_downsample_test.cpp"), "-o", exe])
+    try:
+        from oracle import rkicp
+        ref = rkicp if rkicp.available() else None
+    except Exception:  # noqa: BLE001
+        ref = None
+    for name, pts, vs in _clouds():
+        f = tmp_path / (name + ".bin")
+        np.ascontiguousarray(pts, dtype=np.float64).tofile(f)
+        got = np.frombuffer(subprocess.check_output([exe, str(f), repr(vs)]), dtype=np.float64).reshape(-1, 3)
+        want = okicp.voxel_downsample(pts, vs)
+        assert np.array_equal(got, want), name
+        if ref is not None:
+            assert np.array_equal(got, ref.voxel_downsample(pts, vs)), name
+        # and it IS order sensitive: first-seen order is a different sequence on anything but trivial inputs
+        if len(want) > 50:
+            keys = np.floor(pts / vs).astype(np.int64)
+            _, first = np.unique(keys, axis=0, return_index=True)
+            assert not np.array_equal(pts[np.sort(first)], want), name

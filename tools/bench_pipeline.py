@@ -86,8 +86,8 @@ def main():
             rel_lidar = okicp.se3_mul(okicp.se3_mul(okicp.se3_inverse(ext), deltas[k]), ext)
             pre = okicp.preprocess(frames[k], stamps[k], rel_lidar, a.max_range, 0.0, bool(a.deskew))
             in_base = okicp.se3_act(ext, pre)
-            down = test_facade._first_seen_downsample(in_base, a.voxel * 0.5)  # the order the device pre-steps emit
-            source = test_facade._first_seen_downsample(down, a.voxel * 1.5)
+            down = okicp.voxel_downsample(in_base, a.voxel * 0.5)  # the reference's table order, which the device pre-steps emit too
+            source = okicp.voxel_downsample(down, a.voxel * 1.5)
             new = reg.ComputeRobotMotion(source, omap, last, deltas[k], thr.ComputeThreshold())
             thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, deltas[k])), new))
             omap.Update(down, new)
