@@ -76,6 +76,9 @@ int kicp_device_count(void); /* number of visible HIP devices, <0 on runtime fai
 /* VoxelHashMap(voxel_size, max_distance, max_points_per_voxel)   -- pipeline/KinematicICP.hpp:79 */
 int kicp_map_create(double voxel_size, double max_distance, unsigned int max_points_per_voxel, kicp_map **out);
 void kicp_map_destroy(kicp_map *map);
+/* VoxelHashMap(const VoxelHashMap &): the reference's map is copyable (it holds its tsl::robin_map by value); a deep copy
+ * of the newest state (pulled back from the GPU first if the device copy is ahead), with its own HBM mirror on first use */
+int kicp_map_clone(const kicp_map *map, kicp_map **out);
 int kicp_map_clear(kicp_map *map);                                           /* Clear()  -- KinematicICP.hpp:88 */
 int kicp_map_empty(const kicp_map *map);                                     /* Empty()  -- Registration.cpp:157 */
 int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n);         /* AddPoints(points) */

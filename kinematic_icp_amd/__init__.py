@@ -56,6 +56,7 @@ _SIGNATURES = {
     "kicp_device_count": (C.c_int, []),
     "kicp_map_create": (C.c_int, [C.c_double, C.c_double, C.c_uint, C.POINTER(C.c_void_p)]),
     "kicp_map_destroy": (None, [C.c_void_p]),
+    "kicp_map_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "kicp_map_clear": (C.c_int, [C.c_void_p]),
     "kicp_map_empty": (C.c_int, [C.c_void_p]),
     "kicp_map_add_points": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
@@ -171,6 +172,15 @@ class VoxelHashMap:
 
     def set_device(self, device):
         _check(lib().kicp_map_set_device(self._h, -1 if device is None else int(device)))
+
+    def copy(self):
+        """VoxelHashMap(const VoxelHashMap&): a deep copy of the newest state."""
+        c = VoxelHashMap.__new__(VoxelHashMap)
+        c.voxel_size_, c.max_distance_, c.max_points_per_voxel_ = self.voxel_size_, self.max_distance_, self.max_points_per_voxel_
+        h = C.c_void_p()
+        _check(lib().kicp_map_clone(self._h, C.byref(h)))
+        c._h = h
+        return c
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

@@ -2,13 +2,15 @@
 // MI355X library (host map + HBM mirror, either side may hold the newest state).  Same struct name, constructor, methods and public
 // configuration fields (reference call sites: registration/Registration.cpp:63,74,157,
 // pipeline/KinematicICP.hpp:79,88,92,94-95, pipeline/KinematicICP.cpp:79).
-// Not reproduced: the public `map_` member (a tsl::robin_map; an implementation detail no caller in the
-// reference touches).  Copying is disabled (the reference never copies its map).
+// Copyable and movable like the reference's struct (a copy is a deep copy of the newest state, wherever it lives).
+// Not reproduced: the public `map_` member (a tsl::robin_map; an implementation detail no caller in the reference touches -
+// the container lives behind the C-ABI as a flat table + bucket pools).
 #pragma once
 #include <Eigen/Core>
 #include <limits>
 #include <sophus/se3.hpp>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "kicp_bridge.hpp"
@@ -21,12 +23,19 @@ struct VoxelHashMap {
         kicp_map_set_device(handle_, device_);  // bulk AddPoints / Update calls from host vectors insert on the GPU
     }
     ~VoxelHashMap() { kicp_map_destroy(handle_); }
-    VoxelHashMap(const VoxelHashMap &) = delete;
-    VoxelHashMap &operator=(const VoxelHashMap &) = delete;
+    VoxelHashMap(const VoxelHashMap &o)
+        : voxel_size_(o.voxel_size_), max_distance_(o.max_distance_), max_points_per_voxel_(o.max_points_per_voxel_), device_(o.device_) {
+        kicp_bridge::check(kicp_map_clone(o.handle_, &handle_), "VoxelHashMap(const VoxelHashMap&)");
+    }
     VoxelHashMap(VoxelHashMap &&o) noexcept
         : voxel_size_(o.voxel_size_), max_distance_(o.max_distance_), max_points_per_voxel_(o.max_points_per_voxel_), device_(o.device_),
           handle_(o.handle_) {
         o.handle_ = nullptr;
+    }
+    VoxelHashMap &operator=(VoxelHashMap o) noexcept {  // copy / move and swap
+        std::swap(voxel_size_, o.voxel_size_), std::swap(max_distance_, o.max_distance_), std::swap(max_points_per_voxel_, o.max_points_per_voxel_);
+        std::swap(device_, o.device_), std::swap(handle_, o.handle_);
+        return *this;
     }
 
     inline void Clear() { kicp_map_clear(handle_); }

@@ -390,6 +390,15 @@ void kicp_map_destroy(kicp_map *map) {
     free_mirror(map->mirror);
     delete map;
 }
+int kicp_map_clone(const kicp_map *map, kicp_map **out) {
+    if (!map || !out) return fail(KICP_ERR_ARG, "null argument");
+    if (int rc = ensure_host_current(const_cast<kicp_map *>(map))) return rc;  // (refreshing the host copy does not change the map's value)
+    kicp_map *c = new kicp_map(map->host.voxel_size(), map->host.max_distance(), map->host.cap());
+    c->host = map->host;  // table, pools, free list, counters; the copy's mirror starts empty and uploads on first use
+    c->bulk_device = map->bulk_device;
+    *out = c;
+    return KICP_OK;
+}
 int kicp_map_set_device(kicp_map *map, int device) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (device >= 0) {

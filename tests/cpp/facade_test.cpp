@@ -52,6 +52,16 @@ int main(int argc, char **argv) {
             reg.max_num_iterations_ = 1;  // public mutable field, as in the reference
             reg.ComputeRobotMotion(frame, map, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]);
             printf("iterations_after_edit %d\n", reg.last_stats().iterations);
+            // the map is copyable like the reference's struct: a copy registers to the same pose, and clearing the original
+            // leaves the copy alone
+            kiss_icp::VoxelHashMap copy(map);
+            map.Clear();
+            kiss_icp::VoxelHashMap assigned(h[2], h[3], 20);
+            assigned = copy;
+            reg.max_num_iterations_ = 10;
+            print_pose("pose_on_copy", reg.ComputeRobotMotion(frame, assigned, kicp_bridge::from_params(last.data()),
+                                                              kicp_bridge::from_params(rel.data()), h[4]));
+            printf("original_empty %d copy_points %zu\n", map.Empty() ? 1 : 0, copy.Pointcloud().size());
         } else if (mode == "pipeline") {
             const auto h = read_doubles(f, 4);  // n_frames, voxel, max_range, deskew
             kinematic_icp::pipeline::Config cfg;

@@ -53,6 +53,8 @@ def test_facade_registration_matches_golden(tmp_path):
     nn, d = m.GetClosestNeighbor(g["a_frame"][:1])
     np.testing.assert_array_equal(np.array([float(x) for x in out[2].split()[1:]]), np.concatenate([nn[0], d]))
     assert out[3] == "iterations_after_edit 1"
+    np.testing.assert_array_equal(np.array([float(x) for x in out[4].split()[1:]]), pose)  # registration against a copy of the map
+    assert out[5] == "original_empty 1 copy_points %d" % m.num_points()
 
 
 @pytest.mark.gpu

@@ -81,6 +81,26 @@ def test_host_map_equals_oracle_map():
         assert g.num_points() > 0
 
 
+def test_map_copy_is_deep():
+    # the reference's VoxelHashMap is copyable: kicp_map_clone / the drop-in's copy constructor
+    rng = np.random.default_rng(22)
+    pts = rng.normal(0, 6, (6000, 3)) * np.array([1, 1, 0.2])
+    g = K.VoxelHashMap(0.8, 50.0, 11)
+    g.AddPoints(pts[:3000])
+    c = g.copy()
+    assert (c.voxel_size_, c.max_distance_, c.max_points_per_voxel_) == (0.8, 50.0, 11)
+    np.testing.assert_array_equal(c.Pointcloud(), g.Pointcloud())  # same points in the same table order
+    assert (c.num_points(), c.num_voxels(), c.check()) == (g.num_points(), g.num_voxels(), 0)
+    before = g.Pointcloud()
+    c.Update(pts[3000:], syn.planar_pose(1.0, 0.5, 0.2))  # the copy moves on ...
+    np.testing.assert_array_equal(g.Pointcloud(), before)   # ... the original does not
+    o = okicp.VoxelHashMap(0.8, 50.0, 11)
+    o.AddPoints(pts[:3000]), o.Update(pts[3000:], syn.planar_pose(1.0, 0.5, 0.2))
+    np.testing.assert_array_equal(sort_rows(c.Pointcloud()), sort_rows(o.Pointcloud()))
+    g.Clear()
+    assert c.num_points() == o.num_points() and g.Empty()
+
+
 def test_host_map_insertion_order_inside_a_bucket():
     # the query's tie rule depends on insertion order, so Pointcloud must list a voxel's points in that order
     g = K.VoxelHashMap(1.0, 100.0, 20)
