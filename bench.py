@@ -4,7 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one BATCH of --scans-per-step (default 64) ComputeRobotMotion calls (all ICP iterations of each scan) on
+One "step" = one BATCH of --scans-per-step (default 64) ComputeRobotMotion calls (all ICP iterations of each scan; the batch
+is ONE call of the C-ABI's kicp_register_device_batch, which registers the scans strictly one after the other - what a C++
+caller sees; the rate with one Python call per scan is reported next to it in `config`) on
 synthetic data of BASELINE.json's headline config: cfg2 = 64-beam x 2048 = 131 072-point scan vs a ~1M-point voxel map
 (voxel 1.0 m, 20 pts/voxel), default ICP parameters (max 10 iterations, 1e-3 stop, adaptive regularisation), tau =
 first-frame adaptive value.  Inputs (scans, map mirror) are resident in HBM when the timed region starts; map
@@ -19,8 +21,9 @@ N > 1: the scan's points are sharded contiguously across the N ranks, the map is
 sums 24 int64 words per rank (the exact limb sums of the 2x2 normal equations), so every rank returns the bit-identical
 pose.  --comm selects the exchange: "rccl" (default, the north star: ncclAllReduce over xGMI on the registration's
 stream), "shm" (every rank's host adds its GPU's rows and the ranks meet in a node-wide host shared segment: no device
-collective), "torch" (torch.distributed all-reduce callback).  With --comm rccl the shm figure is measured too and
-reported in `config`.  Total work is fixed -> "scaling": "strong".  (--mode replicas, not the default: every rank
+collective), "p2p" (one-shot exchange: every pass kernel writes its totals into all ranks' HBM mailboxes over xGMI peer
+mappings and adds the node's totals itself - no collective library), "torch" (torch.distributed all-reduce callback).  With
+--comm rccl the shm and p2p figures are measured too and reported in `config`.  Total work is fixed -> "scaling": "strong".  (--mode replicas, not the default: every rank
 registers whole scans on its own - one robot per GPU - no exchange, "scaling": "weak".)
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
@@ -68,9 +71,10 @@ def main():
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "torch"],
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "p2p", "torch"],
                     help="N>1 exchange of the per-iteration sums: built-in RCCL all-reduce (default), host shared segment (no device "
-                         "collective), or torch.distributed all-reduce callback")
+                         "collective), one-shot peer-mailbox exchange over xGMI mappings (no collective library), or torch.distributed "
+                         "all-reduce callback")
     ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for barriers/timing")
     ap.add_argument("--mode", default="shard", choices=["shard", "replicas"],
                     help="N>1: 'shard' (default, the north star) splits every scan's points across the ranks and exchanges the sums each "
@@ -157,6 +161,12 @@ def main():
                 uid.copy_(torch.frombuffer(bytearray(K.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
             reg.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        elif comm == "p2p":
+            mine = torch.frombuffer(bytearray(reg.p2p_export(world, rank)), dtype=torch.uint8).to(pg_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            reg.p2p_connect([bytes(t.cpu().numpy().tobytes()) for t in every])
+            dist.barrier()
         elif comm == "torch":
             def allreduce(ptr, count, stream):
                 # wrap the device buffer without copying and reduce it in place on the registration's own stream
@@ -172,10 +182,12 @@ def main():
     def release(reg, comm):
         if comm == "rccl":
             reg.comm_destroy()
-        if comm in ("rccl", "shm", "torch"):
+        if comm in ("rccl", "shm", "torch", "p2p"):
             dist.barrier()
         if comm == "shm":
             reg.shm_destroy()
+        if comm == "p2p":
+            reg.p2p_destroy()
 
     def barrier():
         if use_comm:
@@ -193,14 +205,26 @@ def main():
 
     B = max(1, args.scans_per_step)
 
-    def timed(reg, rels, steps, warmup):
-        """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks."""
-        for i in range(warmup * B):
-            run_scan(reg, i, rels)
+    def timed(reg, rels, steps, warmup, per_call=False):
+        """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
+        A step is ONE kicp_register_device_batch call: the library registers the step's B scans one after the other (a plain
+        loop of ComputeRobotMotion, each scan run to completion before the next starts) - what a C++ caller of the C-ABI
+        sees.  per_call=True issues the B calls from Python instead (adds the interpreter's ~3 us per call)."""
+        batch = reg.prepare_batch([frames[i % len(scans)] for i in range(B)], [scans[i % len(scans)]["last_pose"] for i in range(B)],
+                                  [rels[i % len(scans)] for i in range(B)])
+
+        def step(k):
+            if per_call:
+                for i in range(k * B, (k + 1) * B):
+                    run_scan(reg, i, rels)
+            else:
+                reg.ComputeRobotMotionBatch(batch, gmap, tau)
+        for k in range(warmup):
+            step(k)
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps * B):
-            run_scan(reg, i, rels)
+        for k in range(steps):
+            step(k)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -229,6 +253,7 @@ def main():
             run_scan(reg, i, rel_single)
     elapsed = timed(reg, rel_single, args.steps, args.warmup)                 # ---- the headline number
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
+    elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
     # ---- second pass over the same steps with HIP events around every pass-kernel launch (roofline) -------------
     reg.set_option("timing", 2)
@@ -271,13 +296,21 @@ def main():
         release(reg, comm)
     del reg
     other = {}
-    if exchange and args.comm == "rccl":  # the host-side exchange on the same box, for comparison
-        reg2, keep2 = make_reg("shm")
-        for i in range(100):
-            run_scan(reg2, i, rel_single)
-        other["shm_scans_per_s"] = round(args.steps * B / timed(reg2, rel_single, args.steps, min(args.warmup, 2)), 1)
-        release(reg2, "shm")
-        del reg2
+    if exchange and args.comm == "rccl":  # the other exchanges on the same box, for comparison
+        for alt in ("shm", "p2p"):
+            try:
+                reg2, keep2 = make_reg(alt)
+            except K.KicpError as e:  # e.g. IPC mappings unavailable: say so, keep the line
+                other[alt + "_note"] = str(e)[:200]
+                continue
+            try:
+                for i in range(100):
+                    run_scan(reg2, i, rel_single)
+                other[alt + "_scans_per_s"] = round(args.steps * B / timed(reg2, rel_single, args.steps, min(args.warmup, 2)), 1)
+            except K.KicpError as e:
+                other[alt + "_note"] = str(e)[:200]
+            release(reg2, alt)
+            del reg2
     if use_comm:  # all GPU work is done: tear the process group down before rank 0's CPU-only epilogue
         dist.barrier()
         dist.destroy_process_group()
@@ -352,11 +385,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
-                               "(mean %.2f per scan, reference %.2f); one step = a batch of %d scans"
+                               "(mean %.2f per scan, reference %.2f); one step = one kicp_register_device_batch call = %d scans registered one after the other"
                                % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(), cfg.voxel_size, tau, iters_gpu,
                                   float(np.mean(iters_ref)), B),
                    "scans_per_step": B, "ms_per_scan": round(1e3 * elapsed / n_scans_timed, 5), "timed_region_s": round(elapsed, 4),
                    "points_per_gpu": hi - lo,
+                   "scans_per_s_one_python_call_per_scan": round((world if replicas else 1) * n_scans_timed / elapsed_py, 2),
                    "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
                                   (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
                    "pass_kernel": pass_kernel, "max_pose_abs_diff_vs_oracle": max_pose_err,

@@ -153,6 +153,14 @@ int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t 
 int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
                          const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
                          kicp_stats *stats);
+/* A queue of INDEPENDENT registrations against one map (several robots on one map, replayed scans): exactly a loop of
+ * kicp_register_device over `count` scans - every scan runs launch -> hand-off -> solve to completion before the next one
+ * starts, nothing is overlapped - without a language binding's per-call cost in between.  Poses: count x 7 doubles.
+ * `out_iterations` (nullable): ICP iterations each scan ran.  Stops at the first error (< 0); otherwise returns the
+ * largest warning code seen (KICP_OK if none). */
+int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const double *const *d_frames_xyz, const size_t *n,
+                               const double *last_poses_qt, const double *rel_odoms_qt, double max_correspondence_distance,
+                               double *out_poses_qt, int *out_iterations);
 /* One fused association+accumulation pass at a fixed pose (DataAssociation + the reduction of
  * ComputePerturbation + the sum of ComputeOdometryRegularization; Registration.cpp:62-81,102-118,51-55).
  * out_sums = {JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2, N_corr}, un-normalised.  Host frame pointer. */
@@ -235,6 +243,18 @@ int kicp_reg_comm_destroy(kicp_reg *reg);
  * of kicp_register* calls. */
 int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name);
 int kicp_reg_shm_destroy(kicp_reg *reg);
+/* One-shot exchange over peer mappings: no collective library, no host shared segment.  Every
+ * rank (one process per GPU) owns a mailbox in its HBM; the last workgroup of every pass kernel writes the rank's 24 exact
+ * limb totals - tagged - into ALL ranks' mailboxes (the peers' through IPC mappings: stores over xGMI), collects the
+ * nranks slots of its own mailbox, adds them in rank order (integers: bit-identical on every rank) and hands the totals
+ * to its host, which solves.  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
+ * transport), every rank calls kicp_reg_p2p_connect with the nranks handles in rank order; a barrier between connect and
+ * the first registration, and before kicp_reg_p2p_destroy, is the caller's.  nranks <= KICP_P2P_MAX_RANKS. */
+#define KICP_P2P_HANDLE_BYTES 64
+#define KICP_P2P_MAX_RANKS 16
+int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2P_HANDLE_BYTES]);
+int kicp_reg_p2p_connect(kicp_reg *reg, const char *handles /* nranks * KICP_P2P_HANDLE_BYTES, rank order */);
+int kicp_reg_p2p_destroy(kicp_reg *reg);
 /* Alternative to the built-in RCCL communicator: the caller supplies the sum-all-reduce (e.g. torch.distributed).
  * Called once per ICP iteration with a device buffer of `count` int64 values to be sum-reduced IN PLACE, ordered
  * on `stream` (a hipStream_t).  Return 0 on success.  Pass NULL to remove. */

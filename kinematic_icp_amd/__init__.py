@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkicp_amd.so")
 MAX_LOG_PASSES = 32
+P2P_HANDLE_BYTES = 64
 COMM_ID_BYTES = 128
 
 KICP_OK = 0
@@ -81,6 +82,8 @@ _SIGNATURES = {
     "kicp_reg_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "kicp_register": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
+    "kicp_register_device_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _dp, _dp,
+                                             C.c_double, _dp, C.POINTER(C.c_int)]),
     "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "kicp_pass_words": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_longlong)]),
     "kicp_pre_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -103,6 +106,9 @@ _SIGNATURES = {
     "kicp_reg_comm_destroy": (C.c_int, [C.c_void_p]),
     "kicp_reg_shm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "kicp_reg_shm_destroy": (C.c_int, [C.c_void_p]),
+    "kicp_reg_p2p_export": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "kicp_reg_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "kicp_reg_p2p_destroy": (C.c_int, [C.c_void_p]),
     "kicp_reg_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
 }
 
@@ -270,6 +276,10 @@ class DeviceFrame:
             self.ptr = None
 
 
+class _Batch:
+    pass
+
+
 class KinematicRegistration:
     """kinematic_icp::KinematicRegistration (registration/Registration.hpp:32-50) on one MI355X."""
 
@@ -329,6 +339,29 @@ class KinematicRegistration:
         self.last_status = rc if rc >= 0 else _check(rc)
         return self._out.copy()
 
+    def prepare_batch(self, frames, last_robot_poses, relative_wheel_odometries):
+        """Marshal a queue of independent scans (DeviceFrames + their poses) once; run it with ComputeRobotMotionBatch."""
+        k = len(frames)
+        b = _Batch()
+        b.frames = list(frames)  # keep the device buffers alive
+        b.ptrs = (C.c_void_p * k)(*[f.ptr.value for f in frames])
+        b.ns = (C.c_size_t * k)(*[f.n for f in frames])
+        b.last = np.ascontiguousarray(np.asarray(last_robot_poses, dtype=np.float64).reshape(k, 7))
+        b.rel = np.ascontiguousarray(np.asarray(relative_wheel_odometries, dtype=np.float64).reshape(k, 7))
+        b.out = np.zeros((k, 7), dtype=np.float64)
+        b.iterations = np.zeros(k, dtype=np.int32)
+        b.count = k
+        return b
+
+    def ComputeRobotMotionBatch(self, batch, voxel_map, max_correspondence_distance):
+        """kicp_register_device_batch: the batch's scans one after the other (a plain loop of ComputeRobotMotion inside the
+        library, nothing overlapped).  Returns the (count, 7) poses; batch.iterations holds the iteration counts."""
+        rc = _lib.kicp_register_device_batch(self._h, voxel_map._h, batch.count, batch.ptrs, batch.ns, batch.last.ctypes.data_as(_dp),
+                                             batch.rel.ctypes.data_as(_dp), max_correspondence_distance, batch.out.ctypes.data_as(_dp),
+                                             batch.iterations.ctypes.data_as(C.POINTER(C.c_int)))
+        self.last_status = rc if rc >= 0 else _check(rc)
+        return batch.out
+
     def pass_sums(self, frame, voxel_map, pose, max_correspondence_distance):
         """One fused association+accumulation pass at a fixed pose -> [JTJ00,JTJ01,JTJ11,JTr0,JTr1,ssq,N]."""
         a, p = _d(frame)
@@ -359,6 +392,20 @@ class KinematicRegistration:
 
     def shm_destroy(self):
         _check(lib().kicp_reg_shm_destroy(self._h))
+
+    def p2p_export(self, nranks, rank):
+        """Peer-mailbox exchange (kicp.h): allocate this rank's mailbox, return its IPC handle (bytes) for the all-gather."""
+        buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+        _check(lib().kicp_reg_p2p_export(self._h, nranks, rank, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        """handles: every rank's handle in rank order (list of bytes, or their concatenation)."""
+        blob = handles if isinstance(handles, (bytes, bytearray)) else b"".join(handles)
+        _check(lib().kicp_reg_p2p_connect(self._h, bytes(blob)))
+
+    def p2p_destroy(self):
+        _check(lib().kicp_reg_p2p_destroy(self._h))
 
     def set_allreduce(self, fn):
         """fn(device_ptr:int, count:int, stream:int) -> None: sum-all-reduce `count` doubles in place on `stream`."""

@@ -90,7 +90,19 @@ struct SolveParams {
     // host, each word carrying the 16-bit tag of this pass; the host adds the rows as they arrive
     unsigned long long *pub_rows;  // host-mapped [groups][kReduceWords]
     uint32_t tag;                  // 1..65535, unique per pass within an epoch (the buffers are cleared when it wraps)
+    // mode 5: one-shot exchange over peer mappings (multi-GPU without a collective library).  The
+    // last workgroup of the launch writes this rank's totals - tagged - into slot `p2p_rank` of EVERY rank's mailbox (its
+    // own included; the peers' mailboxes are IPC mappings of their HBM, reached over xGMI), collects the p2p_nranks slots of
+    // its own mailbox, adds them in rank order and hands the node-wide totals to its host as in mode 2.
+    unsigned long long *const *p2p_peers;  // device array [p2p_nranks]: every rank's mailbox as seen from this GPU
+    int32_t p2p_nranks, p2p_rank;
+    uint32_t p2p_tag;     // 1..65535 (step % 65535 + 1); double-buffered by p2p_parity, so a stale slot can never match
+    uint32_t p2p_parity;  // step & 1
 };
+// a rank's mailbox: [2 parities][nranks][kP2pWords] tagged words; a 64-bit total travels as two tagged 32-bit halves
+constexpr int kP2pWords = 2 * 24;
+constexpr int kP2pMaxRanks = 16;
+constexpr long long kP2pTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock: a missing peer becomes KICP_ERR_COMM
 
 // Wave-uniform numbers of the pre-selection over the 16-bit mirror, computed once per call on the host (search_params()).
 struct SearchParams {
@@ -420,6 +432,46 @@ __device__ __forceinline__ long long sum_rows_tagged(const unsigned long long *r
     return v + __shfl_down(v, kReduceWords, 64);
 }
 
+// mode 5 (last workgroup of the launch, wave 0; lanes 0..23 hold this rank's totals): all-gather of the totals through the
+// ranks' mailboxes + sum in rank order.  Every word is self-validating (value << 16 | tag), so no ordering between the
+// stores of a slot - which travel over xGMI - is assumed.  Returns the node-wide totals in lanes 0..23; word kNumLimbs + 1
+// (padding in the single-GPU layout) is set to 1 when a peer's slot did not arrive in time.
+__device__ __forceinline__ long long p2p_exchange(const SolveParams &f, long long total, int lane) {
+    const uint32_t nr = static_cast<uint32_t>(f.p2p_nranks), tag = f.p2p_tag;
+    const size_t buf = static_cast<size_t>(f.p2p_parity) * nr * kP2pWords;
+    // lane l < 48 owns half (l & 1) of word (l >> 1)
+    const long long mine = __shfl(total, lane >> 1, 64);
+    const unsigned long long half = (lane & 1) ? (static_cast<unsigned long long>(mine) >> 32) : (static_cast<unsigned long long>(mine) & 0xFFFFFFFFull);
+    long long lo_hi = 0;
+    int late = 0;
+    if (lane < kP2pWords) {
+        const unsigned long long w = (half << 16) | tag;
+        for (uint32_t r = 0; r < nr; ++r)
+            __hip_atomic_store(f.p2p_peers[r] + buf + static_cast<size_t>(f.p2p_rank) * kP2pWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long *box = f.p2p_peers[f.p2p_rank] + buf;
+        const long long t0 = wall_clock64();
+        for (uint32_t r = 0; r < nr && !late; ++r) {
+            unsigned long long got;
+            for (;;) {
+                got = __hip_atomic_load(box + static_cast<size_t>(r) * kP2pWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((static_cast<uint32_t>(got) & 0xFFFFu) == tag) break;
+                if (wall_clock64() - t0 > kP2pTimeoutTicks) {
+                    late = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            lo_hi += static_cast<long long>((got >> 16) & 0xFFFFFFFFull);  // sums of <= 16 32-bit halves: no overflow
+        }
+    }
+    late = __any(late) ? 1 : 0;
+    // word = lo + (hi << 32), carries included (the halves were summed separately)
+    const long long lo = __shfl(lo_hi, 2 * (lane % kReduceWords), 64), hi = __shfl(lo_hi, 2 * (lane % kReduceWords) + 1, 64);
+    long long sum = static_cast<long long>(static_cast<unsigned long long>(lo) + (static_cast<unsigned long long>(hi) << 32));
+    if (lane == kNumLimbs + 1) sum = late;
+    return sum;
+}
+
 // Sum of a 32-bit value over the wave with DPP adds only (no LDS crossbar): inclusive scan inside each row of 16 lanes
 // (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of row 0 / 2 is added to every lane of
 // row 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).  LANE 63 holds the wave total.
@@ -542,11 +594,12 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             total += sum_rows(p.partials + (static_cast<size_t>(nblocks) + base) * kReduceWords, min(static_cast<uint32_t>(kGroup), ngroups - base), lane);
     }
     // ---- last workgroup of the launch ------------------------------------------------------------------------
+    if (p.sol.mode == 5) total = p2p_exchange(p.sol, total, lane);
     if (lane < kReduceWords) st->reduce[lane] = total;
     long long limbs[kNumLimbs + 1];
 #pragma unroll
     for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
-    if (p.sol.mode == 2) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
+    if (p.sol.mode == 2 || p.sol.mode == 5) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
         if (lane < kReduceWords) __hip_atomic_store(p.sol.pub_words + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(p.sol.pub_seq, p.sol.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

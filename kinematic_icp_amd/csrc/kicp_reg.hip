@@ -116,6 +116,12 @@ struct kicp_reg {
     size_t shm_bytes = 0;
     unsigned long long shm_step = 0;  // hand-offs issued so far (same on every rank)
     std::string shm_name;
+    // one-shot exchange over peer mappings (kicp_reg_p2p_*): this rank's mailbox in its own HBM (fine-grained), the peers'
+    // mailboxes as IPC mappings, and the table of all of them the pass kernel reads
+    unsigned long long *p2p_box = nullptr;
+    void *p2p_mapped[kP2pMaxRanks] = {};
+    unsigned long long **d_p2p_table = nullptr;
+    unsigned long long p2p_step = 0;  // exchanges issued so far (same on every rank)
 };
 
 namespace {
@@ -357,7 +363,9 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
+    const bool p2p = r->d_p2p_table != nullptr;
     if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
+    if (p2p && (!r->host_solve || multi || shm)) return fail(KICP_ERR_ARG, "the peer-mailbox mode needs host_solve = 1 and no other exchange attached");
     const unsigned long long call_id = ++r->call_id;
 
     PassParams pp{};
@@ -394,8 +402,13 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         double beta = 0.0;
         int iter = 0, converged = 0, nan_flag = 0;
         for (int it = 0; it < max_it; ++it) {
-            const bool rows_mode = !multi && r->group_rows != 0;
-            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : (rows_mode ? 4 : 2);
+            const bool rows_mode = !multi && !p2p && r->group_rows != 0;
+            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : (p2p ? 5 : (rows_mode ? 4 : 2));
+            if (p2p) {  // every rank issues the same sequence of exchanges: the step number doubles as tag and buffer parity
+                const unsigned long long step = r->p2p_step++;
+                sp.p2p_peers = r->d_p2p_table, sp.p2p_nranks = r->nranks, sp.p2p_rank = r->rank;
+                sp.p2p_tag = static_cast<uint32_t>(step % 65535ull) + 1u, sp.p2p_parity = static_cast<uint32_t>(step & 1ull);
+            }
             long long words[kReduceWords];
             unsigned long long shm_value = 0;
             kicp_reg::ShmSlot *mine_host = nullptr;
@@ -438,6 +451,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
             } else {
                 if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
                 for (int i = 0; i < kReduceWords; ++i) words[i] = rec->words[i];
+                if (p2p && words[kNumLimbs + 1] != 0) return fail(KICP_ERR_COMM, "a peer rank's totals did not arrive in this rank's mailbox in time");
             }
             double sums[kNumSums];
             for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(words + 3 * i);
@@ -576,6 +590,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->comm) g_comm.CommDestroy(reg->comm);
     if (reg->stream) hipStreamSynchronize(reg->stream);
     if (reg->shm) kicp_reg_shm_destroy(reg);
+    if (reg->p2p_box) kicp_reg_p2p_destroy(reg);
     if (reg->d_state) hipFree(reg->d_state);
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->rows) hipHostFree(reg->rows);
@@ -645,6 +660,23 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
     KICP_TRACE_CALL();
     if (!d_frame_xyz && n) return fail(KICP_ERR_ARG, "null frame");
     return run_registration(reg, map, d_frame_xyz, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const double *const *d_frames_xyz, const size_t *n,
+                               const double *last_poses_qt, const double *rel_odoms_qt, double max_correspondence_distance,
+                               double *out_poses_qt, int *out_iterations) {
+    KICP_TRACE_CALL();
+    if (count && (!d_frames_xyz || !n || !last_poses_qt || !rel_odoms_qt || !out_poses_qt)) return fail(KICP_ERR_ARG, "null argument");
+    int worst = KICP_OK;
+    kicp_stats st;
+    for (size_t k = 0; k < count; ++k) {
+        if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
+        const int rc = run_registration(reg, map, d_frames_xyz[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, max_correspondence_distance,
+                                        out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
+        if (rc < 0) return rc;
+        worst = std::max(worst, rc);
+        if (out_iterations) out_iterations[k] = st.iterations;
+    }
+    return worst;
 }
 int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
                   const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
@@ -823,6 +855,76 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr) + 1;
     reg->d_shm = dptr ? static_cast<kicp_reg::ShmSlot *>(dptr) + 1 : nullptr;
     reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
+    return KICP_OK;
+}
+// ---- one-shot exchange over peer mappings -----------------------------------------------------
+// Each rank owns a mailbox in its own HBM: [2 parities][nranks][kP2pWords] tagged words, fine-grained so that a peer's stores
+// (over xGMI) become visible to a kernel that is polling it.  Export -> the caller gathers every rank's handle (any
+// transport: torch.distributed, MPI, a file) -> connect opens the peers' mailboxes -> every pass kernel's last workgroup
+// writes this rank's totals into all mailboxes and collects its own (mode 5, kicp_kernels.hpp::p2p_exchange).
+int kicp_reg_p2p_destroy(kicp_reg *reg) {
+    if (!reg) return fail(KICP_ERR_ARG, "null argument");
+    if (reg->p2p_box || reg->d_p2p_table) {
+        hipSetDevice(reg->device);
+        hipStreamSynchronize(reg->stream);
+        for (void *&m : reg->p2p_mapped)
+            if (m) (void)hipIpcCloseMemHandle(m), m = nullptr;
+        if (reg->d_p2p_table) hipFree(reg->d_p2p_table);
+        if (reg->p2p_box) hipFree(reg->p2p_box);
+        reg->d_p2p_table = nullptr, reg->p2p_box = nullptr;
+        (void)hipGetLastError();
+    }
+    reg->nranks = 1, reg->rank = 0, reg->p2p_step = 0;
+    return KICP_OK;
+}
+int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2P_HANDLE_BYTES]) {
+    static_assert(KICP_P2P_HANDLE_BYTES == sizeof(hipIpcMemHandle_t), "handle size");
+    static_assert(KICP_P2P_MAX_RANKS == kP2pMaxRanks, "rank limit");
+    if (!reg || !handle || nranks < 1 || nranks > kP2pMaxRanks || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad peer-mailbox arguments");
+    if (reg->comm || reg->shm || reg->allreduce_fn) return fail(KICP_ERR_ARG, "another exchange is already attached");
+    kicp_reg_p2p_destroy(reg);
+    if (int rc = set_device(reg->device)) return rc;
+    const size_t bytes = 2 * static_cast<size_t>(nranks) * kP2pWords * sizeof(unsigned long long);
+    // fine-grained: stores arriving from a peer GPU must be visible to a wave that is polling (no stale L2 line)
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&reg->p2p_box), bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        reg->p2p_box = nullptr;
+        return fail(KICP_ERR_HIP, std::string("hipExtMallocWithFlags(fine-grained mailbox): ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemset(reg->p2p_box, 0, bytes));  // tag 0 never matches
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, reg->p2p_box);
+    if (e != hipSuccess) {
+        hipFree(reg->p2p_box), reg->p2p_box = nullptr;
+        return fail(KICP_ERR_COMM, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    }
+    std::memcpy(handle, &h, sizeof h);
+    reg->nranks = nranks, reg->rank = rank;
+    return KICP_OK;
+}
+int kicp_reg_p2p_connect(kicp_reg *reg, const char *handles) {
+    if (!reg || !handles) return fail(KICP_ERR_ARG, "null argument");
+    if (!reg->p2p_box) return fail(KICP_ERR_ARG, "kicp_reg_p2p_export first");
+    if (int rc = set_device(reg->device)) return rc;
+    unsigned long long *table[kP2pMaxRanks] = {};
+    for (int k = 0; k < reg->nranks; ++k) {
+        if (k == reg->rank) {
+            table[k] = reg->p2p_box;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + static_cast<size_t>(k) * KICP_P2P_HANDLE_BYTES, sizeof h);
+        void *ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(KICP_ERR_COMM, "hipIpcOpenMemHandle(rank " + std::to_string(k) + "): " + hipGetErrorString(e));
+        }
+        reg->p2p_mapped[k] = ptr, table[k] = static_cast<unsigned long long *>(ptr);
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&reg->d_p2p_table), sizeof table));
+    HIP_TRY(hipMemcpy(reg->d_p2p_table, table, sizeof table, hipMemcpyHostToDevice));
+    reg->p2p_step = 0;
     return KICP_OK;
 }
 int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user) {

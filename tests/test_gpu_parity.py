@@ -342,3 +342,29 @@ def test_hand_off_modes_and_tag_wraparound(case1):
                 pose = reg.ComputeRobotMotion(scans[i % 3]["frame"][:n], gmap, scans[i % 3]["last_pose"], rel[i % 3], tau)
                 assert np.array_equal(pose, expected[i], equal_nan=True), (wait, rounds, i)
         assert 0 < reg.get_option("debug_tag") < 65528  # the wrap happened inside the loop
+
+
+def test_batch_call_equals_a_loop_of_single_calls(case1):
+    """kicp_register_device_batch = ComputeRobotMotion scan after scan (bits), incl. a scan that needs several iterations,
+    an empty frame (warning code) and the iteration counts."""
+    cfg, scans, gmap, omap = case1
+    tau = cfg.first_frame_tau()
+    reg = K.KinematicRegistration()
+    far = syn.pose_mul(scans[1]["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(1.0)))
+    items = [(scans[0]["frame"], scans[0]["last_pose"], scans[0]["rel_odom"]), (scans[1]["frame"], scans[1]["last_pose"], far),
+             (scans[2]["frame"][:777], scans[2]["last_pose"], scans[2]["rel_odom"]), (scans[0]["frame"], scans[2]["last_pose"], far)]
+    frames = [K.DeviceFrame(f) for f, _, _ in items]
+    single, iters = [], []
+    for fr, (_, last, rel) in zip(frames, items):
+        single.append(reg.ComputeRobotMotion(fr, gmap, last, rel, tau))
+        iters.append(reg.last_stats.iterations)
+    batch = reg.prepare_batch(frames, [i[1] for i in items], [i[2] for i in items])
+    out = reg.ComputeRobotMotionBatch(batch, gmap, tau)
+    assert np.array_equal(out, np.array(single)) and list(batch.iterations) == iters and max(iters) > 1
+    for (f, last, rel), pose in zip(items, out):
+        np.testing.assert_allclose(pose, okicp.KinematicRegistration().ComputeRobotMotion(f, omap, last, rel, tau), rtol=0, atol=POSE_TOL)
+    # a frame without points: NaN pose and the warning code, as the single call reports it; the rest of the batch still runs
+    empty = K.DeviceFrame(np.zeros((0, 3)))
+    b2 = reg.prepare_batch([empty, frames[0]], [items[0][1], items[0][1]], [items[0][2], items[0][2]])
+    out2 = reg.ComputeRobotMotionBatch(b2, gmap, tau)
+    assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES and np.isnan(out2[0]).any() and np.array_equal(out2[1], single[0])
