@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include "kicp_aql.hpp"
 #include "kicp_internal.hpp"
 #include "kicp_kernels.hpp"
 
@@ -122,15 +123,37 @@ struct kicp_reg {
     void *p2p_mapped[kP2pMaxRanks] = {};
     unsigned long long **d_p2p_table = nullptr;
     unsigned long long p2p_step = 0;  // exchanges issued so far (same on every rank)
+    // direct AQL dispatch of the pass kernel (kicp_aql.hpp): the handle's own user-mode queue next to its HIP stream
+    AqlDispatcher aql;
+    int use_aql = 1;            // option "aql": 1 (default) dispatch the pass kernel with hand-written AQL packets where possible, 0 always through HIP
+    bool aql_tried = false;     // set-up attempted (it is lazy: the first registration pays for it)
+    bool stream_dirty = true;   // HIP work may be pending on `stream`: synchronise before the next AQL dispatch
+    bool last_via_aql = false;  // how the pass the host is waiting for was launched
+    std::map<int, const AqlKernel *> aql_kernels;
 };
 
 namespace {
+
+// Every spin-wait below is bounded by wall-clock time (default 20 s, KICP_WAIT_TIMEOUT_S): a wedged kernel or a dead peer
+// rank turns into KICP_ERR_HIP / KICP_ERR_COMM instead of a hung caller.
+double wait_timeout_s() {
+    static const double t = [] {
+        const char *e = std::getenv("KICP_WAIT_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 20.0;
+    }();
+    return t;
+}
+struct Deadline {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool passed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_s(); }
+};
 
 template <int BLOCK>
 void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
     hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
 }
-int normalized_block(int b) { return (b == 64 || b == 256) ? b : 128; }
+int normalized_block(int b) { return (b == 64 || b == 256 || b == 512) ? b : 128; }
 // Sub-lanes per query of variant 3.  Small scans are latency bound (few waves, each lane's chain of dependent bucket
 // visits decides the kernel time): spreading a query's neighbour voxels over 2-4 lanes shortens that chain.  Large
 // scans already fill the machine and only pay for the extra waves.
@@ -138,15 +161,59 @@ int lanes_for(const kicp_reg *r, size_t n) {
     if (r->lanes_per_query > 0) return r->lanes_per_query;
     return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
 }
+// 512-thread workgroups exist for variant 3 with one lane per query only (large scans: one workgroup per CU); elsewhere 256
+int effective_block(const kicp_reg *r, size_t n) {
+    const int b = normalized_block(r->block);
+    return (b == 512 && !(r->pass_kernel == 3 && lanes_for(r, n) == 1)) ? 256 : b;
+}
 uint32_t pass_grid(const kicp_reg *r, size_t n) {
-    const int block = normalized_block(r->block);
+    const int block = effective_block(r, n);
     const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
     return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
 }
-void launch_pass(const kicp_reg *r, const PassParams &p) {
+// the pass kernel of variant 3 as an AQL kernel object (looked up once per template instantiation), or nullptr
+const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split) {
+    if (!r->aql_tried) {
+        r->aql_tried = true;
+        if (r->aql.init(r->device) != 0 && env_flag("KICP_TRACE")) std::fprintf(stderr, "[kicp] AQL dispatch unavailable: %s\n", r->aql.why.c_str());
+    }
+    if (!r->aql.ready) return nullptr;
+    const int key = b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0);
+    auto it = r->aql_kernels.find(key);
+    if (it != r->aql_kernels.end()) return it->second;
+    char name[128];
+    std::snprintf(name, sizeof name, "_ZN4kicp15k_pass_gather32ILi%dELi%dELi%dELb%dEEEvNS_10PassParamsE", b, g, occ, split ? 1 : 0);
+    const AqlKernel &k = r->aql.kernel(name);
+    return r->aql_kernels[key] = k.usable ? &k : nullptr;
+}
+// allow_aql: nothing on the handle's HIP stream has to be ordered behind this kernel and the host will poll for the result
+void launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
     const uint32_t grid = pass_grid(r, p.n);
     if (r->pass_kernel == 3) {
-        const int b = normalized_block(r->block), g = lanes_for(r, p.n);
+        const int b = effective_block(r, p.n), g = lanes_for(r, p.n);
+        // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
+        // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
+        const int occ = (r->occupancy == 3 && b != 512) ? 3 : 4;
+        const bool split = g == 2 && r->split_buckets;
+        // While HIP work may be pending on the handle's stream (a frame upload, a mirror refresh, a clear) the kernel goes
+        // through the stream, ordered behind it; once the host has that pass's result the stream is known to be idle.
+        if (allow_aql && r->use_aql && !r->stream_dirty) {
+            if (const AqlKernel *k = aql_kernel_for(r, b, g, occ, split)) {
+                // Fences of the packet.  Acquire: agent scope - the kernel start invalidates the vector / scalar L1s and the
+                // XCDs' L2 lines of device memory, so everything earlier kernels released and every DMA the host has waited
+                // for is seen; it is what makes a kernarg slot re-read from host memory, too (no acquire: stale arguments).
+                // System scope costs 3.4 us more per dispatch on this part (measured: 25.9 vs 22.6 us per cfg2 scan).
+                // Release: agent scope; the results leave through system-scope stores into host-mapped memory, and
+                // AqlDispatcher::drain() puts a system-scope release behind the kernels before HIP work follows them.
+                if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &p, sizeof p, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
+                    r->last_via_aql = true;
+                    return;
+                }
+            }
+        }
+        if (allow_aql) r->stream_dirty = false;  // the host waits for this pass: by then everything queued before it is done
+        if (r->aql.busy()) (void)r->aql.drain(20.0);  // kernels dispatched through the AQL queue come first
+        r->last_via_aql = false;
 #define KICP_G32(B, G, SPLIT)                                                                                     \
     do {                                                                                                          \
         if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3, SPLIT>), dim3(grid), dim3(B), 0, r->stream, p); \
@@ -158,18 +225,18 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
         else if (b == 256) KICP_G32(256, G, SPLIT); \
         else KICP_G32(128, G, SPLIT);               \
     } while (0)
-        // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
-        // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
-        const int occ = r->occupancy == 3 ? 3 : 4;
-        if (g == 1) KICP_G32_BLOCKS(1, false);
-        else if (g == 2 && r->split_buckets) KICP_G32_BLOCKS(2, true);
+        if (g == 1 && b == 512) hipLaunchKernelGGL((k_pass_gather32<512, 1, 4, false>), dim3(grid), dim3(512), 0, r->stream, p);  // experiment: one workgroup per CU
+        else if (g == 1) KICP_G32_BLOCKS(1, false);
+        else if (split) KICP_G32_BLOCKS(2, true);
         else if (g == 2) KICP_G32_BLOCKS(2, false);
         else KICP_G32_BLOCKS(4, false);
 #undef KICP_G32_BLOCKS
 #undef KICP_G32
         return;
     }
-    switch (normalized_block(r->block)) {
+    if (r->aql.busy()) (void)r->aql.drain(20.0);
+    r->last_via_aql = false;
+    switch (effective_block(r, p.n)) {
         case 64: launch_gather<64>(p, grid, r->stream); break;
         case 256: launch_gather<256>(p, grid, r->stream); break;
         default: launch_gather<128>(p, grid, r->stream); break;
@@ -178,12 +245,14 @@ void launch_pass(const kicp_reg *r, const PassParams &p) {
 
 int ensure_partials(kicp_reg *r, size_t blocks) {
     if (blocks <= r->partial_blocks) return KICP_OK;
+    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
     if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
     if (r->d_tickets) HIP_TRY(hipFree(r->d_tickets));
     r->d_partials = nullptr, r->d_tickets = nullptr;
     const size_t want = blocks + blocks / 2 + 64, groups = want / kGroup + 2;
     HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
+    r->stream_dirty = true;
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_partials, 0, (want + groups) * kReduceWords * sizeof(unsigned long long), r->stream));  // tag 0 = never valid
     r->partial_blocks = want;
@@ -192,6 +261,7 @@ int ensure_partials(kicp_reg *r, size_t blocks) {
 // host-mapped rows of the first-level groups (mode 4)
 int ensure_rows(kicp_reg *r, size_t groups) {
     if (groups <= r->rows_groups) return KICP_OK;
+    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->rows) HIP_TRY(hipHostFree(r->rows));
     r->rows = nullptr, r->d_rows = nullptr, r->rows_groups = 0;
@@ -206,6 +276,8 @@ int ensure_rows(kicp_reg *r, size_t groups) {
 // from 65535 passes ago can never be mistaken for a fresh one
 int next_tag(kicp_reg *r, uint32_t *tag) {
     if (r->tag >= 0xFFFFu) {
+        if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
+        r->stream_dirty = true;
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->rows) std::memset(r->rows, 0, r->rows_groups * kReduceWords * sizeof(unsigned long long));
         if (r->d_partials) {
@@ -219,6 +291,7 @@ int next_tag(kicp_reg *r, uint32_t *tag) {
 }
 int ensure_frame(kicp_reg *r, size_t n) {
     if (n <= r->frame_cap) return KICP_OK;
+    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
     if (r->d_frame) HIP_TRY(hipFree(r->d_frame));
     r->d_frame = nullptr;
     const size_t want = n + n / 4 + 1024;
@@ -238,21 +311,6 @@ int enqueue_allreduce(kicp_reg *r) {
     if (rc != ncclSuccess) return fail(KICP_ERR_COMM, std::string("ncclAllReduce: ") + g_comm.GetErrorString(rc));
     return KICP_OK;
 }
-
-// Every spin-wait below is bounded by wall-clock time (default 20 s, KICP_WAIT_TIMEOUT_S): a wedged kernel or a dead peer
-// rank turns into KICP_ERR_HIP / KICP_ERR_COMM instead of a hung caller.
-double wait_timeout_s() {
-    static const double t = [] {
-        const char *e = std::getenv("KICP_WAIT_TIMEOUT_S");
-        const double v = e ? std::atof(e) : 0.0;
-        return v > 0.0 ? v : 20.0;
-    }();
-    return t;
-}
-struct Deadline {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    bool passed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_s(); }
-};
 
 // wait until the record carries `call_id` with at least `min_iter` completed iterations (or its done bit);
 // returns the observed seq.  Polls host-mapped memory; falls back to a stream sync when asked to or on a fault.
@@ -280,6 +338,11 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
             return KICP_OK;
         }
         if (spins % query_every == 0) {
+            if (r->last_via_aql) {  // the kernel went through the handle's own AQL queue: its error callback is the fault check
+                if (r->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(r->aql.queue_error));
+                if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the registration kernels (KICP_WAIT_TIMEOUT_S)");
+                continue;
+            }
             const hipError_t q = hipStreamQuery(r->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
             if (q == hipSuccess && ++drained > 4 && !ready(__atomic_load_n(seq, __ATOMIC_ACQUIRE)))
@@ -307,6 +370,13 @@ int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kRed
                 v[i] = static_cast<long long>(w) >> 16;
             }
             if (ok) break;
+            if (r->last_via_aql) {
+                if (++spins % query_every == 0) {
+                    if (r->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(r->aql.queue_error));
+                    if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
+                }
+                continue;
+            }
             if (r->wait_mode == 1 || ++spins % query_every == 0) {
                 // the query makes the runtime flush commands it may still hold back, and reports device faults
                 const hipError_t q = r->wait_mode == 1 ? hipStreamSynchronize(r->stream) : hipStreamQuery(r->stream);
@@ -359,7 +429,9 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (max_it > 0x7FFF) return fail(KICP_ERR_ARG, "max_num_iterations > 32767");
     if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
     if (int rc = set_device(r->device)) return rc;
+    const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    if (map->mirror.synced_epoch != epoch_before) r->stream_dirty = true;  // the mirror was (re)uploaded through the HIP stream
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
@@ -433,7 +505,8 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
             }
             const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
-            launch_pass(r, pp);
+            // direct AQL dispatch when the host polls for the result and nothing follows the kernel on the HIP stream
+            launch_pass(r, pp, !multi && r->timing == 0 && r->wait_mode == 0);
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
             if (multi) {
                 if (int rc = enqueue_allreduce(r)) return rc;
@@ -588,6 +661,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (!reg) return;
     hipSetDevice(reg->device);
     if (reg->comm) g_comm.CommDestroy(reg->comm);
+    (void)reg->aql.drain(5.0);
     if (reg->stream) hipStreamSynchronize(reg->stream);
     if (reg->shm) kicp_reg_shm_destroy(reg);
     if (reg->p2p_box) kicp_reg_p2p_destroy(reg);
@@ -602,6 +676,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->ev1) hipEventDestroy(reg->ev1);
     for (auto &e : reg->evp)
         if (e) hipEventDestroy(e);
+    reg->aql.release();
     if (reg->stream) hipStreamDestroy(reg->stream);
     delete reg;
 }
@@ -632,6 +707,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
+    else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
     else return fail(KICP_ERR_ARG, "unknown option " + k);
@@ -651,6 +727,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "occupancy") return reg->occupancy;
     if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
+    if (k == "aql") return reg->use_aql;
+    if (k == "aql_active") return (reg->aql.ready && reg->last_via_aql) ? 1.0 : 0.0;  // was the last pass dispatched through the AQL queue
     return -1.0;
 }
 
@@ -685,6 +763,7 @@ int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t 
     if (!kicp_map_empty(map) && n) {
         if (int rc = set_device(reg->device)) return rc;
         if (int rc = ensure_frame(reg, n)) return rc;
+        reg->stream_dirty = true;  // (the kernels of earlier calls have long read d_frame: the host had their results)
         if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
     }
     return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);

@@ -368,3 +368,31 @@ def test_batch_call_equals_a_loop_of_single_calls(case1):
     b2 = reg.prepare_batch([empty, frames[0]], [items[0][1], items[0][1]], [items[0][2], items[0][2]])
     out2 = reg.ComputeRobotMotionBatch(b2, gmap, tau)
     assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES and np.isnan(out2[0]).any() and np.array_equal(out2[1], single[0])
+
+
+def test_aql_dispatch_equals_hip_launch(case1):
+    """The pass kernel dispatched with hand-written AQL packets on the handle's own HSA queue (default, kicp_aql.hpp) and the
+    same kernel launched through hipLaunchKernelGGL: the same bits, for every sub-lane variant, across switches between the
+    two paths, with a host frame in between (HIP upload on the stream, then AQL again)."""
+    cfg, scans, gmap, omap = case1
+    tau = cfg.first_frame_tau()
+    far = syn.pose_mul(scans[1]["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(1.0)))
+    frames = [K.DeviceFrame(s["frame"]) for s in scans]
+    for lanes in (None, 1, 2, 4):
+        a, b = _reg(3, 256, lanes), _reg(3, 256, lanes)
+        b.set_option("aql", 0)
+        for k, (fr, s) in enumerate(zip(frames, scans)):
+            rel = far if k == 1 else s["rel_odom"]
+            pa, pb = a.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau), b.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+            assert np.array_equal(pa, pb) and a.last_stats.iterations == b.last_stats.iterations
+            assert b.get_option("aql_active") == 0.0
+        assert a.get_option("aql_active") == 1.0, "the AQL path did not come up on this box (KICP_TRACE=1 says why)"
+        # host frame (staged upload through the HIP stream), then device frames again; toggling the option on one handle
+        ph = a.ComputeRobotMotion(scans[0]["frame"], gmap, scans[0]["last_pose"], scans[0]["rel_odom"], tau)
+        a.set_option("aql", 0)
+        p0 = a.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], scans[0]["rel_odom"], tau)
+        a.set_option("aql", 1)
+        p1 = a.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], scans[0]["rel_odom"], tau)
+        assert np.array_equal(ph, p0) and np.array_equal(p0, p1) and a.get_option("aql_active") == 1.0
+    np.testing.assert_allclose(p1, okicp.KinematicRegistration().ComputeRobotMotion(scans[0]["frame"], omap, scans[0]["last_pose"], scans[0]["rel_odom"], tau),
+                               rtol=0, atol=POSE_TOL)
