@@ -217,6 +217,12 @@ int kicp_pre_ingested(const kicp_pre *pre, double *out_xyz, double *out_stamps, 
 int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, int dst_buffer, size_t *out_n);
 int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
 int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
+/* The same download in the background: _begin queues the copy of the buffer's current contents on a stream of its own
+ * (pinned landing area) and returns at once; the caller goes on with the pipeline's next steps and collects the points
+ * with _finish.  One download in flight per handle; the buffer must not be refilled in between.  (RegisterFrame returns the
+ * whole preprocessed frame - pipeline/KinematicICP.cpp:84 - 3 MB that nothing on the device waits for.) */
+int kicp_pre_download_begin(kicp_pre *pre, int buffer);
+int kicp_pre_download_finish(kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 const double *kicp_pre_device_ptr(const kicp_pre *pre, int buffer, size_t *out_n);
 
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kicp_pre_download_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "kicp_pre_download_finish": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kicp_pre_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "kicp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
@@ -499,6 +501,17 @@ class PreSteps:
         out = np.empty((n.value, 3), dtype=np.float64)
         _check(lib().kicp_pre_download(self._h, buffer, out.ctypes.data_as(_dp), n.value, C.byref(n)))
         return out
+
+    def download_begin(self, buffer):
+        """Start copying a buffer to the host in the background; collect it with download_finish."""
+        _check(lib().kicp_pre_download_begin(self._h, buffer))
+
+    def download_finish(self, buffer):
+        n = C.c_size_t()
+        _check(lib().kicp_pre_download(self._h, buffer, None, 0, C.byref(n)))  # (size only)
+        out = np.empty((n.value, 3), dtype=np.float64)
+        _check(lib().kicp_pre_download_finish(self._h, buffer, out.ctypes.data_as(_dp), n.value, C.byref(n)))
+        return out[:n.value]
 
     def frame(self, buffer):
         """A DeviceFrame view of a buffer (no copy; valid until the buffer is overwritten)."""

@@ -19,6 +19,12 @@ struct kicp_pre {
     unsigned char *d_raw = nullptr;
     size_t raw_cap = 0;
     mutable HostStage stage;  // pinned staging for transfers from / to caller memory
+    // background download of one buffer (kicp_pre_download_begin / _finish): its own stream, pinned landing area and event
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    unsigned char *copy_host = nullptr;
+    size_t copy_cap = 0, copy_n = 0;
+    int copy_buffer = -1;
     unsigned long long *d_minmax = nullptr;
     size_t ingested_n = 0;
     bool ingested = false, ingested_stamps = false;
@@ -116,6 +122,9 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
     hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
     p->stage.release();
+    if (p->copy_stream) hipStreamSynchronize(p->copy_stream), hipStreamDestroy(p->copy_stream);
+    if (p->copy_done) hipEventDestroy(p->copy_done);
+    if (p->copy_host) hipHostFree(p->copy_host);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -264,6 +273,40 @@ int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap
     if (k && out_xyz)
         if (int rc = staged_download(p->stage, out_xyz, p->buf[buffer], k * 24, p->stream)) return rc;
     if (out_n) *out_n = n;
+    return KICP_OK;
+}
+// Background download: the copy runs on its own stream while the caller goes on with the next steps (downsampling,
+// registration, map update), and lands in pinned memory; _finish waits for it and hands the points over.
+int kicp_pre_download_begin(kicp_pre *p, int buffer) {
+    KICP_TRACE_CALL();
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(p->device)) return rc;
+    if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
+    if (p->copy_buffer >= 0) HIP_TRY(hipStreamSynchronize(p->copy_stream));  // an earlier download nobody collected
+    const size_t n = p->buf_n[buffer], bytes = n * 24;
+    if (bytes > p->copy_cap) {
+        if (p->copy_host) HIP_TRY(hipHostFree(p->copy_host));
+        p->copy_host = nullptr, p->copy_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->copy_host), bytes + bytes / 2 + (1u << 20), hipHostMallocDefault));
+        p->copy_cap = bytes + bytes / 2 + (1u << 20);
+    }
+    // the buffer's contents are final: every call that fills a buffer returns only after its kernels have finished
+    if (bytes) HIP_TRY(hipMemcpyAsync(p->copy_host, p->buf[buffer], bytes, hipMemcpyDeviceToHost, p->copy_stream));
+    HIP_TRY(hipEventRecord(p->copy_done, p->copy_stream));
+    p->copy_buffer = buffer, p->copy_n = n;
+    return KICP_OK;
+}
+int kicp_pre_download_finish(kicp_pre *p, int buffer, double *out_xyz, size_t cap_points, size_t *out_n) {
+    KICP_TRACE_CALL();
+    if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
+    if (p->copy_buffer != buffer) return fail(KICP_ERR_ARG, "no download of this buffer in flight: kicp_pre_download_begin first");
+    if (int rc = set_device(p->device)) return rc;
+    HIP_TRY(hipEventSynchronize(p->copy_done));
+    const size_t k = std::min(p->copy_n, cap_points);
+    if (k && out_xyz) std::memcpy(out_xyz, p->copy_host, k * 24);
+    if (out_n) *out_n = p->copy_n;
+    p->copy_buffer = -1;
     return KICP_OK;
 }
 const double *kicp_pre_device_ptr(const kicp_pre *p, int buffer, size_t *out_n) {

@@ -65,6 +65,21 @@ def test_voxel_downsample_matches_oracle(raw):
     assert e.value.code == K.KICP_ERR_CAPACITY
 
 
+def test_background_download_overlaps_the_next_steps(raw):
+    frame, ts, rel, ext = raw
+    pre = K.PreSteps()
+    n = pre.Preprocess(frame, ts, rel, ext, 30.0, 3.0, 1, dst=0)
+    want = pre.download(0)
+    pre.download_begin(0)                      # the copy runs while the pipeline goes on ...
+    pre.VoxelDownsample(0, 0.5, 1), pre.VoxelDownsample(1, 1.5, 2)
+    got = pre.download_finish(0)               # ... and is collected afterwards
+    assert len(got) == n and np.array_equal(got, want)
+    with pytest.raises(K.KicpError):           # nothing in flight any more
+        pre.download_finish(0)
+    pre.download_begin(2)
+    assert np.array_equal(pre.download_finish(2), pre.download(2))
+
+
 def test_presteps_feed_registration_without_leaving_the_gpu(raw):
     frame, ts, rel, ext = raw
     cfg, scene, scans, rng = syn.make_case("cfg1", n_scans=1)
