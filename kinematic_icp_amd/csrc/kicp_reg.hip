@@ -203,6 +203,7 @@ void launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
                 // XCDs' L2 lines of device memory, so everything earlier kernels released and every DMA the host has waited
                 // for is seen; it is what makes a kernarg slot re-read from host memory, too (no acquire: stale arguments).
                 // System scope costs 3.4 us more per dispatch on this part (measured: 25.9 vs 22.6 us per cfg2 scan).
+                // (Dropping the acquire for the later passes of a call - same frame, same map - was measured too: no gain.)
                 // Release: agent scope; the results leave through system-scope stores into host-mapped memory, and
                 // AqlDispatcher::drain() puts a system-scope release behind the kernels before HIP work follows them.
                 if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &p, sizeof p, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
