@@ -252,6 +252,8 @@ def main():
         for i in range(50):
             run_scan(reg, i, rel_single)
     elapsed = timed(reg, rel_single, args.steps, args.warmup)                 # ---- the headline number
+    launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp)" if reg.get_option("aql_active") == 1.0
+                   else "hipLaunchKernelGGL on the handle's stream")
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
     elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
@@ -393,7 +395,7 @@ def main():
                    "scans_per_s_one_python_call_per_scan": round((world if replicas else 1) * n_scans_timed / elapsed_py, 2),
                    "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
                                   (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
-                   "pass_kernel": pass_kernel, "max_pose_abs_diff_vs_oracle": max_pose_err,
+                   "pass_kernel": pass_kernel, "launch_path": launch_path, "max_pose_abs_diff_vs_oracle": max_pose_err,
                    "multi_iteration": {
                        "workload": "same scans, odometry error +%.2f m / +%.1f deg: %.2f ICP iterations per scan (reference %.2f)"
                                    % (MULTI_ITER_ERROR[0], MULTI_ITER_ERROR[1], iters_gpu_multi, float(np.mean(iters_ref_multi))),

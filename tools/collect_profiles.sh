@@ -3,7 +3,7 @@
 # gpurun_out/r02/; the summaries that are meant to be judged are copied into profiles/ by hand (profiles/README.md).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" $O/pytest.log | tail -4
 timeout 300 python tools/prof_target.py --workload cfg2 --calls 2000 2>> $O/target.err | tee -a $O/targets.txt
 timeout 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 1500 $O/bench_n1.json
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python bench.py --steps 10 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/kt_bench.err
@@ -24,5 +24,11 @@ done
 for w in cfg1 cfg4 cfg5; do timeout 400 python bench.py --workload $w --cpu-seconds 6 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; done
 timeout 300 python tools/bench_presteps.py > $O/presteps.txt 2>&1; tail -4 $O/presteps.txt
 (timeout 300 python tools/bench_pipeline.py --frames 40 --dump /tmp/pipe.bin > /dev/null 2>&1 && timeout 300 tests/cpp/facade_test pipeline_timed /tmp/pipe.bin > /tmp/pipe.txt && timeout 600 python tools/bench_pipeline.py --frames 40 --check /tmp/pipe.txt --oracle-frames 40 2>&1 | grep -v "^frame [0-9]* ms" > $O/pipeline.txt); tail -3 $O/pipeline.txt
+# two ranks sharing this box's one GPU (functional check of the exchanges, not a scaling figure): host shared segment and peer mailboxes
+for comm in shm p2p; do
+  KICP_BENCH_DEVICE=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 bench.py --gpus 2 --comm $comm --pg-backend gloo --no-cpu-baseline > $O/bench_2ranks_1gpu_$comm.json 2> $O/bench_2ranks_1gpu_$comm.err; echo "2 ranks / 1 GPU, $comm: rc=$?"
+done
+# launch path A/B on this box: the same bench with the pass kernel launched through HIP instead of the AQL queue
+KICP_AQL=0 timeout 400 python bench.py --no-cpu-baseline > $O/bench_n1_hip_launch.json 2> $O/bench_n1_hip_launch.err; echo "hip-launch bench rc=$?"
 find $O -name "*.db" -delete
 du -sh $O
