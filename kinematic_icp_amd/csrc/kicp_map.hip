@@ -336,9 +336,12 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     }
     const size_t slots = mr.live_slots;
     hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
-    hipLaunchKernelGGL(k_up_apply, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
+    if (c.touched <= 16384)  // a frame's worth of voxels: one wave each; bulk insertions: one thread each (kicp_mapdev.hpp steps 4 / 4b)
+        hipLaunchKernelGGL(k_up_apply, dim3((c.touched + kApplyWaves - 1) / kApplyWaves), dim3(64 * kApplyWaves), 0, st, up);
+    else
+        hipLaunchKernelGGL(k_up_apply_thread, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
     if (remove_origin)
-        hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((slots + 255) / 256, 8192))), dim3(256), 0, st, up.m,
+        hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((slots / 4 + 255) / 256, 8192))), dim3(256), 0, st, up.m,
                            remove_origin[0], remove_origin[1], remove_origin[2]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));

@@ -159,8 +159,96 @@ static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p)
     p.order[p.m.seg_start[h] + atomicAdd(p.m.cnt + h, 1u)] = i;
 }
 
-// 4. one thread per touched voxel: the reference's AddPoints rule over the voxel's new points in input order
-static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
+// 4. one WAVE per touched voxel: the reference's AddPoints rule over the voxel's new points in input order.  The order
+//    dependence (a point is judged against everything accepted before it) stays sequential; what the 64 lanes share is the
+//    work inside a step: finding the next input index of the group, the distance test against the bucket's points (held in
+//    LDS, one point per lane and trip, same fp64 expression as the reference), and - when the voxel becomes occupied - the
+//    27 neighbour records, one neighbour per lane.  Used for the updates a pipeline issues (a few thousand touched voxels:
+//    one THREAD per voxel leaves the machine empty there and took 80 us per frame; this takes ~15); see 4b for large ones.
+constexpr int kApplyWaves = 4;  // voxels per workgroup
+static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const UpdateParams p) {
+    __shared__ double s_pts[kApplyWaves][kMaxPointsPerVoxel * 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * kApplyWaves + wave;
+    const DevMap &m = p.m;
+    if (t >= m.ctr->touched) return;  // (wave-uniform)
+    const uint32_t h = p.touched[t];
+    const uint32_t g = m.cnt[h], start = m.seg_start[h];
+    Slot &e = m.table[h];
+    const uint32_t old_val = e.val;
+    const uint32_t old_count = old_val & 0xffu;
+    uint32_t count = old_count, bucket = old_val >> 8;
+    if (lane == 0) {
+        if (g != 0xFFFFFFFFu) m.cnt[h] = 0;  // (after g has arrived) leave the per-slot scratch clean for the next update
+        if (old_count == 0) {  // first points of this voxel: take a bucket (re-use a freed one if any)
+            const uint32_t f = atomicSub(&m.ctr->free_count, 1u);
+            if (f != 0u && f <= m.bucket_capacity) {
+                bucket = m.free_list[f - 1];
+            } else {
+                atomicAdd(&m.ctr->free_count, 1u);
+                bucket = atomicAdd(&m.ctr->n_buckets_hi, 1u);
+                if (bucket >= m.bucket_capacity) m.ctr->error = 2u, bucket = kNoSlot;  // cannot happen: the host checked the capacity beforehand
+            }
+        }
+    }
+    bucket = __shfl(bucket, 0, 64);
+    if (bucket == kNoSlot) return;
+    const double vs = m.voxel_size;
+    const double map_resolution = sqrt(vs * vs / m.cap);
+    double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
+    MirrorPoint *b16 = m.pool16 + static_cast<size_t>(bucket) * mirror_stride(m.cap);
+    const double upm = mirror_units_per_metre(vs);
+    double *sp = s_pts[wave];
+    if (old_count == 0) {  // a fresh or re-used bucket: every slot of its mirror is empty until a point is stored there
+        for (uint32_t k = lane; k < mirror_stride(m.cap); k += 64) b16[k] = mirror_empty();
+    } else {
+        for (uint32_t k = lane; k < 3 * old_count; k += 64) sp[k] = b[k];  // the bucket as it stands
+    }
+    // walk the group in ascending input index
+    uint32_t last = 0;
+    bool first = true;
+    for (uint32_t step = 0; step < g && count < m.cap; ++step) {
+        uint32_t idx = 0xFFFFFFFFu;
+        for (uint32_t k = lane; k < g; k += 64) {
+            const uint32_t c = p.order[start + k];
+            if ((first || c > last) && c < idx) idx = c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) idx = min(idx, static_cast<uint32_t>(__shfl_xor(idx, off, 64)));
+        first = false, last = idx;
+        const double px = p.world[3 * idx], py = p.world[3 * idx + 1], pz = p.world[3 * idx + 2];
+        bool too_close = false;
+        for (uint32_t k = lane; k < count; k += 64) {
+            const double dx = sp[3 * k] - px, dy = sp[3 * k + 1] - py, dz = sp[3 * k + 2] - pz;
+            too_close = too_close || sqrt(dx * dx + dy * dy + dz * dz) < map_resolution;
+        }
+        if (__any(too_close)) continue;
+        if (lane == 0) {
+            sp[3 * count] = px, sp[3 * count + 1] = py, sp[3 * count + 2] = pz;
+            b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
+            b16[count] = mirror_point(px - e.x * vs, py - e.y * vs, pz - e.z * vs, upm);
+        }
+        ++count;
+    }
+    if (count == old_count) return;
+    if (lane == 0) {
+        e.val = (bucket << 8) | count;
+        atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
+        if (old_count == 0) atomicAdd(&m.ctr->n_voxels, 1u);
+    }
+    if (old_count == 0 && lane < 27) {  // newly occupied: tell the 27 voxels that see this one (U + shift[s] == this  <=>  U = this - shift[s])
+        const int s = lane;
+        const uint32_t u = dev_find_or_insert(m, e.x - shift_component(kShiftX, s), e.y - shift_component(kShiftY, s), e.z - shift_component(kShiftZ, s));
+        if (u != kNoSlot) {  // (kNoSlot: table full, error raised)
+            m.table[u].nb[s] = bucket;
+            atomicOr(&m.table[u].nbr, 1u << s);
+        }
+    }
+}
+
+// 4b. the same step with one THREAD per touched voxel: what large updates use (tens of thousands of touched voxels - bulk
+//     insertions, map building - fill the machine with independent voxels; a wave per voxel only adds overhead there)
+static __global__ __launch_bounds__(64) void k_up_apply_thread(const UpdateParams p) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     const DevMap &m = p.m;
     if (t >= m.ctr->touched) return;
@@ -228,25 +316,37 @@ static __global__ __launch_bounds__(64) void k_up_apply(const UpdateParams p) {
     }
 }
 
-// 5. RemovePointsFarFromLocation(origin): a voxel goes when its FIRST point is >= max_distance away
+// 5. RemovePointsFarFromLocation(origin): a voxel goes when its FIRST point is >= max_distance away.
+//    The sweep runs over the packed-key side array (8 B per slot, four slots per lane and trip), not over the 128-byte
+//    slots: most of the table is free (load factor <= 0.25 after a re-hash) and most live entries are halo entries, so only
+//    the entries that exist are looked at, and only the occupied ones touch the point pool.  (Sweeping the slots themselves
+//    took 0.7 ms per update on cfg2's 2M-slot table - the largest single item of a frame's map update.)
 static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, double oy, double oz) {
     const uint32_t slots = m.mask + 1;
     const double max_distance2 = m.max_distance * m.max_distance;
-    for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
-        Slot &e = m.table[h];
-        const uint32_t val = e.val;
-        if (val == kEmptyVal || (val & 0xffu) == 0u) continue;
-        const uint32_t bucket = val >> 8;
-        const double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
-        const double dx = b[0] - ox, dy = b[1] - oy, dz = b[2] - oz;
-        if (!(dx * dx + dy * dy + dz * dz >= max_distance2)) continue;
-        e.val = kHaloVal;
-        m.free_list[atomicAdd(&m.ctr->free_count, 1u)] = bucket;
-        atomicSub(&m.ctr->n_voxels, 1u);
-        atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val & 0xffu) + 1ull);
-        for (int s = 0; s < 27; ++s) {
-            const uint32_t u = dev_find(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
-            if (u != kNoSlot) atomicAnd(&m.table[u].nbr, ~(1u << s));
+    const ulonglong2 *keys2 = reinterpret_cast<const ulonglong2 *>(m.keys64);
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < slots / 4; q += gridDim.x * 256) {  // (slots is a power of two >= 1024)
+        const ulonglong2 ka = keys2[2 * q], kb = keys2[2 * q + 1];
+        const unsigned long long key[4] = {ka.x, ka.y, kb.x, kb.y};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (key[u] == kEmptyKey64) continue;
+            const uint32_t h = 4 * q + u;
+            Slot &e = m.table[h];
+            const uint32_t val = e.val;
+            if (val == kEmptyVal || (val & 0xffu) == 0u) continue;
+            const uint32_t bucket = val >> 8;
+            const double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
+            const double dx = b[0] - ox, dy = b[1] - oy, dz = b[2] - oz;
+            if (!(dx * dx + dy * dy + dz * dz >= max_distance2)) continue;
+            e.val = kHaloVal;
+            m.free_list[atomicAdd(&m.ctr->free_count, 1u)] = bucket;
+            atomicSub(&m.ctr->n_voxels, 1u);
+            atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val & 0xffu) + 1ull);
+            for (int s = 0; s < 27; ++s) {
+                const uint32_t w = dev_find(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
+                if (w != kNoSlot) atomicAnd(&m.table[w].nbr, ~(1u << s));
+            }
         }
     }
 }

@@ -107,3 +107,27 @@ def test_bulk_host_calls_insert_on_the_device():
 
 def lib_last_on_device(m):
     return bool(K.lib().kicp_map_last_update_on_device(m._h))
+
+
+def test_both_apply_kernels_build_the_reference_map():
+    """The insertion step has two kernels (kicp_mapdev.hpp 4 / 4b): a wave per touched voxel for frame-sized updates, a
+    thread per voxel beyond 16384 touched voxels.  One large update (> 16384 voxels, many points per voxel, buckets that
+    fill up) and a series of small ones on top, against the sequential oracle - points in bucket order, not just as a set."""
+    rng = np.random.default_rng(31)
+    big = rng.uniform(-40, 40, (400000, 3)) * np.array([1, 1, 0.005])     # ~26k-50k voxels of 0.5 m, ~10 points offered to each
+    g, o = K.VoxelHashMap(0.5, 200.0, 12, device=0), okicp.VoxelHashMap(0.5, 200.0, 12)
+    ident = np.array([0.0, 0, 0, 1, 0, 0, 0])
+    assert g.UpdateDevice(K.DeviceFrame(big), ident)
+    o.Update(big, ident)
+    assert g.num_voxels() == o.num_voxels() > 16384 and g.num_points() == o.num_points()
+    for k in range(6):                                                    # frame-sized updates: the wave-per-voxel kernel
+        pose = syn.planar_pose(0.7 * k, -0.3 * k, 0.05 * k)
+        small = rng.uniform(-25, 25, (6000, 3)) * np.array([1, 1, 0.005])
+        assert g.UpdateDevice(K.DeviceFrame(small), pose)
+        o.Update(small, pose)
+        assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels()), k
+    q = rng.uniform(-30, 30, (4000, 3)) * np.array([1, 1, 0.005])
+    nn_g, d_g = g.GetClosestNeighbor(q)
+    nn_o, d_o = o.GetClosestNeighbor(q)
+    assert np.array_equal(nn_g, nn_o) and np.array_equal(d_g, d_o)   # the tie rule sees the buckets' internal order
+    assert np.array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud())) and g.check() == 0
