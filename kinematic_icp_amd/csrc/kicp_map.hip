@@ -501,10 +501,10 @@ size_t kicp_map_pointcloud(const kicp_map *cmap, double *out_xyz, size_t cap_poi
             mr.pc_points = total + total / 4 + 1024;
         }
         hipStream_t st = nullptr;
-        hipLaunchKernelGGL(k_pc_count, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(slots), mr.d_pc_blocks);
+        hipLaunchKernelGGL(k_pc_count, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots), mr.d_pc_blocks);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, mr.d_pc_blocks, static_cast<uint32_t>(blocks), mr.d_pc_blocks + blocks);
-        hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(slots), mr.d_pool,
-                           map->host.cap(), mr.d_pc_blocks, mr.d_pc);
+        hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots),
+                           mr.d_pool, map->host.cap(), mr.d_pc_blocks, mr.d_pc);
         HIP_TRY(hipGetLastError());
         uint32_t counted = 0;
         HIP_TRY(hipMemcpy(&counted, mr.d_pc_blocks + blocks, 4, hipMemcpyDeviceToHost));

@@ -354,24 +354,25 @@ static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double
 // ---- Pointcloud() from the device copy (KinematicICP.hpp:92, published by the ROS node when someone listens) ----------
 // All points, voxel by voxel in table order - the order HostMap::Pointcloud emits - without bringing the table and the
 // pools back to the host: count per 256-slot block, scan the block totals, then every slot copies its bucket's points.
-static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, uint32_t slots, uint32_t *block_counts) {
+// (Free slots are recognised in the packed-key side array, 8 B per slot: the 128-byte slots of a mostly empty table are never read.)
+static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, const unsigned long long *keys64, uint32_t slots, uint32_t *block_counts) {
     __shared__ uint32_t s_sum[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     uint32_t c = 0;
-    if (h < slots && table[h].val != kEmptyVal) c = table[h].val & 0xffu;
+    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = table[h].val & 0xffu;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
-static __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, uint32_t slots, const double *pool, uint32_t cap,
-                                                   const uint32_t *block_offsets, double *out) {
+static __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, const unsigned long long *keys64, uint32_t slots, const double *pool,
+                                                   uint32_t cap, const uint32_t *block_offsets, double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t c = 0, bucket = 0;
-    if (h < slots && table[h].val != kEmptyVal) c = table[h].val & 0xffu, bucket = table[h].val >> 8;
+    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = table[h].val & 0xffu, bucket = table[h].val >> 8;
     uint32_t incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
