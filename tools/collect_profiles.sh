@@ -30,5 +30,9 @@ for comm in shm p2p; do
 done
 # launch path A/B on this box: the same bench with the pass kernel launched through HIP instead of the AQL queue
 KICP_AQL=0 timeout 400 python bench.py --no-cpu-baseline > $O/bench_n1_hip_launch.json 2> $O/bench_n1_hip_launch.err; echo "hip-launch bench rc=$?"
+timeout 300 python tools/bench_mapupdate.py > $O/mapupdate.txt 2>&1; tail -2 $O/mapupdate.txt
+timeout 300 python tools/gpu_dbg.py cfg2 > $O/ablation_cfg2.txt 2>&1; timeout 300 python tools/gpu_dbg.py cfg5 > $O/ablation_cfg5.txt 2>&1
+KICP_AQL=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_cfg2_hip -o kt -- python tools/prof_target.py --workload cfg2 --calls 300 > /dev/null 2> $O/kt_cfg2_hip.err
+python tools/prof_summary.py $(find $O/kt_cfg2_hip -name "*.db" | head -1) > $O/kernel_trace_cfg2_hip_launch.txt 2>&1; grep k_pass $O/kernel_trace_cfg2_hip_launch.txt
 find $O -name "*.db" -delete
 du -sh $O
