@@ -703,6 +703,41 @@ __device__ __forceinline__ uint32_t tree_min_u32(const uint32_t (&v)[N]) {
     return a[0];
 }
 
+// minimum AND runner-up of N register-resident unsigned keys in one tournament: every node carries (min, second).  For three
+// nodes a, b, c:  min = min3(a.m, b.m, c.m);  second = min(med3(a.m, b.m, c.m), min3(a.s, b.s, c.s)) - the seconds of the two
+// losing nodes are never smaller than the median of the minima, so they may take part unharmed (no selects).  20 keys: 26
+// instructions, against 11 + 20 + 11 for a minimum, a re-keying subtraction and a second minimum.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }  // -> v_med3_u32
+template <int N>
+__device__ __forceinline__ void tree_min2_u32(const uint32_t (&v)[N], uint32_t &first, uint32_t &second) {
+    constexpr int L1 = (N + 2) / 3;
+    uint32_t m[L1], s[L1];
+#pragma unroll
+    for (int u = 0; u < L1; ++u) {  // leaves: triples (the last node may hold one or two keys)
+        const int i0 = 3 * u, i1 = 3 * u + 1, i2 = 3 * u + 2;
+        if (i2 < N) m[u] = min(v[i0], min(v[i1], v[i2])), s[u] = umed3(v[i0], v[i1], v[i2]);
+        else if (i1 < N) m[u] = min(v[i0], v[i1]), s[u] = max(v[i0], v[i1]);
+        else m[u] = v[i0], s[u] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int width = L1; width > 1; width = (width + 2) / 3) {
+#pragma unroll
+        for (int u = 0; u < (width + 2) / 3; ++u) {
+            const int i0 = 3 * u, i1 = 3 * u + 1, i2 = 3 * u + 2;
+            if (i2 < width) {
+                const uint32_t mm = min(m[i0], min(m[i1], m[i2])), md = umed3(m[i0], m[i1], m[i2]), ss = min(s[i0], min(s[i1], s[i2]));
+                m[u] = mm, s[u] = min(md, ss);
+            } else if (i1 < width) {
+                const uint32_t mm = min(m[i0], m[i1]), mx = max(m[i0], m[i1]), ss = min(s[i0], s[i1]);
+                m[u] = mm, s[u] = min(mx, ss);
+            } else {
+                m[u] = m[i0], s[u] = s[i0];
+            }
+        }
+    }
+    first = m[0], second = s[0];
+}
+
 // merge the three-smallest record of another lane into `t`
 __device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
     best3_update(t, o.b1, o.i1, o.o1);
@@ -839,24 +874,20 @@ __device__ __forceinline__ void visit_bucket(const Probe &P, Best3 &t, const Map
         uint32_t last_word = c[kMine / 2 - 1].w;
         if (PARTS == 2) last_word = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(last_word), 0xF5, 0xf, 0xf, false));
         const bool more = (last_word >> 16) == 0u;
-        const uint32_t key1 = tree_min_u32<kMine>(key);
+        // winner and runner-up in one tournament (the keys are unique, so the runner-up is a different candidate)
+        uint32_t key1, key2;
+        tree_min2_u32<kMine>(key, key1, key2);
         const float m1 = __uint_as_float(key1 & ~31u);
         if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
-            // Runner-up: the keys are unique, so key - (key1 + 1) wraps to the top of the range for the winner alone and
-            // keeps the order of all the others (one subtraction per key instead of compare + select).  The third place is
-            // only worth a tournament when the runner-up lies within the margin of the winner; otherwise the runner-up's
-            // value stands in for it (a lower bound that can never look like a near tie).
-            const uint32_t after1 = key1 + 1u;
-#pragma unroll
-            for (int u = 0; u < kMine; ++u) key[u] -= after1;
-            const uint32_t rest2 = tree_min_u32<kMine>(key);
-            const uint32_t key2 = after1 + rest2;
+            // The third place is only worth a tournament when the runner-up lies within the margin of the winner; otherwise the
+            // runner-up's value stands in for it (a lower bound that can never look like a near tie).  key - (key2 + 1) wraps to
+            // the top of the range for the winner and the runner-up alone and keeps the order of all the others.
             uint32_t key3 = key2;
             if (__uint_as_float(min(key2, kFarKey) & ~31u) - m1 <= margin) {
-                const uint32_t after2 = rest2 + 1u;  // (= key2 + 1 in the shifted keys; the winner stays at the top: it wrapped)
+                const uint32_t after2 = key2 + 1u;
 #pragma unroll
                 for (int u = 0; u < kMine; ++u) key[u] -= after2;
-                key3 = key2 + 1u + tree_min_u32<kMine>(key);
+                key3 = after2 + tree_min_u32<kMine>(key);
             }
             const uint32_t k1 = k0 + first + (key1 & 31u), k2 = k0 + first + (key2 & 31u);  // positions within the bucket
             // with fewer than three points the far key stands in (finite, beyond every real distance)
