@@ -985,6 +985,7 @@ int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2
 int kicp_reg_p2p_connect(kicp_reg *reg, const char *handles) {
     if (!reg || !handles) return fail(KICP_ERR_ARG, "null argument");
     if (!reg->p2p_box) return fail(KICP_ERR_ARG, "kicp_reg_p2p_export first");
+    if (reg->d_p2p_table) return fail(KICP_ERR_ARG, "already connected: kicp_reg_p2p_destroy / _export first");
     if (int rc = set_device(reg->device)) return rc;
     unsigned long long *table[kP2pMaxRanks] = {};
     for (int k = 0; k < reg->nranks; ++k) {
