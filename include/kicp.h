@@ -140,7 +140,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  one record first (six)
  *   "loop"         device-side solve only: 1 stepped (host polls the stop flag), 0 all iterations queued up front
  *   "wait"         0 (default) poll the host-mapped result record; 1 hipStreamSynchronize
- *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[] */
+ *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[]
+ *   "aql"          1 (default) dispatch the pass kernel with hand-written AQL packets on the handle's own HSA queue wherever the
+ *                  host polls for the result and nothing on the HIP stream must follow the kernel; 0 always launch through the
+ *                  HIP stream (also: KICP_AQL=0 in the environment).  "aql_active" (read only): how the last pass was launched */
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value);
 double kicp_reg_get_option(const kicp_reg *reg, const char *name);
 
