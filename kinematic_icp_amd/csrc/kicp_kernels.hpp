@@ -902,7 +902,7 @@ __device__ __forceinline__ void visit_bucket(const Probe &P, Best3 &t, const Map
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || p.dbg != 0) return;
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
@@ -910,12 +910,12 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
     const double bound = p.search.bound;
     double best = bound;
     uint32_t best_idx = kNoIndex32;
-    if (t.b3 - t.b1 <= margin) {  // three near-equal candidates: leave it to the exact fp64 search
+    if (t.b3 - t.b1 <= margin && p.dbg != 9) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
         search_global(m, q, best, best_idx);
     } else {
         const double d1 = exact_d2(m, t.i1, q);
         if (d1 < best) best = d1, best_idx = t.i1;
-        if (t.b2 - t.b1 <= margin) {
+        if (t.b2 - t.b1 <= margin && t.i2 != kNoIndex32) {
             const double d2 = exact_d2(m, t.i2, q);
             // the reference keeps the FIRST candidate (in visiting order) that attains the strict minimum
             if (d2 < bound && (best_idx == kNoIndex32 || d2 < best || (d2 == best && t.o2 < t.o1))) best = d2, best_idx = t.i2;
