@@ -218,3 +218,47 @@ def test_peer_mailbox_reports_a_missing_peer():
     assert e.value.code == K.KICP_ERR_COMM
     reg.p2p_destroy(), reg2.p2p_destroy()
     reg.ComputeRobotMotion(g["a_frame"], m, g["a_last"], g["a_rel"], float(g["a_tau"]))  # usable again, single GPU
+
+
+def _p2p_timeout_worker(rank, world, barrier, handles, q):
+    """rank 0 registers, rank 1 connects its mailbox but never shows up: rank 0's kernel must give up after its bounded
+    wait and the call must come back with KICP_ERR_COMM (then work again, single GPU)."""
+    sys.path.insert(0, ROOT)
+    try:
+        import kinematic_icp_amd as K
+        g = np.load(GOLD)
+        reg = K.KinematicRegistration(device=0)
+        handles[rank] = reg.p2p_export(world, rank)
+        barrier.wait()
+        reg.p2p_connect([handles[r] for r in range(world)])
+        barrier.wait()
+        out = None
+        if rank == 0:
+            m = K.VoxelHashMap(float(g["a_voxel"]), float(g["a_maxrange"]), 20)
+            m.AddPoints(g["a_map"])
+            try:
+                reg.ComputeRobotMotion(g["a_frame"][:1000], m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+                out = "no error"
+            except K.KicpError as e:
+                out = e.code
+        barrier.wait()
+        reg.p2p_destroy()
+        if rank == 0:
+            pose = reg.ComputeRobotMotion(g["a_frame"], m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+            out = (out, bool(np.allclose(pose, g["a_pose"], rtol=0, atol=1e-9)))
+        q.put((rank, out, None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, repr(e) + "\n" + traceback.format_exc()))
+        try:
+            barrier.abort()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def test_peer_mailbox_gives_up_on_a_silent_peer():
+    import kinematic_icp_amd as K
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = _spawn(_p2p_timeout_worker, 2, (ctx.Barrier(2), mgr.dict()))
+    assert results[0] == (K.KICP_ERR_COMM, True)
