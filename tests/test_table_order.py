@@ -25,6 +25,11 @@ def test_cluster_replay_equals_sequential_robin_hood(tmp_path):
     assert int(out.split()[1]) > 80
 
 
+def _build_host_filter(exe):
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", CPP, "-I", os.path.join(CPP, "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_downsample_test.cpp"), "-o", exe, "-Wl,--unresolved-symbols=ignore-all"])
+
+
 def _clouds():
     rng = np.random.Generator(np.random.PCG64(5))
     cfg, scene, scans, _ = syn.make_case("cfg1", n_scans=1)
@@ -38,8 +43,7 @@ def _clouds():
 
 def test_host_drop_in_downsample_has_the_reference_order(tmp_path):
     exe = str(tmp_path / "host_downsample_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", CPP, "-I", os.path.join(CPP, "compat"),
-                           os.path.join(ROOT, "tests", "cpp", "host_downsample_test.cpp"), "-o", exe])
+    _build_host_filter(exe)
     try:
         from oracle import rkicp
         ref = rkicp if rkicp.available() else None
@@ -48,7 +52,7 @@ def test_host_drop_in_downsample_has_the_reference_order(tmp_path):
     for name, pts, vs in _clouds():
         f = tmp_path / (name + ".bin")
         np.ascontiguousarray(pts, dtype=np.float64).tofile(f)
-        got = np.frombuffer(subprocess.check_output([exe, str(f), repr(vs)]), dtype=np.float64).reshape(-1, 3)
+        got = np.frombuffer(subprocess.check_output([exe, "downsample", str(f), repr(vs)]), dtype=np.float64).reshape(-1, 3)
         want = okicp.voxel_downsample(pts, vs)
         assert np.array_equal(got, want), name
         if ref is not None:
@@ -58,3 +62,23 @@ def test_host_drop_in_downsample_has_the_reference_order(tmp_path):
             keys = np.floor(pts / vs).astype(np.int64)
             _, first = np.unique(keys, axis=0, return_index=True)
             assert not np.array_equal(pts[np.sort(first)], want), name
+
+
+def test_host_drop_in_preprocess_matches_the_oracle(tmp_path):
+    """kiss_icp::Preprocessor::Preprocess of the drop-in headers (constant-velocity deskew to the scan end + strict range
+    crop, order kept) against the oracle and the reference build's stand-in: same survivors, points to 1e-12 (the compat
+    Sophus exp / log against the oracle's)."""
+    exe = str(tmp_path / "host_filter")
+    _build_host_filter(exe)
+    cfg, scene, scans, _ = syn.make_case("cfg1", n_scans=1)
+    frame = scans[0]["frame"][:6000]
+    stamps = np.linspace(0.0, 1.0, len(frame))
+    rel = syn.pose_mul(syn.planar_pose(0.6, 0.05, 0.04), np.array([0.004, -0.003, 0, np.sqrt(1 - 25e-6), 0, 0, 0.01]))
+    np.ascontiguousarray(frame).tofile(tmp_path / "p.bin"), stamps.tofile(tmp_path / "t.bin"), rel.tofile(tmp_path / "r.bin")
+    np.zeros(0).tofile(tmp_path / "none.bin")
+    for deskew, tfile in ((1, "t.bin"), (0, "t.bin"), (1, "none.bin")):  # (no stamps: no deskew even when asked)
+        got = np.frombuffer(subprocess.check_output([exe, "preprocess", str(tmp_path / "p.bin"), str(tmp_path / tfile), str(tmp_path / "r.bin"),
+                                                     "4.6", "3.9", str(deskew)]), dtype=np.float64).reshape(-1, 3)
+        want = okicp.preprocess(frame, stamps if tfile == "t.bin" else None, rel, 4.6, 3.9, bool(deskew))
+        assert 0 < len(got) == len(want) < len(frame)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
