@@ -3,11 +3,13 @@
 // doubles.  tests/test_table_order.py compares the bytes with the oracle's / the reference build's.
 //   host_downsample_test downsample <points.bin> <voxel_size>
 //   host_downsample_test preprocess <points.bin> <stamps.bin> <pose7.bin> <max_range> <min_range> <deskew 0|1>
+//   host_downsample_test threshold <errors7.bin> <map_discretization_error> <max_range>   -> tau before / after every update
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <kiss_icp/core/Preprocessing.hpp>
 #include <kiss_icp/core/VoxelUtils.hpp>
+#include <kinematic_icp/correspondence_threshold/CorrespondenceThreshold.hpp>
 #include <vector>
 
 #include "kicp_bridge.hpp"
@@ -35,6 +37,17 @@ int main(int argc, char **argv) {
         const auto pose = read_all(argv[4]);
         const kiss_icp::Preprocessor pre(std::atof(argv[5]), std::atof(argv[6]), std::atoi(argv[7]) != 0, 1);
         out = pre.Preprocess(points_of(read_all(argv[2])), read_all(argv[3]), kicp_bridge::from_params(pose.data()));
+    } else if (!std::strcmp(argv[1], "threshold") && argc >= 5) {
+        const auto errs = read_all(argv[2]);
+        kinematic_icp::CorrespondenceThreshold thr(std::atof(argv[3]), std::atof(argv[4]), true, 1.0);
+        double tau = thr.ComputeThreshold();
+        std::fwrite(&tau, sizeof tau, 1, stdout);
+        for (size_t i = 0; i + 6 < errs.size(); i += 7) {
+            thr.UpdateOdometryError(kicp_bridge::from_params(&errs[i]));
+            tau = thr.ComputeThreshold();
+            std::fwrite(&tau, sizeof tau, 1, stdout);
+        }
+        return 0;
     } else {
         return 2;
     }

@@ -52,7 +52,7 @@ def test_host_drop_in_downsample_has_the_reference_order(tmp_path):
     for name, pts, vs in _clouds():
         f = tmp_path / (name + ".bin")
         np.ascontiguousarray(pts, dtype=np.float64).tofile(f)
-        got = np.frombuffer(subprocess.check_output([exe, "downsample", str(f), repr(vs)]), dtype=np.float64).reshape(-1, 3)
+        got = np.frombuffer(subprocess.check_output([exe, "downsample", str(f), "%.17g" % vs]), dtype=np.float64).reshape(-1, 3)
         want = okicp.voxel_downsample(pts, vs)
         assert np.array_equal(got, want), name
         if ref is not None:
@@ -82,3 +82,15 @@ def test_host_drop_in_preprocess_matches_the_oracle(tmp_path):
         want = okicp.preprocess(frame, stamps if tfile == "t.bin" else None, rel, 4.6, 3.9, bool(deskew))
         assert 0 < len(got) == len(want) < len(frame)
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_host_drop_in_threshold_reproduces_the_reference_builds_sequence(tmp_path):
+    """kinematic_icp::CorrespondenceThreshold of the drop-in headers (host scalar code, SURVEY.md section 8f row 4) on the error
+    sequence frozen in tests/golden/ref_outputs.npz: the taus the reference build's CorrespondenceThreshold.cpp returned."""
+    exe = str(tmp_path / "host_filter")
+    _build_host_filter(exe)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_outputs.npz"))
+    np.ascontiguousarray(g["thr_errs"], dtype=np.float64).tofile(tmp_path / "e.bin")
+    got = np.frombuffer(subprocess.check_output([exe, "threshold", str(tmp_path / "e.bin"), "%.17g" % (1.0 / np.sqrt(20)), "100.0"]), dtype=np.float64)
+    assert len(got) == len(g["thr_taus"]) > 3
+    np.testing.assert_allclose(got, g["thr_taus"], rtol=1e-15, atol=0)
