@@ -27,8 +27,14 @@ def build_facade():
     return BIN
 
 
-def test_facade_compiles_and_links():
+def test_facade_compiles_and_links(tmp_path):
     assert os.path.exists(build_facade())
+    # the KICP_HOST_PRESTEPS variant of RegisterFrame (host Preprocess / VoxelDownsample, registration and map on the GPU) compiles too
+    tu = tmp_path / "host_presteps.cpp"
+    tu.write_text('#define KICP_HOST_PRESTEPS\n#include "kinematic_icp/pipeline/KinematicICP.hpp"\n'
+                  'int main() { kinematic_icp::pipeline::Config c; return c.max_num_iterations == 10 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", CPP, "-I", os.path.join(CPP, "compat"),
+                           "-I", os.path.join(ROOT, "include"), str(tu)])
     # the reference's include lines for this path resolve inside the drop-in tree
     for inc in ("kinematic_icp/pipeline/KinematicICP.hpp", "kinematic_icp/registration/Registration.hpp",
                 "kinematic_icp/correspondence_threshold/CorrespondenceThreshold.hpp", "kiss_icp/core/VoxelHashMap.hpp",
