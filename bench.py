@@ -66,7 +66,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scans-per-step", type=int, default=64, help="registrations per step (one batch of synthetic scans)")
+    ap.add_argument("--scans-per-step", type=int, default=0,
+                    help="registrations per step (one batch of synthetic scans); 0 (default) = chosen after a calibration batch so that the "
+                         "timed region of the K steps lasts at least --min-timed-s, never fewer than 64")
+    ap.add_argument("--min-timed-s", type=float, default=0.3, help="shortest acceptable timed region (auto batch size)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic")
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
@@ -203,7 +207,7 @@ def main():
             stats_out.append((k, list(reg.last_stats.pass_ms[:k])))
         return pose
 
-    B = max(1, args.scans_per_step)
+    B = max(1, args.scans_per_step) if args.scans_per_step > 0 else 64  # (auto: fixed below, after the calibration batch)
 
     def timed(reg, rels, steps, warmup, per_call=False):
         """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
@@ -251,9 +255,16 @@ def main():
     while time.perf_counter() - t_settle < 0.5:
         for i in range(50):
             run_scan(reg, i, rel_single)
+    if args.scans_per_step <= 0:
+        # calibration (setup, not measurement): size the batch so that the K timed steps last >= --min-timed-s whatever K is;
+        # identical on every rank (max over ranks)
+        t_cal = timed(reg, rel_single, 4, 1) / (4 * B)
+        B = int(min(8192, max(64, -(-args.min_timed_s // (max(1, args.steps) * t_cal)))))
     elapsed = timed(reg, rel_single, args.steps, args.warmup)                 # ---- the headline number
-    launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp)" if reg.get_option("aql_active") == 1.0
-                   else "hipLaunchKernelGGL on the handle's stream")
+    launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp), kernel arguments in %s"
+                   % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
+                   if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
+    small_active = reg.get_option("small_active") == 1.0  # the small-scan path (kicp_small.hpp: resident kernel, rows straight to the host)
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
     elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
@@ -346,33 +357,56 @@ def main():
     bytes_per_launch = float(np.mean(balgo_pass)) / share
     bmin_per_launch = float(np.mean(bmin_pass)) / share
     pass_ms = np.array([ms for _, lst in per_call for ms in lst], dtype=np.float64)
-    kernel_us = float(pass_ms.mean() * 1e3) if pass_ms.size else float("nan")
-    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if pass_ms.size else None
     iters_gpu = float(np.mean([it for it, _ in per_call]))
     iters_gpu_multi = float(np.mean([it for it, _ in per_call_multi])) if per_call_multi else float("nan")
+    kernel_us = float(pass_ms.mean() * 1e3) if pass_ms.size else float("nan")
+    kernel_time_source = "HIP events around every pass launch on the handle's stream (the event pair adds ~2 us to the ~kernel-trace duration)"
+    if small_active and np.isfinite(iters_gpu_multi):
+        # a resident kernel serves all passes of a call and cannot be bracketed per pass: wall clock per ICP iteration instead
+        kernel_us = 1e6 * elapsed_multi / (args.steps * B) / iters_gpu_multi
+        kernel_time_source = ("wall clock per ICP iteration of the multi-iteration run (the small-scan kernel stays resident for a call's passes; "
+                              "includes the host-side solve and the command round trip)")
+    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if pass_ms.size else None
     pass_ms_multi = np.array([ms for _, lst in per_call_multi for ms in lst], dtype=np.float64)
 
     cpu = None if args.no_cpu_baseline else _cpu_baseline(args, cfg, scans, rel_single, tau, omap, map_points, okicp, rkicp)
 
     n_scans_timed = args.steps * B
     value = (world if replicas else 1) * n_scans_timed / elapsed  # replicas: every rank completed its own scans
+    # ---- HBM traffic of the pass kernel, measured in THIS run: one rocprofv3 --pmc pass per counter over a bare loop of the
+    #      same registrations (tools/prof_target.py), after everything timed is over.  Falls back to the committed profile
+    #      (stamped with the commit it was taken at) where rocprofv3 cannot run.
+    kernel_sub = "k_pass_small" if small_active else "k_pass_gather32"
+    traffic, traffic_src = (None, "not measured (--no-pmc)") if (args.no_pmc or world != 1) else _pmc_traffic(args.workload, kernel_sub)
     prof = _profile_counters(args.workload, world)
-    roof = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
-            "kernel": "fused association+accumulation pass (k_pass_gather32)", "kernel_avg_us": round(kernel_us, 2),
-            "algorithmic_bytes_per_launch": round(bytes_per_launch), "launches_timed": int(pass_ms.size),
+    if traffic is None and prof and prof.get("hbm_bytes_per_launch"):
+        traffic = float(prof["hbm_bytes_per_launch"])
+        traffic_src = "%s; in-run measurement unavailable: %s" % (prof.get("source"), traffic_src)
+    t_kernel = kernel_us * 1e-6
+    traffic_gbs = None if (traffic is None or not pass_ms.size) else traffic / t_kernel / 1e9
+    roof = {"bound": "hbm", "achieved": None if traffic_gbs is None else round(traffic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 4),
+            "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
+            "kernel": "fused association+accumulation pass (%s)" % kernel_sub, "kernel_avg_us": round(kernel_us, 2),
+            "kernel_time_source": kernel_time_source, "launches_timed": int(pass_ms.size),
+            "what": "achieved = HBM bytes the pass kernel moved per launch (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) / its "
+                    "average duration; frac = achieved / 8 TB/s.  The kernel is bound by its waves' dependent-load chains and a fixed launch + "
+                    "reduction floor, not by HBM: see time_split_us and counters",
+            "algorithmic": {"bytes_per_launch": round(bytes_per_launch),
+                            "GBps": None if achieved is None else round(achieved, 1),
+                            "ratio_to_hbm_peak": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                            "what": "SURVEY.md section 8d: what the REFERENCE's search touches per pass (12 B per query + 16 B per probed slot, 27 per "
+                                    "query, + 12 B per bucket point it scans, counted by the oracle) / the kernel's duration.  NOT a roofline fraction: "
+                                    "this kernel skips provably irrelevant voxels and reads a 16-bit mirror, so it moves a fraction of these bytes and "
+                                    "the ratio can exceed 1"},
             "b_min": {"bytes_per_launch": round(bmin_per_launch),
-                      "achieved": None if achieved is None else round(bmin_per_launch / (kernel_us * 1e-6) / 1e9, 1),
-                      "frac": None if achieved is None else round(bmin_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                      "what": "compulsory bytes: 12 B per query + every touched table slot (16 B) and bucket point (12 B) once"},
+                      "achieved": None if achieved is None else round(bmin_per_launch / t_kernel / 1e9, 1),
+                      "frac": None if achieved is None else round(bmin_per_launch / t_kernel / 1e9 / HBM_PEAK_GBS, 4),
+                      "what": "compulsory bytes: 12 B per query + every touched table slot (16 B) and bucket point (12 B) once",
+                      "traffic_over_b_min": None if traffic is None else round(traffic / bmin_per_launch, 2)},
             "time_split_us": None if floor_us is None else {"fixed_floor_launch_reduction_handoff": round(floor_us, 2),
                                                             "query_work": round(kernel_us - floor_us, 2)},
-            "counters": prof or None,
-            "note": "latency bound, not HBM bound: `achieved` counts what the REFERENCE algorithm touches (27 probes + every scanned "
-                    "bucket point per query), which this kernel neither moves (provably irrelevant voxels are skipped) nor fetches from "
-                    "DRAM (the map mirror is L2 / Infinity-Cache resident), so it can exceed the peak; b_min.frac is the fraction of the "
-                    "HBM roofline a kernel that moved only compulsory bytes would show at this duration"}
+            "counters": prof or None}
     out = {
         "metric": "scans/sec (ICP registration only), 128k-pt scan vs 1M-pt map",
         "value": round(value, 2),
@@ -405,11 +439,18 @@ def main():
                        "pass_kernel_avg_us": round(float(pass_ms_multi.mean() * 1e3), 2) if pass_ms_multi.size else None},
                    "scans_per_s_with_host_input_incl_pcie": None if host_rate is None else round(host_rate, 1), **other,
                    **({"comm_note": comm_note} if comm_note else {})},
+        "value_multi_iteration": {"scans_per_s": round((world if replicas else 1) * n_scans_timed / elapsed_multi, 2),
+                                  "iterations_per_scan": None if not np.isfinite(iters_gpu_multi) else round(iters_gpu_multi, 3),
+                                  "us_per_iteration": None if not np.isfinite(iters_gpu_multi) else round(1e6 * elapsed_multi / n_scans_timed / iters_gpu_multi, 3),
+                                  "what": "the same scans with +%.2f m / +%.1f deg odometry error, same steps and batch" % MULTI_ITER_ERROR},
+        "value_host_vector_input": None if host_rate is None else
+        {"scans_per_s": round(host_rate, 1), "what": "kicp_register with the scan handed over as a HOST array, the reference's own signature "
+                                                      "(Registration.hpp:39-43): upload over PCIe inside the call"},
         "roofline": roof,
         "cpu_baseline": cpu,
     }
-    if elapsed < 0.010:
-        out["config"]["warning"] = "timed region shorter than 10 ms: raise --steps or --scans-per-step"
+    if elapsed < 0.25:
+        out["config"]["warning"] = "timed region shorter than 0.25 s: raise --steps or --scans-per-step (0 = automatic)"
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
@@ -491,6 +532,50 @@ def _cpu_baseline(args, cfg, scans, rels, tau, omap, map_points, okicp, rkicp):
     return res
 
 
+def _pmc_traffic(workload, kernel_sub, calls=200):
+    """HBM bytes per launch of the pass kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, as
+    MI355X_MICROARCH.md prescribes) over tools/prof_target.py - the same registrations as the timed region, nothing else in
+    the process.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB: the guide's gfx950 correction (FETCH_SIZE tallies 128-byte requests
+    at 64 B).  Returns (bytes or None, provenance)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found on this box"
+    means = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kicp_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "prof_target.py"), "--workload", workload,
+               "--calls", str(calls)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            vals = []
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if not f.endswith(".db"):
+                        continue
+                    c = sqlite3.connect(os.path.join(root, f))
+                    cols = [row[1] for row in c.execute("pragma table_info('counters_collection')")]
+                    name_col = "kernel_name" if "kernel_name" in cols else "name"
+                    vals += [float(v) for (v,) in c.execute("select value from counters_collection where counter_name = ? and %s like ?" % name_col,
+                                                             (ctr, "%" + kernel_sub + "%"))]
+                    c.close()
+            if not vals:
+                return None, "rocprofv3 --pmc %s gave no rows for %s (rc %d: %s)" % (ctr, kernel_sub, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            means[ctr] = (float(np.mean(vals)), len(vals))
+        except (OSError, subprocess.SubprocessError, sqlite3.Error) as e:
+            return None, "rocprofv3 --pmc %s failed: %s" % (ctr, str(e)[:200])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    kib = 2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]
+    return kib * 1024.0, ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `tools/prof_target.py --workload %s --calls %d` "
+                          "after the timed region; means over %d / %d dispatches of %s: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB; bytes = (2 x FETCH_SIZE + "
+                          "WRITE_SIZE) x 1024" % (workload, calls, means["FETCH_SIZE"][1], means["WRITE_SIZE"][1], kernel_sub, means["FETCH_SIZE"][0],
+                                                   means["WRITE_SIZE"][0]))
+
+
 def _profile_counters(workload, world):
     """Counters of the pass kernel from the committed rocprofv3 PMC passes of THIS workload (profiles/r02_counters_<workload>.json,
     written by tools/prof_counters_json.py from separate --pmc passes; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per
@@ -498,13 +583,16 @@ def _profile_counters(workload, world):
     not been profiled: nothing is borrowed from another configuration."""
     if world != 1:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_counters_%s.json" % workload)) as f:
-            d = json.load(f)
-        d["source"] = "profiles/r02_counters_%s.json (offline rocprofv3 --pmc passes of this workload, not this run)" % workload
-        return d
-    except (OSError, ValueError):
-        return None
+    for rnd in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (rnd, workload))) as f:
+                d = json.load(f)
+            d["source"] = ("profiles/%s_counters_%s.json (offline rocprofv3 --pmc passes of this workload, NOT this run; taken at commit %s)"
+                           % (rnd, workload, d.get("git_sha", "of round " + rnd[1:])))
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def _cgroup_cpu_max():

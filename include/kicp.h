@@ -38,7 +38,8 @@ enum {
     KICP_WARN_NO_CORRESPONDENCES = 1, /* N_corr == 0 in some pass -> NaN pose, as the reference produces */
     KICP_ERR_HIP = -1,                /* HIP runtime / device failure (message in kicp_last_error) */
     KICP_ERR_ARG = -2,                /* bad argument */
-    KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 255, > 2^24-2 voxels) */
+    KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 255, > 2^24-2 voxels, a per-point term
+                                         of the normal equations >= 2^43: source points ~2 900 km from the base frame) */
     KICP_ERR_COMM = -4                /* RCCL failure */
 };
 
@@ -121,18 +122,22 @@ void kicp_reg_destroy(kicp_reg *reg);
 int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
 int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
 /* Backend tuning knobs (not part of the reference API):
- *   "pass_kernel"  3 (default) thread-per-query gather over the fp32 mirror with exact fp64 resolution; 0 plain fp64
+ *   "pass_kernel"  3 (default) thread-per-query gather over the 16-bit mirror with exact fp64 resolution; 0 plain fp64
  *                  gather (baseline of the ablation)
- *   "block"        workgroup size (64|128|256; default 256)
- *   "lanes_per_query" variant 3: sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
- *   "split_buckets" variant 3 with two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing
- *                  the neighbour voxels between them (1 default | 0)
- *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (4 default | 3)
- *   "split_buckets" variant 3 with two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing
- *                  the neighbour voxels between them (1 default | 0)
- *   "occupancy"    variant 3: waves per SIMD the kernel's register allocation aims for (4 default | 3)
- *   "pool_visits"  variant 3: after a wave's first round of bucket visits, deal the remaining ones evenly over its lanes
- *                  instead of letting every lane walk its own list (1 | 0 | -1 = for scans of 262144 points and more, default)
+ *   "block"        workgroup size of the generic pass kernel (64|128|256; default 256; 512 is accepted for the one-lane-per-query
+ *                  variant only - an experiment that measured no faster)
+ *   "lanes_per_query" sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
+ *   "split_buckets" two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing the neighbour
+ *                  voxels between them (1 default | 0)
+ *   "occupancy"    waves per SIMD the generic kernel's register allocation aims for (4 default | 3)
+ *   "small"        1 (default): scans of at most 16 384 lanes (points x sub-lanes: up to 4 096 points by default) take the
+ *                  small-scan path - every workgroup's exact sums go straight to the host (no reduction tree) and the kernel
+ *                  stays resident for the iterations of the call, polling a command line in host-mapped memory for the next
+ *                  pose; 0: always the generic pass kernel.  "small_active" (read only): which path the last call took
+ *   "small_resident" 1 (default) | 0: one launch per iteration on the small path
+ *   "small_block"  workgroup size of the small-scan kernel (256 default | 512 | 1024)
+ *   "small_timeout_us" how long a resident workgroup waits for the next command before it leaves on its own (default 20 000;
+ *                  the host then launches afresh - "small_relaunches" counts those)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the
@@ -141,9 +146,11 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *   "loop"         device-side solve only: 1 stepped (host polls the stop flag), 0 all iterations queued up front
  *   "wait"         0 (default) poll the host-mapped result record; 1 hipStreamSynchronize
  *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[]
- *   "aql"          1 (default) dispatch the pass kernel with hand-written AQL packets on the handle's own HSA queue wherever the
+ *   "aql"          1 (default) dispatch the pass kernels with hand-written AQL packets on the handle's own HSA queue wherever the
  *                  host polls for the result and nothing on the HIP stream must follow the kernel; 0 always launch through the
- *                  HIP stream (also: KICP_AQL=0 in the environment).  "aql_active" (read only): how the last pass was launched */
+ *                  HIP stream (also: KICP_AQL=0 in the environment).  "aql_active" (read only): how the last pass was launched;
+ *                  "aql_kernarg" (read only): 0 kernel arguments in host memory, 1 in device memory (KICP_KERNARG=dev), 2 + HDP
+ *                  flush (KICP_KERNARG=devhdp) */
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value);
 double kicp_reg_get_option(const kicp_reg *reg, const char *name);
 
@@ -228,6 +235,11 @@ int kicp_pre_download_begin(kicp_pre *pre, int buffer);
 int kicp_pre_download_finish(kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 const double *kicp_pre_device_ptr(const kicp_pre *pre, int buffer, size_t *out_n);
 
+/* Diagnostics: the demangled-name prefixes under which the registration's direct-dispatch path looks its kernels up in the
+ * embedded code object, newline separated (tests check each against build/kicp_reg.hsaco, so a change of the compiler's
+ * mangling or of a template signature fails a CPU test instead of silently disabling the path).  Returns the bytes needed. */
+size_t kicp_aql_kernel_names(char *out, size_t cap);
+
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */
 int kicp_device_malloc(int device, size_t bytes, void **out_dptr);
 int kicp_device_free(int device, void *dptr);
@@ -258,7 +270,12 @@ int kicp_reg_shm_destroy(kicp_reg *reg);
  * nranks slots of its own mailbox, adds them in rank order (integers: bit-identical on every rank) and hands the totals
  * to its host, which solves.  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
  * transport), every rank calls kicp_reg_p2p_connect with the nranks handles in rank order; a barrier between connect and
- * the first registration, and before kicp_reg_p2p_destroy, is the caller's.  nranks <= KICP_P2P_MAX_RANKS. */
+ * the first registration, and before kicp_reg_p2p_destroy, is the caller's.  nranks <= KICP_P2P_MAX_RANKS.
+ * Recovery contract: the ranks stay in step only while every exchange completes on every rank.  When a registration fails
+ * after it has started an exchange (a peer's slot did not arrive within 0.8 x KICP_WAIT_TIMEOUT_S - the in-kernel wait is
+ * derived from the host's setting -, a device fault), this rank's state is POISONED: every later kicp_register* call on the
+ * handle returns KICP_ERR_COMM until kicp_reg_p2p_destroy, kicp_reg_p2p_export and kicp_reg_p2p_connect have been redone
+ * (on every rank: the step counters restart from zero). */
 #define KICP_P2P_HANDLE_BYTES 64
 #define KICP_P2P_MAX_RANKS 16
 int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2P_HANDLE_BYTES]);

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "kicp_reg_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p]),
     "kicp_reg_p2p_destroy": (C.c_int, [C.c_void_p]),
     "kicp_reg_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "kicp_aql_kernel_names": (C.c_size_t, [C.c_char_p, C.c_size_t]),
 }
 
 

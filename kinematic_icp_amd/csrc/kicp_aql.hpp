@@ -28,8 +28,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
+#include <immintrin.h>
+
 #include <map>
 #include <string>
+#include <vector>
 
 extern "C" const unsigned char kicp_hsaco_start[];
 extern "C" const unsigned char kicp_hsaco_end[];
@@ -73,15 +77,23 @@ public:
         have_exe_ = true;
         if (hsa_executable_load_agent_code_object(exe_, agent_, reader_, nullptr, nullptr) != HSA_STATUS_SUCCESS) return off("loading the code object failed");
         if (hsa_executable_freeze(exe_, nullptr) != HSA_STATUS_SUCCESS) return off("hsa_executable_freeze failed");
-        // kernarg ring: host-coherent pinned memory the GPU reads the arguments from
-        if (hipHostMalloc(reinterpret_cast<void **>(&kernarg_), kSlots * kSlotBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-            (void)hipGetLastError();
-            return off("kernarg allocation failed");
+        // Kernarg ring.  KICP_KERNARG=dev | devhdp: in the GPU's own memory, written by the CPU through the PCIe BAR - the
+        // scalar loads of a kernel's first waves then hit HBM instead of crossing PCIe to host memory ("devhdp" also pokes the
+        // host-data-path flush register before the doorbell).  Default / fallback: host-coherent pinned memory.
+        const char *place = std::getenv("KICP_KERNARG");
+        if (place && (std::strcmp(place, "dev") == 0 || std::strcmp(place, "devhdp") == 0)) {
+            if (!kernarg_in_hbm(std::strcmp(place, "devhdp") == 0)) why = "device-memory kernarg ring unavailable (" + why + "): using host memory";
         }
-        void *dev = nullptr;
-        if (hipHostGetDevicePointer(&dev, kernarg_, 0) != hipSuccess || dev != kernarg_) {
-            (void)hipGetLastError();
-            return off("kernarg memory is not identity mapped");
+        if (!kernarg_) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&kernarg_), kSlots * kSlotBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                (void)hipGetLastError();
+                return off("kernarg allocation failed");
+            }
+            void *dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, kernarg_, 0) != hipSuccess || dev != kernarg_) {
+                (void)hipGetLastError();
+                return off("kernarg memory is not identity mapped");
+            }
         }
         if (hsa_signal_create(1, 0, nullptr, &done_) != HSA_STATUS_SUCCESS) return off("hsa_signal_create failed");
         have_signal_ = true;
@@ -89,45 +101,68 @@ public:
         return 0;
     }
 
-    // kernel descriptor + segment sizes of `name` (mangled, without the .kd suffix); cached
-    const AqlKernel &kernel(const std::string &name) {
-        auto it = kernels_.find(name);
+    // Kernel descriptor + segment sizes of the kernel whose DEMANGLED name starts with `prefix`, e.g.
+    // "void kicp::k_pass_gather32<256, 1, 4, false>(" - resolved by enumerating the code object's kernel symbols
+    // (hsa_executable_iterate_symbols) and demangling them, so a change in the compiler's mangling scheme cannot silently
+    // turn every look-up into a miss; tests/test_host.py checks the same names against build/kicp_reg.hsaco.  Cached.
+    const AqlKernel &kernel(const std::string &prefix) {
+        auto it = kernels_.find(prefix);
         if (it != kernels_.end()) return it->second;
+        if (symbols_.empty() && ready) hsa_executable_iterate_symbols(exe_, &AqlDispatcher::collect_symbol, this);
         AqlKernel k;
-        hsa_executable_symbol_t sym;
-        const std::string kd = name + ".kd";
-        if (hsa_executable_get_symbol_by_name(exe_, kd.c_str(), &agent_, &sym) == HSA_STATUS_SUCCESS &&
-            hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object) == HSA_STATUS_SUCCESS &&
-            hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_size) == HSA_STATUS_SUCCESS &&
-            hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_size) == HSA_STATUS_SUCCESS &&
-            hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_size) == HSA_STATUS_SUCCESS)
-            k.usable = k.object != 0 && k.private_size == 0 && k.kernarg_size <= kSlotBytes;
-        return kernels_.emplace(name, k).first->second;
+        for (const auto &entry : symbols_) {
+            if (entry.first.compare(0, prefix.size(), prefix) != 0) continue;
+            const hsa_executable_symbol_t sym = entry.second;
+            if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object) == HSA_STATUS_SUCCESS &&
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_size) == HSA_STATUS_SUCCESS &&
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_size) == HSA_STATUS_SUCCESS &&
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_size) == HSA_STATUS_SUCCESS)
+                k.usable = k.object != 0 && k.private_size == 0 && k.kernarg_size <= kSlotBytes;
+            break;
+        }
+        return kernels_.emplace(prefix, k).first->second;
     }
+    size_t symbol_count() const { return symbols_.size(); }
+    const char *kernarg_place() const { return kernarg_in_hbm_ ? (hdp_flush_ ? "device memory + HDP flush" : "device memory") : "host memory"; }
 
     // one 1-D dispatch: `grid` workgroups of `block` work-items; `args` = the kernel's explicit argument block
     // acquire / release: HSA_FENCE_SCOPE_{NONE, AGENT, SYSTEM} of the packet's fences
-    bool dispatch(const AqlKernel &k, uint32_t grid, uint32_t block, const void *args, size_t args_bytes, int acquire = HSA_FENCE_SCOPE_SYSTEM,
+    bool dispatch(const AqlKernel &k, uint32_t grid, uint32_t block_size, const void *args, size_t args_bytes, int acquire = HSA_FENCE_SCOPE_SYSTEM,
                   int release = HSA_FENCE_SCOPE_SYSTEM) {
         const size_t implicit = (args_bytes + 7) & ~size_t(7);  // code object v5: the implicit arguments follow, 8-byte aligned
-        if (!ready || !k.usable || queue_error || implicit + 80 > k.kernarg_size) return false;
+        // (a kernel that reads no hidden argument has none: its kernarg segment ends with the explicit block)
+        const bool has_implicit = implicit + 80 <= k.kernarg_size;
+        if (!ready || !k.usable || queue_error || args_bytes > k.kernarg_size) return false;
         unsigned char *ka = kernarg_ + (slot_++ % kSlots) * kSlotBytes;
-        std::memcpy(ka, args, args_bytes);
+        // The whole kernarg segment is built in a local block (zeroed: every hidden argument this file does not set - hostcall /
+        // printf buffer, heap, dynamic LDS size, queue pointer - reads as 0 instead of a stale byte of an earlier dispatch) and
+        // copied to the slot in one go.
         // hidden_block_count_{x,y,z} u32 @0, hidden_group_size_{x,y,z} u16 @12, hidden_remainder_{x,y,z} u16 @18,
         // hidden_global_offset_{x,y,z} u64 @40, hidden_grid_dims u16 @64 (llvm AMDGPU usage, code object v5)
-        unsigned char *ia = ka + implicit;
-        std::memset(ia, 0, 80);
+        alignas(64) unsigned char block[kSlotBytes];
+        const size_t total = (static_cast<size_t>(k.kernarg_size) + 63) & ~size_t(63);
+        std::memset(block, 0, total);
+        std::memcpy(block, args, args_bytes);
+        unsigned char *ia = block + implicit;
         const uint32_t counts[3] = {grid, 1u, 1u};
-        const uint16_t sizes[3] = {static_cast<uint16_t>(block), 1, 1}, dims = 1;
-        std::memcpy(ia, counts, 12), std::memcpy(ia + 12, sizes, 6), std::memcpy(ia + 64, &dims, 2);
+        const uint16_t sizes[3] = {static_cast<uint16_t>(block_size), 1, 1}, dims = 1;
+        if (has_implicit) std::memcpy(ia, counts, 12), std::memcpy(ia + 12, sizes, 6), std::memcpy(ia + 64, &dims, 2);
+        std::memcpy(ka, block, total);
+        if (kernarg_in_hbm_) {
+            // The ring lives in HBM and was written through the PCIe BAR (write-combining): drain the CPU's WC buffers, then
+            // make the device's host data path hand the bytes on to memory.  Both the flush register and the doorbell below
+            // are posted writes to the same device, so PCIe keeps them behind the argument bytes.
+            _mm_sfence();
+            if (hdp_flush_) *hdp_flush_ = 1u;
+        }
 
         const uint64_t index = hsa_queue_add_write_index_relaxed(queue_, 1);
         while (index - hsa_queue_load_read_index_scacquire(queue_) >= queue_->size) {
         }
         auto *pkt = static_cast<hsa_kernel_dispatch_packet_t *>(queue_->base_address) + (index & (queue_->size - 1));
-        pkt->workgroup_size_x = static_cast<uint16_t>(block), pkt->workgroup_size_y = 1, pkt->workgroup_size_z = 1;
+        pkt->workgroup_size_x = static_cast<uint16_t>(block_size), pkt->workgroup_size_y = 1, pkt->workgroup_size_z = 1;
         pkt->reserved0 = 0;
-        pkt->grid_size_x = grid * block, pkt->grid_size_y = 1, pkt->grid_size_z = 1;
+        pkt->grid_size_x = grid * block_size, pkt->grid_size_y = 1, pkt->grid_size_z = 1;
         pkt->private_segment_size = 0, pkt->group_segment_size = k.group_size;
         pkt->kernel_object = k.object;
         pkt->kernarg_address = ka;
@@ -168,8 +203,18 @@ public:
     }
     bool busy() const { return ready && drained_ != dispatched_; }
 
+    // After a queue error nothing more can be dispatched here: forget the kernels in flight (the queue is dead) so that the
+    // handle can go on through its HIP stream.
+    void disable() {
+        ready = false;
+        drained_ = dispatched_;
+    }
+
     void release() {
-        if (kernarg_) (void)hipHostFree(kernarg_);
+        if (kernarg_ && kernarg_in_hbm_) (void)hsa_amd_memory_pool_free(kernarg_);
+        else if (kernarg_) (void)hipHostFree(kernarg_);
+        kernarg_in_hbm_ = false, hdp_flush_ = nullptr;
+        symbols_.clear();
         if (have_signal_) hsa_signal_destroy(done_);
         if (queue_) hsa_queue_destroy(queue_);
         if (have_exe_) hsa_executable_destroy(exe_);
@@ -199,6 +244,79 @@ private:
         }
         return HSA_STATUS_SUCCESS;
     }
+    static hsa_status_t collect_symbol(hsa_executable_t, hsa_executable_symbol_t sym, void *self_) {
+        auto *self = static_cast<AqlDispatcher *>(self_);
+        hsa_symbol_kind_t kind;
+        uint32_t len = 0;
+        if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL) return HSA_STATUS_SUCCESS;
+        if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len) != HSA_STATUS_SUCCESS || len == 0) return HSA_STATUS_SUCCESS;
+        std::string name(len, '\0');
+        if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME, &name[0]) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        while (!name.empty() && name.back() == '\0') name.pop_back();
+        if (name.size() > 3 && name.compare(name.size() - 3, 3, ".kd") == 0) name.resize(name.size() - 3);
+        int status = 0;
+        char *dem = abi::__cxa_demangle(name.c_str(), nullptr, nullptr, &status);
+        if (status == 0 && dem) self->symbols_.emplace_back(dem, sym);
+        std::free(dem);
+        return HSA_STATUS_SUCCESS;
+    }
+    // the GPU's own memory pools / the first CPU agent, for the device-memory kernarg ring
+    struct PoolPick {
+        hsa_amd_memory_pool_t fine{}, coarse{};
+        bool have_fine = false, have_coarse = false;
+    };
+    static hsa_status_t pick_pool(hsa_amd_memory_pool_t pool, void *out_) {
+        auto *out = static_cast<PoolPick *>(out_);
+        hsa_amd_segment_t seg;
+        uint32_t flags = 0;
+        bool alloc = false;
+        if (hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+        hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+        hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+        if (!alloc) return HSA_STATUS_SUCCESS;
+        if ((flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED) && !out->have_fine) out->fine = pool, out->have_fine = true;
+        if ((flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !out->have_coarse) out->coarse = pool, out->have_coarse = true;
+        return HSA_STATUS_SUCCESS;
+    }
+    static hsa_status_t pick_cpu(hsa_agent_t a, void *out_) {
+        hsa_device_type_t type;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) == HSA_STATUS_SUCCESS && type == HSA_DEVICE_TYPE_CPU) {
+            *static_cast<hsa_agent_t *>(out_) = a;
+            return HSA_STATUS_INFO_BREAK;
+        }
+        return HSA_STATUS_SUCCESS;
+    }
+    // allocate the ring in the GPU's memory (fine-grained pool when there is one: GPU reads are then not served from a stale L2
+    // line), let the CPU write it through the BAR, and verify that what the CPU wrote is what the CPU reads back
+    bool kernarg_in_hbm(bool with_hdp_flush) {
+        PoolPick pick;
+        hsa_amd_agent_iterate_memory_pools(agent_, &AqlDispatcher::pick_pool, &pick);
+        if (!pick.have_fine && !pick.have_coarse) return why = "no allocatable global pool on the GPU agent", false;
+        hsa_agent_t cpu{};
+        if (hsa_iterate_agents(&AqlDispatcher::pick_cpu, &cpu) != HSA_STATUS_INFO_BREAK) return why = "no CPU agent", false;
+        void *ptr = nullptr;
+        if (hsa_amd_memory_pool_allocate(pick.have_fine ? pick.fine : pick.coarse, kSlots * kSlotBytes, 0, &ptr) != HSA_STATUS_SUCCESS || !ptr)
+            return why = "hsa_amd_memory_pool_allocate failed", false;
+        const hsa_agent_t both[2] = {cpu, agent_};
+        if (hsa_amd_agents_allow_access(2, both, nullptr, ptr) != HSA_STATUS_SUCCESS) {
+            hsa_amd_memory_pool_free(ptr);
+            return why = "the CPU cannot map the GPU's memory (no large BAR?)", false;
+        }
+        volatile uint64_t *probe = static_cast<volatile uint64_t *>(ptr);
+        probe[0] = 0x4B49435041524753ull, probe[kSlots * kSlotBytes / 8 - 1] = 0x1234567890ABCDEFull;
+        _mm_sfence();
+        if (probe[0] != 0x4B49435041524753ull || probe[kSlots * kSlotBytes / 8 - 1] != 0x1234567890ABCDEFull) {
+            hsa_amd_memory_pool_free(ptr);
+            return why = "BAR write / read-back mismatch", false;
+        }
+        if (with_hdp_flush) {
+            hsa_amd_hdp_flush_t hdp{};
+            if (hsa_agent_get_info(agent_, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_HDP_FLUSH), &hdp) == HSA_STATUS_SUCCESS && hdp.HDP_MEM_FLUSH_CNTL)
+                hdp_flush_ = hdp.HDP_MEM_FLUSH_CNTL;
+        }
+        kernarg_ = static_cast<unsigned char *>(ptr), kernarg_in_hbm_ = true;
+        return true;
+    }
     static void on_queue_error(hsa_status_t status, hsa_queue_t *, void *self_) {
         static_cast<AqlDispatcher *>(self_)->queue_error = static_cast<int>(status) ? static_cast<int>(status) : -1;
     }
@@ -213,6 +331,9 @@ private:
     uint32_t want_bdf_ = 0, want_domain_ = 0;
     bool found_ = false, inited_ = false, have_reader_ = false, have_exe_ = false, have_signal_ = false;
     std::map<std::string, AqlKernel> kernels_;
+    std::vector<std::pair<std::string, hsa_executable_symbol_t>> symbols_;  // demangled kernel names of the code object
+    bool kernarg_in_hbm_ = false;
+    volatile uint32_t *hdp_flush_ = nullptr;
 };
 
 }  // namespace host

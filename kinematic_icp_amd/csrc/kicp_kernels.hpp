@@ -37,7 +37,7 @@ constexpr int kNumSums = 7;           // JTJ00 JTJ01 JTJ11 JTr0 JTr1 ssq count
 constexpr int kNumLimbs = 3 * kNumSums;
 constexpr int kReduceWords = 24;      // all-reduce payload: 21 limb sums + padding (int64)
 constexpr double kFixScale = 1099511627776.0;  // 2^40
-constexpr double kFixLimit = 8388608.0;        // 2^23: |term| must stay below this
+constexpr double kFixLimit = 8796093022208.0;  // 2^43: |term| must stay below this (source points within ~2900 km of the base frame)
 
 // Result record in host-mapped pinned memory: written by the finalising lane, polled by the host.
 struct HostRecord {
@@ -98,11 +98,11 @@ struct SolveParams {
     int32_t p2p_nranks, p2p_rank;
     uint32_t p2p_tag;     // 1..65535 (step % 65535 + 1); double-buffered by p2p_parity, so a stale slot can never match
     uint32_t p2p_parity;  // step & 1
+    long long p2p_timeout_ticks;  // 100 MHz ticks a rank waits for its peers' slots (derived from the host's KICP_WAIT_TIMEOUT_S)
 };
 // a rank's mailbox: [2 parities][nranks][kP2pWords] tagged words; a 64-bit total travels as two tagged 32-bit halves
 constexpr int kP2pWords = 2 * 24;
 constexpr int kP2pMaxRanks = 16;
-constexpr long long kP2pTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock: a missing peer becomes KICP_ERR_COMM
 
 // Wave-uniform numbers of the pre-selection over the 16-bit mirror, computed once per call on the host (search_params()).
 struct SearchParams {
@@ -151,16 +151,6 @@ __device__ __forceinline__ void i128_add(I128 &a, const I128 &b) {
     a.lo += b.lo;
     a.hi += b.hi + (a.lo < old ? 1 : 0);
 }
-__device__ __forceinline__ void i128_add_fixed(I128 &a, double x, int &range_error) {
-    if (!(fabs(x) < kFixLimit)) {
-        range_error = 1;
-        return;
-    }
-    const long long v = __double2ll_rn(x * kFixScale);
-    const unsigned long long old = a.lo;
-    a.lo += static_cast<unsigned long long>(v);
-    a.hi += (v >> 63) + (a.lo < old ? 1 : 0);
-}
 // T = l0 + l1*2^40 + l2*2^80 with 0 <= l0,l1 < 2^40, l2 signed
 __device__ __forceinline__ void i128_to_limbs(const I128 &t, long long l[3]) {
     const unsigned long long m40 = (1ull << 40) - 1;
@@ -184,17 +174,35 @@ __device__ __forceinline__ double limbs_to_double(const long long l[3]) {
 }
 
 // A lane's contribution to the seven sums of one pass: every lane serves at most ONE correspondence per pass, so each sum is
-// a single fixed-point term |t| < 2^63 (x * 2^40 with |x| < 2^23).
+// a single fixed-point term x * 2^40 with |x| < 2^43, held as four 21-bit limbs (the top one signed) - a wave's 64 values of
+// a limb then add up in int32 (finish_pass).  The term is formed without leaving the integers' range: x = ip + fr with
+// ip = rint(x) (exact in int64) and fr = x - ip (exact, |fr| <= 1/2), so round(x * 2^40) = ip * 2^40 + round(fr * 2^40)
+// - the same integer the single conversion gives wherever that one fits (ties included: ip * 2^40 is even).
+constexpr int kTermLimbs = 4;
+constexpr int kWaveLimbs = kTermLimbs * kNumSums;
 struct Acc {
-    long long v[kNumSums];
+    int limb[kWaveLimbs];
     int range_error;
 };
-__device__ __forceinline__ long long to_fixed(double x, int &range_error) {
+__device__ __forceinline__ void to_fixed(double x, int *limb, int &range_error) {
     if (!(fabs(x) < kFixLimit)) {
         range_error = 1;
-        return 0;
+        limb[0] = limb[1] = limb[2] = limb[3] = 0;
+        return;
     }
-    return __double2ll_rn(x * kFixScale);
+    const long long ip = __double2ll_rn(x);
+    const long long fp = __double2ll_rn((x - static_cast<double>(ip)) * kFixScale);
+    I128 t{static_cast<unsigned long long>(ip) << 40, ip >> 24};
+    i128_add(t, I128{static_cast<unsigned long long>(fp), fp >> 63});
+    limb[0] = static_cast<int>(t.lo & 0x1FFFFF), limb[1] = static_cast<int>((t.lo >> 21) & 0x1FFFFF), limb[2] = static_cast<int>((t.lo >> 42) & 0x1FFFFF);
+    limb[3] = static_cast<int>(static_cast<long long>((t.lo >> 63) | (static_cast<unsigned long long>(t.hi) << 1)));
+}
+// the 128-bit sum of one term's limb sums s[0..3] (each a sum of at most 2^10 limbs)
+__device__ __forceinline__ void i128_add_limb_sums(I128 &t, long long s0, long long s1, long long s2, long long s3) {
+    const long long low = s0 + (s1 << 21);  // < 2^53
+    i128_add(t, I128{static_cast<unsigned long long>(low), low >> 63});
+    i128_add(t, I128{static_cast<unsigned long long>(s2) << 42, s2 >> 22});
+    i128_add(t, I128{static_cast<unsigned long long>(s3) << 63, s3 >> 1});
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -262,7 +270,18 @@ __device__ __forceinline__ void table_lookup_entry(const MapView &m, int32_t x, 
     }
 }
 
-// scan one bucket in insertion order; strict '<' keeps the first minimum (std::min_element + `distance < closest`)
+// `a` beats the running minimum `best` (both exact squared distances) under the reference's rule: kiss-icp compares
+// (p - query).norm(), i.e. the ROUNDED SQUARE ROOTS, with strict '<' (std::min_element inside a voxel, `distance <
+// closest_distance` across voxels - kiss-icp v1.2.0 core/VoxelHashMap.cpp GetClosestNeighbor), so a later candidate whose
+// squared distance is smaller by an ulp or two but whose square root rounds to the same double does NOT replace the earlier
+// one.  The square roots are only taken when the squared distances are that close (sqrt halves a relative difference: beyond
+// 2^-50 the roots differ by more than their rounding).
+__device__ __forceinline__ bool closer_by_norm(double a, double best) {
+    if (!(a < best)) return false;
+    if (a < best * (1.0 - 8.8817841970012523e-16)) return true;  // 1 - 2^-50
+    return sqrt(a) < sqrt(best);
+}
+// scan one bucket in insertion order; strict '<' on the norms keeps the first minimum (std::min_element + `distance < closest`)
 __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32_t count, uint32_t base_index, const Query &q,
                                             double &best, uint32_t &best_idx) {
     uint32_t k = 0;
@@ -273,13 +292,13 @@ __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32
         const double bdx = bx - q.x, bdy = by - q.y, bdz = bz - q.z;
         const double a2 = adx * adx + ady * ady + adz * adz;
         const double b2 = bdx * bdx + bdy * bdy + bdz * bdz;
-        if (a2 < best) best = a2, best_idx = base_index + k;
-        if (b2 < best) best = b2, best_idx = base_index + k + 1;
+        if (closer_by_norm(a2, best)) best = a2, best_idx = base_index + k;
+        if (closer_by_norm(b2, best)) best = b2, best_idx = base_index + k + 1;
     }
     if (k < count) {
         const double dx = p[3 * k] - q.x, dy = p[3 * k + 1] - q.y, dz = p[3 * k + 2] - q.z;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < best) best = d2, best_idx = base_index + k;
+        if (closer_by_norm(d2, best)) best = d2, best_idx = base_index + k;
     }
 }
 
@@ -315,13 +334,13 @@ __device__ __forceinline__ void accumulate(Acc &a, const Pose &T, double sx, dou
     double j0x, j0y, j0z, j1x, j1y, j1z;
     quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
     quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)
-    a.v[0] = to_fixed(j0x * j0x + j0y * j0y + j0z * j0z, a.range_error);
-    a.v[1] = to_fixed(j0x * j1x + j0y * j1y + j0z * j1z, a.range_error);
-    a.v[2] = to_fixed(j1x * j1x + j1y * j1y + j1z * j1z, a.range_error);
-    a.v[3] = to_fixed(j0x * rx + j0y * ry + j0z * rz, a.range_error);
-    a.v[4] = to_fixed(j1x * rx + j1y * ry + j1z * rz, a.range_error);
-    a.v[5] = to_fixed(rx * rx + ry * ry + rz * rz, a.range_error);
-    a.v[6] = static_cast<long long>(kFixScale);  // the count: 1.0
+    to_fixed(j0x * j0x + j0y * j0y + j0z * j0z, a.limb + 0 * kTermLimbs, a.range_error);
+    to_fixed(j0x * j1x + j0y * j1y + j0z * j1z, a.limb + 1 * kTermLimbs, a.range_error);
+    to_fixed(j1x * j1x + j1y * j1y + j1z * j1z, a.limb + 2 * kTermLimbs, a.range_error);
+    to_fixed(j0x * rx + j0y * ry + j0z * rz, a.limb + 3 * kTermLimbs, a.range_error);
+    to_fixed(j1x * rx + j1y * ry + j1z * rz, a.limb + 4 * kTermLimbs, a.range_error);
+    to_fixed(rx * rx + ry * ry + rz * rz, a.limb + 5 * kTermLimbs, a.range_error);
+    a.limb[6 * kTermLimbs + 1] = 1 << 19;  // the count: 1.0 = 2^40 = 2^19 * 2^21 (the other limbs stay 0)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -455,7 +474,7 @@ __device__ __forceinline__ long long p2p_exchange(const SolveParams &f, long lon
             for (;;) {
                 got = __hip_atomic_load(box + static_cast<size_t>(r) * kP2pWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((static_cast<uint32_t>(got) & 0xFFFFu) == tag) break;
-                if (wall_clock64() - t0 > kP2pTimeoutTicks) {
+                if (wall_clock64() - t0 > f.p2p_timeout_ticks) {
                     late = 1;
                     break;
                 }
@@ -484,7 +503,6 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
     return v;
 }
-constexpr int kWaveLimbs = 3 * kNumSums;  // per sum three 21-bit limbs (the top one signed): a wave's 64 values add up in int32
 
 template <int BLOCK>
 __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag) {
@@ -501,17 +519,12 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         }
         return;
     }
-    // Every lane contributes at most ONE correspondence per pass, so its seven sums are single terms |t| < 2^63 (the
-    // accumulation range, to_fixed): three limbs of 21 bits each, and a wave's 64 values of a limb add up in int32.
+    // Every lane contributes at most ONE correspondence per pass, so its seven sums are single terms (to_fixed): four limbs
+    // of 21 bits each, and a wave's 64 values of a limb add up in int32.
     int range_error = a.range_error;
     int limb[kWaveLimbs];
 #pragma unroll
-    for (int i = 0; i < kNumSums; ++i) {
-        const long long t = a.v[i];
-        limb[3 * i] = static_cast<int>(t & 0x1FFFFF), limb[3 * i + 1] = static_cast<int>((t >> 21) & 0x1FFFFF), limb[3 * i + 2] = static_cast<int>(t >> 42);
-    }
-#pragma unroll
-    for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(limb[k]);
+    for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
     range_error = __any(range_error) ? 1 : 0;
     if (lane == 63) {
 #pragma unroll
@@ -525,13 +538,8 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     // 40-bit limbs.
     I128 t{0ull, 0ll};
     if (lane < kNumSums) {
-        for (int w = 0; w < BLOCK / 64; ++w) {
-            const long long s0 = s_red[w][3 * lane], s1 = s_red[w][3 * lane + 1], s2 = s_red[w][3 * lane + 2];
-            const long long low = s0 + (s1 << 21);                                           // < 2^49
-            I128 part{static_cast<unsigned long long>(s2) << 42, s2 >> 22};                     // s2 * 2^42 as a 128-bit integer
-            I128 lowpart{static_cast<unsigned long long>(low), low >> 63};
-            i128_add(t, part), i128_add(t, lowpart);
-        }
+        for (int w = 0; w < BLOCK / 64; ++w)
+            i128_add_limb_sums(t, s_red[w][kTermLimbs * lane], s_red[w][kTermLimbs * lane + 1], s_red[w][kTermLimbs * lane + 2], s_red[w][kTermLimbs * lane + 3]);
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
@@ -917,8 +925,12 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
         if (d1 < best) best = d1, best_idx = t.i1;
         if (t.b2 - t.b1 <= margin && t.i2 != kNoIndex32) {
             const double d2 = exact_d2(m, t.i2, q);
-            // the reference keeps the FIRST candidate (in visiting order) that attains the strict minimum
-            if (d2 < bound && (best_idx == kNoIndex32 || d2 < best || (d2 == best && t.o2 < t.o1))) best = d2, best_idx = t.i2;
+            // the reference keeps the FIRST candidate (in visiting order) whose NORM attains the strict minimum: the later of
+            // the two only replaces the earlier when its rounded square root is smaller (closer_by_norm)
+            if (d2 < bound) {
+                if (best_idx == kNoIndex32) best = d2, best_idx = t.i2;
+                else if (t.o2 < t.o1 ? !closer_by_norm(d1, d2) : closer_by_norm(d2, d1)) best = d2, best_idx = t.i2;
+            }
         }
     }
     if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75

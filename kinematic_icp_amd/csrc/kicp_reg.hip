@@ -11,6 +11,7 @@
 #include "kicp_aql.hpp"
 #include "kicp_internal.hpp"
 #include "kicp_kernels.hpp"
+#include "kicp_small.hpp"
 
 using namespace kicp;
 using namespace kicp::host;
@@ -123,6 +124,7 @@ struct kicp_reg {
     void *p2p_mapped[kP2pMaxRanks] = {};
     unsigned long long **d_p2p_table = nullptr;
     unsigned long long p2p_step = 0;  // exchanges issued so far (same on every rank)
+    bool p2p_poisoned = false;        // a registration failed while the mailboxes were attached: the ranks may be out of step
     // direct AQL dispatch of the pass kernel (kicp_aql.hpp): the handle's own user-mode queue next to its HIP stream
     AqlDispatcher aql;
     int use_aql = 1;            // option "aql": 1 (default) dispatch the pass kernel with hand-written AQL packets where possible, 0 always through HIP
@@ -130,6 +132,17 @@ struct kicp_reg {
     bool stream_dirty = true;   // HIP work may be pending on `stream`: synchronise before the next AQL dispatch
     bool last_via_aql = false;  // how the pass the host is waiting for was launched
     std::map<int, const AqlKernel *> aql_kernels;
+    // small-scan path (kicp_small.hpp): the command line the resident kernel polls (host-mapped, 64-byte aligned), the
+    // sequence number of the last command issued, and the knobs
+    unsigned long long *cmd = nullptr, *d_cmd = nullptr;
+    unsigned long long cmd_seq = 0;
+    int use_small = 1;            // option "small": scans of up to kSmallMaxLanes lanes take k_pass_small
+    int small_block = 256;        // option "small_block": its workgroup size (256 | 512 | 1024)
+    int small_resident = 1;       // option "small_resident": the kernel stays for the call's later iterations
+    double small_timeout_us = 20000.0;  // option "small_timeout_us": how long a resident workgroup waits for a command
+    double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
+    unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
+    int last_small = 0;           // 1 when the last registration ran on the small path
 };
 
 namespace {
@@ -171,23 +184,51 @@ uint32_t pass_grid(const kicp_reg *r, size_t n) {
     const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
     return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
 }
-// the pass kernel of variant 3 as an AQL kernel object (looked up once per template instantiation), or nullptr
-const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split) {
+// AQL kernel objects, looked up once per template instantiation by DEMANGLED name (kicp_aql.hpp), or nullptr
+bool aql_up(kicp_reg *r) {
     if (!r->aql_tried) {
         r->aql_tried = true;
         if (r->aql.init(r->device) != 0 && env_flag("KICP_TRACE")) std::fprintf(stderr, "[kicp] AQL dispatch unavailable: %s\n", r->aql.why.c_str());
+        else if (env_flag("KICP_TRACE")) std::fprintf(stderr, "[kicp] AQL dispatch ready, kernel arguments in %s%s%s\n", r->aql.kernarg_place(), r->aql.why.empty() ? "" : "; ", r->aql.why.c_str());
     }
-    if (!r->aql.ready) return nullptr;
-    const int key = b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0);
+    if (r->aql.ready && r->aql.queue_error) {  // a dead queue: forget it, the handle goes on through its HIP stream
+        if (env_flag("KICP_TRACE")) std::fprintf(stderr, "[kicp] AQL queue error %d: falling back to the HIP stream\n", r->aql.queue_error);
+        r->aql.disable();
+    }
+    return r->aql.ready;
+}
+const AqlKernel *aql_lookup(kicp_reg *r, int key, const char *demangled_prefix) {
+    if (!aql_up(r)) return nullptr;
     auto it = r->aql_kernels.find(key);
     if (it != r->aql_kernels.end()) return it->second;
-    char name[128];
-    std::snprintf(name, sizeof name, "_ZN4kicp15k_pass_gather32ILi%dELi%dELi%dELb%dEEEvNS_10PassParamsE", b, g, occ, split ? 1 : 0);
-    const AqlKernel &k = r->aql.kernel(name);
+    const AqlKernel &k = r->aql.kernel(demangled_prefix);
     return r->aql_kernels[key] = k.usable ? &k : nullptr;
 }
+// the names below must agree with tools/aql_kernel_names.py (tests/test_host.py checks them against build/kicp_reg.hsaco)
+const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split) {
+    char name[128];
+    std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s>(", b, g, occ, split ? "true" : "false");
+    return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0), name);
+}
+const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g) {
+    char name[128];
+    std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(", block, g);
+    return aql_lookup(r, -(block * 10 + g), name);
+}
+// Before HIP work follows kernels that went through the handle's AQL queue: wait for them.  A time-out is an error (a kernel
+// of ours may still be writing the buffers the next launch reuses); a queue error retires the dispatcher instead - its kernels
+// are gone with the queue - and the handle goes on through HIP.
+int aql_quiesce(kicp_reg *r) {
+    if (!r->aql.busy()) return KICP_OK;
+    if (r->aql.drain(wait_timeout_s())) return KICP_OK;
+    if (r->aql.queue_error) {
+        r->aql.disable();
+        return KICP_OK;
+    }
+    return fail(KICP_ERR_HIP, "the AQL queue did not drain (KICP_WAIT_TIMEOUT_S)");
+}
 // allow_aql: nothing on the handle's HIP stream has to be ordered behind this kernel and the host will poll for the result
-void launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
+int launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
     const uint32_t grid = pass_grid(r, p.n);
     if (r->pass_kernel == 3) {
         const int b = effective_block(r, p.n), g = lanes_for(r, p.n);
@@ -208,12 +249,12 @@ void launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
                 // AqlDispatcher::drain() puts a system-scope release behind the kernels before HIP work follows them.
                 if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &p, sizeof p, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
                     r->last_via_aql = true;
-                    return;
+                    return KICP_OK;
                 }
             }
         }
         if (allow_aql) r->stream_dirty = false;  // the host waits for this pass: by then everything queued before it is done
-        if (r->aql.busy()) (void)r->aql.drain(20.0);  // kernels dispatched through the AQL queue come first
+        if (int rc = aql_quiesce(r)) return rc;  // kernels dispatched through the AQL queue come first
         r->last_via_aql = false;
 #define KICP_G32(B, G, SPLIT)                                                                                     \
     do {                                                                                                          \
@@ -233,20 +274,21 @@ void launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
         else KICP_G32_BLOCKS(4, false);
 #undef KICP_G32_BLOCKS
 #undef KICP_G32
-        return;
+        return KICP_OK;
     }
-    if (r->aql.busy()) (void)r->aql.drain(20.0);
+    if (int rc = aql_quiesce(r)) return rc;
     r->last_via_aql = false;
     switch (effective_block(r, p.n)) {
         case 64: launch_gather<64>(p, grid, r->stream); break;
         case 256: launch_gather<256>(p, grid, r->stream); break;
         default: launch_gather<128>(p, grid, r->stream); break;
     }
+    return KICP_OK;
 }
 
 int ensure_partials(kicp_reg *r, size_t blocks) {
     if (blocks <= r->partial_blocks) return KICP_OK;
-    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
+    if (int rc = aql_quiesce(r)) return rc;
     if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
     if (r->d_tickets) HIP_TRY(hipFree(r->d_tickets));
     r->d_partials = nullptr, r->d_tickets = nullptr;
@@ -262,7 +304,7 @@ int ensure_partials(kicp_reg *r, size_t blocks) {
 // host-mapped rows of the first-level groups (mode 4)
 int ensure_rows(kicp_reg *r, size_t groups) {
     if (groups <= r->rows_groups) return KICP_OK;
-    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
+    if (int rc = aql_quiesce(r)) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->rows) HIP_TRY(hipHostFree(r->rows));
     r->rows = nullptr, r->d_rows = nullptr, r->rows_groups = 0;
@@ -277,7 +319,7 @@ int ensure_rows(kicp_reg *r, size_t groups) {
 // from 65535 passes ago can never be mistaken for a fresh one
 int next_tag(kicp_reg *r, uint32_t *tag) {
     if (r->tag >= 0xFFFFu) {
-        if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
+        if (int rc = aql_quiesce(r)) return rc;
         r->stream_dirty = true;
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->rows) std::memset(r->rows, 0, r->rows_groups * kReduceWords * sizeof(unsigned long long));
@@ -292,7 +334,7 @@ int next_tag(kicp_reg *r, uint32_t *tag) {
 }
 int ensure_frame(kicp_reg *r, size_t n) {
     if (n <= r->frame_cap) return KICP_OK;
-    if (r->aql.busy() && !r->aql.drain(wait_timeout_s())) return fail(KICP_ERR_HIP, "the AQL queue did not drain");
+    if (int rc = aql_quiesce(r)) return rc;
     if (r->d_frame) HIP_TRY(hipFree(r->d_frame));
     r->d_frame = nullptr;
     const size_t want = n + n / 4 + 1024;
@@ -411,8 +453,210 @@ int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceW
     return KICP_OK;
 }
 
-int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
-                     const double rel_odom_qt[7], double tau, double out_pose_qt[7], kicp_stats *stats) {
+// ---- the small-scan path (kicp_small.hpp) ------------------------------------------------------------------------------
+// sub-lanes per query and workgroups of k_pass_small for a scan of n points; 0 workgroups = the scan does not fit
+uint32_t small_grid(const kicp_reg *r, size_t n, int *g_out) {
+    const int g = lanes_for(r, n);
+    *g_out = g;
+    const size_t lanes = n * static_cast<size_t>(g);
+    if (n == 0 || lanes > static_cast<size_t>(kSmallMaxLanes)) return 0u;
+    return static_cast<uint32_t>((lanes + r->small_block - 1) / r->small_block);
+}
+int ensure_cmd(kicp_reg *r) {
+    if (r->cmd) return KICP_OK;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), 128, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(r->cmd, 0, 128);
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
+    return KICP_OK;
+}
+// `count` consecutive pass tags (the same wrap rule as next_tag)
+int next_tag_range(kicp_reg *r, uint32_t count, uint32_t *first) {
+    if (r->tag + count > 0xFFFFu) r->tag = 0xFFFFu;  // not enough room before the wrap: wrap now
+    if (int rc = next_tag(r, first)) return rc;
+    r->tag += count - 1;
+    return KICP_OK;
+}
+// the command that starts pass `seq - seq_base` of the resident kernel: seven pose words, then the control word (release)
+void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &T) {
+    unsigned long long w[7];
+    const double v[7] = {T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz};
+    std::memcpy(w, v, sizeof w);
+    for (int i = 0; i < 7; ++i) __atomic_store_n(r->cmd + i, w[i], __ATOMIC_RELAXED);
+    __atomic_store_n(r->cmd + 7, ((seq << 8) | op) ^ cmd_fold(w), __ATOMIC_RELEASE);
+}
+int launch_small(kicp_reg *r, const SmallParams &sp, uint32_t grid, int g) {
+    const int b = r->small_block;
+    if (r->use_aql && !r->stream_dirty) {
+        if (const AqlKernel *k = aql_small_kernel_for(r, b, g)) {
+            if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &sp, sizeof sp, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
+                r->last_via_aql = true;
+                return KICP_OK;
+            }
+        }
+    }
+    r->stream_dirty = false;  // the host waits for this kernel's rows: by then everything queued before it is done
+    if (int rc = aql_quiesce(r)) return rc;
+    r->last_via_aql = false;
+#define KICP_SMALL(B)                                                                                     \
+    do {                                                                                                  \
+        if (g == 1) hipLaunchKernelGGL((k_pass_small<B, 1>), dim3(grid), dim3(B), 0, r->stream, sp);      \
+        else if (g == 2) hipLaunchKernelGGL((k_pass_small<B, 2>), dim3(grid), dim3(B), 0, r->stream, sp); \
+        else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
+    } while (0)
+    if (b == 1024) KICP_SMALL(1024);
+    else if (b == 512) KICP_SMALL(512);
+    else KICP_SMALL(256);
+#undef KICP_SMALL
+    HIP_TRY(hipGetLastError());
+    return KICP_OK;
+}
+// add the rows of the `grid` workgroups as they arrive; out_words in the layout of the all-reduce payload (three 40-bit limbs
+// per sum, then the range flag).  *gave_up: a resident workgroup left without having seen the command of this pass.
+int wait_rows_small(kicp_reg *r, uint32_t grid, uint32_t tag, long long out_words[kReduceWords], bool *gave_up) {
+    __int128 total[kNumSums] = {};
+    unsigned long long flags = 0;
+    const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
+    unsigned drained = 0;
+    unsigned long long spins = 0;
+    const Deadline deadline;
+    for (uint32_t g = 0; g < grid; ++g) {
+        const unsigned long long *row = r->rows + static_cast<size_t>(g) * kSmallRowWords;
+        unsigned long long w[kSmallRowWords];
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < kSmallRowWords; ++i) {
+                w[i] = __atomic_load_n(row + i, __ATOMIC_RELAXED);
+                ok = ok && (static_cast<uint32_t>(w[i]) & 0xFFFFu) == tag;
+            }
+            if (ok) break;
+            if (++spins % query_every != 0) continue;
+            if (r->last_via_aql) {
+                if (r->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(r->aql.queue_error));
+            } else {
+                const hipError_t q = hipStreamQuery(r->stream);  // makes the runtime flush what it may hold back; reports faults
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (q == hipSuccess && ++drained > 4) return fail(KICP_ERR_HIP, "kernels finished without publishing a result");
+            }
+            if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the small-scan kernel's rows (KICP_WAIT_TIMEOUT_S)");
+        }
+        for (int i = 0; i < kNumSums; ++i)
+            total[i] += static_cast<__int128>(w[2 * i] >> 16) + (static_cast<__int128>(static_cast<long long>(w[2 * i + 1]) >> 16) << 48);
+        flags |= w[2 * kNumSums] >> 16;
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    const unsigned __int128 m40 = (static_cast<unsigned __int128>(1) << 40) - 1;
+    for (int i = 0; i < kNumSums; ++i) {
+        const unsigned __int128 u = static_cast<unsigned __int128>(total[i]);
+        out_words[3 * i] = static_cast<long long>(u & m40), out_words[3 * i + 1] = static_cast<long long>((u >> 40) & m40);
+        out_words[3 * i + 2] = static_cast<long long>(total[i] >> 80);
+    }
+    out_words[kNumLimbs] = (flags & 1ull) ? 1 : 0;
+    *gave_up = (flags & kSmallGaveUp) != 0;
+    return KICP_OK;
+}
+
+// What the host does with the exact sums of one pass: Registration.cpp:119-125 (solve), :159-167,181-182 (update), :184 (stop
+// test), and on pass 0 the regularisation of :48-60,171-177.  Shared by the generic and the small-scan loops.
+struct HostLoop {
+    Pose T;
+    double beta = 0.0;
+    int iter = 0, converged = 0, nan_flag = 0;
+    // returns true when the loop ends with this pass
+    bool step(const kicp_reg *r, const long long words[kReduceWords], kicp_stats *stats) {
+        const int it = iter;
+        double sums[kNumSums];
+        for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(words + 3 * i);
+        const bool range_error = words[kNumLimbs] != 0;
+        const double n = sums[6];
+        if (it == 0) beta = r->cfg.use_adaptive_odometry_regularization ? 1.0 / (sums[5] / n + DBL_MIN) : r->cfg.fixed_regularization;
+        double dx0, dx1;
+        solve_perturbation(sums, n, beta, dx0, dx1);
+        T = pose_mul(T, motion_model(dx0, dx1));
+        iter = it + 1;
+        if (stats && it < KICP_MAX_LOG_PASSES) {
+            stats->n_corr[it] = n;
+            for (int j = 0; j < 6; ++j) stats->sums[it][j] = sums[j];
+            stats->dx[it][0] = dx0, stats->dx[it][1] = dx1;
+        }
+        if (std::sqrt(dx0 * dx0 + dx1 * dx1) < r->cfg.convergence_criterion) {  // Registration.cpp:184
+            converged = 1;
+            return true;
+        }
+        if (!(n > 0.0) || range_error) {
+            // 0/0: the pose is NaN from here on.  The reference keeps iterating to max_num_iterations (no NaN ever passes the
+            // stop test, every later association is empty, Registration.cpp:179-187); those passes cannot change anything, so
+            // they are accounted for without being run.
+            nan_flag = range_error ? 2 : 1;
+            const int max_it = r->cfg.max_num_iterations;
+            for (int j = iter; stats && j < max_it && j < KICP_MAX_LOG_PASSES; ++j) {
+                stats->n_corr[j] = 0.0;
+                for (int q = 0; q < 6; ++q) stats->sums[j][q] = 0.0;
+                stats->dx[j][0] = stats->dx[j][1] = std::nan("");
+            }
+            iter = max_it;
+            return true;
+        }
+        return iter >= r->cfg.max_num_iterations;
+    }
+};
+
+int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, uint32_t grid, int g, const Pose &T0, double tau, double out_pose_qt[7],
+              kicp_stats *stats) {
+    const int max_it = r->cfg.max_num_iterations;
+    if (int rc = ensure_rows(r, grid)) return rc;
+    if (int rc = ensure_cmd(r)) return rc;
+    SmallParams sp{};
+    PassParams &pp = sp.p;
+    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.search = search_params(tau, map->mirror.view.voxel_size);
+    pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
+    sp.cmd = r->d_cmd, sp.rows = r->d_rows;
+    sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);  // 100 MHz wall clock
+    HostLoop loop;
+    loop.T = T0;
+    bool finished = false;
+    while (!finished) {
+        const uint32_t left = static_cast<uint32_t>(max_it - loop.iter);
+        const uint32_t cnt = r->small_resident ? std::min(left, kSmallMaxPasses) : 1u;
+        if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
+        pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
+        sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
+        r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
+        if (int rc = launch_small(r, sp, grid, g)) return rc;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            long long words[kReduceWords];
+            bool gave_up = false;
+            if (int rc = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up)) {
+                if (k + 1 < cnt) send_command(r, sp.seq_base + k + 1, kCmdStop, loop.T);
+                return rc;
+            }
+            if (gave_up) {  // (part of) the kernel left while this thread was away: run this pass and the rest in a fresh launch
+                ++r->small_relaunches;
+                if (k + 1 < cnt) send_command(r, sp.seq_base + k + 1, kCmdStop, loop.T);  // workgroups that did see the command
+                break;
+            }
+            finished = loop.step(r, words, stats);
+            if (k + 1 == cnt) break;
+            if (r->debug_stall_us > 0.0) {  // tests: be late once
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < r->debug_stall_us) {
+                }
+                r->debug_stall_us = 0.0;
+            }
+            send_command(r, sp.seq_base + k + 1, finished ? kCmdStop : kCmdContinue, loop.T);
+            if (finished) break;
+        }
+    }
+    pose_to(loop.T, out_pose_qt);
+    if (stats) stats->iterations = loop.iter, stats->converged = loop.converged, stats->beta = loop.beta;
+    r->last_small = 1;
+    if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
+    return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+}
+
+int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7],
+                          const double rel_odom_qt[7], double tau, double out_pose_qt[7], kicp_stats *stats) {
     if (!r || !map || !last_pose_qt || !rel_odom_qt || !out_pose_qt) return fail(KICP_ERR_ARG, "null argument");
     if (stats) std::memset(stats, 0, sizeof(*stats));
     // current_estimate = last_robot_pose * relative_wheel_odometry   (Registration.cpp:156)
@@ -433,12 +677,19 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
     if (map->mirror.synced_epoch != epoch_before) r->stream_dirty = true;  // the mirror was (re)uploaded through the HIP stream
-    if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
     const bool p2p = r->d_p2p_table != nullptr;
+    r->last_small = 0;
+    if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0) {
+        int g = 1;
+        if (const uint32_t grid = small_grid(r, n, &g)) return run_small(r, map, d_frame, n, grid, g, T0, tau, out_pose_qt, stats);
+    }
+    if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
     if (p2p && (!r->host_solve || multi || shm)) return fail(KICP_ERR_ARG, "the peer-mailbox mode needs host_solve = 1 and no other exchange attached");
+    if (p2p && r->p2p_poisoned)
+        return fail(KICP_ERR_COMM, "the peer-mailbox exchange is out of step after an earlier failure: kicp_reg_p2p_destroy, _export and _connect again on every rank");
     const unsigned long long call_id = ++r->call_id;
 
     PassParams pp{};
@@ -459,7 +710,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
         sp.pass = it;
         const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
         if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
-        launch_pass(r, pp);
+        if (int rc = launch_pass(r, pp)) return rc;
         if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
         if (multi) {
             if (int rc = enqueue_allreduce(r)) return rc;
@@ -471,16 +722,18 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     if (r->host_solve) {
         // ---- host-side solve: one launch per iteration, the pose travels as a kernel argument ----------------------
         HostRecord *rec = r->rec;
-        Pose T = T0;
-        double beta = 0.0;
-        int iter = 0, converged = 0, nan_flag = 0;
+        HostLoop loop;
+        loop.T = T0;
+        int passes_run = 0;
         for (int it = 0; it < max_it; ++it) {
+            ++passes_run;
             const bool rows_mode = !multi && !p2p && r->group_rows != 0;
-            sp.pass = it, sp.pose0 = T, sp.mode = multi ? 3 : (p2p ? 5 : (rows_mode ? 4 : 2));
+            sp.pass = it, sp.pose0 = loop.T, sp.mode = multi ? 3 : (p2p ? 5 : (rows_mode ? 4 : 2));
             if (p2p) {  // every rank issues the same sequence of exchanges: the step number doubles as tag and buffer parity
                 const unsigned long long step = r->p2p_step++;
                 sp.p2p_peers = r->d_p2p_table, sp.p2p_nranks = r->nranks, sp.p2p_rank = r->rank;
                 sp.p2p_tag = static_cast<uint32_t>(step % 65535ull) + 1u, sp.p2p_parity = static_cast<uint32_t>(step & 1ull);
+                sp.p2p_timeout_ticks = static_cast<long long>(wait_timeout_s() * 0.8 * 1.0e8);  // the kernel gives up before the host does
             }
             long long words[kReduceWords];
             unsigned long long shm_value = 0;
@@ -507,7 +760,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
             const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
             // direct AQL dispatch when the host polls for the result and nothing follows the kernel on the HIP stream
-            launch_pass(r, pp, !multi && r->timing == 0 && r->wait_mode == 0);
+            if (int rc = launch_pass(r, pp, !multi && r->timing == 0 && r->wait_mode == 0)) return rc;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
             if (multi) {
                 if (int rc = enqueue_allreduce(r)) return rc;
@@ -527,48 +780,26 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
                 for (int i = 0; i < kReduceWords; ++i) words[i] = rec->words[i];
                 if (p2p && words[kNumLimbs + 1] != 0) return fail(KICP_ERR_COMM, "a peer rank's totals did not arrive in this rank's mailbox in time");
             }
-            double sums[kNumSums];
-            for (int i = 0; i < kNumSums; ++i) sums[i] = host_limbs_to_double(words + 3 * i);
-            const bool range_error = words[kNumLimbs] != 0;
-            const double n = sums[6];
-            if (it == 0)  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
-                beta = r->cfg.use_adaptive_odometry_regularization ? 1.0 / (sums[5] / n + DBL_MIN) : r->cfg.fixed_regularization;
-            double dx0, dx1;
-            solve_perturbation(sums, n, beta, dx0, dx1);    // Registration.cpp:119-125
-            T = pose_mul(T, motion_model(dx0, dx1));        // Registration.cpp:159-167,181-182
-            iter = it + 1;
-            if (stats && it < KICP_MAX_LOG_PASSES) {
-                stats->n_corr[it] = n;
-                for (int j = 0; j < 6; ++j) stats->sums[it][j] = sums[j];
-                stats->dx[it][0] = dx0, stats->dx[it][1] = dx1;
-            }
-            if (std::sqrt(dx0 * dx0 + dx1 * dx1) < r->cfg.convergence_criterion) {  // Registration.cpp:184
-                converged = 1;
-                break;
-            }
-            if (!(n > 0.0) || range_error) {  // 0/0: NaN pose from here on, exactly as in the reference
-                nan_flag = range_error ? 2 : 1;
-                break;
-            }
+            if (loop.step(r, words, stats)) break;
         }
         HIP_TRY(hipGetLastError());
         if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
-        pose_to(T, out_pose_qt);
+        pose_to(loop.T, out_pose_qt);
         if (stats) {
-            stats->iterations = iter, stats->converged = converged, stats->beta = beta;
+            stats->iterations = loop.iter, stats->converged = loop.converged, stats->beta = loop.beta;
             if (r->timing) {
                 float ms = 0.f;
                 HIP_TRY(hipEventSynchronize(r->ev1));
                 HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
                 stats->gpu_ms = ms;
-                for (int i = 0; pass_events && i < iter && i < KICP_MAX_LOG_PASSES; ++i) {
+                for (int i = 0; pass_events && i < passes_run && i < KICP_MAX_LOG_PASSES; ++i) {
                     HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
                     stats->pass_ms[i] = ms;
                 }
             }
         }
-        if (nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
-        return nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+        if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
+        return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
     }
     if (r->loop_mode == 0) {
         for (int it = 0; it < max_it; ++it)
@@ -598,7 +829,9 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     const HostRecord *rec = r->rec;  // stable: after `done` no kernel writes the record again
     pose_to(rec->T, out_pose_qt);
     if (stats) {
-        stats->iterations = rec->iter, stats->converged = rec->converged, stats->beta = rec->beta;
+        // (a NaN pose: the reference runs on to max_num_iterations with empty associations - accounted for, not run)
+        stats->iterations = rec->nan_flag ? max_it : rec->iter, stats->converged = rec->converged, stats->beta = rec->beta;
+        for (int j = rec->iter; rec->nan_flag && j < max_it && j < KICP_MAX_LOG_PASSES; ++j) stats->dx[j][0] = stats->dx[j][1] = std::nan("");
         const int k = rec->iter < KICP_MAX_LOG_PASSES ? rec->iter : KICP_MAX_LOG_PASSES;
         for (int i = 0; i < k; ++i) {
             stats->n_corr[i] = rec->log_ncorr[i];
@@ -616,8 +849,21 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
             }
         }
     }
-    if (rec->nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^23)");
+    if (rec->nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
     return rec->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
+}
+
+// Peer-mailbox mode: the ranks stay in step only while every exchange completes on every rank (tags and buffer parity are
+// the step number).  A registration that fails after it has started an exchange - a peer's slot that did not arrive in time,
+// a device fault - leaves this rank's later steps paired with other scans' steps on the peers, silently.  So the state is
+// poisoned: every later call fails with KICP_ERR_COMM until the caller has torn the mailboxes down and connected them again
+// on every rank (kicp_reg_p2p_destroy / _export / _connect), which resets the step counters.
+int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const double last_pose_qt[7], const double rel_odom_qt[7],
+                     double tau, double out_pose_qt[7], kicp_stats *stats) {
+    const unsigned long long step_before = r ? r->p2p_step : 0ull;
+    const int rc = run_registration_impl(r, map, d_frame, n, last_pose_qt, rel_odom_qt, tau, out_pose_qt, stats);
+    if (rc < 0 && r && r->d_p2p_table && r->p2p_step != step_before) r->p2p_poisoned = true;
+    return rc;
 }
 
 }  // namespace
@@ -655,6 +901,8 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_QUERY_EVERY")) r->query_every = std::atoi(env);
+    if (const char *env = std::getenv("KICP_SMALL")) r->use_small = std::atoi(env) != 0;
+    if (const char *env = std::getenv("KICP_SMALL_RESIDENT")) r->small_resident = std::atoi(env) != 0;
     *out = r;
     return KICP_OK;
 }
@@ -669,6 +917,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->d_state) hipFree(reg->d_state);
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->rows) hipHostFree(reg->rows);
+    if (reg->cmd) hipHostFree(reg->cmd);
     reg->stage.release();
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
@@ -709,6 +958,11 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
+    else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
+    else if (k == "small_resident") reg->small_resident = value != 0.0 ? 1 : 0;
+    else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
+    else if (k == "small_timeout_us") reg->small_timeout_us = value;
+    else if (k == "debug_stall_us") reg->debug_stall_us = value;
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
     else if (k == "query_every") reg->query_every = static_cast<int>(value);
     else return fail(KICP_ERR_ARG, "unknown option " + k);
@@ -729,6 +983,13 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
     if (k == "aql") return reg->use_aql;
+    if (k == "aql_kernarg") return !reg->aql.ready ? -1.0 : (std::strcmp(reg->aql.kernarg_place(), "host memory") == 0 ? 0.0 : (std::strcmp(reg->aql.kernarg_place(), "device memory") == 0 ? 1.0 : 2.0));
+    if (k == "small") return reg->use_small;
+    if (k == "small_resident") return reg->small_resident;
+    if (k == "small_block") return reg->small_block;
+    if (k == "small_timeout_us") return reg->small_timeout_us;
+    if (k == "small_active") return reg->last_small;  // did the last registration run on the small-scan path
+    if (k == "small_relaunches") return static_cast<double>(reg->small_relaunches);
     if (k == "aql_active") return (reg->aql.ready && reg->last_via_aql) ? 1.0 : 0.0;  // was the last pass dispatched through the AQL queue
     return -1.0;
 }
@@ -800,7 +1061,7 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
     pp.st = reg->d_state, pp.search = search_params(max_correspondence_distance, map->mirror.view.voxel_size);
     pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
-    launch_pass(reg, pp);
+    if (int rc = launch_pass(reg, pp)) return rc;
     hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);
     HIP_TRY(hipGetLastError());
     unsigned long long seq = 0;
@@ -954,7 +1215,7 @@ int kicp_reg_p2p_destroy(kicp_reg *reg) {
         reg->d_p2p_table = nullptr, reg->p2p_box = nullptr;
         (void)hipGetLastError();
     }
-    reg->nranks = 1, reg->rank = 0, reg->p2p_step = 0;
+    reg->nranks = 1, reg->rank = 0, reg->p2p_step = 0, reg->p2p_poisoned = false;
     return KICP_OK;
 }
 int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2P_HANDLE_BYTES]) {
@@ -1007,6 +1268,34 @@ int kicp_reg_p2p_connect(kicp_reg *reg, const char *handles) {
     HIP_TRY(hipMemcpy(reg->d_p2p_table, table, sizeof table, hipMemcpyHostToDevice));
     reg->p2p_step = 0;
     return KICP_OK;
+}
+size_t kicp_aql_kernel_names(char *out, size_t cap) {
+    // every (template instantiation of a) kernel launch_pass / launch_small may dispatch through the AQL queue, in the form
+    // aql_kernel_for / aql_small_kernel_for look it up
+    std::string all;
+    char name[128];
+    for (int b : {64, 128, 256}) {
+        for (int occ : {4, 3}) {
+            for (int g : {1, 2, 4}) {
+                std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, false>(\n", b, g, occ);
+                all += name;
+            }
+            std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 2, %d, true>(\n", b, occ);
+            all += name;
+        }
+    }
+    all += "void kicp::k_pass_gather32<512, 1, 4, false>(\n";
+    for (int b : {256, 512, 1024})
+        for (int g : {1, 2, 4}) {
+            std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(\n", b, g);
+            all += name;
+        }
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, all.size());
+        std::memcpy(out, all.data(), n);
+        out[n] = '\0';
+    }
+    return all.size() + 1;
 }
 int kicp_reg_set_allreduce(kicp_reg *reg, kicp_allreduce_fn fn, void *user) {
     if (!reg) return fail(KICP_ERR_ARG, "null argument");

@@ -1,0 +1,190 @@
+"""The small-scan registration path (kicp_small.hpp: <= 16 workgroups, rows straight to the host, kernel resident for the
+call's iterations) against the oracle, the reference build and the generic path - on BASELINE.json's config 4 (1 080-point 2-D
+scan vs 50k-point map) and on sources of the size the pipeline registers (pipeline/KinematicICP.cpp:38-44,68-72)."""
+import numpy as np
+import pytest
+
+import kinematic_icp_amd as K
+from checkers import okicp, ref_available, ref_map_like, rkicp
+from kinematic_icp_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def case4():
+    cfg, scene, scans, rng = syn.make_case("cfg4", n_scans=4)
+    gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
+    omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    omap.AddPoints(gmap.Pointcloud())
+    rmap = ref_map_like(omap) if ref_available() else None
+    return cfg, scans, gmap, omap, rmap
+
+
+def _rels(scans, dx=0.0, yaw_deg=0.0):
+    return [syn.pose_mul(s["rel_odom"], syn.planar_pose(dx, 0.0, np.deg2rad(yaw_deg))) for s in scans]
+
+
+@pytest.mark.parametrize("err", [(0.0, 0.0), (0.05, 0.5), (0.1, 2.0)])
+def test_cfg4_small_path_matches_oracle_and_reference(case4, err):
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+    iters = []
+    for s, rel in zip(scans, _rels(scans, *err)):
+        a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+        assert reg.get_option("small_active") == 1.0
+        b = oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau)
+        k = reg.last_stats.iterations
+        iters.append(k)
+        assert k == oreg.last_stats.iterations and reg.last_stats.converged == oreg.last_stats.converged
+        np.testing.assert_allclose(a, b, rtol=0, atol=POSE_TOL)
+        np.testing.assert_array_equal(np.array(reg.last_stats.n_corr[:k]), np.array(oreg.last_stats.n_corr[:k]))
+        np.testing.assert_allclose(np.array([list(reg.last_stats.dx[i]) for i in range(k)]), np.array([list(oreg.last_stats.dx[i]) for i in range(k)]), rtol=0, atol=1e-10)
+        if rmap is not None:
+            c = rkicp.KinematicRegistration().ComputeRobotMotion(s["frame"], rmap, s["last_pose"], rel, tau)
+            np.testing.assert_allclose(a, c, rtol=0, atol=POSE_TOL)
+    if err != (0.0, 0.0):
+        assert max(iters) > 1  # the resident loop really served later passes
+    assert reg.get_option("small_relaunches") == 0.0
+
+
+def test_small_path_bits_equal_generic_path(case4):
+    """Exact accumulation: the small kernel (resident or one launch per pass, AQL or HIP launch, 1 / 2 / 4 sub-lanes) and the
+    generic pass kernel give the same bits, iteration counts and per-pass counts."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    rels = _rels(scans, 0.08, 1.2)
+    frames = [K.DeviceFrame(s["frame"]) for s in scans]
+    base = K.KinematicRegistration()
+    base.set_option("small", 0)
+    want = []
+    for fr, s, rel in zip(frames, scans, rels):
+        want.append((base.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau), base.last_stats.iterations, list(base.last_stats.n_corr[:base.last_stats.iterations])))
+        assert base.get_option("small_active") == 0.0
+    assert max(w[1] for w in want) > 1
+    for resident, aql, lanes, block in [(r, a, l, 256) for r in (1, 0) for a in (1, 0) for l in (0, 1, 2, 4)] + [(1, 1, l, b) for l in (1, 2, 4) for b in (512, 1024)]:
+        if True:
+            if True:
+                reg = K.KinematicRegistration()
+                reg.set_option("small_resident", resident), reg.set_option("aql", aql), reg.set_option("lanes_per_query", lanes)
+                reg.set_option("small_block", block)
+                for rounds in range(2):
+                    for fr, s, rel, (pose, k, ncorr) in zip(frames, scans, rels, want):
+                        got = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+                        assert reg.get_option("small_active") == 1.0
+                        assert np.array_equal(got, pose), (resident, aql, lanes, block)
+                        assert reg.last_stats.iterations == k and list(reg.last_stats.n_corr[:k]) == ncorr
+                if aql:
+                    assert reg.get_option("aql_active") == 1.0
+
+
+def test_small_path_sizes_and_limits(case4):
+    """1 point, one workgroup's worth, the largest scan the path takes (16 workgroups) and one point more (generic path)."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    big = np.concatenate([s["frame"] for s in scans] * 8)  # 34 560 points of the same scene
+    reg, gen, oreg = K.KinematicRegistration(), K.KinematicRegistration(), okicp.KinematicRegistration()
+    gen.set_option("small", 0)
+    s = scans[0]
+    rel = _rels(scans, 0.05, 0.8)[0]
+    for n, lanes, small in ((1, 0, 1), (255, 0, 1), (256, 0, 1), (257, 0, 1), (4096, 0, 1), (4097, 0, 1), (8192, 0, 1), (8193, 0, 0), (16384, 1, 1), (16385, 1, 0)):
+        reg.set_option("lanes_per_query", lanes), gen.set_option("lanes_per_query", lanes)
+        fr = np.ascontiguousarray(big[:n])
+        a = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+        assert reg.get_option("small_active") == float(small), n
+        b = gen.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+        assert np.array_equal(a, b, equal_nan=True) and reg.last_stats.iterations == gen.last_stats.iterations, n
+        c = oreg.ComputeRobotMotion(fr, omap, s["last_pose"], rel, tau)
+        np.testing.assert_allclose(a, c, rtol=0, atol=POSE_TOL)
+        assert reg.last_stats.iterations == oreg.last_stats.iterations
+
+
+def test_resident_kernel_gives_up_and_the_host_relaunches(case4):
+    """A host that is late with its next command (descheduled thread): the resident workgroups leave after their time-out and
+    mark the pass they did not run; the host sees the marks, launches afresh and still returns the same bits."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    s, rel = scans[1], _rels(scans, 0.08, 1.2)[1]
+    ref = K.KinematicRegistration()
+    want = ref.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+    assert ref.last_stats.iterations > 2
+    reg = K.KinematicRegistration()
+    reg.set_option("small_timeout_us", 200.0)
+    for stall in (2000.0, 150.0, 260.0):  # far beyond, just inside and just beyond the time-out (either outcome must give the same bits)
+        before = reg.get_option("small_relaunches")
+        reg.set_option("debug_stall_us", stall)
+        got = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+        assert np.array_equal(got, want) and reg.last_stats.iterations == ref.last_stats.iterations
+        if stall == 2000.0:
+            assert reg.get_option("small_relaunches") == before + 1
+    # and the handle is fine afterwards
+    assert np.array_equal(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau), want)
+
+
+def test_many_passes_and_tag_wraparound(case4):
+    """More iterations than one launch serves (kSmallMaxPasses = 48: the loop relaunches), max_num_iterations reached, and the
+    16-bit tag's wrap-around inside a reserved tag range."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    s, rel = scans[2], _rels(scans, 0.1, 2.0)[2]
+    for max_it in (1, 2, 3, 60):
+        kw = dict(max_num_iteration=max_it, convergence_criterion=0.0)  # never converges: runs to max_num_iterations
+        reg, gen, oreg = K.KinematicRegistration(**kw), K.KinematicRegistration(**kw), okicp.KinematicRegistration(**kw)
+        gen.set_option("small", 0)
+        a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+        assert reg.get_option("small_active") == 1.0 and reg.last_stats.iterations == max_it and reg.last_stats.converged == 0
+        assert np.array_equal(a, gen.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau))
+        np.testing.assert_allclose(a, oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau), rtol=0, atol=POSE_TOL)
+        assert oreg.last_stats.iterations == max_it
+    reg = K.KinematicRegistration()
+    want = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
+    reg.set_option("debug_tag", 65535 - 12)
+    for _ in range(6):
+        assert np.array_equal(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau), want)
+    assert reg.get_option("debug_tag") < 1000
+
+
+def test_zero_correspondences_iteration_count(case4):
+    """N_corr == 0: NaN pose, and - like the reference, whose loop cannot stop on a NaN (Registration.cpp:179-187) -
+    max_num_iterations iterations are reported, on the small path and on the generic one."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    s = scans[0]
+    far = s["frame"] + np.array([0.0, 0.0, 300.0])
+    oreg = okicp.KinematicRegistration()
+    assert np.isnan(oreg.ComputeRobotMotion(far, omap, s["last_pose"], s["rel_odom"], tau)).any()
+    for small in (1, 0):
+        reg = K.KinematicRegistration()
+        reg.set_option("small", small)
+        pose = reg.ComputeRobotMotion(far, gmap, s["last_pose"], s["rel_odom"], tau)
+        assert np.isnan(pose).any() and reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+        assert reg.last_stats.iterations == oreg.last_stats.iterations == 10
+        assert list(reg.last_stats.n_corr[:10]) == list(oreg.last_stats.n_corr[:10])
+    dev = K.KinematicRegistration()
+    dev.set_option("host_solve", 0), dev.set_option("small", 0)
+    assert np.isnan(dev.ComputeRobotMotion(far, gmap, s["last_pose"], s["rel_odom"], tau)).any() and dev.last_stats.iterations == 10
+
+
+def test_pipeline_sized_sources(case4):
+    """Sources of the size the drop-in pipeline registers: a double-downsampled 3-D frame (a few thousand points) against a 3-D
+    map, through kicp_register_device as KinematicICP::RegisterFrame calls it."""
+    cfg, scene, scans, rng = syn.make_case("cfg1", n_scans=2)
+    gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    syn.build_map_points(scene, cfg, gmap.AddPoints, gmap.num_points, rng)
+    omap = okicp.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
+    omap.AddPoints(gmap.Pointcloud())
+    rmap = ref_map_like(omap) if ref_available() else None
+    reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+    for s in scans:
+        src = okicp.voxel_downsample(okicp.voxel_downsample(s["frame"], cfg.voxel_size * 0.5), cfg.voxel_size * 1.5)
+        assert 200 < len(src) < 4096
+        rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.06, 0.0, np.deg2rad(0.7)))
+        a = reg.ComputeRobotMotion(K.DeviceFrame(src), gmap, s["last_pose"], rel, cfg.first_frame_tau())
+        assert reg.get_option("small_active") == 1.0
+        np.testing.assert_allclose(a, oreg.ComputeRobotMotion(src, omap, s["last_pose"], rel, cfg.first_frame_tau()), rtol=0, atol=POSE_TOL)
+        assert reg.last_stats.iterations == oreg.last_stats.iterations
+        if rmap is not None:
+            np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(src, rmap, s["last_pose"], rel, cfg.first_frame_tau()), rtol=0, atol=POSE_TOL)

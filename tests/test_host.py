@@ -37,6 +37,39 @@ def test_library_contains_gfx950_code_and_no_oracle():
         assert "oracle/" not in open(os.path.join(ROOT, "kinematic_icp_amd", "csrc", f)).read()
 
 
+def test_every_aql_kernel_name_exists_in_the_embedded_code_object():
+    """The direct-dispatch path resolves its kernels by demangled name in the code object embedded in the library
+    (kicp_aql.hpp).  Every name the host code can ask for must be a kernel of build/kicp_reg.hsaco - and must need no
+    scratch memory, which the path refuses - so a compiler or signature change fails HERE instead of silently turning
+    every dispatch into a HIP launch."""
+    import ctypes as C
+    lib = K.lib()
+    need = lib.kicp_aql_kernel_names(None, 0)
+    buf = C.create_string_buffer(need)
+    lib.kicp_aql_kernel_names(buf, need)
+    wanted = [n for n in buf.value.decode().split("\n") if n]
+    assert len(wanted) >= 30 and any("k_pass_small" in n for n in wanted)
+    hsaco = os.path.join(ROOT, "kinematic_icp_amd", "csrc", "build", "kicp_reg.hsaco")
+    assert os.path.exists(hsaco), "build/kicp_reg.hsaco missing: run __graft_entry__.build()"
+    llvm = "/opt/rocm/lib/llvm/bin"
+    syms = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--symbols", "--wide", hsaco], text=True)
+    descriptors = [ln.split()[-1] for ln in syms.splitlines() if ln.strip().endswith(".kd")]
+    assert descriptors
+    demangled = sorted(set(subprocess.check_output(["c++filt"], input="\n".join(d[:-3] for d in descriptors), text=True).splitlines()))  # (.dynsym and .symtab list each)
+    for name in wanted:
+        assert sum(d.startswith(name) for d in demangled) == 1, name
+    # no kernel the path dispatches may use scratch: .private_segment_fixed_size == 0 in the code object's metadata
+    notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", hsaco], text=True)
+    blocks = notes.split("- .agpr_count")[1:]
+    checked = 0
+    for b in blocks:
+        m = re.search(r"\.name:\s+(\S+)", b)
+        if m and ("k_pass_gather32" in m.group(1) or "k_pass_small" in m.group(1)):
+            assert re.search(r"\.private_segment_fixed_size:\s+0\b", b), m.group(1)
+            checked += 1
+    assert checked >= len(wanted)
+
+
 def test_no_cpu_fallback_without_a_gpu():
     if K.device_count() > 0:
         pytest.skip("a GPU is visible here")
