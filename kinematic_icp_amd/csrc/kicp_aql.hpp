@@ -286,29 +286,44 @@ private:
         }
         return HSA_STATUS_SUCCESS;
     }
-    // allocate the ring in the GPU's memory (fine-grained pool when there is one: GPU reads are then not served from a stale L2
-    // line), let the CPU write it through the BAR, and verify that what the CPU wrote is what the CPU reads back
-    bool kernarg_in_hbm(bool with_hdp_flush) {
+    // `bytes` of the GPU's own memory that the CPU may write through the PCIe BAR (fine-grained pool when there is one: GPU reads
+    // are then not served from a stale L2 line); verified by a write / read-back of the first and last word.  nullptr (and
+    // `why`) when the platform does not allow it.  Free with free_bar().
+public:
+    void *alloc_bar(size_t bytes) {
+        if (!inited_ || !found_) return why = "HSA not initialised", nullptr;
         PoolPick pick;
         hsa_amd_agent_iterate_memory_pools(agent_, &AqlDispatcher::pick_pool, &pick);
-        if (!pick.have_fine && !pick.have_coarse) return why = "no allocatable global pool on the GPU agent", false;
+        if (!pick.have_fine && !pick.have_coarse) return why = "no allocatable global pool on the GPU agent", nullptr;
         hsa_agent_t cpu{};
-        if (hsa_iterate_agents(&AqlDispatcher::pick_cpu, &cpu) != HSA_STATUS_INFO_BREAK) return why = "no CPU agent", false;
+        if (hsa_iterate_agents(&AqlDispatcher::pick_cpu, &cpu) != HSA_STATUS_INFO_BREAK) return why = "no CPU agent", nullptr;
         void *ptr = nullptr;
-        if (hsa_amd_memory_pool_allocate(pick.have_fine ? pick.fine : pick.coarse, kSlots * kSlotBytes, 0, &ptr) != HSA_STATUS_SUCCESS || !ptr)
-            return why = "hsa_amd_memory_pool_allocate failed", false;
+        if (hsa_amd_memory_pool_allocate(pick.have_fine ? pick.fine : pick.coarse, bytes, 0, &ptr) != HSA_STATUS_SUCCESS || !ptr)
+            return why = "hsa_amd_memory_pool_allocate failed", nullptr;
         const hsa_agent_t both[2] = {cpu, agent_};
         if (hsa_amd_agents_allow_access(2, both, nullptr, ptr) != HSA_STATUS_SUCCESS) {
             hsa_amd_memory_pool_free(ptr);
-            return why = "the CPU cannot map the GPU's memory (no large BAR?)", false;
+            return why = "the CPU cannot map the GPU's memory (no large BAR?)", nullptr;
         }
         volatile uint64_t *probe = static_cast<volatile uint64_t *>(ptr);
-        probe[0] = 0x4B49435041524753ull, probe[kSlots * kSlotBytes / 8 - 1] = 0x1234567890ABCDEFull;
+        probe[0] = 0x4B49435041524753ull, probe[bytes / 8 - 1] = 0x1234567890ABCDEFull;
         _mm_sfence();
-        if (probe[0] != 0x4B49435041524753ull || probe[kSlots * kSlotBytes / 8 - 1] != 0x1234567890ABCDEFull) {
+        if (probe[0] != 0x4B49435041524753ull || probe[bytes / 8 - 1] != 0x1234567890ABCDEFull) {
             hsa_amd_memory_pool_free(ptr);
-            return why = "BAR write / read-back mismatch", false;
+            return why = "BAR write / read-back mismatch", nullptr;
         }
+        probe[0] = 0ull, probe[bytes / 8 - 1] = 0ull;
+        _mm_sfence();
+        return ptr;
+    }
+    void free_bar(void *ptr) {
+        if (ptr) (void)hsa_amd_memory_pool_free(ptr);
+    }
+
+private:
+    bool kernarg_in_hbm(bool with_hdp_flush) {
+        void *ptr = alloc_bar(kSlots * kSlotBytes);
+        if (!ptr) return false;
         if (with_hdp_flush) {
             hsa_amd_hdp_flush_t hdp{};
             if (hsa_agent_get_info(agent_, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_HDP_FLUSH), &hdp) == HSA_STATUS_SUCCESS && hdp.HDP_MEM_FLUSH_CNTL)

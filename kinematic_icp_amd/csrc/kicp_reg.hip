@@ -135,9 +135,14 @@ struct kicp_reg {
     // small-scan path (kicp_small.hpp): the command line the resident kernel polls (host-mapped, 64-byte aligned), the
     // sequence number of the last command issued, and the knobs
     unsigned long long *cmd = nullptr, *d_cmd = nullptr;
+    unsigned long long *d_cmd_copies = nullptr;  // kCmdReplicas copies of the command line in device memory
+    unsigned long long *cmd_bar = nullptr;       // host view of the same copies when they live in BAR-writable HBM (option "small_cmd" 1)
+    int small_cmd = 0;            // option "small_cmd": 0 workgroup 0 relays the host line into the copies; 1 the host writes them through the BAR
     unsigned long long cmd_seq = 0;
     int use_small = 1;            // option "small": scans of up to kSmallMaxLanes lanes take k_pass_small
     int small_block = 256;        // option "small_block": its workgroup size (256 | 512 | 1024)
+    int small_wave = 1;           // option "small_wave": scans of up to kWaveMaxPoints points take k_pass_wave (one wave per query)
+    int wave_block = 0;           // option "wave_block": its workgroup size (256 | 512 | 1024; 0 = by scan size)
     int small_resident = 1;       // option "small_resident": the kernel stays for the call's later iterations
     double small_timeout_us = 20000.0;  // option "small_timeout_us": how long a resident workgroup waits for a command
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
@@ -210,10 +215,11 @@ const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split) 
     std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s>(", b, g, occ, split ? "true" : "false");
     return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0), name);
 }
-const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g) {
+const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
-    std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(", block, g);
-    return aql_lookup(r, -(block * 10 + g), name);
+    if (wave) std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(", block);
+    else std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(", block, g);
+    return aql_lookup(r, -(block * 10 + (wave ? 9 : g)), name);
 }
 // Before HIP work follows kernels that went through the handle's AQL queue: wait for them.  A time-out is an error (a kernel
 // of ours may still be writing the buffers the next launch reuses); a queue error retires the dispatcher instead - its kernels
@@ -454,19 +460,59 @@ int wait_shm(kicp_reg *r, unsigned long long value, long long out_words[kReduceW
 }
 
 // ---- the small-scan path (kicp_small.hpp) ------------------------------------------------------------------------------
-// sub-lanes per query and workgroups of k_pass_small for a scan of n points; 0 workgroups = the scan does not fit
-uint32_t small_grid(const kicp_reg *r, size_t n, int *g_out) {
-    const int g = lanes_for(r, n);
-    *g_out = g;
-    const size_t lanes = n * static_cast<size_t>(g);
-    if (n == 0 || lanes > static_cast<size_t>(kSmallMaxLanes)) return 0u;
-    return static_cast<uint32_t>((lanes + r->small_block - 1) / r->small_block);
+// How the small-scan path runs a scan of n points: one wave per query (k_pass_wave, up to kWaveMaxPoints points) or G
+// sub-lanes per query (k_pass_small, up to kSmallMaxLanes lanes); grid == 0: the scan does not fit, the generic path takes it.
+struct SmallPlan {
+    uint32_t grid = 0;
+    int block = 256, g = 1;
+    bool wave = false;
+};
+SmallPlan small_plan(const kicp_reg *r, size_t n) {
+    SmallPlan pl;
+    if (n == 0) return pl;
+    if (r->small_wave && n <= kWaveMaxPoints) {
+        pl.wave = true;
+        pl.block = r->wave_block ? r->wave_block : (n <= 1088 ? 256 : (n <= 2176 ? 512 : 1024));  // <= kWaveMaxRows rows
+        const size_t per_group = static_cast<size_t>(pl.block) / 64;
+        pl.grid = static_cast<uint32_t>((n + per_group - 1) / per_group);
+        if (pl.grid <= static_cast<uint32_t>(kWaveMaxRows)) return pl;
+        pl.block = 1024, pl.grid = static_cast<uint32_t>((n + 15) / 16);
+        return pl;
+    }
+    pl.g = lanes_for(r, n), pl.block = r->small_block;
+    const size_t lanes = n * static_cast<size_t>(pl.g);
+    if (lanes > static_cast<size_t>(kSmallMaxLanes)) return pl;
+    pl.grid = static_cast<uint32_t>((lanes + pl.block - 1) / pl.block);
+    return pl;
 }
 int ensure_cmd(kicp_reg *r) {
-    if (r->cmd) return KICP_OK;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), 128, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(r->cmd, 0, 128);
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
+    if (!r->cmd) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), 128, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(r->cmd, 0, 128);
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
+    }
+    const size_t bytes = static_cast<size_t>(kCmdReplicas) * kCmdWords * sizeof(unsigned long long);
+    if (r->small_cmd == 1 && !r->cmd_bar) {  // the copies in host-writable HBM: needs the HSA side of the AQL dispatcher
+        if (r->d_cmd_copies) {
+            if (int rc = aql_quiesce(r)) return rc;
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            HIP_TRY(hipFree(r->d_cmd_copies));
+            r->d_cmd_copies = nullptr;
+        }
+        if (aql_up(r)) r->cmd_bar = static_cast<unsigned long long *>(r->aql.alloc_bar(bytes));
+        if (r->cmd_bar) {
+            for (size_t i = 0; i < bytes / 8; ++i) r->cmd_bar[i] = 0ull;
+            _mm_sfence();
+            r->d_cmd_copies = r->cmd_bar;
+        } else {
+            if (env_flag("KICP_TRACE")) std::fprintf(stderr, "[kicp] command line in BAR-writable HBM unavailable (%s): relaying through workgroup 0\n", r->aql.why.c_str());
+            r->small_cmd = 0;
+        }
+    }
+    if (!r->d_cmd_copies) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_cmd_copies), bytes));
+        HIP_TRY(hipMemset(r->d_cmd_copies, 0, bytes));
+    }
     return KICP_OK;
 }
 // `count` consecutive pass tags (the same wrap rule as next_tag)
@@ -478,16 +524,24 @@ int next_tag_range(kicp_reg *r, uint32_t count, uint32_t *first) {
 }
 // the command that starts pass `seq - seq_base` of the resident kernel: seven pose words, then the control word (release)
 void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &T) {
-    unsigned long long w[7];
+    unsigned long long w[kCmdWords];
     const double v[7] = {T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz};
-    std::memcpy(w, v, sizeof w);
+    std::memcpy(w, v, 7 * sizeof(double));
+    w[7] = ((seq << 8) | op) ^ cmd_fold(w);
+    if (r->small_cmd == 1 && r->cmd_bar) {  // straight into the copies the workgroups poll (write-combined BAR stores)
+        for (int c = 0; c < kCmdReplicas; ++c)
+            for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[c * kCmdWords + i] = w[i];
+        _mm_sfence();
+        return;
+    }
     for (int i = 0; i < 7; ++i) __atomic_store_n(r->cmd + i, w[i], __ATOMIC_RELAXED);
-    __atomic_store_n(r->cmd + 7, ((seq << 8) | op) ^ cmd_fold(w), __ATOMIC_RELEASE);
+    __atomic_store_n(r->cmd + 7, w[7], __ATOMIC_RELEASE);
 }
-int launch_small(kicp_reg *r, const SmallParams &sp, uint32_t grid, int g) {
-    const int b = r->small_block;
+int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
+    const int b = pl.block, g = pl.g;
+    const uint32_t grid = pl.grid;
     if (r->use_aql && !r->stream_dirty) {
-        if (const AqlKernel *k = aql_small_kernel_for(r, b, g)) {
+        if (const AqlKernel *k = aql_small_kernel_for(r, b, g, pl.wave)) {
             if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &sp, sizeof sp, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
                 r->last_via_aql = true;
                 return KICP_OK;
@@ -499,7 +553,8 @@ int launch_small(kicp_reg *r, const SmallParams &sp, uint32_t grid, int g) {
     r->last_via_aql = false;
 #define KICP_SMALL(B)                                                                                     \
     do {                                                                                                  \
-        if (g == 1) hipLaunchKernelGGL((k_pass_small<B, 1>), dim3(grid), dim3(B), 0, r->stream, sp);      \
+        if (pl.wave) hipLaunchKernelGGL((k_pass_wave<B>), dim3(grid), dim3(B), 0, r->stream, sp);         \
+        else if (g == 1) hipLaunchKernelGGL((k_pass_small<B, 1>), dim3(grid), dim3(B), 0, r->stream, sp); \
         else if (g == 2) hipLaunchKernelGGL((k_pass_small<B, 2>), dim3(grid), dim3(B), 0, r->stream, sp); \
         else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
     } while (0)
@@ -601,9 +656,10 @@ struct HostLoop {
     }
 };
 
-int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, uint32_t grid, int g, const Pose &T0, double tau, double out_pose_qt[7],
+int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const SmallPlan &pl, const Pose &T0, double tau, double out_pose_qt[7],
               kicp_stats *stats) {
     const int max_it = r->cfg.max_num_iterations;
+    const uint32_t grid = pl.grid;
     if (int rc = ensure_rows(r, grid)) return rc;
     if (int rc = ensure_cmd(r)) return rc;
     SmallParams sp{};
@@ -611,7 +667,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, uint3
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
-    sp.cmd = r->d_cmd, sp.rows = r->d_rows;
+    sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);  // 100 MHz wall clock
     HostLoop loop;
     loop.T = T0;
@@ -623,7 +679,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, uint3
         pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
         sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
         r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
-        if (int rc = launch_small(r, sp, grid, g)) return rc;
+        if (int rc = launch_small(r, sp, pl)) return rc;
         for (uint32_t k = 0; k < cnt; ++k) {
             long long words[kReduceWords];
             bool gave_up = false;
@@ -650,7 +706,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, uint3
     }
     pose_to(loop.T, out_pose_qt);
     if (stats) stats->iterations = loop.iter, stats->converged = loop.converged, stats->beta = loop.beta;
-    r->last_small = 1;
+    r->last_small = pl.wave ? 2 : 1;
     if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
     return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
 }
@@ -682,8 +738,8 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     const bool p2p = r->d_p2p_table != nullptr;
     r->last_small = 0;
     if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0) {
-        int g = 1;
-        if (const uint32_t grid = small_grid(r, n, &g)) return run_small(r, map, d_frame, n, grid, g, T0, tau, out_pose_qt, stats);
+        const SmallPlan pl = small_plan(r, n);
+        if (pl.grid) return run_small(r, map, d_frame, n, pl, T0, tau, out_pose_qt, stats);
     }
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
@@ -903,6 +959,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (const char *env = std::getenv("KICP_QUERY_EVERY")) r->query_every = std::atoi(env);
     if (const char *env = std::getenv("KICP_SMALL")) r->use_small = std::atoi(env) != 0;
     if (const char *env = std::getenv("KICP_SMALL_RESIDENT")) r->small_resident = std::atoi(env) != 0;
+    if (const char *env = std::getenv("KICP_SMALL_CMD")) r->small_cmd = std::atoi(env) != 0;
     *out = r;
     return KICP_OK;
 }
@@ -918,6 +975,8 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->rows) hipHostFree(reg->rows);
     if (reg->cmd) hipHostFree(reg->cmd);
+    if (reg->cmd_bar) reg->aql.free_bar(reg->cmd_bar);
+    else if (reg->d_cmd_copies) hipFree(reg->d_cmd_copies);
     reg->stage.release();
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
@@ -961,6 +1020,12 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
     else if (k == "small_resident") reg->small_resident = value != 0.0 ? 1 : 0;
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
+    else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
+    else if (k == "small_cmd") {
+        if (reg->cmd_bar || (value != 0.0) == (reg->small_cmd != 0)) return KICP_OK;  // (once the copies live in the BAR they stay there)
+        reg->small_cmd = value != 0.0 ? 1 : 0;
+    }
+    else if (k == "wave_block") reg->wave_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : (value == 256.0 ? 256 : 0));
     else if (k == "small_timeout_us") reg->small_timeout_us = value;
     else if (k == "debug_stall_us") reg->debug_stall_us = value;
     else if (k == "dbg") reg->dbg = static_cast<int>(value);
@@ -987,8 +1052,11 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "small") return reg->use_small;
     if (k == "small_resident") return reg->small_resident;
     if (k == "small_block") return reg->small_block;
+    if (k == "small_wave") return reg->small_wave;
+    if (k == "small_cmd") return (reg->small_cmd == 1 && reg->cmd_bar) ? 1.0 : (reg->small_cmd ? 0.5 : 0.0);  // 1: BAR copies in use; 0.5: requested, not yet set up
+    if (k == "wave_block") return reg->wave_block;
     if (k == "small_timeout_us") return reg->small_timeout_us;
-    if (k == "small_active") return reg->last_small;  // did the last registration run on the small-scan path
+    if (k == "small_active") return reg->last_small;  // path of the last registration: 0 generic, 1 small (sub-lanes per query), 2 small (wave per query)
     if (k == "small_relaunches") return static_cast<double>(reg->small_relaunches);
     if (k == "aql_active") return (reg->aql.ready && reg->last_via_aql) ? 1.0 : 0.0;  // was the last pass dispatched through the AQL queue
     return -1.0;
@@ -1290,6 +1358,10 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
             std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(\n", b, g);
             all += name;
         }
+    for (int b : {256, 512, 1024}) {
+        std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(\n", b);
+        all += name;
+    }
     if (out && cap) {
         const size_t n = std::min(cap - 1, all.size());
         std::memcpy(out, all.data(), n);

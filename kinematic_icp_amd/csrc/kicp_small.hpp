@@ -43,6 +43,8 @@ KICP_HD unsigned long long cmd_fold(const unsigned long long w[7]) {
 struct SmallParams {
     PassParams p;                   // (p.sol.mode is not used: the host always solves; p.partials / p.tickets unused)
     const unsigned long long *cmd;  // device view of the host-mapped command line (kCmdWords words, 64-byte aligned)
+    unsigned long long *cmd_dev;    // kCmdReplicas copies of the command line in device memory (await_command)
+    int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
     unsigned long long *rows;       // device view of the host-mapped rows [gridDim.x][kSmallRowWords]
     unsigned long long seq_base;    // the command that starts pass k (k >= 1) carries sequence seq_base + k
     uint32_t tag0;                  // pass k publishes with tag tag0 + k (the host reserves the range)
@@ -66,6 +68,59 @@ __device__ __forceinline__ uint32_t fresh_tid() {
     uint32_t t = threadIdx.x;
     asm volatile("; per-pass copy of the lane id" : "+v"(t));
     return t;
+}
+
+// Wait for the command that starts pass `pass + 1` and hand its pose to the workgroup through LDS.  Hundreds of workgroups
+// polling one line of HOST memory over PCIe starve each other (measured: 270 pollers, 80 us per command), so the command
+// reaches the workgroups through DEVICE memory: `cmd_dev` holds kCmdReplicas copies of the 64-byte line (a workgroup polls copy
+// blockIdx % kCmdReplicas with agent-scope loads, lanes 0..7 one word each).  Who fills them:
+//   relay = 1: wave 0 of workgroup 0 polls the host line (ONE PCIe reader) and stores what it finds into every copy;
+//   relay = 0: the host writes the copies itself through the PCIe BAR (the line lives in host-visible fine-grained HBM).
+// false: STOP, or no command in time (the rows of the pass that will not run are then marked so that the host launches
+// afresh).  Ends in a workgroup barrier.
+constexpr int kCmdReplicas = 16;
+__device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
+    if ((tid >> 6) == 0) {
+        const int lane = tid & 63;
+        const unsigned long long want = sp.seq_base + pass + 1;
+        const long long t0 = wall_clock64();
+        const bool relay = sp.relay != 0 && blockIdx.x == 0;
+        const unsigned long long *line = relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdWords;
+        unsigned long long w = 0, ctrl = 0;
+        for (;;) {
+            if (lane < kCmdWords)
+                w = relay ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                          : __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long pose[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pose[k] = __shfl(w, k, 64);
+            ctrl = __shfl(w, 7, 64) ^ cmd_fold(pose);
+            if ((ctrl >> 8) == want && ((ctrl & 0xFFull) == kCmdContinue || (ctrl & 0xFFull) == kCmdStop)) break;
+            if (wall_clock64() - t0 > sp.timeout_ticks) {
+                ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
+                if (lane < kSmallRowWords)
+                    __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + lane,
+                                       ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            if (!relay) __builtin_amdgcn_s_sleep(4);  // (~0.1 us: hundreds of workgroups share the copies' memory channel)
+        }
+        if (relay && ctrl != 0ull && lane < kCmdWords) {  // pass the command on: every word is self-validating, no ordering needed
+#pragma unroll
+            for (int r = 0; r < kCmdReplicas; ++r)
+                __hip_atomic_store(sp.cmd_dev + static_cast<size_t>(r) * kCmdWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < 7) s_cmd[lane] = w;
+        if (lane == 7) s_cmd[7] = ctrl & 0xFFull;
+    }
+    __syncthreads();
+    return static_cast<uint32_t>(s_cmd[7]) == kCmdContinue;
+}
+// value of a double in lane l, wave-uniform
+__device__ __forceinline__ double uniform_lane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), l), hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), l);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
 // workgroup sum of the lanes' terms -> one row of self-validating words in host memory
@@ -154,37 +209,194 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
         tid = fresh_tid();
         small_publish<BLOCK>(acc, sp, tid, sp.tag0 + pass, s_red, &s_flag);
         if (pass + 1 >= sp.max_passes) return;
-        // ---- wait for the next command: wave 0 polls the host line, lanes 0..7 one word each (ONE 64-byte read) -------------
-        if ((tid >> 6) == 0) {
-            const int lane = tid & 63;
-            const unsigned long long want = sp.seq_base + pass + 1;
-            const long long t0 = wall_clock64();
-            unsigned long long w = 0, ctrl = 0;
-            for (;;) {
-                if (lane < kCmdWords) w = __hip_atomic_load(sp.cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                unsigned long long pose[7];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) pose[k] = __shfl(w, k, 64);
-                ctrl = __shfl(w, 7, 64) ^ cmd_fold(pose);
-                if ((ctrl >> 8) == want && ((ctrl & 0xFFull) == kCmdContinue || (ctrl & 0xFFull) == kCmdStop)) break;
-                if (wall_clock64() - t0 > sp.timeout_ticks) {
-                    ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
-                    if (lane < kSmallRowWords)
-                        __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + lane,
-                                           ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-            if (lane < 7) s_cmd[lane] = w;
-            if (lane == 7) s_cmd[7] = ctrl & 0xFFull;
-        }
-        __syncthreads();
-        if (static_cast<uint32_t>(s_cmd[7]) != kCmdContinue) return;
+        if (!await_command(sp, tid, pass, s_cmd)) return;
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[6])))};
         // (no barrier here: wave 0 reaches its next poll only through the two barriers of the next pass's epilogue)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_pass_wave: ONE WAVE PER QUERY, for scans of up to kWaveMaxPoints points (the 2-D LaserScan entry, the pipeline's
+// double-downsampled source).  A thread-per-query wave walks ~600 VALU instructions per visited bucket plus the fp64 transform
+// and accumulation of its 64 queries in lock step - ~10 us of dependent issue however few queries there are, on a machine of
+// 1024 SIMDs of which a 1 080-point scan then uses 17.  Here the 64 lanes of a wave share ONE query: the transform, the probe
+// and the culling are wave-uniform; a round of the search looks at up to THREE neighbour buckets at once, one mirror point per
+// lane (lanes 0-19 / 20-39 / 40-59), the minimum is a DPP reduction, and every candidate within the error margin of the running
+// minimum is re-evaluated in fp64 by its own lane in the same round - so there is no three-smallest bookkeeping and no exact
+// fall-back search.  The winner is decided among the exactly evaluated candidates by the reference's rule (closer_by_norm, ties
+// to the earlier one in visiting order), which is the generic kernel's decision: the two paths give the same bits.  A query
+// costs its wave ~600 instructions in all and 4-5 dependent memory accesses; a 1 080-point scan occupies 1 080 SIMDs.
+// The wave's single correspondence needs no wave reduction: lane 0's seven 128-bit terms go to LDS, wave 0 adds the workgroup's
+// (<= 16) and stores the row as small_publish does.  Resident loop and command protocol: as k_pass_small.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kWaveMaxPoints = 4096;
+constexpr int kWaveMaxRows = 272;  // rows one launch may produce (ceil(kWaveMaxPoints / 16) = 256, and 1 080 / 4 = 270)
+
+// exact 128-bit fixed-point term of x (to_fixed without the limb split)
+__device__ __forceinline__ I128 to_fixed128(double x, int &range_error) {
+    if (!(fabs(x) < kFixLimit)) {
+        range_error = 1;
+        return I128{0ull, 0ll};
+    }
+    const long long ip = __double2ll_rn(x);
+    const long long fp = __double2ll_rn((x - static_cast<double>(ip)) * kFixScale);
+    I128 t{static_cast<unsigned long long>(ip) << 40, ip >> 24};
+    i128_add(t, I128{static_cast<unsigned long long>(fp), fp >> 63});
+    return t;
+}
+// minimum of a non-negative float over the wave (as the unsigned order of its bits), in every lane
+__device__ __forceinline__ float wave_min_nonneg(float v) {
+    uint32_t b = __float_as_uint(v);
+    b = min(b, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b), static_cast<int>(b), 0x111, 0xF, 0xF, false)));  // row_shr:1
+    b = min(b, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b), static_cast<int>(b), 0x112, 0xF, 0xF, false)));  // row_shr:2
+    b = min(b, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b), static_cast<int>(b), 0x114, 0xF, 0xF, false)));  // row_shr:4
+    b = min(b, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b), static_cast<int>(b), 0x118, 0xF, 0xF, false)));  // row_shr:8
+    // lane 15 of every row now holds the row's minimum: fold the four rows through readlane (wave-uniform result)
+    const uint32_t r0 = __builtin_amdgcn_readlane(static_cast<int>(b), 15), r1 = __builtin_amdgcn_readlane(static_cast<int>(b), 31);
+    const uint32_t r2 = __builtin_amdgcn_readlane(static_cast<int>(b), 47), r3 = __builtin_amdgcn_readlane(static_cast<int>(b), 63);
+    return __uint_as_float(min(min(r0, r1), min(r2, r3)));
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read through fresh_args() */) {
+    constexpr int kWaves = BLOCK / 64;
+    __shared__ unsigned long long s_term[kWaves][2 * kNumSums];  // lo / hi of the wave's seven 128-bit terms
+    __shared__ int s_flag;
+    __shared__ unsigned long long s_cmd[kCmdWords];
+    Pose T = fresh_args().p.sol.pose0;
+    for (uint32_t pass = 0;; ++pass) {
+        const SmallParams &sp = fresh_args();
+        const PassParams &p = sp.p;
+        const MapView &m = p.map;
+        uint32_t tid = fresh_tid();
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
+        if (tid == 0) s_flag = 0;
+        const uint32_t qi = blockIdx.x * kWaves + static_cast<uint32_t>(wave);  // this wave's query (wave-uniform)
+        I128 term[kNumSums];
+#pragma unroll
+        for (int k = 0; k < kNumSums; ++k) term[k] = I128{0ull, 0ll};
+        int range_error = 0;
+        if (qi < p.n) {
+            const SearchParams &sq = p.search;
+            const float margin = sq.margin_u;
+            Query q;
+            make_query_of(q, p, T, qi);
+            const double vs = m.voxel_size;
+            Lane L;  // (only the probe part: offsets inside the own voxel, the slot of its entry)
+            L.q.lx = static_cast<float>((q.x - q.vx * vs) * sq.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sq.upm),
+            L.q.lz = static_cast<float>((q.z - q.vz * vs) * sq.upm);
+            L.q.slot0 = 0u, L.todo = 0u;
+            table_lookup_entry(m, q.vx, q.vy, q.vz, L.q.slot0, L.todo);
+            uint32_t todo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(L.todo)));
+            const uint32_t slot0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(L.q.slot0)));
+            float cur_min = sq.bound_u;  // running minimum of the mirror distances (units^2), wave-uniform
+            const double bound = sq.bound;
+            double best = bound;         // exact squared distance of the best candidate so far (reference rule), wave-uniform
+            uint32_t best_idx = kNoIndex32, best_ord = 0u;
+            const int group = lane / static_cast<int>(kMirrorTrip), kk = lane % static_cast<int>(kMirrorTrip);
+            while (todo) {
+                L.todo = todo;
+                todo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(cull_todo(L, cur_min, margin))));
+                if (!todo) break;
+                // up to three neighbour voxels this round, in the reference's visiting order
+                int sv[3], ns = 0;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    sv[g] = 0;
+                    if (todo) {
+                        sv[g] = __ffs(todo) - 1;
+                        todo &= todo - 1u;
+                        ns = g + 1;
+                    }
+                }
+                const bool active = group < ns;
+                const int s = group == 0 ? sv[0] : (group == 1 ? sv[1] : sv[2]);
+                const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
+                const uint32_t bucket = active ? m.table[slot0].nb[s] : 0u;
+                const float qx = L.q.lx - dx * kCell, qy = L.q.ly - dy * kCell, qz = L.q.lz - dz * kCell;
+                bool more = true;
+                for (uint32_t k0 = 0; more && k0 < m.cap16; k0 += kMirrorTrip) {
+                    MirrorPoint mp = mirror_empty();
+                    if (active) mp = m.pool16[static_cast<size_t>(bucket) * m.cap16 + k0 + kk];
+                    const float ddx = static_cast<float>(mp.x & 0xffffu) - qx, ddy = static_cast<float>(mp.x >> 16) - qy, ddz = static_cast<float>(mp.y) - qz;
+                    const float d = active ? __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx)) : 3.0e38f;
+                    cur_min = fminf(cur_min, wave_min_nonneg(d));
+                    // every candidate that can still be the reference's choice: within the margin of the running minimum
+                    unsigned long long near = __ballot(d <= cur_min + margin);
+                    if (near) {
+                        const uint32_t k = k0 + static_cast<uint32_t>(kk);
+                        const uint32_t gidx = bucket * m.cap + k;
+                        double d2 = DBL_MAX;
+                        if ((near >> lane) & 1ull) d2 = exact_d2(m, gidx, q);
+                        const uint32_t ord = static_cast<uint32_t>(s) * 256u + k;
+                        while (near) {
+                            const int l = __ffsll(static_cast<long long>(near)) - 1;
+                            near &= near - 1ull;
+                            const double cd = uniform_lane_d(d2, l);
+                            const uint32_t co = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ord), l));
+                            const uint32_t ci = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(gidx), l));
+                            if (!(cd < bound)) continue;
+                            // the reference keeps the FIRST candidate (visiting order) whose norm attains the strict minimum
+                            bool take;
+                            if (best_idx == kNoIndex32) take = true;
+                            else if (co < best_ord) take = !closer_by_norm(best, cd);
+                            else take = closer_by_norm(cd, best);
+                            if (take) best = cd, best_idx = ci, best_ord = co;
+                        }
+                    }
+                    // a bucket goes on where the last slot of this trip holds a point (any of the round's buckets)
+                    more = __ballot(active && kk == static_cast<int>(kMirrorTrip) - 1 && (mp.y >> 16) == 0u) != 0ull;
+                }
+            }
+            if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+                const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
+                const double sx = p.src[3 * qi], sy = p.src[3 * qi + 1];
+                const double rx = q.x - tp[0], ry = q.y - tp[1], rz = q.z - tp[2];  // residual = T*source - target
+                double j0x, j0y, j0z, j1x, j1y, j1z;
+                quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
+                quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)   (Registration.cpp:86-93,108-113)
+                term[0] = to_fixed128(j0x * j0x + j0y * j0y + j0z * j0z, range_error);
+                term[1] = to_fixed128(j0x * j1x + j0y * j1y + j0z * j1z, range_error);
+                term[2] = to_fixed128(j1x * j1x + j1y * j1y + j1z * j1z, range_error);
+                term[3] = to_fixed128(j0x * rx + j0y * ry + j0z * rz, range_error);
+                term[4] = to_fixed128(j1x * rx + j1y * ry + j1z * rz, range_error);
+                term[5] = to_fixed128(rx * rx + ry * ry + rz * rz, range_error);
+                term[6] = I128{1ull << 40, 0ll};  // the count: 1.0
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kNumSums; ++k) s_term[wave][2 * k] = term[k].lo, s_term[wave][2 * k + 1] = static_cast<unsigned long long>(term[k].hi);
+        }
+        __syncthreads();  // (also: s_flag is reset)
+        if (lane == 0 && range_error) atomicOr(&s_flag, 2);
+        __syncthreads();
+        tid = fresh_tid();
+        if ((tid >> 6) == 0) {
+            const int ln = tid & 63;
+            I128 t{0ull, 0ll};
+            if (ln < kNumSums)
+                for (int w = 0; w < kWaves; ++w) i128_add(t, I128{s_term[w][2 * ln], static_cast<long long>(s_term[w][2 * ln + 1])});
+            const unsigned long long m48 = (1ull << 48) - 1;
+            const unsigned long long h0 = t.lo & m48, h1 = ((t.lo >> 48) | (static_cast<unsigned long long>(t.hi) << 16)) & m48;
+            const unsigned long long v0 = __shfl(h0, ln >> 1, 64), v1 = __shfl(h1, ln >> 1, 64);
+            unsigned long long word = (ln & 1) ? v1 : v0;
+            if (ln == 2 * kNumSums) word = (s_flag & 2) ? 1ull : 0ull;
+            if (ln > 2 * kNumSums) word = 0ull;
+            if (ln < kSmallRowWords)
+                __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (pass + 1 >= sp.max_passes) return;
+        if (!await_command(sp, tid, pass, s_cmd)) return;
+        T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[6])))};
     }
 }
 

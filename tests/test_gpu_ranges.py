@@ -126,20 +126,21 @@ def test_exact_accumulation_range_is_reported_not_wrapped():
         g, o = K.VoxelHashMap(1.0, 1e7, 20), okicp.VoxelHashMap(1.0, 1e7, 20)
         g.AddPoints(mpts), o.AddPoints(mpts)
         ident = okicp.IDENTITY
+        rel = syn.planar_pose(0.01, 0.0, min(1e-4, 0.1 / far))  # (the far point must stay within tau of its map point)
         for small in (1, 0):  # the small-scan path and the generic pass kernel share the accumulation
             reg = K.KinematicRegistration()
             reg.set_option("small", small)
             if ok:
-                a = reg.ComputeRobotMotion(frame, g, ident, syn.planar_pose(0.01, 0.0, 1e-4), 0.5)
+                a = reg.ComputeRobotMotion(frame, g, ident, rel, 0.5)
                 oreg = okicp.KinematicRegistration()
-                b = oreg.ComputeRobotMotion(frame, o, ident, syn.planar_pose(0.01, 0.0, 1e-4), 0.5)
+                b = oreg.ComputeRobotMotion(frame, o, ident, rel, 0.5)
                 np.testing.assert_allclose(a, b, rtol=0, atol=tol)
                 assert reg.last_stats.iterations == oreg.last_stats.iterations
                 assert list(reg.last_stats.n_corr[:reg.last_stats.iterations]) == list(oreg.last_stats.n_corr[:reg.last_stats.iterations])
                 if ref_available() and far <= 5000.0:
-                    c = rkicp.KinematicRegistration().ComputeRobotMotion(frame, ref_map_like(o), ident, syn.planar_pose(0.01, 0.0, 1e-4), 0.5)
+                    c = rkicp.KinematicRegistration().ComputeRobotMotion(frame, ref_map_like(o), ident, rel, 0.5)
                     np.testing.assert_allclose(a, c, rtol=0, atol=tol)
             else:
                 with pytest.raises(K.KicpError) as e:
-                    reg.ComputeRobotMotion(frame, g, ident, syn.planar_pose(0.01, 0.0, 1e-4), 0.5)
+                    reg.ComputeRobotMotion(frame, g, ident, rel, 0.5)
                 assert e.value.code == K.KICP_ERR_CAPACITY

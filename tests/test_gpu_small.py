@@ -27,15 +27,17 @@ def _rels(scans, dx=0.0, yaw_deg=0.0):
     return [syn.pose_mul(s["rel_odom"], syn.planar_pose(dx, 0.0, np.deg2rad(yaw_deg))) for s in scans]
 
 
+@pytest.mark.parametrize("wave", [1, 0])
 @pytest.mark.parametrize("err", [(0.0, 0.0), (0.05, 0.5), (0.1, 2.0)])
-def test_cfg4_small_path_matches_oracle_and_reference(case4, err):
+def test_cfg4_small_path_matches_oracle_and_reference(case4, err, wave):
     cfg, scans, gmap, omap, rmap = case4
     tau = cfg.first_frame_tau()
     reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+    reg.set_option("small_wave", wave)
     iters = []
     for s, rel in zip(scans, _rels(scans, *err)):
         a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
-        assert reg.get_option("small_active") == 1.0
+        assert reg.get_option("small_active") == (2.0 if wave else 1.0)  # 2: one wave per query, 1: sub-lanes per query
         b = oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau)
         k = reg.last_stats.iterations
         iters.append(k)
@@ -65,24 +67,26 @@ def test_small_path_bits_equal_generic_path(case4):
         want.append((base.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau), base.last_stats.iterations, list(base.last_stats.n_corr[:base.last_stats.iterations])))
         assert base.get_option("small_active") == 0.0
     assert max(w[1] for w in want) > 1
-    for resident, aql, lanes, block in [(r, a, l, 256) for r in (1, 0) for a in (1, 0) for l in (0, 1, 2, 4)] + [(1, 1, l, b) for l in (1, 2, 4) for b in (512, 1024)]:
-        if True:
-            if True:
-                reg = K.KinematicRegistration()
-                reg.set_option("small_resident", resident), reg.set_option("aql", aql), reg.set_option("lanes_per_query", lanes)
-                reg.set_option("small_block", block)
-                for rounds in range(2):
-                    for fr, s, rel, (pose, k, ncorr) in zip(frames, scans, rels, want):
-                        got = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
-                        assert reg.get_option("small_active") == 1.0
-                        assert np.array_equal(got, pose), (resident, aql, lanes, block)
-                        assert reg.last_stats.iterations == k and list(reg.last_stats.n_corr[:k]) == ncorr
-                if aql:
-                    assert reg.get_option("aql_active") == 1.0
+    variants = [dict(small_wave=0, small_resident=r, aql=a, lanes_per_query=l) for r in (1, 0) for a in (1, 0) for l in (0, 1, 2, 4)]
+    variants += [dict(small_wave=0, lanes_per_query=l, small_block=b) for l in (1, 2, 4) for b in (512, 1024)]
+    variants += [dict(small_wave=1, small_resident=r, aql=a, wave_block=b) for r in (1, 0) for a in (1, 0) for b in (0, 256, 512, 1024)]
+    variants += [dict(small_wave=w, small_cmd=1, aql=a) for w in (1, 0) for a in (1, 0)]  # the host writes the command copies through the BAR
+    for opts in variants:
+        reg = K.KinematicRegistration()
+        for k, v in opts.items():
+            reg.set_option(k, v)
+        for rounds in range(2):
+            for fr, s, rel, (pose, k, ncorr) in zip(frames, scans, rels, want):
+                got = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+                assert reg.get_option("small_active") == (2.0 if opts["small_wave"] else 1.0)
+                assert np.array_equal(got, pose), opts
+                assert reg.last_stats.iterations == k and list(reg.last_stats.n_corr[:k]) == ncorr, opts
+        if opts.get("aql", 1):
+            assert reg.get_option("aql_active") == 1.0, opts
 
 
 def test_small_path_sizes_and_limits(case4):
-    """1 point, one workgroup's worth, the largest scan the path takes (16 workgroups) and one point more (generic path)."""
+    """1 point, one workgroup's worth, the largest scans the two small kernels take and one point more (next path)."""
     cfg, scans, gmap, omap, rmap = case4
     tau = cfg.first_frame_tau()
     big = np.concatenate([s["frame"] for s in scans] * 8)  # 34 560 points of the same scene
@@ -90,7 +94,8 @@ def test_small_path_sizes_and_limits(case4):
     gen.set_option("small", 0)
     s = scans[0]
     rel = _rels(scans, 0.05, 0.8)[0]
-    for n, lanes, small in ((1, 0, 1), (255, 0, 1), (256, 0, 1), (257, 0, 1), (4096, 0, 1), (4097, 0, 1), (8192, 0, 1), (8193, 0, 0), (16384, 1, 1), (16385, 1, 0)):
+    for n, lanes, small in ((1, 0, 2), (3, 0, 2), (4, 0, 2), (5, 0, 2), (255, 0, 2), (1088, 0, 2), (1089, 0, 2), (2177, 0, 2), (4096, 0, 2), (4097, 0, 1), (8192, 0, 1),
+                            (8193, 0, 0), (16384, 1, 1), (16385, 1, 0)):
         reg.set_option("lanes_per_query", lanes), gen.set_option("lanes_per_query", lanes)
         fr = np.ascontiguousarray(big[:n])
         a = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
@@ -102,7 +107,9 @@ def test_small_path_sizes_and_limits(case4):
         assert reg.last_stats.iterations == oreg.last_stats.iterations
 
 
-def test_resident_kernel_gives_up_and_the_host_relaunches(case4):
+@pytest.mark.parametrize("cmd", [0, 1])
+@pytest.mark.parametrize("wave", [1, 0])
+def test_resident_kernel_gives_up_and_the_host_relaunches(case4, wave, cmd):
     """A host that is late with its next command (descheduled thread): the resident workgroups leave after their time-out and
     mark the pass they did not run; the host sees the marks, launches afresh and still returns the same bits."""
     cfg, scans, gmap, omap, rmap = case4
@@ -112,6 +119,7 @@ def test_resident_kernel_gives_up_and_the_host_relaunches(case4):
     want = ref.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
     assert ref.last_stats.iterations > 2
     reg = K.KinematicRegistration()
+    reg.set_option("small_wave", wave), reg.set_option("small_cmd", cmd)
     reg.set_option("small_timeout_us", 200.0)
     for stall in (2000.0, 150.0, 260.0):  # far beyond, just inside and just beyond the time-out (either outcome must give the same bits)
         before = reg.get_option("small_relaunches")
@@ -135,7 +143,7 @@ def test_many_passes_and_tag_wraparound(case4):
         reg, gen, oreg = K.KinematicRegistration(**kw), K.KinematicRegistration(**kw), okicp.KinematicRegistration(**kw)
         gen.set_option("small", 0)
         a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
-        assert reg.get_option("small_active") == 1.0 and reg.last_stats.iterations == max_it and reg.last_stats.converged == 0
+        assert reg.get_option("small_active") == 2.0 and reg.last_stats.iterations == max_it and reg.last_stats.converged == 0
         assert np.array_equal(a, gen.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau))
         np.testing.assert_allclose(a, oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau), rtol=0, atol=POSE_TOL)
         assert oreg.last_stats.iterations == max_it
@@ -183,8 +191,35 @@ def test_pipeline_sized_sources(case4):
         assert 200 < len(src) < 4096
         rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.06, 0.0, np.deg2rad(0.7)))
         a = reg.ComputeRobotMotion(K.DeviceFrame(src), gmap, s["last_pose"], rel, cfg.first_frame_tau())
-        assert reg.get_option("small_active") == 1.0
+        assert reg.get_option("small_active") == 2.0
         np.testing.assert_allclose(a, oreg.ComputeRobotMotion(src, omap, s["last_pose"], rel, cfg.first_frame_tau()), rtol=0, atol=POSE_TOL)
         assert reg.last_stats.iterations == oreg.last_stats.iterations
         if rmap is not None:
             np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(src, rmap, s["last_pose"], rel, cfg.first_frame_tau()), rtol=0, atol=POSE_TOL)
+
+
+@pytest.mark.parametrize("cap", [1, 20, 21, 60, 255])
+def test_wave_kernel_on_deep_and_shallow_buckets(cap):
+    """max_points_per_voxel 1 ... 255: buckets of one point and buckets that take several 20-point trips of the wave kernel
+    (the mirror's bucket stride is 20, 40, 60, 260), dense enough to fill them; against the oracle, the reference build and the
+    generic kernel."""
+    rng = np.random.default_rng(cap)
+    vs = 0.5
+    mpts = rng.uniform(-4, 4, (60000, 3)) * np.array([1.0, 1.0, 0.15])
+    gmap, omap = K.VoxelHashMap(vs, 100.0, cap), okicp.VoxelHashMap(vs, 100.0, cap)
+    gmap.AddPoints(mpts), omap.AddPoints(mpts)
+    assert gmap.num_points() == omap.num_points()
+    frame = mpts[rng.choice(len(mpts), 900, replace=False)] + rng.normal(0, 0.02, (900, 3))
+    last, rel = okicp.IDENTITY, syn.planar_pose(0.03, 0.0, np.deg2rad(0.6))
+    reg, gen, oreg = K.KinematicRegistration(), K.KinematicRegistration(), okicp.KinematicRegistration()
+    gen.set_option("small", 0)
+    for tau in (0.3, 0.05):
+        a = reg.ComputeRobotMotion(frame, gmap, last, rel, tau)
+        assert reg.get_option("small_active") == 2.0
+        assert np.array_equal(a, gen.ComputeRobotMotion(frame, gmap, last, rel, tau)) and reg.last_stats.iterations == gen.last_stats.iterations
+        b = oreg.ComputeRobotMotion(frame, omap, last, rel, tau)
+        np.testing.assert_allclose(a, b, rtol=0, atol=POSE_TOL)
+        k = reg.last_stats.iterations
+        assert k == oreg.last_stats.iterations and list(reg.last_stats.n_corr[:k]) == list(oreg.last_stats.n_corr[:k])
+        if ref_available():
+            np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(frame, ref_map_like(omap), last, rel, tau), rtol=0, atol=POSE_TOL)

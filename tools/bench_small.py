@@ -53,28 +53,30 @@ def run(label, env=None, **opts):
         us = (time.perf_counter() - t0) / (steps * B) * 1e6
         iters = float(np.mean(batch.iterations))
         out.append("%s: %.2f us/scan, %.2f iterations, %.2f us/iteration" % (name, us, iters, us / iters))
-    out.append("small %d aql %d kernarg %d relaunches %d" % (reg.get_option("small_active"), reg.get_option("aql_active"), reg.get_option("aql_kernarg"),
-                                                              reg.get_option("small_relaunches")))
+    out.append("small %d aql %d kernarg %d cmd %.1f relaunches %d" % (reg.get_option("small_active"), reg.get_option("aql_active"), reg.get_option("aql_kernarg"),
+                                                                       reg.get_option("small_cmd"), reg.get_option("small_relaunches")))
     for k in (env or {}):
         os.environ.pop(k, None)
     print(" | ".join(out), flush=True)
 
 
 print("%s: %d-point scans vs %d-point map" % (cfg.name, len(scans[0]["frame"]), gmap.num_points()), flush=True)
-fits = len(scans[0]["frame"]) <= 8192
+fits = len(scans[0]["frame"]) <= 4096
 run("generic pass kernel (round 2 path)", small=0)
 run("generic, HIP launch               ", small=0, aql=0)
 run("generic, kernargs in HBM          ", env={"KICP_KERNARG": "dev"}, small=0)
 run("generic, kernargs in HBM + HDP    ", env={"KICP_KERNARG": "devhdp"}, small=0)
 if fits:
-    run("small path, one launch per pass   ", small_resident=0)
-    run("small path, resident (default)    ")
-    run("small path, resident, HIP launch  ", aql=0)
-    run("small resident, kernargs in HBM   ", env={"KICP_KERNARG": "dev"})
-    run("small resident, kernargs HBM + HDP", env={"KICP_KERNARG": "devhdp"})
-    run("small 1 launch/pass, kernargs HBM ", env={"KICP_KERNARG": "dev"}, small_resident=0)
-    for lanes in (1, 2, 4):
-        run("small resident, %d sub-lanes/query  " % lanes, lanes_per_query=lanes)
-    for block in (512, 1024):
-        run("small resident, %4d-lane groups  " % block, small_block=block)
-        run("small 1 launch/pass, %4d-lane grp" % block, small_block=block, small_resident=0)
+    for b in (0, 256, 512, 1024):
+        run("wave/query resident relay, block %4d" % b, wave_block=b)
+    for b in (0, 512, 1024):
+        run("wave/query resident BAR,   block %4d" % b, wave_block=b, small_cmd=1)
+    run("wave per query, 1 launch per pass   ", small_resident=0)
+    run("wave/query resident relay, HBM kargs", env={"KICP_KERNARG": "dev"})
+    run("wave/query resident BAR, HBM kargs  ", env={"KICP_KERNARG": "dev"}, small_cmd=1)
+    run("wave/query 1 launch/pass, HBM kargs ", env={"KICP_KERNARG": "dev"}, small_resident=0)
+    run("wave/query resident relay, HIP launch", aql=0)
+    run("sub-lanes, one launch per pass      ", small_wave=0, small_resident=0)
+    run("sub-lanes, resident relay           ", small_wave=0)
+    run("sub-lanes, resident BAR             ", small_wave=0, small_cmd=1)
+    run("sub-lanes, resident BAR, HBM kargs  ", small_wave=0, small_cmd=1, env={"KICP_KERNARG": "dev"})
