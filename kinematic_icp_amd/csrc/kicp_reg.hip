@@ -137,7 +137,7 @@ struct kicp_reg {
     unsigned long long *cmd = nullptr, *d_cmd = nullptr;
     unsigned long long *d_cmd_copies = nullptr;  // kCmdReplicas copies of the command line in device memory
     unsigned long long *cmd_bar = nullptr;       // host view of the same copies when they live in BAR-writable HBM (option "small_cmd" 1)
-    int small_cmd = 0;            // option "small_cmd": 0 workgroup 0 relays the host line into the copies; 1 the host writes them through the BAR
+    int small_cmd = 1;            // option "small_cmd": 1 (default) the host writes the command copies through the BAR; 0 workgroup 0 relays the host line
     unsigned long long cmd_seq = 0;
     int use_small = 1;            // option "small": scans of up to kSmallMaxLanes lanes take k_pass_small
     int small_block = 256;        // option "small_block": its workgroup size (256 | 512 | 1024)
@@ -148,6 +148,9 @@ struct kicp_reg {
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
+    long long *d_trace = nullptr; // option "small_trace": device buffer of the kernel's per-pass wall-clock stamps
+    double trace_host_us = 0.0, trace_dev_us = 0.0, trace_first_us = 0.0;  // host: rows seen -> command sent; device: command sent -> rows seen; launch -> first rows
+    unsigned long long trace_n = 0, trace_first_n = 0;
 };
 
 namespace {
@@ -472,7 +475,7 @@ SmallPlan small_plan(const kicp_reg *r, size_t n) {
     if (n == 0) return pl;
     if (r->small_wave && n <= kWaveMaxPoints) {
         pl.wave = true;
-        pl.block = r->wave_block ? r->wave_block : (n <= 1088 ? 256 : (n <= 2176 ? 512 : 1024));  // <= kWaveMaxRows rows
+        pl.block = r->wave_block ? r->wave_block : (n <= 512 ? 256 : (n <= 2176 ? 512 : 1024));  // <= kWaveMaxRows rows; 512 measured best at 1 080 points
         const size_t per_group = static_cast<size_t>(pl.block) / 64;
         pl.grid = static_cast<uint32_t>((n + per_group - 1) / per_group);
         if (pl.grid <= static_cast<uint32_t>(kWaveMaxRows)) return pl;
@@ -491,7 +494,7 @@ int ensure_cmd(kicp_reg *r) {
         std::memset(r->cmd, 0, 128);
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
     }
-    const size_t bytes = static_cast<size_t>(kCmdReplicas) * kCmdWords * sizeof(unsigned long long);
+    const size_t bytes = static_cast<size_t>(kCmdReplicas) * kCmdStrideWords * sizeof(unsigned long long);
     if (r->small_cmd == 1 && !r->cmd_bar) {  // the copies in host-writable HBM: needs the HSA side of the AQL dispatcher
         if (r->d_cmd_copies) {
             if (int rc = aql_quiesce(r)) return rc;
@@ -530,7 +533,7 @@ void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &
     w[7] = ((seq << 8) | op) ^ cmd_fold(w);
     if (r->small_cmd == 1 && r->cmd_bar) {  // straight into the copies the workgroups poll (write-combined BAR stores)
         for (int c = 0; c < kCmdReplicas; ++c)
-            for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[c * kCmdWords + i] = w[i];
+            for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[static_cast<size_t>(c) * kCmdStrideWords + i] = w[i];
         _mm_sfence();
         return;
     }
@@ -577,6 +580,9 @@ int wait_rows_small(kicp_reg *r, uint32_t grid, uint32_t tag, long long out_word
     for (uint32_t g = 0; g < grid; ++g) {
         const unsigned long long *row = r->rows + static_cast<size_t>(g) * kSmallRowWords;
         unsigned long long w[kSmallRowWords];
+        // the rows land within a few microseconds of each other, and every line the device has just written misses the CPU's
+        // caches: ask for the lines a few rows ahead while this row is being checked
+        __builtin_prefetch(row + 6 * kSmallRowWords), __builtin_prefetch(row + 6 * kSmallRowWords + 8);
         for (;;) {
             bool ok = true;
             for (int i = 0; i < kSmallRowWords; ++i) {
@@ -679,11 +685,20 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
         pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
         sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
         r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
+        sp.trace = r->d_trace;
+        auto t_sent = std::chrono::steady_clock::now();
         if (int rc = launch_small(r, sp, pl)) return rc;
         for (uint32_t k = 0; k < cnt; ++k) {
             long long words[kReduceWords];
             bool gave_up = false;
-            if (int rc = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up)) {
+            const int rc_rows = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up);
+            const auto t_rows = std::chrono::steady_clock::now();
+            if (r->d_trace) {
+                const double us = std::chrono::duration<double, std::micro>(t_rows - t_sent).count();
+                if (k == 0) r->trace_first_us += us, ++r->trace_first_n;
+                else r->trace_dev_us += us, ++r->trace_n;
+            }
+            if (int rc = rc_rows) {
                 if (k + 1 < cnt) send_command(r, sp.seq_base + k + 1, kCmdStop, loop.T);
                 return rc;
             }
@@ -701,6 +716,10 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
                 r->debug_stall_us = 0.0;
             }
             send_command(r, sp.seq_base + k + 1, finished ? kCmdStop : kCmdContinue, loop.T);
+            if (r->d_trace) {
+                t_sent = std::chrono::steady_clock::now();
+                r->trace_host_us += std::chrono::duration<double, std::micro>(t_sent - t_rows).count();
+            }
             if (finished) break;
         }
     }
@@ -975,6 +994,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->rec) hipHostFree(reg->rec);
     if (reg->rows) hipHostFree(reg->rows);
     if (reg->cmd) hipHostFree(reg->cmd);
+    if (reg->d_trace) hipFree(reg->d_trace);
     if (reg->cmd_bar) reg->aql.free_bar(reg->cmd_bar);
     else if (reg->d_cmd_copies) hipFree(reg->d_cmd_copies);
     reg->stage.release();
@@ -1021,6 +1041,13 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "small_resident") reg->small_resident = value != 0.0 ? 1 : 0;
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
     else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
+    else if (k == "small_trace") {  // debugging aid: per-pass wall-clock stamps of workgroup 0 + host-side phase times
+        if (value != 0.0 && !reg->d_trace) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&reg->d_trace), 1024 * 4 * sizeof(long long)));
+            HIP_TRY(hipMemset(reg->d_trace, 0, 1024 * 4 * sizeof(long long)));
+        }
+        reg->trace_host_us = reg->trace_dev_us = reg->trace_first_us = 0.0, reg->trace_n = reg->trace_first_n = 0;
+    }
     else if (k == "small_cmd") {
         if (reg->cmd_bar || (value != 0.0) == (reg->small_cmd != 0)) return KICP_OK;  // (once the copies live in the BAR they stay there)
         reg->small_cmd = value != 0.0 ? 1 : 0;
@@ -1053,6 +1080,16 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "small_resident") return reg->small_resident;
     if (k == "small_block") return reg->small_block;
     if (k == "small_wave") return reg->small_wave;
+    if (k == "trace_host_us") return reg->trace_n ? reg->trace_host_us / static_cast<double>(reg->trace_n) : 0.0;
+    if (k == "trace_device_us") return reg->trace_n ? reg->trace_dev_us / static_cast<double>(reg->trace_n) : 0.0;
+    if (k == "trace_first_us") return reg->trace_first_n ? reg->trace_first_us / static_cast<double>(reg->trace_first_n) : 0.0;
+    if (k.rfind("trace_stamp_", 0) == 0) {  // trace_stamp_<i>: word i of the device stamps of the LAST call (100 MHz ticks), [workgroup][4]
+        if (!reg->d_trace) return -1.0;
+        static long long v[4096];
+        const int i = std::atoi(k.c_str() + 12);
+        if (i == 0 && hipMemcpy(v, reg->d_trace, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;  // (word 0 refreshes the copy)
+        return (i >= 0 && i < 4096) ? static_cast<double>(v[i]) : -1.0;
+    }
     if (k == "small_cmd") return (reg->small_cmd == 1 && reg->cmd_bar) ? 1.0 : (reg->small_cmd ? 0.5 : 0.0);  // 1: BAR copies in use; 0.5: requested, not yet set up
     if (k == "wave_block") return reg->wave_block;
     if (k == "small_timeout_us") return reg->small_timeout_us;

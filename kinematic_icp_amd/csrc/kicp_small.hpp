@@ -45,6 +45,7 @@ struct SmallParams {
     const unsigned long long *cmd;  // device view of the host-mapped command line (kCmdWords words, 64-byte aligned)
     unsigned long long *cmd_dev;    // kCmdReplicas copies of the command line in device memory (await_command)
     int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
+    long long *trace;               // debugging aid (option "small_trace"): workgroup 0 stamps its passes here, 4 wall-clock words each
     unsigned long long *rows;       // device view of the host-mapped rows [gridDim.x][kSmallRowWords]
     unsigned long long seq_base;    // the command that starts pass k (k >= 1) carries sequence seq_base + k
     uint32_t tag0;                  // pass k publishes with tag tag0 + k (the host reserves the range)
@@ -78,14 +79,15 @@ __device__ __forceinline__ uint32_t fresh_tid() {
 //   relay = 0: the host writes the copies itself through the PCIe BAR (the line lives in host-visible fine-grained HBM).
 // false: STOP, or no command in time (the rows of the pass that will not run are then marked so that the host launches
 // afresh).  Ends in a workgroup barrier.
-constexpr int kCmdReplicas = 16;
+constexpr int kCmdReplicas = 64;         // copies of the command line ...
+constexpr int kCmdStrideWords = 544;     // ... 4352 bytes apart (4 KiB + 256 B), so that the pollers spread over memory channels
 __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
     if ((tid >> 6) == 0) {
         const int lane = tid & 63;
         const unsigned long long want = sp.seq_base + pass + 1;
         const long long t0 = wall_clock64();
         const bool relay = sp.relay != 0 && blockIdx.x == 0;
-        const unsigned long long *line = relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdWords;
+        const unsigned long long *line = relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdStrideWords;
         unsigned long long w = 0, ctrl = 0;
         for (;;) {
             if (lane < kCmdWords)
@@ -103,12 +105,11 @@ __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t ti
                                        ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-            if (!relay) __builtin_amdgcn_s_sleep(4);  // (~0.1 us: hundreds of workgroups share the copies' memory channel)
         }
         if (relay && ctrl != 0ull && lane < kCmdWords) {  // pass the command on: every word is self-validating, no ordering needed
 #pragma unroll
             for (int r = 0; r < kCmdReplicas; ++r)
-                __hip_atomic_store(sp.cmd_dev + static_cast<size_t>(r) * kCmdWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sp.cmd_dev + static_cast<size_t>(r) * kCmdStrideWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane < 7) s_cmd[lane] = w;
         if (lane == 7) s_cmd[7] = ctrl & 0xFFull;
@@ -223,14 +224,18 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
 // double-downsampled source).  A thread-per-query wave walks ~600 VALU instructions per visited bucket plus the fp64 transform
 // and accumulation of its 64 queries in lock step - ~10 us of dependent issue however few queries there are, on a machine of
 // 1024 SIMDs of which a 1 080-point scan then uses 17.  Here the 64 lanes of a wave share ONE query: the transform, the probe
-// and the culling are wave-uniform; a round of the search looks at up to THREE neighbour buckets at once, one mirror point per
-// lane (lanes 0-19 / 20-39 / 40-59), the minimum is a DPP reduction, and every candidate within the error margin of the running
-// minimum is re-evaluated in fp64 by its own lane in the same round - so there is no three-smallest bookkeeping and no exact
-// fall-back search.  The winner is decided among the exactly evaluated candidates by the reference's rule (closer_by_norm, ties
-// to the earlier one in visiting order), which is the generic kernel's decision: the two paths give the same bits.  A query
-// costs its wave ~600 instructions in all and 4-5 dependent memory accesses; a 1 080-point scan occupies 1 080 SIMDs.
-// The wave's single correspondence needs no wave reduction: lane 0's seven 128-bit terms go to LDS, wave 0 adds the workgroup's
-// (<= 16) and stores the row as small_publish does.  Resident loop and command protocol: as k_pass_small.
+// and the culling are wave-uniform.  The probe is ONE access: lane l reads word l of the own voxel's 128-byte slot (key,
+// neighbour mask and the 27 neighbours' bucket indices; lanes 32-63 read the next slot of the probe sequence).  A round of the
+// search looks at up to SIX neighbour buckets at once, one point per lane and bucket (lanes 0-19 / 20-39 / 40-59, two buckets
+// each): the fp64 point AND its 16-bit mirror word (which only says whether the slot holds a point) are loaded together, the
+// distance is the reference's own fp64 expression - no pre-selection, no margin, no exact fall-back - and the minimum is a DPP
+// reduction followed by the reference's rule among the lanes whose norm could tie (closer_by_norm, ties to the earlier one in
+// visiting order): the generic kernel's decision, so the two paths give the same bits.  The six products of the normal
+// equations are formed side by side by lanes 0-5, which also convert and park them (no wave reduction: a wave has ONE
+// correspondence).  A query costs its wave a few hundred instructions and three dependent memory accesses (probe, buckets,
+// nothing else: the source point stays in registers across the passes of a call); a 1 080-point scan occupies 1 080 SIMDs.
+// Wave 0 adds the workgroup's (<= 16) correspondences and stores the row as small_publish does.  Resident loop and command
+// protocol: as k_pass_small.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kWaveMaxPoints = 4096;
 constexpr int kWaveMaxRows = 272;  // rows one launch may produce (ceil(kWaveMaxPoints / 16) = 256, and 1 080 / 4 = 270)
@@ -260,13 +265,53 @@ __device__ __forceinline__ float wave_min_nonneg(float v) {
     return __uint_as_float(min(min(r0, r1), min(r2, r3)));
 }
 
+// minimum of a double >= 0 over the wave (as the unsigned order of its bits), wave-uniform
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long b) {
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b), static_cast<int>(b), CTRL, 0xF, 0xF, false));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(b >> 32), static_cast<int>(b >> 32), CTRL, 0xF, 0xF, false));
+    const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
+    return o < b ? o : b;
+}
+__device__ __forceinline__ double wave_min_nonneg_d(double v) {
+    unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    // row_shr 1, 2, 4, 8: lane 15 of every row of 16 ends up with the row's minimum
+    b = dpp_min_u64<0x111>(b), b = dpp_min_u64<0x112>(b), b = dpp_min_u64<0x114>(b), b = dpp_min_u64<0x118>(b);
+    unsigned long long r = ~0ull;
+#pragma unroll
+    for (int l = 15; l < 64; l += 16) {
+        const unsigned long long o = (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b >> 32), l))) << 32) |
+                                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b), l));
+        r = o < r ? o : r;
+    }
+    return __longlong_as_double(static_cast<long long>(r));
+}
+// the running best of a wave's search under the reference's rule: smallest norm, ties to the earlier one in visiting order
+struct WaveBest {
+    double d2;           // exact squared distance (the acceptance bound while idx == kNoIndex32)
+    uint32_t idx, ord;   // pool index and visiting order (shift * 256 + position in the bucket)
+    double x, y, z;      // the point itself
+};
+__device__ __forceinline__ bool better_candidate(double cd, uint32_t co, const WaveBest &b) {
+    if (b.idx == kNoIndex32) return true;
+    return co < b.ord ? !closer_by_norm(b.d2, cd) : closer_by_norm(cd, b.d2);
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read through fresh_args() */) {
     constexpr int kWaves = BLOCK / 64;
+    constexpr int kTripPoints = static_cast<int>(kMirrorTrip);  // 20 lanes per bucket: three buckets side by side, two such sets per lane
     __shared__ unsigned long long s_term[kWaves][2 * kNumSums];  // lo / hi of the wave's seven 128-bit terms
     __shared__ int s_flag;
     __shared__ unsigned long long s_cmd[kCmdWords];
     Pose T = fresh_args().p.sol.pose0;
+    // this wave's query (wave-uniform) and its source point: the same for every pass of the call, so it is read once
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    {
+        const SmallParams &sp0 = fresh_args();
+        const uint32_t q0 = blockIdx.x * kWaves + (fresh_tid() >> 6);
+        if (q0 < sp0.p.n) sx = sp0.p.src[3 * q0], sy = sp0.p.src[3 * q0 + 1], sz = sp0.p.src[3 * q0 + 2];
+    }
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         const PassParams &p = sp.p;
@@ -275,37 +320,68 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
         if (tid == 0) s_flag = 0;
-        const uint32_t qi = blockIdx.x * kWaves + static_cast<uint32_t>(wave);  // this wave's query (wave-uniform)
-        I128 term[kNumSums];
-#pragma unroll
-        for (int k = 0; k < kNumSums; ++k) term[k] = I128{0ull, 0ll};
-        int range_error = 0;
+        const uint32_t qi = blockIdx.x * kWaves + static_cast<uint32_t>(wave);
+        const bool stamp = sp.trace != nullptr && tid == 0 && pass == 1;  // every workgroup stamps its second pass: [workgroup][4]
+        if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
+        bool accepted = false;
+        double term_value = 0.0;  // lane k < 6: the k-th term of this wave's correspondence (lane 6: the count)
         if (qi < p.n) {
             const SearchParams &sq = p.search;
             const float margin = sq.margin_u;
-            Query q;
-            make_query_of(q, p, T, qi);
             const double vs = m.voxel_size;
-            Lane L;  // (only the probe part: offsets inside the own voxel, the slot of its entry)
+            // T * source (Registration.cpp:74,88) and its voxel
+            Query q;
+            {
+                double rx, ry, rz;
+                quat_rotate(T, sx, sy, sz, rx, ry, rz);
+                q.x = rx + T.tx, q.y = ry + T.ty, q.z = rz + T.tz;
+                q.vx = voxel_coord(q.x, vs, sq.inv_vs), q.vy = voxel_coord(q.y, vs, sq.inv_vs), q.vz = voxel_coord(q.z, vs, sq.inv_vs);
+            }
+            // ---- probe: lane l reads word (l & 31) of the 128-byte slot h (lanes 0..31) or h + 1 (lanes 32..63): key, neighbour
+            //      mask and the 27 neighbours' buckets arrive in ONE access
+            uint32_t h = voxel_hash(q.vx, q.vy, q.vz) & m.mask;
+            uint32_t todo = 0u, line = 0u;
+            int base_lane = 0;  // lane that holds word 0 of the matching slot
+            for (;;) {
+                const uint32_t hh = (h + static_cast<uint32_t>(lane >> 5)) & m.mask;
+                line = reinterpret_cast<const uint32_t *>(m.table + hh)[lane & 31];
+                bool found = false, absent = false;
+#pragma unroll
+                for (int half = 0; half < 2 && !found && !absent; ++half) {
+                    const int b0 = 32 * half;
+                    const uint32_t val = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(line), b0 + 3));
+                    if (val == kEmptyVal) {
+                        absent = true;
+                    } else if (__builtin_amdgcn_readlane(static_cast<int>(line), b0) == q.vx && __builtin_amdgcn_readlane(static_cast<int>(line), b0 + 1) == q.vy &&
+                               __builtin_amdgcn_readlane(static_cast<int>(line), b0 + 2) == q.vz) {
+                        found = true, base_lane = b0;
+                        todo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(line), b0 + 4));
+                    }
+                }
+                if (found || absent) break;
+                h = (h + 2u) & m.mask;
+            }
+            // J.col(0) = R * UnitX, J.col(1) = R * (-s.y, s.x, 0)  (Registration.cpp:86-93): wave-uniform, issued here so that they run
+            // in the shadow of the bucket loads
+            double j0x, j0y, j0z, j1x, j1y, j1z;
+            quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);
+            quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);
+            Lane L;  // (the culling helpers' view: offsets inside the own voxel in mirror units)
             L.q.lx = static_cast<float>((q.x - q.vx * vs) * sq.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sq.upm),
             L.q.lz = static_cast<float>((q.z - q.vz * vs) * sq.upm);
-            L.q.slot0 = 0u, L.todo = 0u;
-            table_lookup_entry(m, q.vx, q.vy, q.vz, L.q.slot0, L.todo);
-            uint32_t todo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(L.todo)));
-            const uint32_t slot0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(L.q.slot0)));
-            float cur_min = sq.bound_u;  // running minimum of the mirror distances (units^2), wave-uniform
+            L.q.slot0 = 0u;
             const double bound = sq.bound;
-            double best = bound;         // exact squared distance of the best candidate so far (reference rule), wave-uniform
-            uint32_t best_idx = kNoIndex32, best_ord = 0u;
-            const int group = lane / static_cast<int>(kMirrorTrip), kk = lane % static_cast<int>(kMirrorTrip);
+            WaveBest best{bound, kNoIndex32, 0u, 0.0, 0.0, 0.0};
+            float cur_u = sq.bound_u;  // the best squared distance so far in mirror units (culling only)
+            const int group = lane / kTripPoints, kk = lane % kTripPoints;
             while (todo) {
                 L.todo = todo;
-                todo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(cull_todo(L, cur_min, margin))));
+                todo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(cull_todo(L, cur_u, margin))));
                 if (!todo) break;
-                // up to three neighbour voxels this round, in the reference's visiting order
-                int sv[3], ns = 0;
+                // up to six neighbour voxels this round (reference visiting order): lane group g takes the g-th and the (g + 3)-rd
+                int sv[6], ns = 0;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
+                for (int g = 0; g < 6; ++g) {
                     sv[g] = 0;
                     if (todo) {
                         sv[g] = __ffs(todo) - 1;
@@ -313,67 +389,95 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
                         ns = g + 1;
                     }
                 }
-                const bool active = group < ns;
-                const int s = group == 0 ? sv[0] : (group == 1 ? sv[1] : sv[2]);
-                const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-                const uint32_t bucket = active ? m.table[slot0].nb[s] : 0u;
-                const float qx = L.q.lx - dx * kCell, qy = L.q.ly - dy * kCell, qz = L.q.lz - dz * kCell;
+                uint32_t bucket[2];
+                int svl[2];
+                bool active[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int g = group + 3 * u;
+                    active[u] = group < 3 && g < ns;
+                    svl[u] = u == 0 ? (group == 0 ? sv[0] : (group == 1 ? sv[1] : sv[2])) : (group == 0 ? sv[3] : (group == 1 ? sv[4] : sv[5]));
+                    // the neighbour's bucket index sits in word 5 + s of the slot line (held by lane base_lane + 5 + s)
+                    const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(line), base_lane + 5 + sv[3 * u]));
+                    const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(line), base_lane + 5 + sv[3 * u + 1]));
+                    const uint32_t b2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(line), base_lane + 5 + sv[3 * u + 2]));
+                    bucket[u] = group == 0 ? b0 : (group == 1 ? b1 : b2);
+                }
                 bool more = true;
                 for (uint32_t k0 = 0; more && k0 < m.cap16; k0 += kMirrorTrip) {
-                    MirrorPoint mp = mirror_empty();
-                    if (active) mp = m.pool16[static_cast<size_t>(bucket) * m.cap16 + k0 + kk];
-                    const float ddx = static_cast<float>(mp.x & 0xffffu) - qx, ddy = static_cast<float>(mp.x >> 16) - qy, ddz = static_cast<float>(mp.y) - qz;
-                    const float d = active ? __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx)) : 3.0e38f;
-                    cur_min = fminf(cur_min, wave_min_nonneg(d));
-                    // every candidate that can still be the reference's choice: within the margin of the running minimum
-                    unsigned long long near = __ballot(d <= cur_min + margin);
-                    if (near) {
-                        const uint32_t k = k0 + static_cast<uint32_t>(kk);
-                        const uint32_t gidx = bucket * m.cap + k;
-                        double d2 = DBL_MAX;
-                        if ((near >> lane) & 1ull) d2 = exact_d2(m, gidx, q);
-                        const uint32_t ord = static_cast<uint32_t>(s) * 256u + k;
+                    const uint32_t k = k0 + static_cast<uint32_t>(kk);
+                    // both loads of both buckets are issued before anything is consumed: the 16-bit mirror says whether the slot holds
+                    // a point, the fp64 pool is what the distance is computed from (exact: no pre-selection, no margin)
+                    MirrorPoint mp[2];
+                    double px[2], py[2], pz[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        mp[u] = mirror_empty();
+                        px[u] = py[u] = pz[u] = 0.0;
+                        if (active[u]) {
+                            mp[u] = m.pool16[static_cast<size_t>(bucket[u]) * m.cap16 + k];
+                            if (k < m.cap) {
+                                const double *t = m.pool + (static_cast<size_t>(bucket[u]) * m.cap + k) * 3;
+                                px[u] = t[0], py[u] = t[1], pz[u] = t[2];
+                            }
+                        }
+                    }
+                    // this lane's better candidate of the two, then the wave's
+                    double d2 = DBL_MAX;
+                    uint32_t ord = 0u, gidx = kNoIndex32;
+                    double cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bool have = active[u] && k < m.cap && (mp[u].y >> 16) == 0u;
+                        const double dx = px[u] - q.x, dy = py[u] - q.y, dz = pz[u] - q.z;
+                        const double e = dx * dx + dy * dy + dz * dz;
+                        const uint32_t o = static_cast<uint32_t>(svl[u]) * 256u + k;
+                        // (u = 1 is later in visiting order than u = 0: it only replaces on a strictly smaller norm)
+                        if (have && e < bound && (gidx == kNoIndex32 || closer_by_norm(e, d2)))
+                            d2 = e, ord = o, gidx = bucket[u] * m.cap + k, cx = px[u], cy = py[u], cz = pz[u];
+                    }
+                    const double dmin = wave_min_nonneg_d(d2);
+                    if (dmin < DBL_MAX) {
+                        // every lane whose squared distance could round to the minimum's norm (closer_by_norm's threshold)
+                        unsigned long long near = __ballot(gidx != kNoIndex32 && d2 * (1.0 - 8.8817841970012523e-16) <= dmin);
                         while (near) {
                             const int l = __ffsll(static_cast<long long>(near)) - 1;
                             near &= near - 1ull;
                             const double cd = uniform_lane_d(d2, l);
                             const uint32_t co = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ord), l));
-                            const uint32_t ci = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(gidx), l));
-                            if (!(cd < bound)) continue;
-                            // the reference keeps the FIRST candidate (visiting order) whose norm attains the strict minimum
-                            bool take;
-                            if (best_idx == kNoIndex32) take = true;
-                            else if (co < best_ord) take = !closer_by_norm(best, cd);
-                            else take = closer_by_norm(cd, best);
-                            if (take) best = cd, best_idx = ci, best_ord = co;
+                            if (better_candidate(cd, co, best)) {
+                                best.d2 = cd, best.ord = co, best.idx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(gidx), l));
+                                best.x = uniform_lane_d(cx, l), best.y = uniform_lane_d(cy, l), best.z = uniform_lane_d(cz, l);
+                            }
                         }
+                        cur_u = fminf(cur_u, static_cast<float>(best.d2 * sq.upm * sq.upm) * 1.00001f + 1.0f);
                     }
                     // a bucket goes on where the last slot of this trip holds a point (any of the round's buckets)
-                    more = __ballot(active && kk == static_cast<int>(kMirrorTrip) - 1 && (mp.y >> 16) == 0u) != 0ull;
+                    more = __ballot((active[0] && kk == kTripPoints - 1 && (mp[0].y >> 16) == 0u) || (active[1] && kk == kTripPoints - 1 && (mp[1].y >> 16) == 0u)) != 0ull;
                 }
             }
-            if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
-                const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
-                const double sx = p.src[3 * qi], sy = p.src[3 * qi + 1];
-                const double rx = q.x - tp[0], ry = q.y - tp[1], rz = q.z - tp[2];  // residual = T*source - target
-                double j0x, j0y, j0z, j1x, j1y, j1z;
-                quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
-                quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)   (Registration.cpp:86-93,108-113)
-                term[0] = to_fixed128(j0x * j0x + j0y * j0y + j0z * j0z, range_error);
-                term[1] = to_fixed128(j0x * j1x + j0y * j1y + j0z * j1z, range_error);
-                term[2] = to_fixed128(j1x * j1x + j1y * j1y + j1z * j1z, range_error);
-                term[3] = to_fixed128(j0x * rx + j0y * ry + j0z * rz, range_error);
-                term[4] = to_fixed128(j1x * rx + j1y * ry + j1z * rz, range_error);
-                term[5] = to_fixed128(rx * rx + ry * ry + rz * rz, range_error);
-                term[6] = I128{1ull << 40, 0ll};  // the count: 1.0
+            if (best.idx != kNoIndex32 && sqrt(best.d2) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+                accepted = true;
+                const double rx = q.x - best.x, ry = q.y - best.y, rz = q.z - best.z;  // residual = T*source - target
+                // the six products of Registration.cpp:108-113 side by side: lane k forms term k = a . b with
+                //   a = j0 j0 j1 j0 j1 r,  b = j0 j1 j1 r r r   (the same three multiplications and two additions, in the same order)
+                const bool a_is_j1 = lane == 2 || lane == 4, a_is_r = lane == 5;
+                const bool b_is_j0 = lane == 0, b_is_j1 = lane == 1 || lane == 2;
+                const double ax = a_is_r ? rx : (a_is_j1 ? j1x : j0x), ay = a_is_r ? ry : (a_is_j1 ? j1y : j0y), az = a_is_r ? rz : (a_is_j1 ? j1z : j0z);
+                const double bx = b_is_j0 ? j0x : (b_is_j1 ? j1x : rx), by = b_is_j0 ? j0y : (b_is_j1 ? j1y : ry), bz = b_is_j0 ? j0z : (b_is_j1 ? j1z : rz);
+                term_value = ax * bx + ay * by + az * bz;
+                if (lane == 6) term_value = 1.0;  // the count
             }
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kNumSums; ++k) s_term[wave][2 * k] = term[k].lo, s_term[wave][2 * k + 1] = static_cast<unsigned long long>(term[k].hi);
+        if (stamp) sp.trace[4 * blockIdx.x + 1] = wall_clock64();
+        int range_error = 0;
+        if (lane < kNumSums) {
+            const I128 t = accepted ? to_fixed128(term_value, range_error) : I128{0ull, 0ll};
+            s_term[wave][2 * lane] = t.lo, s_term[wave][2 * lane + 1] = static_cast<unsigned long long>(t.hi);
         }
+        const bool any_range_error = __ballot(range_error != 0) != 0ull;
         __syncthreads();  // (also: s_flag is reset)
-        if (lane == 0 && range_error) atomicOr(&s_flag, 2);
+        if (lane == 0 && any_range_error) atomicOr(&s_flag, 2);
         __syncthreads();
         tid = fresh_tid();
         if ((tid >> 6) == 0) {
@@ -391,8 +495,10 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
                 __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;
         if (!await_command(sp, tid, pass, s_cmd)) return;
+        if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),

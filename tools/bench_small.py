@@ -62,21 +62,16 @@ def run(label, env=None, **opts):
 
 print("%s: %d-point scans vs %d-point map" % (cfg.name, len(scans[0]["frame"]), gmap.num_points()), flush=True)
 fits = len(scans[0]["frame"]) <= 4096
-run("generic pass kernel (round 2 path)", small=0)
-run("generic, HIP launch               ", small=0, aql=0)
-run("generic, kernargs in HBM          ", env={"KICP_KERNARG": "dev"}, small=0)
-run("generic, kernargs in HBM + HDP    ", env={"KICP_KERNARG": "devhdp"}, small=0)
+run("generic pass kernel, kernargs in host memory (round 2 path)", env={"KICP_KERNARG": "host"}, small=0)
+run("generic pass kernel, HIP launch                              ", small=0, aql=0)
+run("generic pass kernel (kernargs in HBM: default)               ", small=0)
 if fits:
-    for b in (0, 256, 512, 1024):
-        run("wave/query resident relay, block %4d" % b, wave_block=b)
-    for b in (0, 512, 1024):
-        run("wave/query resident BAR,   block %4d" % b, wave_block=b, small_cmd=1)
-    run("wave per query, 1 launch per pass   ", small_resident=0)
-    run("wave/query resident relay, HBM kargs", env={"KICP_KERNARG": "dev"})
-    run("wave/query resident BAR, HBM kargs  ", env={"KICP_KERNARG": "dev"}, small_cmd=1)
-    run("wave/query 1 launch/pass, HBM kargs ", env={"KICP_KERNARG": "dev"}, small_resident=0)
-    run("wave/query resident relay, HIP launch", aql=0)
-    run("sub-lanes, one launch per pass      ", small_wave=0, small_resident=0)
-    run("sub-lanes, resident relay           ", small_wave=0)
-    run("sub-lanes, resident BAR             ", small_wave=0, small_cmd=1)
-    run("sub-lanes, resident BAR, HBM kargs  ", small_wave=0, small_cmd=1, env={"KICP_KERNARG": "dev"})
+    run("small: wave per query, resident, commands over BAR (default) ")
+    run("small: wave per query, resident, kernargs in host memory     ", env={"KICP_KERNARG": "host"})
+    run("small: wave per query, resident, commands relayed by wg 0    ", small_cmd=0)
+    run("small: wave per query, one launch per pass                   ", small_resident=0)
+    run("small: wave per query, resident, HIP launch                  ", aql=0)
+    for b in (256, 512, 1024):
+        run("small: wave per query, resident, %4d-lane workgroups        " % b, wave_block=b)
+    run("small: sub-lanes per query, resident                         ", small_wave=0)
+    run("small: sub-lanes per query, one launch per pass              ", small_wave=0, small_resident=0)
