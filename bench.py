@@ -264,7 +264,8 @@ def main():
     launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp), kernel arguments in %s"
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
-    small_active = reg.get_option("small_active") == 1.0  # the small-scan path (kicp_small.hpp: resident kernel, rows straight to the host)
+    small_kind = int(reg.get_option("small_active"))  # 0 generic pass kernel; small-scan path (kicp_small.hpp): 1 sub-lanes per query, 2 one wave per query
+    small_active = small_kind > 0
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
     elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
@@ -281,13 +282,13 @@ def main():
     barrier()
     # fixed floor of a pass, measured live: the same launch with every query switched off (launch + reduction + hand-off)
     floor_us = None
-    if not use_comm:
+    if not use_comm and not small_active:  # (the dbg switches belong to the generic pass kernel)
         reg.set_option("dbg", 7)
         tmp = []
         for i in range(64 + 256):
             run_scan(reg, i, rel_single, tmp)
         reg.set_option("dbg", 0)
-        fl = np.array([ms for _, lst in tmp[64:] for ms in lst], dtype=np.float64)
+        fl = np.array([lst[0] for _, lst in tmp[64:] if lst], dtype=np.float64)  # (pass 0: with every query off the call ends there)
         floor_us = float(fl.mean() * 1e3) if fl.size else None
     reg.set_option("timing", 0)
     poses = [run_scan(reg, i, rel_single) for i in range(len(scans))]
@@ -376,7 +377,7 @@ def main():
     # ---- HBM traffic of the pass kernel, measured in THIS run: one rocprofv3 --pmc pass per counter over a bare loop of the
     #      same registrations (tools/prof_target.py), after everything timed is over.  Falls back to the committed profile
     #      (stamped with the commit it was taken at) where rocprofv3 cannot run.
-    kernel_sub = "k_pass_small" if small_active else "k_pass_gather32"
+    kernel_sub = {0: "k_pass_gather32", 1: "k_pass_small", 2: "k_pass_wave"}[small_kind]
     traffic, traffic_src = (None, "not measured (--no-pmc)") if (args.no_pmc or world != 1) else _pmc_traffic(args.workload, kernel_sub)
     prof = _profile_counters(args.workload, world)
     if traffic is None and prof and prof.get("hbm_bytes_per_launch"):

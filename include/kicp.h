@@ -134,8 +134,13 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  small-scan path - every workgroup's exact sums go straight to the host (no reduction tree) and the kernel
  *                  stays resident for the iterations of the call, polling a command line in host-mapped memory for the next
  *                  pose; 0: always the generic pass kernel.  "small_active" (read only): which path the last call took
- *   "small_resident" 1 (default) | 0: one launch per iteration on the small path
- *   "small_block"  workgroup size of the small-scan kernel (256 default | 512 | 1024)
+ *   "small_resident" 1 (default): resident unless the previous call converged in one iteration (a call that needs more gets a
+ *                  resident launch from its second pass on); 2: always resident; 0: one launch per iteration
+ *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
+ *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
+ *                  wave_block 0 = by scan size, default)
+ *   "small_cmd"    1 (default): the host writes the resident kernel's command copies straight into HBM through the PCIe BAR;
+ *                  0: workgroup 0 polls a line of host memory and relays it
  *   "small_timeout_us" how long a resident workgroup waits for the next command before it leaves on its own (default 20 000;
  *                  the host then launches afresh - "small_relaunches" counts those)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the

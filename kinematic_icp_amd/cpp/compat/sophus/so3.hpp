@@ -24,6 +24,12 @@ public:
 
     SO3() : q_(Scalar(1), Scalar(0), Scalar(0), Scalar(0)) {}
     explicit SO3(const Eigen::Quaternion<Scalar> &quat) : q_(quat) { q_.normalize(); }
+    // (test plumbing: the raw parameters, no normalisation)
+    static SO3 fromParams(Scalar x, Scalar y, Scalar z, Scalar w) {
+        SO3 r;
+        r.q_ = Eigen::Quaternion<Scalar>(w, x, y, z);
+        return r;
+    }
 
     const Eigen::Quaternion<Scalar> &unit_quaternion() const { return q_; }
     Transformation matrix() const { return q_.toRotationMatrix(); }

@@ -148,6 +148,7 @@ struct kicp_reg {
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
+    int small_prev_iters = 2;     // iterations of the previous small-path call: a scan that converged at once makes the next launch leave after its first pass
     long long *d_trace = nullptr; // option "small_trace": device buffer of the kernel's per-pass wall-clock stamps
     double trace_host_us = 0.0, trace_dev_us = 0.0, trace_first_us = 0.0;  // host: rows seen -> command sent; device: command sent -> rows seen; launch -> first rows
     unsigned long long trace_n = 0, trace_first_n = 0;
@@ -680,7 +681,12 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     bool finished = false;
     while (!finished) {
         const uint32_t left = static_cast<uint32_t>(max_it - loop.iter);
-        const uint32_t cnt = r->small_resident ? std::min(left, kSmallMaxPasses) : 1u;
+        // Residency pays from the second pass on and costs ~1 us when there is none (the kernel lingers until it sees STOP, and
+        // the next dispatch waits for it).  Consecutive scans of a drive need about the same number of iterations, so the first
+        // launch of a call stays resident only if the previous call needed more than one; a call that turns out to need more
+        // gets a resident launch for the rest.
+        const bool stay = r->small_resident == 1 ? (loop.iter > 0 || r->small_prev_iters > 1) : r->small_resident != 0;
+        const uint32_t cnt = stay ? std::min(left, kSmallMaxPasses) : 1u;
         if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
         pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
         sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
@@ -726,6 +732,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pose_to(loop.T, out_pose_qt);
     if (stats) stats->iterations = loop.iter, stats->converged = loop.converged, stats->beta = loop.beta;
     r->last_small = pl.wave ? 2 : 1;
+    r->small_prev_iters = loop.iter;
     if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
     return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
 }
@@ -1038,7 +1045,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
-    else if (k == "small_resident") reg->small_resident = value != 0.0 ? 1 : 0;
+    else if (k == "small_resident") reg->small_resident = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);  // 1 adaptive (default), 2 always, 0 never
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
     else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
     else if (k == "small_trace") {  // debugging aid: per-pass wall-clock stamps of workgroup 0 + host-side phase times

@@ -7,7 +7,34 @@
 
 #include "kicp_bridge.hpp"
 
-int main() {
+// `bridge_test math <in.bin>`: records of 23 doubles [a(7) b(7) xi(6) p(3)] -> per record 36 doubles
+// [a*p (3), params(a*b) (7), params(a^-1) (7), params(exp(xi)) (7), log(exp(xi)) (6), log(a) (6)], all through the Sophus types
+// on the include path and kicp_bridge's conversions (tests/test_host.py compares them with scipy).
+static int math_mode(const char *path) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return 2;
+    double in[23];
+    while (std::fread(in, sizeof(double), 23, f) == 23) {
+        const Sophus::SE3d a = kicp_bridge::from_params(in), b = kicp_bridge::from_params(in + 7);
+        Eigen::Matrix<double, 6, 1> xi;
+        for (int i = 0; i < 6; ++i) xi[i] = in[14 + i];
+        double out[36];
+        const Eigen::Vector3d q = a * Eigen::Vector3d(in[20], in[21], in[22]);
+        out[0] = q.x(), out[1] = q.y(), out[2] = q.z();
+        kicp_bridge::to_params(a * b, out + 3);
+        kicp_bridge::to_params(a.inverse(), out + 10);
+        const Sophus::SE3d e = Sophus::SE3d::exp(xi);
+        kicp_bridge::to_params(e, out + 17);
+        const Eigen::Matrix<double, 6, 1> le = e.log(), la = a.log();
+        for (int i = 0; i < 6; ++i) out[24 + i] = le[i], out[30 + i] = la[i];
+        std::fwrite(out, sizeof(double), 36, stdout);
+    }
+    std::fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 3 && std::string(argv[1]) == "math") return math_mode(argv[2]);
     const double s = std::sqrt(0.5);
     const double p[7] = {0.0, 0.0, s, s, 1.0, 2.0, 3.0};  // 90 degrees about z, then translate
     const Sophus::SE3d T = kicp_bridge::from_params(p);

@@ -52,12 +52,33 @@ def test_pipeline_fixture_is_the_reference_builds_output():
     assert np.array_equal(G["final_map_sorted"], R["pipe1_final_map_sorted"])
 
 
+class ProductThreshold:
+    """kinematic_icp::CorrespondenceThreshold of the PRODUCT's drop-in header (kinematic_icp_amd/cpp/kinematic_icp/
+    correspondence_threshold/CorrespondenceThreshold.hpp), driven through tests/cpp/host_downsample_test.cpp: the tau after the
+    odometry errors seen so far."""
+
+    def __init__(self, tmp_path, map_discretization_error, max_range):
+        from test_table_order import _build_host_filter
+        self.exe, self.file = str(tmp_path / "host_filter"), tmp_path / "errs.bin"
+        _build_host_filter(self.exe)
+        self.args, self.errs = ["%.17g" % map_discretization_error, "%.17g" % max_range], []
+
+    def UpdateOdometryError(self, err_qt):
+        self.errs.append(np.asarray(err_qt, dtype=np.float64))
+
+    def ComputeThreshold(self):
+        import subprocess
+        np.array(self.errs, dtype=np.float64).reshape(-1).tofile(self.file)
+        return float(np.frombuffer(subprocess.check_output([self.exe, "threshold", str(self.file)] + self.args), dtype=np.float64)[-1])
+
+
 @pytest.mark.gpu
-def test_device_pipeline_reproduces_pipeline_fixture():
+def test_device_pipeline_reproduces_pipeline_fixture(tmp_path):
     import kinematic_icp_amd as K
     ext = G["ext"]
     pre, gmap, reg = K.PreSteps(), K.VoxelHashMap(VOXEL, MAX_RANGE, 20), K.KinematicRegistration()
-    thr = okicp.CorrespondenceThreshold(VOXEL / np.sqrt(20), MAX_RANGE, True, 1.0)  # host scalar bookkeeping (same in the drop-in header)
+    thr = ProductThreshold(tmp_path, VOXEL / np.sqrt(20), MAX_RANGE)  # the product's own header, not the oracle's restatement
+    othr = okicp.CorrespondenceThreshold(VOXEL / np.sqrt(20), MAX_RANGE, True, 1.0)
     last = okicp.IDENTITY.copy()
     for k in range(N):
         raw, delta = G["raw%d" % k], G["delta%d" % k]
@@ -75,9 +96,12 @@ def test_device_pipeline_reproduces_pipeline_fixture():
         assert (n_down, n_src) == (len(G["down%d" % k]), len(G["source%d" % k]))
         np.testing.assert_allclose(pre.download(1), G["down%d" % k], rtol=0, atol=1e-11)    # same survivors, in the reference's order
         np.testing.assert_allclose(pre.download(2), G["source%d" % k], rtol=0, atol=1e-11)
-        new = reg.ComputeRobotMotion(pre.frame(2), gmap, last, delta, thr.ComputeThreshold())
+        tau = thr.ComputeThreshold()
+        assert tau == othr.ComputeThreshold()  # the product header and the oracle agree to the bit on this sequence
+        new = reg.ComputeRobotMotion(pre.frame(2), gmap, last, delta, tau)
         np.testing.assert_allclose(new, G["pose%d" % k], rtol=0, atol=1e-9)
-        thr.UpdateOdometryError(okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new))
+        err = okicp.se3_mul(okicp.se3_inverse(okicp.se3_mul(last, delta)), new)
+        thr.UpdateOdometryError(err), othr.UpdateOdometryError(err)
         assert gmap.UpdateDevice(pre.frame(1), new)
         last = new
         assert (gmap.num_points(), gmap.num_voxels()) == (int(G["map_points%d" % k]), int(G["map_voxels%d" % k]))

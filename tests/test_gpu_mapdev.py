@@ -1,15 +1,63 @@
-"""VoxelHashMap::Update(points, pose) on the GPU (kicp_map_update_pose_device) against the sequential oracle: a drive
-through a scene with pruning and bucket re-use; after every frame the device-maintained map must hold exactly the oracle's
-points (per voxel, in the same order), satisfy the table invariants, and give the same registration results."""
+"""VoxelHashMap::Update(points, pose) on the GPU (kicp_map_update_pose_device) against the sequential oracle AND the reference
+build's own kiss_icp::VoxelHashMap (oracle/_ref, where present): a drive through a scene with pruning and bucket re-use; after
+every frame the device-maintained map must hold exactly their points (per voxel, in the same order), satisfy the table
+invariants, and give the same registration results."""
 import numpy as np
 import pytest
 
 import kinematic_icp_amd as K
 from conftest import sort_rows
 from kinematic_icp_amd import synthetic as syn
-from oracle import okicp
+from checkers import okicp, ref_available, rkicp
 
 pytestmark = pytest.mark.gpu
+
+
+class Checkers:
+    """The oracle's map and - where oracle/_ref is present - the reference build's, driven in lock step: every query is answered
+    by both and must agree bit for bit before the device result is compared with it."""
+
+    def __init__(self, vs, max_range, cap):
+        self.o = okicp.VoxelHashMap(vs, max_range, cap)
+        self.r = rkicp.VoxelHashMap(vs, max_range, cap) if ref_available() else None
+
+    def AddPoints(self, pts):
+        self.o.AddPoints(pts)
+        if self.r is not None:
+            self.r.AddPoints(pts)
+
+    def Update(self, pts, pose_or_origin):
+        self.o.Update(pts, pose_or_origin)
+        if self.r is not None:
+            self.r.Update(pts, pose_or_origin)
+
+    def Clear(self):
+        self.o.Clear()
+        if self.r is not None:
+            self.r.Clear()
+
+    def num_points(self):
+        n = self.o.num_points()
+        assert self.r is None or self.r.num_points() == n
+        return n
+
+    def num_voxels(self):
+        n = self.o.num_voxels()
+        assert self.r is None or self.r.num_voxels() == n
+        return n
+
+    def Pointcloud(self):
+        pc = self.o.Pointcloud()
+        if self.r is not None:  # (the two tables iterate in different orders: compare as sets)
+            np.testing.assert_array_equal(sort_rows(pc), sort_rows(self.r.Pointcloud()))
+        return pc
+
+    def GetClosestNeighbor(self, q):
+        nn, d = self.o.GetClosestNeighbor(q)
+        if self.r is not None:
+            nn_r, d_r = self.r.GetClosestNeighbor(q)
+            assert np.array_equal(nn, nn_r) and np.array_equal(d, d_r)
+        return nn, d
 
 
 def first_seen_downsample(pts, vs):
@@ -23,7 +71,7 @@ def test_device_update_equals_sequential_reference(vs, max_range):
     rng = np.random.Generator(np.random.PCG64(7))
     scene = syn.make_scene(rng, half=30.0, height=5.0, n_boxes=14, box_xy=(2.0, 6.0), box_z=(1.5, 4.0), keep_clear=3.0)
     dirs = syn.beam_directions(16, 512, (-22.0, 6.0))
-    gmap, omap = K.VoxelHashMap(vs, max_range, 20), okicp.VoxelHashMap(vs, max_range, 20)
+    gmap, omap = K.VoxelHashMap(vs, max_range, 20), Checkers(vs, max_range, 20)
     reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
     pose = syn.planar_pose(-18.0, -15.0, 0.6)
     on_device = 0
@@ -35,9 +83,11 @@ def test_device_update_equals_sequential_reference(vs, max_range):
         if k > 0:
             rel = syn.pose_mul(step, syn.planar_pose(0.05, 0.0, np.deg2rad(0.4)))
             a = reg.ComputeRobotMotion(scan, gmap, pose, rel, 3 * vs / np.sqrt(20))
-            b = oreg.ComputeRobotMotion(scan, omap, pose, rel, 3 * vs / np.sqrt(20))
+            b = oreg.ComputeRobotMotion(scan, omap.o, pose, rel, 3 * vs / np.sqrt(20))
             assert reg.last_stats.iterations == oreg.last_stats.iterations
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+            if omap.r is not None:  # the reference's Registration.cpp on the reference build's map
+                np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(scan, omap.r, pose, rel, 3 * vs / np.sqrt(20)), rtol=0, atol=1e-9)
         on_device += int(gmap.UpdateDevice(K.DeviceFrame(scan), true_next))
         omap.Update(scan, true_next)
         assert (gmap.num_points(), gmap.num_voxels()) == (omap.num_points(), omap.num_voxels()), "frame %d" % k
@@ -60,7 +110,7 @@ def test_device_update_equals_sequential_reference(vs, max_range):
 
 def test_mixed_host_and_device_updates():
     rng = np.random.default_rng(5)
-    g, o = K.VoxelHashMap(1.0, 40.0, 20), okicp.VoxelHashMap(1.0, 40.0, 20)
+    g, o = K.VoxelHashMap(1.0, 40.0, 20), Checkers(1.0, 40.0, 20)
     pts = rng.normal(0, 8, (30000, 3)) * np.array([1, 1, 0.2])
     g.AddPoints(pts[:20000]), o.AddPoints(pts[:20000])
     for k in range(6):
@@ -87,7 +137,7 @@ def test_bulk_host_calls_insert_on_the_device():
     the host, and host / bulk calls mix freely."""
     rng = np.random.default_rng(11)
     pts = rng.normal(0, 9, (60000, 3)) * np.array([1, 1, 0.15])
-    g, h, o = K.VoxelHashMap(1.0, 30.0, 20, device=0), K.VoxelHashMap(1.0, 30.0, 20), okicp.VoxelHashMap(1.0, 30.0, 20)
+    g, h, o = K.VoxelHashMap(1.0, 30.0, 20, device=0), K.VoxelHashMap(1.0, 30.0, 20), Checkers(1.0, 30.0, 20)
     g.AddPoints(pts[:30000]), h.AddPoints(pts[:30000]), o.AddPoints(pts[:30000])      # bulk / host / oracle
     assert lib_last_on_device(g) and not lib_last_on_device(h)
     g.AddPoints(pts[30000:30100]), h.AddPoints(pts[30000:30100]), o.AddPoints(pts[30000:30100])  # small: host path (after a download)
@@ -115,7 +165,7 @@ def test_both_apply_kernels_build_the_reference_map():
     fill up) and a series of small ones on top, against the sequential oracle - points in bucket order, not just as a set."""
     rng = np.random.default_rng(31)
     big = rng.uniform(-40, 40, (400000, 3)) * np.array([1, 1, 0.005])     # ~26k-50k voxels of 0.5 m, ~10 points offered to each
-    g, o = K.VoxelHashMap(0.5, 200.0, 12, device=0), okicp.VoxelHashMap(0.5, 200.0, 12)
+    g, o = K.VoxelHashMap(0.5, 200.0, 12, device=0), Checkers(0.5, 200.0, 12)
     ident = np.array([0.0, 0, 0, 1, 0, 0, 0])
     assert g.UpdateDevice(K.DeviceFrame(big), ident)
     o.Update(big, ident)

@@ -215,3 +215,49 @@ def test_bridge_parameter_order_and_layout(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", cpp, "-I", os.path.join(cpp, "compat"), "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "bridge_test.cpp"), "-o", exe, "-Wl,--unresolved-symbols=ignore-all"])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "OK"
+
+
+def test_compat_sophus_and_bridge_math_against_scipy(tmp_path):
+    """The ONE set of Eigen / Sophus stand-ins in the tree (kinematic_icp_amd/cpp/compat: what the drop-in headers compile against
+    where the real libraries are absent, and - since round 3 - also what the reference build of oracle/_ref is compiled against)
+    pinned to an INDEPENDENT implementation: SE3 product, inverse, action, exp and log through kicp_bridge and the compat Sophus
+    types against scipy.spatial.transform.Rotation and the closed-form V matrices of tests/ref_numpy.py - so an error in those
+    formulas cannot hide behind the checker sharing them."""
+    import subprocess
+    import ref_numpy as rn
+    cpp = os.path.join(ROOT, "kinematic_icp_amd", "cpp")
+    exe = str(tmp_path / "bridge_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", cpp, "-I", os.path.join(cpp, "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "bridge_test.cpp"), "-o", exe, "-Wl,--unresolved-symbols=ignore-all"])
+    rng = np.random.default_rng(12)
+
+    def rand_pose():
+        q = rng.normal(size=4)
+        return np.concatenate([q / np.linalg.norm(q), rng.normal(0, 10, 3)])
+
+    rows = []
+    for scale in (1.0, 1.0, 1.0, 1e-3, 1e-9, 1e-12, 0.0):
+        for _ in range(12):
+            xi = rng.normal(size=6) * np.array([1, 1, 1, scale, scale, scale])
+            xi[3:] *= min(1.0, 2.5 / max(np.linalg.norm(xi[3:]), 1e-300))
+            rows.append(np.concatenate([rand_pose(), rand_pose(), xi, rng.normal(0, 5, 3)]))
+    rows = np.array(rows)
+    rows.tofile(tmp_path / "in.bin")
+    out = np.frombuffer(subprocess.check_output([exe, "math", str(tmp_path / "in.bin")]), dtype=np.float64).reshape(len(rows), 36)
+
+    def same_pose(p, T, tol):  # (a quaternion and its negative are the same rotation)
+        want = rn.to_qt(T)
+        if np.dot(p[:4], want[:4]) < 0:
+            want = np.concatenate([-want[:4], want[4:]])
+        np.testing.assert_allclose(p, want, rtol=0, atol=tol)
+
+    for r, o in zip(rows, out):
+        a, b, xi, pt = rn.from_qt(r[:7]), rn.from_qt(r[7:14]), r[14:20], r[20:23]
+        np.testing.assert_allclose(o[0:3], rn.act(a, pt[None])[0], rtol=0, atol=1e-12)
+        same_pose(o[3:10], rn.mul(a, b), 1e-12)
+        same_pose(o[10:17], rn.inv(a), 1e-12)
+        # (below its 1e-10 switch Sophus takes V = R, the closed form above it: either is within |omega| |upsilon| of the series)
+        same_pose(o[17:24], rn.se3_exp(xi), 1e-12 if np.linalg.norm(xi[3:]) > 1e-6 else 1e-9)
+        # log(exp(xi)) == xi (Sophus' closed-form V loses digits to cancellation for angles just above its 1e-10 Taylor switch: 5e-9)
+        np.testing.assert_allclose(o[24:30], xi, rtol=0, atol=5e-9)
+        np.testing.assert_allclose(o[30:36], rn.se3_log(a), rtol=0, atol=5e-9)  # (|omega| < pi: scipy's rotvec is the principal one too)

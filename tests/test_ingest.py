@@ -142,6 +142,13 @@ def test_gpu_pipeline_from_raw_bytes_equals_pipeline_from_host_arrays(deskew):
     np.testing.assert_array_equal(a.download(0), b.download(0))
     ref = okicp.se3_act(ext, okicp.preprocess(xyz, st, rel, 60.0, 1.0, deskew))
     np.testing.assert_allclose(a.download(0), ref, rtol=0, atol=1e-11)
+    # (the wire-format decoding itself - RosUtils.cpp / TimeStampHandler.cpp - needs ROS headers and is not part of the reference
+    # build; what follows it is: kiss_icp::Preprocessor::Preprocess of oracle/_ref on the decoded cloud)
+    from oracle import rkicp
+    if rkicp.available():
+        theirs = rkicp.preprocess(xyz, st, rel, 60.0, 1.0, deskew)
+        assert len(theirs) == na
+        np.testing.assert_allclose(a.download(0), okicp.se3_act(ext, theirs), rtol=0, atol=1e-11)
 
 
 def test_ordered_integer_keys_of_doubles_are_monotone():

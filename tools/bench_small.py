@@ -69,6 +69,7 @@ if fits:
     run("small: wave per query, resident, commands over BAR (default) ")
     run("small: wave per query, resident, kernargs in host memory     ", env={"KICP_KERNARG": "host"})
     run("small: wave per query, resident, commands relayed by wg 0    ", small_cmd=0)
+    run("small: wave per query, always resident                       ", small_resident=2)
     run("small: wave per query, one launch per pass                   ", small_resident=0)
     run("small: wave per query, resident, HIP launch                  ", aql=0)
     for b in (256, 512, 1024):
