@@ -9,7 +9,8 @@ namespace kicp {
 
 // One slot of the open-addressing voxel table: 128 B = one cache line.
 //   key : the reference's Voxel = Eigen::Vector3i (kiss-icp v1.2.0 core/VoxelUtils.hpp)
-//   val : (bucket_index << 8) | point_count ; kEmptyVal marks a free slot; kHaloVal an entry without points.
+//   val : (bucket_index << cb) | point_count, cb = the map's count bits (count_bits_for: 8 for max_points_per_voxel <= 255,
+//         12 up to 4 095, 16 up to 65 535); kEmptyVal marks a free slot; halo_val(cb) an entry without points.
 //   nbr : bit s set <=> voxel key + shift[s] holds points (s in the reference's visiting order, bit 0 = this voxel).
 //   nb  : bucket index of voxel key + shift[s] for every set bit of nbr (that bucket's point count sits in the
 //         bucket itself, see MapView::pool16).
@@ -24,9 +25,16 @@ struct alignas(128) Slot {
 };
 static_assert(sizeof(Slot) == 128, "Slot must be one cache line");
 constexpr uint32_t kEmptyVal = 0xFFFFFFFFu;
-constexpr uint32_t kHaloVal = 0xFFFFFF00u;  // no bucket, zero points
-constexpr uint32_t kMaxBuckets = (1u << 24) - 2;
-constexpr uint32_t kMaxPointsPerVoxel = 255;
+constexpr uint32_t kMaxPointsPerVoxel = 65535;  // (the reference's max_points_per_voxel is a plain unsigned int, KinematicICP.hpp:43)
+// The split of `val` follows the map's max_points_per_voxel: the default 20 (any value <= 255) leaves 24 bits = 16.7M voxels;
+// larger buckets trade voxels for points (4 095 points: 1M voxels; 65 535 points: 65 534 voxels).
+KICP_HD uint32_t count_bits_for(uint32_t cap) { return cap <= 255u ? 8u : (cap <= 4095u ? 12u : 16u); }
+KICP_HD uint32_t val_count(uint32_t val, uint32_t cb) { return val & ((1u << cb) - 1u); }
+KICP_HD uint32_t val_bucket(uint32_t val, uint32_t cb) { return val >> cb; }
+KICP_HD uint32_t make_val(uint32_t bucket, uint32_t count, uint32_t cb) { return (bucket << cb) | count; }
+KICP_HD uint32_t halo_val(uint32_t cb) { return 0xFFFFFFFFu << cb; }            // no bucket, zero points
+KICP_HD uint32_t max_buckets(uint32_t cb) { return (1u << (32u - cb)) - 2u; }   // (the all-ones bucket index belongs to halo / free slots)
+constexpr uint32_t kOrdStride = 65536;  // visiting-order key of a candidate = shift * kOrdStride + position inside its bucket
 
 // Table hash.  The reference's std::hash<Voxel> (three-prime XOR, App. A.1) followed by a murmur3
 // finaliser so that a power-of-two mask sees well mixed low bits.  The hash only decides slot positions;
@@ -77,6 +85,7 @@ struct MapView {
     uint32_t cap;         // max_points_per_voxel = bucket stride of `pool` in points
     uint32_t cap16;       // bucket stride of `pool16` in points: cap rounded up to a multiple of kMirrorTrip (mirror_stride)
     double voxel_size;
+    uint32_t cbits;       // count bits of Slot::val (count_bits_for(cap))
 };
 // The pass kernel reads a mirror bucket kMirrorTrip points (= kMirrorTrip / 2 16-byte loads at immediate offsets) at a time
 // without ever looking at the count first; the stride is padded so that such a trip never leaves the bucket.

@@ -23,13 +23,15 @@ namespace kicp {
 class HostMap {
 public:
     HostMap(double voxel_size, double max_distance, uint32_t max_points_per_voxel)
-        : voxel_size_(voxel_size), max_distance_(max_distance), cap_(max_points_per_voxel), cap16_(mirror_stride(max_points_per_voxel)) {
+        : voxel_size_(voxel_size), max_distance_(max_distance), cap_(max_points_per_voxel), cap16_(mirror_stride(max_points_per_voxel)),
+          cb_(count_bits_for(max_points_per_voxel)) {
         Clear();
     }
 
     double voxel_size() const { return voxel_size_; }
     double max_distance() const { return max_distance_; }
     uint32_t cap() const { return cap_; }
+    uint32_t count_bits() const { return cb_; }  // split of Slot::val (kicp_common.hpp::count_bits_for)
     uint32_t cap16() const { return cap16_; }  // bucket stride of the 16-bit mirror (kicp_common.hpp::mirror_stride)
     size_t num_voxels() const { return n_voxels_; }
     size_t num_points() const { return n_points_; }
@@ -58,7 +60,7 @@ public:
         for (const Slot &e : table_) {
             if (e.val == kEmptyVal) continue;
             ++n_entries_;
-            const uint32_t c = e.val & 0xffu;
+            const uint32_t c = val_count(e.val, cb_);
             if (c) ++n_voxels_, n_points_ += c;
             else if (e.nbr == 0) ++n_dead_;
         }
@@ -102,9 +104,9 @@ public:
             const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
             const int32_t vx = to_voxel(px), vy = to_voxel(py), vz = to_voxel(pz);
             const int64_t s = find(vx, vy, vz);
-            if (s >= 0 && (table_[static_cast<size_t>(s)].val & 0xffu) != 0) {
+            if (s >= 0 && (val_count(table_[static_cast<size_t>(s)].val, cb_)) != 0) {
                 Slot &slot = table_[static_cast<size_t>(s)];
-                const uint32_t count = slot.val & 0xffu, bucket = slot.val >> 8;
+                const uint32_t count = val_count(slot.val, cb_), bucket = val_bucket(slot.val, cb_);
                 if (count == cap_) continue;
                 double *b = &pool_[static_cast<size_t>(bucket) * cap_ * 3];
                 bool too_close = false;
@@ -118,16 +120,16 @@ public:
                 if (too_close) continue;
                 b[3 * count] = px, b[3 * count + 1] = py, b[3 * count + 2] = pz;
                 store32(bucket, count, px, py, pz, vx, vy, vz);
-                slot.val = (bucket << 8) | (count + 1);
+                slot.val = make_val(bucket, count + 1, cb_);
                 touch_slot(static_cast<size_t>(s)), touch_bucket(bucket);
             } else {
-                if (n_voxels_ + 1 > kMaxBuckets) return false;
+                if (n_voxels_ + 1 > max_buckets(cb_)) return false;
                 const uint32_t bucket = alloc_bucket();
                 double *b = &pool_[static_cast<size_t>(bucket) * cap_ * 3];
                 b[0] = px, b[1] = py, b[2] = pz;
                 store32(bucket, 0, px, py, pz, vx, vy, vz);
                 touch_bucket(bucket);
-                occupy(vx, vy, vz, (bucket << 8) | 1u);
+                occupy(vx, vy, vz, make_val(bucket, 1u, cb_));
             }
             ++n_points_;
         }
@@ -140,8 +142,8 @@ public:
         const double max_distance2 = max_distance_ * max_distance_;
         for (size_t i = 0; i < table_.size(); ++i) {  // no entry moves during the sweep (erase leaves a halo/dead entry)
             const Slot &slot = table_[i];
-            if (slot.val == kEmptyVal || (slot.val & 0xffu) == 0) continue;
-            const double *b = &pool_[static_cast<size_t>(slot.val >> 8) * cap_ * 3];
+            if (slot.val == kEmptyVal || (val_count(slot.val, cb_)) == 0) continue;
+            const double *b = &pool_[static_cast<size_t>(val_bucket(slot.val, cb_)) * cap_ * 3];
             const double dx = b[0] - origin[0], dy = b[1] - origin[1], dz = b[2] - origin[2];
             if (dx * dx + dy * dy + dz * dz >= max_distance2) erase_voxel(i);
         }
@@ -171,8 +173,8 @@ public:
         size_t w = 0;
         for (const Slot &slot : table_) {
             if (slot.val == kEmptyVal) continue;
-            const uint32_t count = slot.val & 0xffu;  // 0 for halo entries
-            const double *b = &pool_[static_cast<size_t>(slot.val >> 8) * cap_ * 3];
+            const uint32_t count = val_count(slot.val, cb_);  // 0 for halo entries
+            const double *b = &pool_[static_cast<size_t>(val_bucket(slot.val, cb_)) * cap_ * 3];
             for (uint32_t k = 0; k < count && w < cap_points; ++k, ++w) std::memcpy(out + 3 * w, b + 3 * k, 24);
         }
         return n_points_;
@@ -190,11 +192,11 @@ public:
         for (const Slot &e : table_) {
             if (e.val == kEmptyVal) continue;
             ++entries;
-            const uint32_t count = e.val & 0xffu;
+            const uint32_t count = val_count(e.val, cb_);
             if (count == 0 && e.nbr == 0) ++dead;
             if (count) {
                 ++occupied, points += count;
-                const uint32_t b = e.val >> 8;
+                const uint32_t b = val_bucket(e.val, cb_);
                 if (b >= n_buckets_hi_ || count > cap_) ++bad;
                 for (uint32_t k = count; k < cap16_; ++k)  // empty slots are marked (what lets the kernel skip testing for them)
                     if ((pool16_[static_cast<size_t>(b) * cap16_ + k].y >> 16) != 0xFFFFu) ++bad;
@@ -211,14 +213,14 @@ public:
                     for (int a = 0; a < 3; ++a)
                         if (std::fabs(q[a] / upm - o[a]) > 1.0 / upm) ++bad;
                 }
-            } else if (e.val != kHaloVal) {
+            } else if (e.val != halo_val(cb_)) {
                 ++bad;
             }
             for (int s = 0; s < 27; ++s) {
                 const int64_t n = find(e.x + kShiftTable[s][0], e.y + kShiftTable[s][1], e.z + kShiftTable[s][2]);
-                const bool occ = n >= 0 && (table_[static_cast<size_t>(n)].val & 0xffu) != 0;
+                const bool occ = n >= 0 && (val_count(table_[static_cast<size_t>(n)].val, cb_)) != 0;
                 if (occ != (((e.nbr >> s) & 1u) != 0)) ++bad;
-                if (occ && e.nb[s] != (table_[static_cast<size_t>(n)].val >> 8)) ++bad;
+                if (occ && e.nb[s] != (val_bucket(table_[static_cast<size_t>(n)].val, cb_))) ++bad;
                 if (count && n < 0) ++bad;  // halo completeness around occupied voxels
             }
         }
@@ -274,9 +276,9 @@ private:
         slot_flag_.assign(slots, 1), dirty_slots_.clear();  // every slot moved: the mirror is re-sent in full
         ++generation_;
         for (const Slot &e : old)
-            if (e.val != kEmptyVal && ((e.val & 0xffu) != 0 || e.nbr != 0)) place(e), ++n_entries_;
+            if (e.val != kEmptyVal && ((val_count(e.val, cb_)) != 0 || e.nbr != 0)) place(e), ++n_entries_;
     }
-    static bool is_dead(const Slot &e) { return (e.val & 0xffu) == 0 && e.nbr == 0; }  // halo entry nobody needs any more
+    bool is_dead(const Slot &e) const { return val_count(e.val, cb_) == 0 && e.nbr == 0; }  // halo entry nobody needs any more
     template <typename F>
     void mutate(size_t i, F f) {
         const bool before = is_dead(table_[i]);
@@ -290,7 +292,7 @@ private:
         if (s >= 0) return static_cast<size_t>(s);
         ++n_entries_, ++n_dead_;
         Slot e{};
-        e.x = x, e.y = y, e.z = z, e.val = kHaloVal;
+        e.x = x, e.y = y, e.z = z, e.val = halo_val(cb_);
         return place(e);
     }
     // voxel (x,y,z) receives its first point: give it a bucket and tell the 27 voxels that see it
@@ -300,14 +302,14 @@ private:
         ++n_voxels_;
         for (int s = 0; s < 27; ++s)  // U + shift[s] == this voxel  <=>  U = this - shift[s]
             mutate(find_or_insert(x - kShiftTable[s][0], y - kShiftTable[s][1], z - kShiftTable[s][2]),
-                   [&](Slot &e) { e.nbr |= 1u << s, e.nb[s] = val >> 8; });
+                   [&](Slot &e) { e.nbr |= 1u << s, e.nb[s] = val_bucket(val, cb_); });
     }
     // the voxel at slot i loses all its points (entries never move here)
     void erase_voxel(size_t i) {
         const int32_t x = table_[i].x, y = table_[i].y, z = table_[i].z;
-        n_points_ -= table_[i].val & 0xffu;
-        free_.push_back(table_[i].val >> 8);
-        mutate(i, [&](Slot &e) { e.val = kHaloVal; });
+        n_points_ -= val_count(table_[i].val, cb_);
+        free_.push_back(val_bucket(table_[i].val, cb_));
+        mutate(i, [&](Slot &e) { e.val = halo_val(cb_); });
         --n_voxels_;
         for (int s = 0; s < 27; ++s) {
             const int64_t u = find(x - kShiftTable[s][0], y - kShiftTable[s][1], z - kShiftTable[s][2]);
@@ -329,7 +331,7 @@ private:
         return b;
     }
     double voxel_size_, max_distance_;
-    uint32_t cap_, cap16_;
+    uint32_t cap_, cap16_, cb_;
     std::vector<Slot> table_;
     std::vector<double> pool_;
     std::vector<MirrorPoint> pool16_;

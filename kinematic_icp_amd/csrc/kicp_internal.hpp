@@ -113,6 +113,9 @@ struct kicp_map {
     bool device_ahead = false;
     kicp::DevMapCounters dev{};
     int last_update_on_device = 0;
+    // a voxel coordinate beyond +-2^20 was seen: the packed keys of the device-side maintenance cannot hold it, so this map's
+    // updates stay on the host from now on (until Clear); registration and queries on the device are unaffected
+    bool host_updates_only = false;
     // preferred device for bulk host-side insertions (kicp_map_set_device; -1 = none: host insertion) and their staging
     int bulk_device = -1;
     double *d_bulk = nullptr;

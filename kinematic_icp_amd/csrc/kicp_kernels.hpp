@@ -245,7 +245,7 @@ __device__ __forceinline__ uint32_t table_lookup(const MapView &m, int32_t x, in
     for (;;) {
         const int4 e = *reinterpret_cast<const int4 *>(m.table + h);
         if (static_cast<uint32_t>(e.w) == kEmptyVal) return kEmptyVal;
-        if (e.x == x && e.y == y && e.z == z) return (e.w & 0xff) ? static_cast<uint32_t>(e.w) : kEmptyVal;
+        if (e.x == x && e.y == y && e.z == z) return val_count(static_cast<uint32_t>(e.w), m.cbits) ? static_cast<uint32_t>(e.w) : kEmptyVal;
         h = (h + 1) & m.mask;
     }
 }
@@ -312,8 +312,8 @@ __device__ __forceinline__ void search_global(const MapView &m, const Query &q, 
         if (box_d2(f, dx, dy, dz) > best + f.slack) continue;  // no point in there can beat `best`
         const uint32_t val = table_lookup(m, q.vx + dx, q.vy + dy, q.vz + dz);
         if (val == kEmptyVal) continue;
-        const uint32_t bucket = val >> 8;
-        scan_points(m.pool + static_cast<size_t>(bucket) * m.cap * 3, val & 0xffu, bucket * m.cap, q, best, best_idx);
+        const uint32_t bucket = val_bucket(val, m.cbits);
+        scan_points(m.pool + static_cast<size_t>(bucket) * m.cap * 3, val_count(val, m.cbits), bucket * m.cap, q, best, best_idx);
     }
 }
 
@@ -680,7 +680,7 @@ constexpr int kTrip = kMirrorTrip;  // bucket points in flight per lane and trip
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct Best3 {
     float b1, b2, b3;
-    uint32_t i1, i2, o1, o2;  // pool index and visiting order (shift * 256 + k) of the two smallest
+    uint32_t i1, i2, o1, o2;  // pool index and visiting order (shift * kOrdStride + k) of the two smallest
 };
 __device__ __forceinline__ void best3_update(Best3 &t, float d, uint32_t idx, uint32_t ord) {
     const bool lt1 = d < t.b1, lt2 = d < t.b2, lt3 = d < t.b3;
@@ -900,7 +900,7 @@ __device__ __forceinline__ void visit_bucket(const Probe &P, Best3 &t, const Map
             const uint32_t k1 = k0 + first + (key1 & 31u), k2 = k0 + first + (key2 & 31u);  // positions within the bucket
             // with fewer than three points the far key stands in (finite, beyond every real distance)
             Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k1,
-                    base + k2, static_cast<uint32_t>(s) * 256u + k1, static_cast<uint32_t>(s) * 256u + k2};
+                    base + k2, static_cast<uint32_t>(s) * kOrdStride + k1, static_cast<uint32_t>(s) * kOrdStride + k2};
             best3_merge(t, o);
         }
         if (!more) break;

@@ -161,7 +161,7 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
     mr.last_upload_full = full ? 1 : 0;
     if (int rc = sync_aux(map, stream)) return rc;
     h.mark_synced(full);
-    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, h.cap16(), h.voxel_size()};
+    mr.view = MapView{mr.d_table, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, h.cap16(), h.voxel_size(), h.count_bits()};
     mr.synced_epoch = h.epoch(), mr.synced_generation = h.generation(), mr.live_slots = slots;
     return KICP_OK;
 }
@@ -240,7 +240,7 @@ int device_rehash(kicp_map *map, size_t extra_entries) {
     const size_t old_slots = mr.live_slots;
     HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched (borrowed as the live counter) + error
     const uint32_t grid_old = static_cast<uint32_t>(std::min<size_t>((old_slots + 255) / 256, 8192));
-    hipLaunchKernelGGL(k_rehash_count, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), &mr.d_ctr->touched);
+    hipLaunchKernelGGL(k_rehash_count, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), map->host.count_bits(), &mr.d_ctr->touched);
     uint32_t live = 0;
     HIP_TRY(hipMemcpy(&live, &mr.d_ctr->touched, 4, hipMemcpyDeviceToHost));
     size_t want = 1024;
@@ -258,7 +258,7 @@ int device_rehash(kicp_map *map, size_t extra_entries) {
     HIP_TRY(hipMemsetAsync(nk, 0xFF, want * 8, st));
     HIP_TRY(hipMemsetAsync(nc, 0, want * 4, st));
     hipLaunchKernelGGL(k_rehash_move, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), nt, nk,
-                       static_cast<uint32_t>(want - 1), &mr.d_ctr->error);
+                       static_cast<uint32_t>(want - 1), map->host.count_bits(), &mr.d_ctr->error);
     HIP_TRY(hipGetLastError());
     map->dev.n_entries = live, map->dev.touched = 0;
     HIP_TRY(hipMemcpyAsync(&mr.d_ctr->n_entries, &map->dev.n_entries, 4, hipMemcpyHostToDevice, st));
@@ -295,12 +295,12 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         if (remove_origin) map->host.RemovePointsFarFromLocation(remove_origin);
         return KICP_OK;
     };
-    if (n == 0 || n > 0x7FFFFFF0ull / 3) return host_fallback();
+    if (n == 0 || n > 0x7FFFFFF0ull / 3 || map->host_updates_only) return host_fallback();
     if (int rc = set_device(device)) return rc;
     if (int rc = map_sync(map, device, nullptr)) return rc;
     const uint32_t cap = map->host.cap();
     // room for the points' own voxels: <= n new buckets (the pools grow on the device) ...
-    if (map->dev.n_buckets_hi + n > 0xFFFFFEull) return fail(KICP_ERR_CAPACITY, "more than 2^24-2 voxels");
+    if (map->dev.n_buckets_hi + n > max_buckets(map->host.count_bits())) return fail(KICP_ERR_CAPACITY, "more voxels than the table's bucket index can address (2^24-2 for max_points_per_voxel <= 255)");
     if (int rc = grow_pools(map, map->dev.n_buckets_hi + n)) return rc;
     if (int rc = ensure_update_scratch(mr, n)) return rc;
     const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
@@ -312,7 +312,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         if ((map->dev.n_entries + n) * 2 > mr.live_slots)
             if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
         const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
-        up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, static_cast<uint32_t>(bucket_cap),
+        up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, map->host.count_bits(), static_cast<uint32_t>(bucket_cap),
                       map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
         up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
         up.touched = mr.d_touched;
@@ -323,7 +323,14 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         HIP_TRY(hipStreamSynchronize(st));
         map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries
         if (c.error == 3) return fail(KICP_ERR_CAPACITY, "device-side map update: voxel table full");
-        if (c.error) return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the device-side map update");
+        if (c.error) {
+            // A voxel coordinate beyond +-2^20 (the packed keys' range; the reference has no such limit): nothing was inserted for
+            // such points, and what the claim step did insert are plain halo entries.  The host map takes this update - and every
+            // later one of this map - over.
+            map->host_updates_only = true;
+            map->dev = c;
+            return host_fallback();
+        }
         // Every touched voxel that holds no point yet - a fresh entry or a halo entry that existed before - may become
         // occupied in k_up_apply and then adds up to 26 halo entries of its own: only continue with that head-room
         // (load factor <= 0.75 in the worst case, so that no probe sequence can run away).
@@ -336,7 +343,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     }
     const size_t slots = mr.live_slots;
     hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
-    if (c.touched <= 16384)  // a frame's worth of voxels: one wave each; bulk insertions: one thread each (kicp_mapdev.hpp steps 4 / 4b)
+    if (c.touched <= 16384 && cap <= kApplyMaxPoints)  // a frame's worth of voxels: one wave each; bulk insertions: one thread each (kicp_mapdev.hpp steps 4 / 4b)
         hipLaunchKernelGGL(k_up_apply, dim3((c.touched + kApplyWaves - 1) / kApplyWaves), dim3(64 * kApplyWaves), 0, st, up);
     else
         hipLaunchKernelGGL(k_up_apply_thread, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
@@ -380,7 +387,7 @@ extern "C" {
 // ---- map ------------------------------------------------------------------------------------------------------------
 int kicp_map_create(double voxel_size, double max_distance, unsigned int max_points_per_voxel, kicp_map **out) {
     if (!out || !(voxel_size > 0.0) || max_points_per_voxel == 0) return fail(KICP_ERR_ARG, "bad map parameters");
-    if (max_points_per_voxel > kMaxPointsPerVoxel) return fail(KICP_ERR_CAPACITY, "max_points_per_voxel > 255");
+    if (max_points_per_voxel > kMaxPointsPerVoxel) return fail(KICP_ERR_CAPACITY, "max_points_per_voxel > 65535");
     *out = new kicp_map(voxel_size, max_distance, max_points_per_voxel);
     return KICP_OK;
 }
@@ -420,6 +427,7 @@ int kicp_map_clear(kicp_map *map) {
     KICP_TRACE_CALL();
     if (!map) return fail(KICP_ERR_ARG, "null map");
     map->device_ahead = false;  // whatever the device holds is obsolete now
+    map->host_updates_only = false;
     map->host.Clear();
     return KICP_OK;
 }
@@ -501,10 +509,10 @@ size_t kicp_map_pointcloud(const kicp_map *cmap, double *out_xyz, size_t cap_poi
             mr.pc_points = total + total / 4 + 1024;
         }
         hipStream_t st = nullptr;
-        hipLaunchKernelGGL(k_pc_count, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots), mr.d_pc_blocks);
+        hipLaunchKernelGGL(k_pc_count, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots), map->host.count_bits(), mr.d_pc_blocks);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, mr.d_pc_blocks, static_cast<uint32_t>(blocks), mr.d_pc_blocks + blocks);
         hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots),
-                           mr.d_pool, map->host.cap(), mr.d_pc_blocks, mr.d_pc);
+                           mr.d_pool, map->host.cap(), map->host.count_bits(), mr.d_pc_blocks, mr.d_pc);
         HIP_TRY(hipGetLastError());
         uint32_t counted = 0;
         HIP_TRY(hipMemcpy(&counted, mr.d_pc_blocks + blocks, 4, hipMemcpyDeviceToHost));

@@ -6,7 +6,8 @@
 // grouped by voxel and every touched voxel is processed by ONE thread that walks its group in input-index order with
 // the reference's fp64 arithmetic: the accepted set and the order inside each bucket are exactly the sequential
 // reference's, while voxels proceed in parallel.  Table slots are claimed with a 64-bit CAS on a parallel array of
-// packed voxel keys (voxel coordinates must fit +-2^20); first-time occupation updates the 27 neighbour masks / bucket
+// packed voxel keys (voxel coordinates within +-2^20: beyond that the host map takes the update over - the reference has no
+// such limit); first-time occupation updates the 27 neighbour masks / bucket
 // records with atomics, creating halo entries on demand.  Table growth and dead-entry cleanup are a device-side re-hash
 // (bottom of this file); the pools grow with device-to-device copies (kicp_map.hip).
 #pragma once
@@ -24,6 +25,7 @@ struct DevMap {
     double *pool;
     MirrorPoint *pool16;
     uint32_t cap;
+    uint32_t cbits;              // count bits of Slot::val (count_bits_for(cap))
     uint32_t bucket_capacity;    // buckets the pools can hold
     double voxel_size, max_distance;
     uint32_t *free_list;         // stack of reusable bucket ids
@@ -59,7 +61,10 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t dev_find_or_insert(const DevMap &m, int32_t x, int32_t y, int32_t z) {
     bool ok;
     const unsigned long long key = pack_key64(x, y, z, ok);
-    if (!ok) m.ctr->error = 1u;
+    if (!ok) {  // outside the packable range: nothing is inserted; the host sees the flag and takes the update over (kicp_map.hip)
+        m.ctr->error = 1u;
+        return kNoSlot;
+    }
     uint32_t h = voxel_hash(x, y, z) & m.mask;
     for (uint32_t probes = 0;; ++probes) {
         if (probes > m.mask) {
@@ -69,7 +74,7 @@ __device__ __forceinline__ uint32_t dev_find_or_insert(const DevMap &m, int32_t 
         const unsigned long long seen = atomicCAS(m.keys64 + h, kEmptyKey64, key);
         if (seen == kEmptyKey64) {  // this thread owns the new entry: key fields and the halo marker (nbr is already 0)
             m.table[h].x = x, m.table[h].y = y, m.table[h].z = z;
-            m.table[h].val = kHaloVal;
+            m.table[h].val = halo_val(m.cbits);
             atomicAdd(&m.ctr->n_entries, 1u);
             return h;
         }
@@ -108,10 +113,14 @@ static __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
     const double wx = rx + p.pose.tx, wy = ry + p.pose.ty, wz = rz + p.pose.tz;  // pose * point
     p.world[3 * i] = wx, p.world[3 * i + 1] = wy, p.world[3 * i + 2] = wz;
     const double vs = p.m.voxel_size;
-    const uint32_t h = dev_find_or_insert(p.m, static_cast<int32_t>(floor(wx / vs)), static_cast<int32_t>(floor(wy / vs)),
-                                          static_cast<int32_t>(floor(wz / vs)));
+    const int32_t vx = static_cast<int32_t>(floor(wx / vs)), vy = static_cast<int32_t>(floor(wy / vs)), vz = static_cast<int32_t>(floor(wz / vs));
+    // (one voxel of head-room: the 26 neighbours of an accepted voxel must be packable too)
+    const int lim = (1 << 20) - 1;
+    uint32_t h = kNoSlot;
+    if (vx > -lim && vx < lim && vy > -lim && vy < lim && vz > -lim && vz < lim) h = dev_find_or_insert(p.m, vx, vy, vz);
+    else p.m.ctr->error = 1u;
     p.slot_of[i] = h;
-    if (h == kNoSlot) return;  // table full (error raised): the host aborts the update
+    if (h == kNoSlot) return;  // out of the packable range / table full (error raised): the host takes over / aborts the update
     if (atomicAdd(p.m.cnt + h, 1u) == 0u) p.touched[atomicAdd(&p.m.ctr->touched, 1u)] = h;
 }
 
@@ -129,7 +138,7 @@ static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
     for (uint32_t j0 = 0; j0 < n_touched; j0 += 1024) {
         const uint32_t j = j0 + threadIdx.x;
         uint32_t h = 0, c = 0;
-        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h], may_become_occupied += (p.m.table[h].val & 0xffu) == 0u ? 1u : 0u;
+        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h], may_become_occupied += val_count(p.m.table[h].val, p.m.cbits) == 0u ? 1u : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -166,8 +175,9 @@ static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p)
 //    27 neighbour records, one neighbour per lane.  Used for the updates a pipeline issues (a few thousand touched voxels:
 //    one THREAD per voxel leaves the machine empty there and took 80 us per frame; this takes ~15); see 4b for large ones.
 constexpr int kApplyWaves = 4;  // voxels per workgroup
+constexpr uint32_t kApplyMaxPoints = 255;  // deepest bucket the wave-per-voxel kernel holds in LDS
 static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const UpdateParams p) {
-    __shared__ double s_pts[kApplyWaves][kMaxPointsPerVoxel * 3];
+    __shared__ double s_pts[kApplyWaves][kApplyMaxPoints * 3];  // (the host sends voxels with deeper buckets to k_up_apply_thread)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * kApplyWaves + wave;
     const DevMap &m = p.m;
@@ -176,8 +186,8 @@ static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const Upda
     const uint32_t g = m.cnt[h], start = m.seg_start[h];
     Slot &e = m.table[h];
     const uint32_t old_val = e.val;
-    const uint32_t old_count = old_val & 0xffu;
-    uint32_t count = old_count, bucket = old_val >> 8;
+    const uint32_t old_count = val_count(old_val, m.cbits);
+    uint32_t count = old_count, bucket = val_bucket(old_val, m.cbits);
     if (lane == 0) {
         if (g != 0xFFFFFFFFu) m.cnt[h] = 0;  // (after g has arrived) leave the per-slot scratch clean for the next update
         if (old_count == 0) {  // first points of this voxel: take a bucket (re-use a freed one if any)
@@ -232,7 +242,7 @@ static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const Upda
     }
     if (count == old_count) return;
     if (lane == 0) {
-        e.val = (bucket << 8) | count;
+        e.val = make_val(bucket, count, m.cbits);
         atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
         if (old_count == 0) atomicAdd(&m.ctr->n_voxels, 1u);
     }
@@ -256,8 +266,8 @@ static __global__ __launch_bounds__(64) void k_up_apply_thread(const UpdateParam
     const uint32_t g = m.cnt[h], start = m.seg_start[h];
     m.cnt[h] = 0;  // leave the per-slot scratch clean for the next update
     Slot &e = m.table[h];
-    const uint32_t old_count = e.val & 0xffu;
-    uint32_t count = old_count, bucket = e.val >> 8;
+    const uint32_t old_count = val_count(e.val, m.cbits);
+    uint32_t count = old_count, bucket = val_bucket(e.val, m.cbits);
     if (old_count == 0) {  // first points of this voxel: take a bucket (re-use a freed one if any)
         const uint32_t f = atomicSub(&m.ctr->free_count, 1u);
         if (f != 0u && f <= m.bucket_capacity) {
@@ -303,7 +313,7 @@ static __global__ __launch_bounds__(64) void k_up_apply_thread(const UpdateParam
         ++count;
     }
     if (count == old_count) return;
-    e.val = (bucket << 8) | count;
+    e.val = make_val(bucket, count, m.cbits);
     atomicAdd(&m.ctr->n_points, static_cast<unsigned long long>(count - old_count));
     if (old_count == 0) {  // newly occupied: tell the 27 voxels that see this one (U + shift[s] == this  <=>  U = this - shift[s])
         atomicAdd(&m.ctr->n_voxels, 1u);
@@ -334,15 +344,15 @@ static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double
             const uint32_t h = 4 * q + u;
             Slot &e = m.table[h];
             const uint32_t val = e.val;
-            if (val == kEmptyVal || (val & 0xffu) == 0u) continue;
-            const uint32_t bucket = val >> 8;
+            if (val == kEmptyVal || val_count(val, m.cbits) == 0u) continue;
+            const uint32_t bucket = val_bucket(val, m.cbits);
             const double *b = m.pool + static_cast<size_t>(bucket) * m.cap * 3;
             const double dx = b[0] - ox, dy = b[1] - oy, dz = b[2] - oz;
             if (!(dx * dx + dy * dy + dz * dz >= max_distance2)) continue;
-            e.val = kHaloVal;
+            e.val = halo_val(m.cbits);
             m.free_list[atomicAdd(&m.ctr->free_count, 1u)] = bucket;
             atomicSub(&m.ctr->n_voxels, 1u);
-            atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val & 0xffu) + 1ull);
+            atomicAdd(&m.ctr->n_points, ~static_cast<unsigned long long>(val_count(val, m.cbits)) + 1ull);
             for (int s = 0; s < 27; ++s) {
                 const uint32_t w = dev_find(m, e.x - kShiftTable[s][0], e.y - kShiftTable[s][1], e.z - kShiftTable[s][2]);
                 if (w != kNoSlot) atomicAnd(&m.table[w].nbr, ~(1u << s));
@@ -355,11 +365,11 @@ static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double
 // All points, voxel by voxel in table order - the order HostMap::Pointcloud emits - without bringing the table and the
 // pools back to the host: count per 256-slot block, scan the block totals, then every slot copies its bucket's points.
 // (Free slots are recognised in the packed-key side array, 8 B per slot: the 128-byte slots of a mostly empty table are never read.)
-static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, const unsigned long long *keys64, uint32_t slots, uint32_t *block_counts) {
+static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, const unsigned long long *keys64, uint32_t slots, uint32_t cbits, uint32_t *block_counts) {
     __shared__ uint32_t s_sum[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     uint32_t c = 0;
-    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = table[h].val & 0xffu;
+    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = val_count(table[h].val, cbits);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
@@ -367,12 +377,12 @@ static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, cons
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 static __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, const unsigned long long *keys64, uint32_t slots, const double *pool,
-                                                   uint32_t cap, const uint32_t *block_offsets, double *out) {
+                                                   uint32_t cap, uint32_t cbits, const uint32_t *block_offsets, double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t c = 0, bucket = 0;
-    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = table[h].val & 0xffu, bucket = table[h].val >> 8;
+    if (h < slots && keys64[h] != kEmptyKey64 && table[h].val != kEmptyVal) c = val_count(table[h].val, cbits), bucket = val_bucket(table[h].val, cbits);
     uint32_t incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -393,11 +403,11 @@ static __global__ __launch_bounds__(256) void k_pc_gather(const Slot *table, con
 // more stay behind as dead weight), so every now and then the live entries - occupied voxels and halo entries that still
 // see an occupied neighbour, the host map's rule - move into a fresh (possibly larger) table.  Entries refer to buckets,
 // never to slots, so they can move freely.
-static __global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_t slots, uint32_t *live) {
+static __global__ __launch_bounds__(256) void k_rehash_count(const Slot *table, uint32_t slots, uint32_t cbits, uint32_t *live) {
     uint32_t c = 0;
     for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < slots; h += gridDim.x * 256) {
         const uint32_t val = table[h].val;
-        c += (val != kEmptyVal && ((val & 0xffu) != 0u || table[h].nbr != 0u)) ? 1u : 0u;
+        c += (val != kEmptyVal && (val_count(val, cbits) != 0u || table[h].nbr != 0u)) ? 1u : 0u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
@@ -410,10 +420,10 @@ static __global__ __launch_bounds__(256) void k_table_clear(Slot *table, uint32_
         w[i] = (i % (sizeof(Slot) / 16) == 0) ? make_int4(0, 0, 0, static_cast<int>(kEmptyVal)) : make_int4(0, 0, 0, 0);
 }
 static __global__ __launch_bounds__(256) void k_rehash_move(const Slot *old_table, uint32_t old_slots, Slot *table, unsigned long long *keys64, uint32_t mask,
-                                                     uint32_t *error) {
+                                                     uint32_t cbits, uint32_t *error) {
     for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < old_slots; o += gridDim.x * 256) {
         const Slot &e = old_table[o];
-        if (e.val == kEmptyVal || ((e.val & 0xffu) == 0u && e.nbr == 0u)) continue;
+        if (e.val == kEmptyVal || (val_count(e.val, cbits) == 0u && e.nbr == 0u)) continue;
         bool ok;
         const unsigned long long key = pack_key64(e.x, e.y, e.z, ok);
         if (!ok) *error = 1u;

@@ -289,7 +289,7 @@ __device__ __forceinline__ double wave_min_nonneg_d(double v) {
 // the running best of a wave's search under the reference's rule: smallest norm, ties to the earlier one in visiting order
 struct WaveBest {
     double d2;           // exact squared distance (the acceptance bound while idx == kNoIndex32)
-    uint32_t idx, ord;   // pool index and visiting order (shift * 256 + position in the bucket)
+    uint32_t idx, ord;   // pool index and visiting order (shift * kOrdStride + position in the bucket)
     double x, y, z;      // the point itself
 };
 __device__ __forceinline__ bool better_candidate(double cd, uint32_t co, const WaveBest &b) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
                         const bool have = active[u] && k < m.cap && (mp[u].y >> 16) == 0u;
                         const double dx = px[u] - q.x, dy = py[u] - q.y, dz = pz[u] - q.z;
                         const double e = dx * dx + dy * dy + dz * dz;
-                        const uint32_t o = static_cast<uint32_t>(svl[u]) * 256u + k;
+                        const uint32_t o = static_cast<uint32_t>(svl[u]) * kOrdStride + k;
                         // (u = 1 is later in visiting order than u = 0: it only replaces on a strictly smaller norm)
                         if (have && e < bound && (gidx == kNoIndex32 || closer_by_norm(e, d2)))
                             d2 = e, ord = o, gidx = bucket[u] * m.cap + k, cx = px[u], cy = py[u], cz = pz[u];

@@ -144,3 +144,67 @@ def test_exact_accumulation_range_is_reported_not_wrapped():
                 with pytest.raises(K.KicpError) as e:
                     reg.ComputeRobotMotion(frame, g, ident, rel, 0.5)
                 assert e.value.code == K.KICP_ERR_CAPACITY
+
+
+@pytest.mark.parametrize("cap", [256, 1000])
+def test_buckets_deeper_than_255_points(cap):
+    """max_points_per_voxel = 1000 (the reference's field is a plain unsigned int, KinematicICP.hpp:43): registration on the
+    generic kernel and on the small-scan kernels, GetClosestNeighbor and the device-side Update against the oracle and the
+    reference build."""
+    rng = np.random.default_rng(cap)
+    vs = 1.0
+    mpts = rng.uniform(-3, 3, (60000, 3)) * np.array([1.0, 1.0, 0.3])
+    g, o = K.VoxelHashMap(vs, 100.0, cap), okicp.VoxelHashMap(vs, 100.0, cap)
+    g.AddPoints(mpts), o.AddPoints(mpts)
+    assert g.num_points() == o.num_points() and g.num_points() / g.num_voxels() > 200
+    rmap = ref_map_like(o) if ref_available() else None
+    last, rel = okicp.IDENTITY, syn.planar_pose(0.02, 0.0, np.deg2rad(0.4))
+    for n in (700, 6000, 30000):  # wave per query / sub-lanes per query / generic kernel
+        frame = mpts[rng.choice(len(mpts), n, replace=False)] + rng.normal(0, 0.01, (n, 3))
+        reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+        a = reg.ComputeRobotMotion(frame, g, last, rel, 0.2)
+        b = oreg.ComputeRobotMotion(frame, o, last, rel, 0.2)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+        k = reg.last_stats.iterations
+        assert k == oreg.last_stats.iterations and list(reg.last_stats.n_corr[:k]) == list(oreg.last_stats.n_corr[:k])
+        if rmap is not None:
+            np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(frame, rmap, last, rel, 0.2), rtol=0, atol=1e-9)
+    q = mpts[::97] + rng.normal(0, 0.05, (len(mpts[::97]), 3))
+    nn_g, d_g = g.GetClosestNeighbor(q)
+    nn_o, d_o = o.GetClosestNeighbor(q)
+    assert np.array_equal(nn_g, nn_o) and np.array_equal(d_g, d_o)
+    # device-side Update into deep buckets (thread-per-voxel insertion: the wave-per-voxel kernel holds <= 255 points in LDS)
+    more = rng.uniform(-3, 3, (20000, 3)) * np.array([1.0, 1.0, 0.3])
+    pose = syn.planar_pose(0.3, -0.2, 0.05)
+    assert g.UpdateDevice(K.DeviceFrame(more), pose)
+    o.Update(more, pose)
+    assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels()) and g.check() == 0
+    nn_g, d_g = g.GetClosestNeighbor(q)
+    nn_o, d_o = o.GetClosestNeighbor(q)
+    assert np.array_equal(nn_g, nn_o) and np.array_equal(d_g, d_o)
+
+
+def test_voxel_coordinates_beyond_the_device_keys_range_fall_back_to_the_host():
+    """The device-side map maintenance packs a voxel into 3 x 21 bits; a map whose voxel coordinates leave +-2^20 (voxel size
+    0.01 m, 12 km from the origin - the reference has no such limit) is updated by the host map instead, with the same result,
+    and registration on the device goes on."""
+    rng = np.random.default_rng(8)
+    vs, off = 0.01, np.array([12000.0, -11000.0, 3.0])
+    base = rng.uniform(-1.0, 1.0, (20000, 3)) * np.array([1.0, 1.0, 0.2])
+    g, o = K.VoxelHashMap(vs, 50.0, 20), okicp.VoxelHashMap(vs, 50.0, 20)
+    pose = np.concatenate([[0, 0, 0, 1.0], off])
+    on_device = g.UpdateDevice(K.DeviceFrame(base), pose)
+    o.Update(base, pose)
+    assert not on_device  # the host took the update over
+    assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels()) and g.check() == 0
+    more = rng.uniform(-1.0, 1.0, (5000, 3)) * np.array([1.0, 1.0, 0.2])
+    g.UpdateDevice(K.DeviceFrame(more), pose), o.Update(more, pose)
+    assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels())
+    frame = base[:3000] + rng.normal(0, 0.001, (3000, 3))
+    reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+    a = reg.ComputeRobotMotion(frame, g, pose, syn.planar_pose(0.002, 0.0, 1e-4), 0.02)
+    b = oreg.ComputeRobotMotion(frame, o, pose, syn.planar_pose(0.002, 0.0, 1e-4), 0.02)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+    assert reg.last_stats.iterations == oreg.last_stats.iterations
+    g.Clear()
+    assert g.UpdateDevice(K.DeviceFrame(base), okicp.IDENTITY)  # a cleared map goes back to device-side updates

@@ -148,6 +148,7 @@ def test_many_passes_and_tag_wraparound(case4):
         np.testing.assert_allclose(a, oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau), rtol=0, atol=POSE_TOL)
         assert oreg.last_stats.iterations == max_it
     reg = K.KinematicRegistration()
+    reg.set_option("small_resident", 2)  # always resident: every launch reserves max_num_iterations tags
     want = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
     reg.set_option("debug_tag", 65535 - 12)
     for _ in range(6):

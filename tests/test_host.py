@@ -84,8 +84,9 @@ def test_no_cpu_fallback_without_a_gpu():
 
 def test_argument_and_capacity_errors():
     with pytest.raises(K.KicpError) as e:
-        K.VoxelHashMap(1.0, 100.0, 256)
+        K.VoxelHashMap(1.0, 100.0, 65536)
     assert e.value.code == K.KICP_ERR_CAPACITY
+    K.VoxelHashMap(1.0, 100.0, 256), K.VoxelHashMap(1.0, 100.0, 65535)  # (the reference's field is a plain unsigned int)
     with pytest.raises(K.KicpError) as e:
         K.VoxelHashMap(0.0, 100.0, 20)
     assert e.value.code == K.KICP_ERR_ARG
@@ -132,6 +133,21 @@ def test_map_copy_is_deep():
     np.testing.assert_array_equal(sort_rows(c.Pointcloud()), sort_rows(o.Pointcloud()))
     g.Clear()
     assert c.num_points() == o.num_points() and g.Empty()
+
+
+@pytest.mark.parametrize("cap", [255, 256, 1000, 5000])
+def test_host_map_with_deep_buckets_equals_oracle(cap):
+    """max_points_per_voxel beyond 255 (the count then takes 12 or 16 bits of the slot's value word): same points per voxel, in the
+    same order, as the oracle's map; invariants hold."""
+    rng = np.random.default_rng(cap)
+    pts = rng.uniform(-1.5, 1.5, (30000, 3))
+    g, o = K.VoxelHashMap(1.0, 100.0, cap), okicp.VoxelHashMap(1.0, 100.0, cap)
+    g.AddPoints(pts), o.AddPoints(pts)
+    assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels()) and g.num_points() > 27 * min(cap, 600)
+    assert g.check() == 0
+    np.testing.assert_array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud()))
+    g.Update(pts[:100] + 500.0, np.array([500.0, 500.0, 500.0])), o.Update(pts[:100] + 500.0, np.array([500.0, 500.0, 500.0]))  # prunes the old voxels
+    assert (g.num_points(), g.num_voxels()) == (o.num_points(), o.num_voxels()) and g.check() == 0
 
 
 def test_host_map_insertion_order_inside_a_bucket():
@@ -261,3 +277,14 @@ def test_compat_sophus_and_bridge_math_against_scipy(tmp_path):
         # log(exp(xi)) == xi (Sophus' closed-form V loses digits to cancellation for angles just above its 1e-10 Taylor switch: 5e-9)
         np.testing.assert_allclose(o[24:30], xi, rtol=0, atol=5e-9)
         np.testing.assert_allclose(o[30:36], rn.se3_log(a), rtol=0, atol=5e-9)  # (|omega| < pi: scipy's rotvec is the principal one too)
+
+
+def test_drop_in_voxel_map_exposes_a_read_only_map_view(tmp_path):
+    """kiss_icp::VoxelHashMap::map_ (the reference's public member, SURVEY.md App. A.2) as a read-only view over the backend:
+    tests/cpp/map_view_test.cpp (host map only: no GPU needed)."""
+    import subprocess
+    cpp = os.path.join(ROOT, "kinematic_icp_amd", "cpp")
+    exe = str(tmp_path / "map_view_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", cpp, "-I", os.path.join(cpp, "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "map_view_test.cpp"), "-o", exe, K.LIB_PATH, "-Wl,-rpath," + os.path.dirname(K.LIB_PATH)])
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.strip().splitlines()[-1] == "OK"
