@@ -235,6 +235,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        timed.last_iterations = float(np.mean(batch.iterations)) if not per_call else float("nan")  # ICP iterations per scan of this run
         return elapsed
 
     rel_single = [s["rel_odom"] for s in scans]
@@ -309,22 +310,42 @@ def main():
     if exchange:
         release(reg, comm)
     del reg
+    # ---- N > 1: every exchange on the same box in the same run (the headline stays --comm's), each with its scans/s, its time
+    #      per ICP iteration on the multi-iteration workload and what the exchange adds per iteration over the same shard
+    #      registered WITHOUT any exchange (a plain handle on this rank's points: the kernel and hand-off alone)
     other = {}
-    if exchange and args.comm == "rccl":  # the other exchanges on the same box, for comparison
-        for alt in ("shm", "p2p"):
-            try:
-                reg2, keep2 = make_reg(alt)
-            except K.KicpError as e:  # e.g. IPC mappings unavailable: say so, keep the line
-                other[alt + "_note"] = str(e)[:200]
+    if exchange:
+        def measure(reg_x):
+            for i in range(60):
+                run_scan(reg_x, i, rel_single)
+            e1 = timed(reg_x, rel_single, args.steps, min(args.warmup, 2))
+            em = timed(reg_x, rel_multi, args.steps, 1)
+            return {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / timed.last_iterations, 3),
+                    "iterations_per_scan": round(timed.last_iterations, 3)}
+        exch = {}
+        plain = K.KinematicRegistration(device=device)
+        exch["none (this rank's shard alone, no exchange: NOT a registration of the scan)"] = base = measure(plain)
+        del plain
+        for alt in ("rccl", "shm", "p2p"):
+            if alt == "rccl" and (torch.cuda.device_count() < world or "KICP_BENCH_DEVICE" in os.environ):
+                exch[alt] = {"note": "skipped: RCCL needs one GPU per rank"}
                 continue
             try:
-                for i in range(100):
-                    run_scan(reg2, i, rel_single)
-                other[alt + "_scans_per_s"] = round(args.steps * B / timed(reg2, rel_single, args.steps, min(args.warmup, 2)), 1)
+                reg2, keep2 = make_reg(alt)
+            except K.KicpError as e:  # e.g. IPC mappings / RCCL unavailable: say so, keep the line
+                exch[alt] = {"note": str(e)[:200]}
+                continue
+            try:
+                exch[alt] = measure(reg2)
+                exch[alt]["exchange_us_per_iteration"] = round(exch[alt]["us_per_iteration"] - base["us_per_iteration"], 3)
             except K.KicpError as e:
-                other[alt + "_note"] = str(e)[:200]
+                exch[alt] = {"note": str(e)[:200]}
             release(reg2, alt)
             del reg2
+        other["exchanges"] = exch
+        for alt in ("shm", "p2p"):  # (kept under their round-2 names too)
+            if "scans_per_s" in exch.get(alt, {}):
+                other[alt + "_scans_per_s"] = exch[alt]["scans_per_s"]
     if use_comm:  # all GPU work is done: tear the process group down before rank 0's CPU-only epilogue
         dist.barrier()
         dist.destroy_process_group()

@@ -70,3 +70,37 @@ def untag_row(row, tag):
         s = w - (1 << 64) if w >> 63 else w  # reinterpret as signed
         vals.append(s >> TAG_BITS)
     return np.array(vals, dtype=np.int64), ok
+
+
+# ---- rows of the small-scan path (kicp_small.hpp small_publish / k_pass_wave; kicp_reg.hip wait_rows_small) -----------------
+# A workgroup's row is 16 tagged words = two 64-byte lines: per sum the low 48 bits and bits 48..95 of its 128-bit total (the
+# upper half carries the sign), then the flag word (bit 0 range error, bit 1 "gave up"), then one spare word.
+SMALL_ROW_WORDS = 16
+HALF_BITS = 48
+HALF_MASK = (1 << HALF_BITS) - 1
+
+
+def small_row(totals, tag, flags=0):
+    """seven fixed-point integer totals (|t| < 2^95) -> uint64[16] tagged row of the small-scan kernels."""
+    assert 1 <= tag <= TAG_MASK
+    words = []
+    for t in totals:
+        u = int(t) & ((1 << 128) - 1)  # two's complement
+        words += [u & HALF_MASK, (u >> HALF_BITS) & HALF_MASK]
+    words += [flags, 0]
+    return np.array([((w << TAG_BITS) | tag) & 0xFFFFFFFFFFFFFFFF for w in words], dtype=np.uint64)
+
+
+def add_small_rows(rows, tag):
+    """what the host does with the rows of one pass: (int64[24] limb words of the totals, flags, all landed?)."""
+    totals, flags, ok = [0] * NUM_SUMS, 0, True
+    for row in rows:
+        for w in row:
+            ok = ok and (int(w) & TAG_MASK) == tag
+        for i in range(NUM_SUMS):
+            lo = int(row[2 * i]) >> TAG_BITS                    # logical shift: 48 unsigned bits
+            hi = int(row[2 * i + 1])
+            hi = (hi - (1 << 64) if hi >> 63 else hi) >> TAG_BITS  # arithmetic shift: 48 signed bits
+            totals[i] += lo + (hi << HALF_BITS)
+        flags |= int(row[2 * NUM_SUMS]) >> TAG_BITS
+    return pack(totals), flags, ok

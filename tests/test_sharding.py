@@ -139,6 +139,51 @@ def test_gloo_world_size_2(tmp_path):
     np.testing.assert_allclose(p0[:7], expect, atol=1e-9)
 
 
+def test_gloo_world_size_8(tmp_path):
+    """The same worker with eight ranks (the node size the north star names): every rank ends with the single-process bits."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    poses = [np.load(tmp_path / ("pose_%d.npy" % r)) for r in range(8)]
+    assert all(np.array_equal(p, poses[0]) for p in poses[1:])
+    cfg, omap, frame, last, rel = _world()
+    ref = okicp.KinematicRegistration()
+    expect = ref.ComputeRobotMotion(frame, omap, last, rel, cfg.first_frame_tau())
+    assert int(poses[0][7]) == ref.last_stats.iterations
+    np.testing.assert_allclose(poses[0][:7], expect, atol=1e-9)
+
+
+def test_small_scan_rows_add_up_exactly():
+    """The small-scan kernels' row format (two 48-bit halves per 128-bit sum, kicp_small.hpp) against the limb payload: totals of
+    either sign up to the accumulation range (|term| < 2^43, 1024 terms per workgroup), 272 rows, stale and marked rows."""
+    from kinematic_icp_amd import sharding as sh
+    rng = np.random.Generator(np.random.PCG64(9))
+    tag = 0x1234
+    per_row, rows = [], []
+    for k in range(272):
+        scale = [1.0, 1e3, 8.7e12][k % 3]
+        totals = [int(sum(sh.quantize(x) for x in rng.uniform(-scale, scale, 64))) for _ in range(sh.NUM_SUMS)]
+        per_row.append(totals)
+        rows.append(sh.small_row(totals, tag))
+    words, flags, ok = sh.add_small_rows(rows, tag)
+    assert ok and flags == 0
+    want = [sum(t[i] for t in per_row) for i in range(sh.NUM_SUMS)]
+    assert [sh.from_limbs(words[3 * i:3 * i + 3]) for i in range(sh.NUM_SUMS)] == want
+    assert any(w < 0 for w in want) and max(abs(w) for w in want) > 1 << 90
+    np.testing.assert_array_equal(words, sh.pack(want))
+    # a row of the previous pass, a torn row and the markers
+    stale = list(rows)
+    stale[5] = sh.small_row(per_row[5], tag - 1)
+    assert not sh.add_small_rows(stale, tag)[2]
+    torn = [r.copy() for r in rows]
+    torn[7][3] = sh.small_row(per_row[7], tag - 1)[3]
+    assert not sh.add_small_rows(torn, tag)[2]
+    marked = list(rows)
+    marked[100] = sh.small_row([0] * 7, tag, flags=2)   # "gave up": the host launches afresh
+    marked[101] = sh.small_row(per_row[101], tag, flags=1)  # range error
+    assert sh.add_small_rows(marked, tag)[1] == 3
+
+
 def test_tagged_rows_carry_group_sums_exactly():
     """The hand-off's word format (value << 16 | tag): a workgroup's limbs, the sum of a group's 32 rows and the top limb's
     sign all survive the round trip; a row with a stale tag is recognised; the tag never collides with value bits."""
@@ -147,8 +192,8 @@ def test_tagged_rows_carry_group_sums_exactly():
     tag = 0xBEEF
     rows = []
     for _ in range(sh.GROUP):
-        # 128 per-lane terms of either sign, each below 2^23 in magnitude (the documented range), 7 sums
-        totals = [int(sum(sh.quantize(x) for x in rng.uniform(-8.3e6, 8.3e6, 128))) for _ in range(sh.NUM_SUMS)]
+        # 512 per-lane terms of either sign, each below 2^43 in magnitude (the documented range), 7 sums
+        totals = [int(sum(sh.quantize(x) for x in rng.uniform(-8.7e12, 8.7e12, 512))) for _ in range(sh.NUM_SUMS)]
         rows.append(sh.pack(totals))
     # worst case of the unsigned limbs: all ones
     rows[0][:2] = sh.LIMB_MASK
