@@ -143,6 +143,8 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  0: workgroup 0 polls a line of host memory and relays it
  *   "small_timeout_us" how long a resident workgroup waits for the next command before it leaves on its own (default 20 000;
  *                  the host then launches afresh - "small_relaunches" counts those)
+ *   "bar_frame"    1 (default): kicp_register writes host frames of up to 8 192 points straight into HBM through the PCIe BAR
+ *                  instead of staging them for the DMA engine; 0: always stage
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the
@@ -237,6 +239,9 @@ int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t c
  * with _finish.  One download in flight per handle; the buffer must not be refilled in between.  (RegisterFrame returns the
  * whole preprocessed frame - pipeline/KinematicICP.cpp:84 - 3 MB that nothing on the device waits for.) */
 int kicp_pre_download_begin(kicp_pre *pre, int buffer);
+/* Same, and a helper thread of the handle also moves the landed points into `out_xyz` (room for cap_points points, which must
+ * stay valid until _finish) while the caller goes on: _finish with the same pointer (or NULL) then only waits for it. */
+int kicp_pre_download_begin_into(kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points);
 int kicp_pre_download_finish(kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 const double *kicp_pre_device_ptr(const kicp_pre *pre, int buffer, size_t *out_n);
 

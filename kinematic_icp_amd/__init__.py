@@ -97,6 +97,7 @@ _SIGNATURES = {
     "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kicp_pre_download_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "kicp_pre_download_begin_into": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download_finish": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kicp_pre_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),

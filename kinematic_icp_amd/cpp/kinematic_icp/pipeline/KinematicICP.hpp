@@ -134,8 +134,12 @@ protected:
     // the threshold and the map - all on the device; only the two returned clouds come back to the host.
     Vector3dVectorTuple RegisterPreprocessed(size_t n_frame, const Sophus::SE3d &relative_odometry) {
         kicp_bridge::Trace trace("downsample");
-        // the preprocessed frame is a return value nothing on the device waits for: its 3 MB travel in the background
-        kicp_bridge::check(kicp_pre_download_begin(pre_, 0), "download");
+        // The preprocessed frame is a return value nothing on the device waits for: its 3 MB travel in the background, and a
+        // helper thread of the backend moves them into the result vector while this thread goes on with the pipeline.
+        // (Real Eigen leaves a default-constructed Vector3d uninitialised, so sizing the vector costs the allocation only.)
+        Vector3dVectorTuple result{Vector3dVector(n_frame), Vector3dVector()};
+        auto &frame = std::get<0>(result);
+        kicp_bridge::check(kicp_pre_download_begin_into(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size()), "download");
         size_t n_down = 0, n_source = 0;
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
@@ -147,12 +151,10 @@ protected:
         correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose);
         local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose);
         last_pose_ = new_pose;
-        trace.lap("allocate results");
-        Vector3dVectorTuple result{Vector3dVector(n_frame), Vector3dVector(n_source)};
         trace.lap("collect results");
         auto &source = std::get<1>(result);
+        source.resize(n_source);
         kicp_bridge::check(kicp_pre_download(pre_, 2, source.empty() ? nullptr : source.front().data(), source.size(), nullptr), "download");
-        auto &frame = std::get<0>(result);
         kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size(), nullptr), "download");
         return result;  // built in place: no copy of the clouds on the way out
     }

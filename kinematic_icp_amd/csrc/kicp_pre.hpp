@@ -144,12 +144,18 @@ __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y,
 // slot's winner to its own index
 static __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+    const bool in_range = i < p.n;
     const double vs = p.voxel_size;
-    const int32_t vx = static_cast<int32_t>(floor(p.in[3 * i] / vs)), vy = static_cast<int32_t>(floor(p.in[3 * i + 1] / vs)),
-                  vz = static_cast<int32_t>(floor(p.in[3 * i + 2] / vs));
+    int32_t vx = 0, vy = 0, vz = 0;
+    if (in_range)
+        vx = static_cast<int32_t>(floor(p.in[3 * i] / vs)), vy = static_cast<int32_t>(floor(p.in[3 * i + 1] / vs)), vz = static_cast<int32_t>(floor(p.in[3 * i + 2] / vs));
     bool ok;
-    const unsigned long long key = pack_voxel21(vx, vy, vz, ok);
+    const unsigned long long key = in_range ? pack_voxel21(vx, vy, vz, ok) : kEmptyVoxelKey;
+    // Consecutive points of a scan ring fall into the same voxel in long runs (hundreds of points per voxel close to the sensor),
+    // and every one of them would hammer the same two words with atomics - the kernel's tail, up to 0.6 ms on some frames.  Only
+    // the FIRST lane of a run inside a wave goes on: it has the lowest index of the run, which is all atomicMin would keep.
+    const unsigned long long prev = __shfl_up(key, 1, 64);
+    if (!in_range || ((threadIdx.x & 63) != 0 && prev == key)) return;
     if (!ok) {
         *p.error = 1u;
         return;

@@ -1,5 +1,9 @@
 // kicp_prestep.hip -- the pipeline's pre-steps behind include/kicp.h (kicp_pre_*): wire-format ingest, deskew + crop +
 // transform, voxel downsample (kernels: kicp_pre.hpp).
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "kicp_internal.hpp"
 #include "kicp_pre.hpp"
 
@@ -25,6 +29,15 @@ struct kicp_pre {
     unsigned char *copy_host = nullptr;
     size_t copy_cap = 0, copy_n = 0;
     int copy_buffer = -1;
+    // kicp_pre_download_begin_into: a helper thread of the handle moves the landed bytes into the caller's memory while the
+    // calling thread goes on with the pipeline (waits for the DMA's event, then one memcpy); _finish only joins it
+    std::thread copy_thread;
+    std::mutex copy_mutex;
+    std::condition_variable copy_cv;
+    int copy_state = 0;  // 0 idle, 1 job posted, 2 job done, -1 shut down
+    double *copy_dst = nullptr;
+    size_t copy_dst_points = 0;
+    hipError_t copy_error = hipSuccess;
     unsigned long long *d_minmax = nullptr;
     size_t ingested_n = 0;
     bool ingested = false, ingested_stamps = false;
@@ -122,6 +135,15 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
     hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
     p->stage.release();
+    if (p->copy_thread.joinable()) {  // the helper thread finishes the job it has, then leaves
+        {
+            std::unique_lock<std::mutex> lock(p->copy_mutex);
+            p->copy_cv.wait(lock, [p] { return p->copy_state != 1; });
+            p->copy_state = -1;
+        }
+        p->copy_cv.notify_all();
+        p->copy_thread.join();
+    }
     if (p->copy_stream) hipStreamSynchronize(p->copy_stream), hipStreamDestroy(p->copy_stream);
     if (p->copy_done) hipEventDestroy(p->copy_done);
     if (p->copy_host) hipHostFree(p->copy_host);
@@ -283,7 +305,15 @@ int kicp_pre_download_begin(kicp_pre *p, int buffer) {
     if (int rc = set_device(p->device)) return rc;
     if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
     if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
-    if (p->copy_buffer >= 0) HIP_TRY(hipStreamSynchronize(p->copy_stream));  // an earlier download nobody collected
+    if (p->copy_buffer >= 0) {  // an earlier download nobody collected: let it (and the helper thread's copy) finish first
+        std::unique_lock<std::mutex> lock(p->copy_mutex);
+        if (p->copy_state == 1 || p->copy_state == 2) {
+            p->copy_cv.wait(lock, [p] { return p->copy_state == 2; });
+            p->copy_state = 0;
+        }
+        lock.unlock();
+        HIP_TRY(hipStreamSynchronize(p->copy_stream));
+    }
     const size_t n = p->buf_n[buffer], bytes = n * 24;
     if (bytes > p->copy_cap) {
         if (p->copy_host) HIP_TRY(hipHostFree(p->copy_host));
@@ -297,14 +327,51 @@ int kicp_pre_download_begin(kicp_pre *p, int buffer) {
     p->copy_buffer = buffer, p->copy_n = n;
     return KICP_OK;
 }
+static void copy_worker(kicp_pre *p) {
+    hipSetDevice(p->device);
+    std::unique_lock<std::mutex> lock(p->copy_mutex);
+    for (;;) {
+        p->copy_cv.wait(lock, [p] { return p->copy_state == 1 || p->copy_state == -1; });
+        if (p->copy_state == -1) return;
+        lock.unlock();
+        const hipError_t e = hipEventSynchronize(p->copy_done);
+        const size_t k = std::min(p->copy_n, p->copy_dst_points);
+        if (e == hipSuccess && k && p->copy_dst) std::memcpy(p->copy_dst, p->copy_host, k * 24);
+        lock.lock();
+        p->copy_error = e, p->copy_state = 2;
+        p->copy_cv.notify_all();
+    }
+}
+int kicp_pre_download_begin_into(kicp_pre *p, int buffer, double *out_xyz, size_t cap_points) {
+    if (int rc = kicp_pre_download_begin(p, buffer)) return rc;
+    if (!p->copy_thread.joinable()) p->copy_thread = std::thread(copy_worker, p);
+    {
+        std::lock_guard<std::mutex> lock(p->copy_mutex);
+        p->copy_dst = out_xyz, p->copy_dst_points = cap_points, p->copy_state = 1;
+    }
+    p->copy_cv.notify_all();
+    return KICP_OK;
+}
 int kicp_pre_download_finish(kicp_pre *p, int buffer, double *out_xyz, size_t cap_points, size_t *out_n) {
     KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
     if (p->copy_buffer != buffer) return fail(KICP_ERR_ARG, "no download of this buffer in flight: kicp_pre_download_begin first");
     if (int rc = set_device(p->device)) return rc;
-    HIP_TRY(hipEventSynchronize(p->copy_done));
-    const size_t k = std::min(p->copy_n, cap_points);
-    if (k && out_xyz) std::memcpy(out_xyz, p->copy_host, k * 24);
+    bool delivered = false;
+    {
+        std::unique_lock<std::mutex> lock(p->copy_mutex);
+        if (p->copy_state == 1 || p->copy_state == 2) {  // the helper thread owns this download: wait for it
+            p->copy_cv.wait(lock, [p] { return p->copy_state == 2; });
+            p->copy_state = 0;
+            HIP_TRY(p->copy_error);
+            delivered = p->copy_dst == out_xyz || out_xyz == nullptr;
+        }
+    }
+    if (!delivered) {
+        HIP_TRY(hipEventSynchronize(p->copy_done));
+        const size_t k = std::min(p->copy_n, cap_points);
+        if (k && out_xyz) std::memcpy(out_xyz, p->copy_host, k * 24);
+    }
     if (out_n) *out_n = p->copy_n;
     p->copy_buffer = -1;
     return KICP_OK;

@@ -224,3 +224,26 @@ def test_wave_kernel_on_deep_and_shallow_buckets(cap):
         assert k == oreg.last_stats.iterations and list(reg.last_stats.n_corr[:k]) == list(oreg.last_stats.n_corr[:k])
         if ref_available():
             np.testing.assert_allclose(a, rkicp.KinematicRegistration().ComputeRobotMotion(frame, ref_map_like(omap), last, rel, tau), rtol=0, atol=POSE_TOL)
+
+
+def test_small_host_frames_through_the_bar(case4):
+    """kicp_register (the reference's own signature: a host vector) with frames of up to 8 192 points: written straight into HBM
+    through the PCIe BAR.  Alternating frames, sizes around the limit and the staged path give the same bits as device-resident
+    frames; a stale cache line anywhere would show as a wrong pose."""
+    cfg, scans, gmap, omap, rmap = case4
+    tau = cfg.first_frame_tau()
+    rels = _rels(scans, 0.05, 0.8)
+    big = np.concatenate([s["frame"] for s in scans] * 3)
+    reg, staged, dev = K.KinematicRegistration(), K.KinematicRegistration(), K.KinematicRegistration()
+    staged.set_option("bar_frame", 0)
+    for rounds in range(3):
+        for i, (s, rel) in enumerate(zip(scans, rels)):
+            n = (1080, 777, 8192, 8193, 1, 4097)[(i + rounds) % 6]
+            fr = np.ascontiguousarray(np.roll(big, 131 * (i + 4 * rounds), axis=0)[:n])
+            a = reg.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+            b = staged.ComputeRobotMotion(fr, gmap, s["last_pose"], rel, tau)
+            c = dev.ComputeRobotMotion(K.DeviceFrame(fr), gmap, s["last_pose"], rel, tau)
+            assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), (rounds, i, n)
+            assert reg.last_stats.iterations == dev.last_stats.iterations
+    assert reg.get_option("bar_frame") == 1.0 and staged.get_option("bar_frame") == 0.0
+    np.testing.assert_allclose(a, okicp.KinematicRegistration().ComputeRobotMotion(fr, omap, s["last_pose"], rel, tau), rtol=0, atol=POSE_TOL)
