@@ -37,7 +37,13 @@ for db in sys.argv[4:]:
 def m(name):
     return vals[name]["mean_per_dispatch"] if name in vals else None
 
-out = {"kernel": sub, "pass_kernel_avg_us": avg_us, "raw": vals}
+import os
+import subprocess
+try:
+    sha = subprocess.check_output(["git", "-C", os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:  # noqa: BLE001  (the GPU box has no .git: the caller passes KICP_GIT_SHA)
+    sha = os.environ.get("KICP_GIT_SHA", "unknown")
+out = {"kernel": sub, "pass_kernel_avg_us": avg_us, "git_sha": sha, "raw": vals}
 if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
     out["hbm_bytes_per_launch"] = int((2.0 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024)
     out["hbm_GBps"] = round(out["hbm_bytes_per_launch"] / (avg_us * 1e-6) / 1e9, 1)
