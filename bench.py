@@ -147,9 +147,9 @@ def main():
     extra = syn.planar_pose(MULTI_ITER_ERROR[0], 0.0, np.deg2rad(MULTI_ITER_ERROR[1]))
     rel_multi = [syn.pose_mul(s["rel_odom"], extra) for s in scans]
 
-    def make_reg(comm):
+    def make_reg(comm, **kw):
         """a registration handle with the requested exchange attached (None: single GPU / replicas)"""
-        reg = K.KinematicRegistration(device=device)  # reference defaults (KinematicICP.hpp:51-56)
+        reg = K.KinematicRegistration(device=device, **kw)  # reference defaults (KinematicICP.hpp:51-56) unless asked otherwise
         keep = []
         if comm == "shm":
             name = "kicp_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
@@ -315,17 +315,21 @@ def main():
     #      registered WITHOUT any exchange (a plain handle on this rank's points: the kernel and hand-off alone)
     other = {}
     if exchange:
-        def measure(reg_x):
+        FIXED = dict(max_num_iteration=4, convergence_criterion=0.0)  # every scan runs exactly four iterations, exchange or not
+
+        def measure(reg_x, reg_fixed):
             for i in range(60):
                 run_scan(reg_x, i, rel_single)
             e1 = timed(reg_x, rel_single, args.steps, min(args.warmup, 2))
             em = timed(reg_x, rel_multi, args.steps, 1)
-            return {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / timed.last_iterations, 3),
-                    "iterations_per_scan": round(timed.last_iterations, 3)}
+            its = timed.last_iterations
+            ef = timed(reg_fixed, rel_single, args.steps, 1)
+            return {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / its, 3),
+                    "iterations_per_scan": round(its, 3), "us_per_iteration_at_4_fixed_iterations": round(1e6 * ef / (args.steps * B) / 4.0, 3)}
         exch = {}
-        plain = K.KinematicRegistration(device=device)
-        exch["none (this rank's shard alone, no exchange: NOT a registration of the scan)"] = base = measure(plain)
-        del plain
+        plain, plain_fixed = K.KinematicRegistration(device=device), K.KinematicRegistration(device=device, **FIXED)
+        exch["none (this rank's shard alone, no exchange: NOT a registration of the scan)"] = base = measure(plain, plain_fixed)
+        del plain, plain_fixed
         for alt in ("rccl", "shm", "p2p"):
             if alt == "rccl" and (torch.cuda.device_count() < world or "KICP_BENCH_DEVICE" in os.environ):
                 exch[alt] = {"note": "skipped: RCCL needs one GPU per rank"}
@@ -336,12 +340,24 @@ def main():
                 exch[alt] = {"note": str(e)[:200]}
                 continue
             try:
-                exch[alt] = measure(reg2)
-                exch[alt]["exchange_us_per_iteration"] = round(exch[alt]["us_per_iteration"] - base["us_per_iteration"], 3)
+                for i in range(60):
+                    run_scan(reg2, i, rel_single)
+                e1 = timed(reg2, rel_single, args.steps, min(args.warmup, 2))
+                em = timed(reg2, rel_multi, args.steps, 1)
+                its = timed.last_iterations
+                release(reg2, alt)
+                del reg2
+                reg3, keep3 = make_reg(alt, **FIXED)
+                ef = timed(reg3, rel_single, args.steps, 1)
+                fixed_us = 1e6 * ef / (args.steps * B) / 4.0
+                exch[alt] = {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / its, 3),
+                             "iterations_per_scan": round(its, 3), "us_per_iteration_at_4_fixed_iterations": round(fixed_us, 3),
+                             # what the exchange adds to an iteration of this rank's shard (both sides run exactly four iterations per scan)
+                             "exchange_us_per_iteration": round(fixed_us - base["us_per_iteration_at_4_fixed_iterations"], 3)}
+                release(reg3, alt)
+                del reg3
             except K.KicpError as e:
                 exch[alt] = {"note": str(e)[:200]}
-            release(reg2, alt)
-            del reg2
         other["exchanges"] = exch
         for alt in ("shm", "p2p"):  # (kept under their round-2 names too)
             if "scans_per_s" in exch.get(alt, {}):

@@ -758,7 +758,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         pose_to(T0, out_pose_qt);
         return KICP_OK;
     }
-    if (max_it > 0x7FFF) return fail(KICP_ERR_ARG, "max_num_iterations > 32767");
+
     if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
     if (int rc = set_device(r->device)) return rc;
     const uint64_t epoch_before = map->mirror.synced_epoch;
@@ -767,6 +767,10 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
     const bool p2p = r->d_p2p_table != nullptr;
+    // (the single-record hand-offs - device-side solve, group_rows = 0, the device collectives - count iterations in 15 bits of
+    // their sequence word; the default tagged-row hand-offs and the small-scan path have no such limit)
+    if (max_it > 0x7FFF && (!r->host_solve || r->group_rows == 0 || multi || p2p))
+        return fail(KICP_ERR_ARG, "max_num_iterations > 32767 with a single-record hand-off (host_solve = 0, group_rows = 0, RCCL / callback / peer-mailbox exchange)");
     r->last_small = 0;
     if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0) {
         const SmallPlan pl = small_plan(r, n);

@@ -61,7 +61,7 @@ def run(label, env=None, **opts):
 
 
 print("%s: %d-point scans vs %d-point map" % (cfg.name, len(scans[0]["frame"]), gmap.num_points()), flush=True)
-fits = len(scans[0]["frame"]) <= 4096
+fits = len(scans[0]["frame"]) <= 8192
 run("generic pass kernel, kernargs in host memory (round 2 path)", env={"KICP_KERNARG": "host"}, small=0)
 run("generic pass kernel, HIP launch                              ", small=0, aql=0)
 run("generic pass kernel (kernargs in HBM: default)               ", small=0)

@@ -18,12 +18,12 @@ tau = cfg.first_frame_tau()
 frames = [K.DeviceFrame(s["frame"]) for s in scans]
 rels = [syn.pose_mul(s["rel_odom"], syn.planar_pose(0.05, 0.0, np.deg2rad(0.5))) for s in scans]
 n = len(scans[0]["frame"])
-for opts in (dict(small_cmd=1), dict(wave_block=512, small_cmd=1), dict(wave_block=1024, small_cmd=1), dict()):
+for opts in (dict(), dict(wave_block=256), dict(wave_block=1024), dict(small_cmd=0)):
     os.environ["KICP_KERNARG"] = "dev"
     reg = K.KinematicRegistration()
     for k, v in opts.items():
         reg.set_option(k, v)
-    grid = -(-n // (opts.get("wave_block", 256) // 64))
+    grid = -(-n // ((opts.get("wave_block") or (256 if n <= 512 else (512 if n <= 2176 else 1024))) // 64))  # (wave_block 0 = by scan size)
     for i in range(200):
         reg.ComputeRobotMotion(frames[i % 8], gmap, scans[i % 8]["last_pose"], rels[i % 8], tau)
     reg.set_option("small_trace", 1)
