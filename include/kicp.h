@@ -232,6 +232,12 @@ int kicp_pre_ingested(const kicp_pre *pre, double *out_xyz, double *out_stamps, 
 /* kiss_icp::VoxelDownsample(buffer src, voxel_size) -> buffer dst: the first point (lowest index) of every voxel, in
  * first-seen order. */
 int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, int dst_buffer, size_t *out_n);
+/* Largest robin-hood displacement (in buckets) the last kicp_pre_voxel_downsample saw while replaying the reference's table
+ * (0 when every probe stayed below 32).  tsl::robin_map grows its table when an insertion's probe exceeds the container's
+ * limit (128 in robin-map 0.6.x once the load factor is >= 0.15, 8192 in 1.x) - a re-hash the replay does not model: a value at
+ * or beyond the limit of the robin-map the reference was built against means the ORDER of that output may differ from the
+ * reference's (the set of survivors never does). */
+unsigned int kicp_pre_last_max_probe(const kicp_pre *pre);
 int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
 int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 /* The same download in the background: _begin queues the copy of the buffer's current contents on a stream of its own

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "kicp_pre_preprocess_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
+    "kicp_pre_last_max_probe": (C.c_uint, [C.c_void_p]),
     "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kicp_pre_download_begin": (C.c_int, [C.c_void_p, C.c_int]),

@@ -131,6 +131,7 @@ struct DownsampleParams {
     uint32_t mask;             // the reference's bucket count - 1
     uint32_t *block_counts;    // occupied buckets per 256-slot block
     uint32_t *error;           // set when a voxel coordinate leaves the 21-bit packable range
+    uint32_t *probe_max;       // largest robin-hood displacement the replay saw (atomicMax; see replay_cluster)
 };
 
 __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y, int32_t z, bool &ok) {
@@ -178,7 +179,8 @@ static __global__ __launch_bounds__(256) void k_downsample_replay(const Downsamp
         if (occupied && p.keys[(s - 1u) & p.mask] == kEmptyVoxelKey) {
             uint32_t len = 1u;
             while (p.keys[(s + len) & p.mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
-            replay_cluster(p.keys, p.min_index, p.order, p.home_at, p.mask, s, len);
+            const uint32_t probe = replay_cluster(p.keys, p.min_index, p.order, p.home_at, p.mask, s, len);
+            if (probe >= 32u) atomicMax(p.probe_max, probe);  // (short probes are the rule: only the rare long one touches the counter)
         }
     }
     block_count_store(occupied, p.block_counts);

@@ -16,7 +16,8 @@ struct kicp_pre {
     double *buf[KICP_PRE_BUFFERS] = {};
     size_t buf_cap[KICP_PRE_BUFFERS] = {}, buf_n[KICP_PRE_BUFFERS] = {};
     double *d_in = nullptr, *d_ts = nullptr, *d_staged = nullptr;
-    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error
+    uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error, [2] largest robin-hood displacement of the last downsample
+    uint32_t last_max_probe = 0;
     unsigned char *d_table = nullptr;  // downsampling table: keys | min_index | order | home_at, 20 B per bucket (kicp_pre.hpp)
     size_t cap_n = 0, table_slots = 0;
     // wire-format ingest: the raw message bytes, the stamps' extrema, what d_in / d_ts currently hold
@@ -69,9 +70,10 @@ int pre_ensure_buf(kicp_pre *p, int b, size_t n) {
 }
 // the survivor count (misc[0]) and the range flag (misc[1]) of the kernels queued so far -> buf_n[dst]
 int pre_finish(kicp_pre *p, int dst, size_t *out_n) {
-    uint32_t misc[2] = {0, 0};
+    uint32_t misc[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    p->last_max_probe = misc[2];
     if (misc[1]) {  // report once: the flag must not poison the calls that follow on this handle
         HIP_TRY(hipMemsetAsync(p->d_misc + 1, 0, 4, p->stream));
         return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
@@ -266,7 +268,8 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     dp.keys = reinterpret_cast<unsigned long long *>(p->d_table);
     dp.min_index = reinterpret_cast<uint32_t *>(p->d_table + slots * 8);
     dp.order = dp.min_index + slots, dp.home_at = dp.order + slots;
-    dp.block_counts = p->d_block_counts, dp.error = p->d_misc + 1;
+    dp.block_counts = p->d_block_counts, dp.error = p->d_misc + 1, dp.probe_max = p->d_misc + 2;
+    HIP_TRY(hipMemsetAsync(p->d_misc + 2, 0, 4, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_table, 0xFF, slots * 16, p->stream));  // keys free, no winner yet, buckets of the replay free
     const uint32_t grid = static_cast<uint32_t>((n + 255) / 256), sgrid = static_cast<uint32_t>((slots + 255) / 256);
     hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
@@ -276,6 +279,7 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     HIP_TRY(hipGetLastError());
     return pre_finish(p, dst, out_n);
 }
+unsigned int kicp_pre_last_max_probe(const kicp_pre *p) { return p ? p->last_max_probe : 0u; }
 int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
     KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");

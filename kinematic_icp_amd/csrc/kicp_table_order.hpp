@@ -35,12 +35,17 @@ inline size_t reference_bucket_count(size_t n) {
 // One cluster (slots head .. head+len-1, cyclic) of the claimed table -> the reference's arrangement of the same keys.
 // keys / min_index are read-only here; order / home_at are written inside the cluster only.  order[] must be kFreeBucket
 // on entry.  Host + device.
-KICP_HD void replay_cluster(const unsigned long long *keys, const uint32_t *min_index, uint32_t *order, uint32_t *home_at, uint32_t mask,
-                            uint32_t head, uint32_t len) {
+// Returns the largest displacement from its ideal bucket any key ended up with (or travelled through): tsl::robin_map gives up
+// robin-hood probing and GROWS the table when an insertion's probe length exceeds its limit (128 in robin-map 0.6.x once the load
+// factor is >= 0.15, 8192 in 1.x) - a re-hash this replay does not model, so beyond the limit of the container the reference was
+// built against the output order may differ from it.  The caller reports the value (kicp_pre_last_max_probe).
+KICP_HD uint32_t replay_cluster(const unsigned long long *keys, const uint32_t *min_index, uint32_t *order, uint32_t *home_at, uint32_t mask,
+                                uint32_t head, uint32_t len) {
     if (len == 1u) {
         order[head] = min_index[head];
-        return;
+        return 0u;
     }
+    uint32_t max_probe = 0u;
     uint32_t last = 0u;  // input index of the previous insertion (+1), so "greater than last" selects the next one
     for (uint32_t t = 0; t < len; ++t) {
         uint32_t best = kFreeBucket, best_slot = head;
@@ -55,6 +60,8 @@ KICP_HD void replay_cluster(const unsigned long long *keys, const uint32_t *min_
         uint32_t pos = carry_home;
         for (;;) {
             const uint32_t resident = order[pos];
+            const uint32_t dist = (pos - carry_home) & mask;
+            max_probe = dist > max_probe ? dist : max_probe;
             if (resident == kFreeBucket) {
                 order[pos] = carry, home_at[pos] = carry_home;
                 break;
@@ -67,6 +74,7 @@ KICP_HD void replay_cluster(const unsigned long long *keys, const uint32_t *min_
             pos = (pos + 1u) & mask;
         }
     }
+    return max_probe;
 }
 
 }  // namespace kicp

@@ -25,7 +25,7 @@ unsigned long long pack(const Vox &v) {
            static_cast<unsigned long long>(static_cast<uint32_t>(v.x + lim) & 0x1FFFFFu);
 }
 // the sequential container: returns, per bucket, the input index of the stored point (kFreeBucket = empty)
-std::vector<uint32_t> sequential_robin_hood(const std::vector<Vox> &pts, size_t buckets) {
+std::vector<uint32_t> sequential_robin_hood(const std::vector<Vox> &pts, size_t buckets, int *max_probe = nullptr) {
     std::vector<uint32_t> who(buckets, kFreeBucket);
     std::vector<int> dist(buckets, -1);
     const size_t mask = buckets - 1;
@@ -47,11 +47,12 @@ std::vector<uint32_t> sequential_robin_hood(const std::vector<Vox> &pts, size_t 
             b = (b + 1) & mask, ++d;
         }
         who[b] = carry, dist[b] = d;
+        if (max_probe) *max_probe = std::max(*max_probe, d);  // (the longest probe any insertion ended with: what robin_map's growth rule looks at)
     }
     return who;
 }
 // what the kernels do: claim (any order) -> replay per cluster
-std::vector<uint32_t> claimed_and_replayed(const std::vector<Vox> &pts, size_t buckets, std::mt19937 &rng) {
+std::vector<uint32_t> claimed_and_replayed(const std::vector<Vox> &pts, size_t buckets, std::mt19937 &rng, uint32_t *max_probe = nullptr) {
     const uint32_t mask = static_cast<uint32_t>(buckets - 1);
     std::vector<unsigned long long> keys(buckets, ~0ull);
     std::vector<uint32_t> min_index(buckets, 0xFFFFFFFFu), order(buckets, kFreeBucket), home_at(buckets, 0xDEADBEEFu);
@@ -69,14 +70,22 @@ std::vector<uint32_t> claimed_and_replayed(const std::vector<Vox> &pts, size_t b
         if (keys[s] == ~0ull || keys[(s - 1u) & mask] != ~0ull) continue;
         uint32_t len = 1;
         while (keys[(s + len) & mask] != ~0ull) ++len;
-        kicp::replay_cluster(keys.data(), min_index.data(), order.data(), home_at.data(), mask, s, len);
+        const uint32_t probe = kicp::replay_cluster(keys.data(), min_index.data(), order.data(), home_at.data(), mask, s, len);
+        if (max_probe) *max_probe = std::max(*max_probe, probe);
     }
     return order;
 }
 int check(const std::vector<Vox> &pts, std::mt19937 &rng, const char *what) {
     const size_t buckets = kicp::reference_bucket_count(pts.size());
     if (buckets == 0) return 0;
-    const auto a = sequential_robin_hood(pts, buckets), b = claimed_and_replayed(pts, buckets, rng);
+    int seq_probe = 0;
+    uint32_t replay_probe = 0;
+    const auto a = sequential_robin_hood(pts, buckets, &seq_probe), b = claimed_and_replayed(pts, buckets, rng, &replay_probe);
+    // the replay reports the longest probe it walked: never below the container's own figure (it is what kicp_pre_last_max_probe hands out)
+    if (static_cast<int>(replay_probe) < seq_probe) {
+        std::printf("PROBE %s: n %zu sequential %d replayed %u\n", what, pts.size(), seq_probe, replay_probe);
+        return 1;
+    }
     for (size_t s = 0; s < buckets; ++s)
         if (a[s] != b[s]) {
             std::printf("MISMATCH %s: n %zu buckets %zu bucket %zu sequential %u replayed %u\n", what, pts.size(), buckets, s, a[s], b[s]);
