@@ -306,6 +306,24 @@ def main():
         for i in range(k_host):
             reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
         host_rate = k_host / (time.perf_counter() - t1)
+    # informational, never `value`: INDEPENDENT scans with four in flight (kicp_register_device_concurrent: one handle, HSA
+    # queue and host thread per lane) - what the device does when a workload has several scans to offer at a time (robots
+    # sharing a map, replayed logs).  The reference's sequential pipeline cannot use it, hence not the headline.
+    conc_rate, conc_lanes = None, 4
+    if world == 1 and not use_comm:
+        lanes = [K.KinematicRegistration(device=device) for _ in range(conc_lanes - 1)]
+        cb = reg.prepare_batch([frames[i % len(scans)] for i in range(512)], [scans[i % len(scans)]["last_pose"] for i in range(512)],
+                               [rel_single[i % len(scans)] for i in range(512)])
+        seq = reg.ComputeRobotMotionBatch(cb, gmap, tau).copy()
+        reg.ComputeRobotMotionConcurrent(lanes, cb, gmap, tau)
+        best = []
+        for _ in range(6):
+            t1 = time.perf_counter()
+            got = reg.ComputeRobotMotionConcurrent(lanes, cb, gmap, tau)
+            best.append(time.perf_counter() - t1)
+        assert np.array_equal(got, seq), "concurrent lanes must return the sequential poses bit for bit"
+        conc_rate = 512 / float(np.median(best))
+        del lanes
     pass_kernel = int(reg.get_option("pass_kernel"))
     if exchange:
         release(reg, comm)
@@ -484,6 +502,10 @@ def main():
         "value_host_vector_input": None if host_rate is None else
         {"scans_per_s": round(host_rate, 1), "what": "kicp_register with the scan handed over as a HOST array, the reference's own signature "
                                                       "(Registration.hpp:39-43): upload over PCIe inside the call"},
+        "value_concurrent_independent_scans": None if conc_rate is None else
+        {"scans_per_s": round(conc_rate, 1), "lanes": conc_lanes,
+         "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each); "
+                 "a throughput mode the reference's sequential pipeline cannot use - never the headline" % conc_lanes},
         "roofline": roof,
         "cpu_baseline": cpu,
     }

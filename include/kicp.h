@@ -130,12 +130,17 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *   "split_buckets" two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing the neighbour
  *                  voxels between them (1 default | 0)
  *   "occupancy"    waves per SIMD the generic kernel's register allocation aims for (4 default | 3)
+ *   "latency_kernel" one lane per query: 1 (default) scans of at most 131 072 points - which leave the device two waves per SIMD
+ *                  anyway - run the build that has TWO neighbour voxels in flight per round (k_pass_gather32<.., LAT>, 185
+ *                  VGPRs); 2: every such scan; 0: never
  *   "small"        1 (default): scans of at most 16 384 lanes (points x sub-lanes: up to 4 096 points by default) take the
  *                  small-scan path - every workgroup's exact sums go straight to the host (no reduction tree) and the kernel
  *                  stays resident for the iterations of the call, polling a command line in host-mapped memory for the next
  *                  pose; 0: always the generic pass kernel.  "small_active" (read only): which path the last call took
  *   "small_resident" 1 (default): resident unless the previous call converged in one iteration (a call that needs more gets a
- *                  resident launch from its second pass on); 2: always resident; 0: one launch per iteration
+ *                  resident launch from its second pass on); 2: always resident; 0: one launch per iteration.  Set 0 on
+ *                  handles that register small scans from several threads at once on one device (a resident kernel holds its
+ *                  CUs until its host answers; kicp_register_device_concurrent does this for its lanes)
  *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
  *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
  *                  wave_block 0 = by scan size, default)
@@ -178,6 +183,16 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
 int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const double *const *d_frames_xyz, const size_t *n,
                                const double *last_poses_qt, const double *rel_odoms_qt, double max_correspondence_distance,
                                double *out_poses_qt, int *out_iterations);
+/* The same queue of INDEPENDENT registrations with `lanes` of them in flight: lane t drives handle regs[t] (its own stream,
+ * AQL queue and hand-off buffers; options and config are taken from each handle) from a host thread of its own, scans are
+ * dealt to the lanes first come, first served.  This is a THROUGHPUT mode for workloads that have independent scans -
+ * several robots localising in one map, replayed logs - and nothing the reference's sequential pipeline can use: a scan's
+ * initial guess there is the previous scan's result.  Every pose is bit-equal to what kicp_register_device returns for that
+ * scan (the lanes share nothing but the read-only map).  The map must not be updated during the call.  Returns like
+ * kicp_register_device_batch; after an error the remaining scans are not started and their poses are unspecified. */
+int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_map *map, size_t count, const double *const *d_frames_xyz,
+                                    const size_t *n, const double *last_poses_qt, const double *rel_odoms_qt,
+                                    double max_correspondence_distance, double *out_poses_qt, int *out_iterations);
 /* One fused association+accumulation pass at a fixed pose (DataAssociation + the reduction of
  * ComputePerturbation + the sum of ComputeOdometryRegularization; Registration.cpp:62-81,102-118,51-55).
  * out_sums = {JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2, N_corr}, un-normalised.  Host frame pointer. */

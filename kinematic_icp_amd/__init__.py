@@ -84,6 +84,8 @@ _SIGNATURES = {
     "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_register_device_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _dp, _dp,
                                              C.c_double, _dp, C.POINTER(C.c_int)]),
+    "kicp_register_device_concurrent": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                  _dp, _dp, C.c_double, _dp, C.POINTER(C.c_int)]),
     "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "kicp_pass_words": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_longlong)]),
     "kicp_pre_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -364,6 +366,16 @@ class KinematicRegistration:
         rc = _lib.kicp_register_device_batch(self._h, voxel_map._h, batch.count, batch.ptrs, batch.ns, batch.last.ctypes.data_as(_dp),
                                              batch.rel.ctypes.data_as(_dp), max_correspondence_distance, batch.out.ctypes.data_as(_dp),
                                              batch.iterations.ctypes.data_as(C.POINTER(C.c_int)))
+        self.last_status = rc if rc >= 0 else _check(rc)
+        return batch.out
+
+    def ComputeRobotMotionConcurrent(self, others, batch, voxel_map, max_correspondence_distance):
+        """kicp_register_device_concurrent: the batch's INDEPENDENT scans with 1 + len(others) of them in flight, one lane per
+        handle (this one and `others`).  Same poses as ComputeRobotMotionBatch, bit for bit."""
+        handles = (C.c_void_p * (1 + len(others)))(self._h, *[o._h for o in others])
+        rc = _lib.kicp_register_device_concurrent(handles, len(handles), voxel_map._h, batch.count, batch.ptrs, batch.ns, batch.last.ctypes.data_as(_dp),
+                                                  batch.rel.ctypes.data_as(_dp), max_correspondence_distance, batch.out.ctypes.data_as(_dp),
+                                                  batch.iterations.ctypes.data_as(C.POINTER(C.c_int)))
         self.last_status = rc if rc >= 0 else _check(rc)
         return batch.out
 

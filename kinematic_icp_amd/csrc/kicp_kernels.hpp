@@ -840,71 +840,127 @@ __device__ __forceinline__ uint32_t cull_todo(const Lane &L, float best, float m
                          (kCell - P.lz) * (kCell - P.lz) * 0.99999f - margin};
     return L.todo & alive_mask(lo, hi, best + margin);
 }
-// scan the bucket of neighbour voxel `s` of query P and merge what it finds into t.  PARTS = 2: two neighbouring lanes serve the same query and share every bucket - this lane
-// takes points [10 part, 10 part + 10) of each 20-point trip (five 16-byte loads), the records are merged by the caller.
+// One trip over N consecutive points of a mirror bucket, in two halves so that a caller can keep several trips in flight:
+// load_trip issues the N / 2 16-byte loads at immediate offsets; process_trip turns the loaded words into distances in mirror
+// units, finds the two smallest by an integer-key tournament and merges them into t.  `pos0` = position of the trip's first
+// point inside the bucket.  process_trip returns whether the bucket goes on behind this trip (its last slot holds a point).
+// PARTS = 2: two neighbouring lanes share the trip (the odd lane holds its last slot).
+template <int N>
+__device__ __forceinline__ void load_trip(const uint4 *bt, uint4 (&c)[N / 2]) {
+#pragma unroll
+    for (int u = 0; u < N / 2; ++u) c[u] = bt[u];
+}
+template <int N, int PARTS>
+__device__ __forceinline__ bool process_trip(const uint4 (&c)[N / 2], uint32_t pos0, uint32_t base, int s, const v2f qx, const v2f qy, const v2f qz, Best3 &t,
+                                             float margin) {
+    // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
+    // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
+    // and yields value and position at once (unique keys: the lower position wins a tie, like the
+    // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
+    // Empty slots need no test: their second word converts to 4.3e9 units (kicp_common.hpp).
+    uint32_t key[N];
+#pragma unroll
+    for (int u = 0; u < N / 2; ++u) {
+        const v2f px = {static_cast<float>(c[u].x & 0xffffu), static_cast<float>(c[u].z & 0xffffu)};
+        const v2f py = {static_cast<float>(c[u].x >> 16), static_cast<float>(c[u].z >> 16)};
+        const v2f pz = {static_cast<float>(c[u].y), static_cast<float>(c[u].w)};  // (the whole word: z, or far away for an empty slot)
+        const v2f ddx = px - qx, ddy = py - qy, ddz = pz - qz;
+        const v2f d = __builtin_elementwise_fma(ddz, ddz, __builtin_elementwise_fma(ddy, ddy, ddx * ddx));
+        key[2 * u] = (__float_as_uint(d.x) & ~31u) | static_cast<uint32_t>(2 * u);
+        key[2 * u + 1] = (__float_as_uint(d.y) & ~31u) | static_cast<uint32_t>(2 * u + 1);
+    }
+    // the bucket ends where a trip's last slot is empty (the pair of lanes of a shared bucket must agree: the odd lane
+    // holds that slot - quad_perm [1, 1, 3, 3])
+    uint32_t last_word = c[N / 2 - 1].w;
+    if (PARTS == 2) last_word = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(last_word), 0xF5, 0xf, 0xf, false));
+    const bool more = (last_word >> 16) == 0u;
+    // winner and runner-up in one tournament (the keys are unique, so the runner-up is a different candidate)
+    uint32_t key1, key2;
+    tree_min2_u32<N>(key, key1, key2);
+    const float m1 = __uint_as_float(key1 & ~31u);
+    if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
+        // The third place is only worth a tournament when the runner-up lies within the margin of the winner; otherwise the
+        // runner-up's value stands in for it (a lower bound that can never look like a near tie).  key - (key2 + 1) wraps to
+        // the top of the range for the winner and the runner-up alone and keeps the order of all the others.
+        uint32_t key3 = key2;
+        if (__uint_as_float(min(key2, kFarKey) & ~31u) - m1 <= margin) {
+            const uint32_t after2 = key2 + 1u;
+#pragma unroll
+            for (int u = 0; u < N; ++u) key[u] -= after2;
+            key3 = after2 + tree_min_u32<N>(key);
+        }
+        const uint32_t k1 = pos0 + (key1 & 31u), k2 = pos0 + (key2 & 31u);  // positions within the bucket
+        // with fewer than three points the far key stands in (finite, beyond every real distance)
+        Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k1,
+                base + k2, static_cast<uint32_t>(s) * kOrdStride + k1, static_cast<uint32_t>(s) * kOrdStride + k2};
+        best3_merge(t, o);
+    }
+    return more;
+}
+// the query as seen from the corner of neighbour voxel `s`, both lanes of the packed arithmetic
+struct QueryFrom {
+    v2f x, y, z;
+};
+__device__ __forceinline__ QueryFrom query_from(const Probe &P, int s) {
+    const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
+    return QueryFrom{{P.lx - dx * kCell, P.lx - dx * kCell}, {P.ly - dy * kCell, P.ly - dy * kCell}, {P.lz - dz * kCell, P.lz - dz * kCell}};
+}
+// scan the bucket of neighbour voxel `s` of query P and merge what it finds into t.  PARTS = 2: two neighbouring lanes serve the
+// same query and share every bucket - this lane takes points [10 part, 10 part + 10) of each 20-point trip (five 16-byte loads),
+// the records are merged by the caller.
 template <int PARTS>
 __device__ __forceinline__ void visit_bucket(const Probe &P, Best3 &t, const MapView &m, int s, float margin, int part = 0) {
     static_assert(PARTS == 1 || PARTS == 2, "a trip is dealt to one lane or to two");
     constexpr int kMine = kTrip / PARTS;  // points of a trip this lane looks at
-    const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
     // the neighbour's bucket comes out of the own voxel's record (same cache line as the probe): no second probe
     const uint32_t bucket = m.table[P.slot0].nb[s];
     const uint32_t base = bucket * m.cap;  // index into the fp64 pool
     const uint32_t stride16 = m.cap16;
     const uint4 *b = reinterpret_cast<const uint4 *>(m.pool16 + static_cast<size_t>(bucket) * stride16);
-    // the query as seen from that voxel's corner, both lanes of the packed arithmetic
-    const v2f qx = {P.lx - dx * kCell, P.lx - dx * kCell}, qy = {P.ly - dy * kCell, P.ly - dy * kCell}, qz = {P.lz - dz * kCell, P.lz - dz * kCell};
-    // Branch-free loads at immediate offsets so that the compiler keeps a whole trip in flight: kTrip points = kTrip / 2
-    // 16-byte loads per trip.  Empty slots need no test: their second word converts to 4.3e9 units (kicp_common.hpp).
+    const QueryFrom q = query_from(P, s);
     const uint32_t first = static_cast<uint32_t>(part) * kMine;  // this lane's first point within a trip
-    for (uint32_t k0 = 0; k0 < stride16; k0 += kTrip) {
+    for (uint32_t k0 = 0; k0 < stride16; k0 += kTrip) {  // (the mirror's bucket stride is a multiple of kTrip: a trip never leaves the bucket)
         uint4 c[kMine / 2];
-        const uint4 *bt = b + (k0 + first) / 2;  // the mirror's bucket stride is a multiple of kTrip: a trip never leaves the bucket
-#pragma unroll
-        for (int u = 0; u < kMine / 2; ++u) c[u] = bt[u];
-        // All distances first (independent), then the minimum as a tournament over integer keys: a non-negative
-        // float orders like its bit pattern, so (bits & ~31) | position is one v_min3_u32 per three candidates
-        // and yields value and position at once (unique keys: the lower position wins a tie, like the
-        // reference's first minimum).  The 5 dropped mantissa bits are part of the margin's error model.
-        uint32_t key[kMine];
-#pragma unroll
-        for (int u = 0; u < kMine / 2; ++u) {
-            const v2f px = {static_cast<float>(c[u].x & 0xffffu), static_cast<float>(c[u].z & 0xffffu)};
-            const v2f py = {static_cast<float>(c[u].x >> 16), static_cast<float>(c[u].z >> 16)};
-            const v2f pz = {static_cast<float>(c[u].y), static_cast<float>(c[u].w)};  // (the whole word: z, or far away for an empty slot)
-            const v2f ddx = px - qx, ddy = py - qy, ddz = pz - qz;
-            const v2f d = __builtin_elementwise_fma(ddz, ddz, __builtin_elementwise_fma(ddy, ddy, ddx * ddx));
-            key[2 * u] = (__float_as_uint(d.x) & ~31u) | static_cast<uint32_t>(2 * u);
-            key[2 * u + 1] = (__float_as_uint(d.y) & ~31u) | static_cast<uint32_t>(2 * u + 1);
-        }
-        // the bucket ends where a trip's last slot is empty (the pair of lanes of a shared bucket must agree: the odd lane
-        // holds that slot - quad_perm [1, 1, 3, 3])
-        uint32_t last_word = c[kMine / 2 - 1].w;
-        if (PARTS == 2) last_word = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(last_word), 0xF5, 0xf, 0xf, false));
-        const bool more = (last_word >> 16) == 0u;
-        // winner and runner-up in one tournament (the keys are unique, so the runner-up is a different candidate)
-        uint32_t key1, key2;
-        tree_min2_u32<kMine>(key, key1, key2);
-        const float m1 = __uint_as_float(key1 & ~31u);
-        if (m1 <= t.b1 + margin) {  // something here can come within the margin of the running minimum
-            // The third place is only worth a tournament when the runner-up lies within the margin of the winner; otherwise the
-            // runner-up's value stands in for it (a lower bound that can never look like a near tie).  key - (key2 + 1) wraps to
-            // the top of the range for the winner and the runner-up alone and keeps the order of all the others.
-            uint32_t key3 = key2;
-            if (__uint_as_float(min(key2, kFarKey) & ~31u) - m1 <= margin) {
-                const uint32_t after2 = key2 + 1u;
-#pragma unroll
-                for (int u = 0; u < kMine; ++u) key[u] -= after2;
-                key3 = after2 + tree_min_u32<kMine>(key);
-            }
-            const uint32_t k1 = k0 + first + (key1 & 31u), k2 = k0 + first + (key2 & 31u);  // positions within the bucket
-            // with fewer than three points the far key stands in (finite, beyond every real distance)
-            Best3 o{m1, __uint_as_float(min(key2, kFarKey) & ~31u), __uint_as_float(min(key3, kFarKey) & ~31u), base + k1,
-                    base + k2, static_cast<uint32_t>(s) * kOrdStride + k1, static_cast<uint32_t>(s) * kOrdStride + k2};
-            best3_merge(t, o);
-        }
-        if (!more) break;
+        load_trip<kMine>(b + (k0 + first) / 2, c);
+        if (!process_trip<kMine, PARTS>(c, k0 + first, base, s, q.x, q.y, q.z, t, margin)) break;
     }
+}
+// Latency-oriented round (scans that leave the machine two waves per SIMD: every dependent memory access is ~0.9 us of a wave's
+// ~12): TWO neighbour voxels per round.  Both bucket records and both buckets' first trips are in flight together; the first is
+// decided, and the second is only looked at if its voxel can still hold something within the margin of the new minimum (its
+// lower bound `lb2`, the same test cull_todo applies) - so the arithmetic saved by culling stays saved, only the wait is shared.
+__device__ __forceinline__ void visit_two(const Probe &P, Best3 &t, const MapView &m, int s1, int s2, bool has2, float lb2, float margin) {
+    const uint32_t bucket1 = m.table[P.slot0].nb[s1], bucket2 = has2 ? m.table[P.slot0].nb[s2] : 0u;
+    const uint32_t stride16 = m.cap16;
+    const uint4 *b1 = reinterpret_cast<const uint4 *>(m.pool16 + static_cast<size_t>(bucket1) * stride16);
+    const uint4 *b2 = reinterpret_cast<const uint4 *>(m.pool16 + static_cast<size_t>(bucket2) * stride16);
+    uint4 c1[kTrip / 2], c2[kTrip / 2];
+    load_trip<kTrip>(b1, c1);
+    if (has2) load_trip<kTrip>(b2, c2);
+    const QueryFrom q1 = query_from(P, s1);
+    bool more = process_trip<kTrip, 1>(c1, 0u, bucket1 * m.cap, s1, q1.x, q1.y, q1.z, t, margin);
+    for (uint32_t k0 = kTrip; more && k0 < stride16; k0 += kTrip) {  // (deeper buckets than one trip: max_points_per_voxel > 20)
+        load_trip<kTrip>(b1 + k0 / 2, c1);
+        more = process_trip<kTrip, 1>(c1, k0, bucket1 * m.cap, s1, q1.x, q1.y, q1.z, t, margin);
+    }
+    if (has2 && lb2 <= t.b1 + margin) {
+        const QueryFrom q2 = query_from(P, s2);
+        more = process_trip<kTrip, 1>(c2, 0u, bucket2 * m.cap, s2, q2.x, q2.y, q2.z, t, margin);
+        for (uint32_t k0 = kTrip; more && k0 < stride16; k0 += kTrip) {
+            load_trip<kTrip>(b2 + k0 / 2, c2);
+            more = process_trip<kTrip, 1>(c2, k0, bucket2 * m.cap, s2, q2.x, q2.y, q2.z, t, margin);
+        }
+    }
+}
+// lower bound (units^2, with cull_todo's slack) of the squared distance from query P to anything in neighbour voxel s
+__device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float margin) {
+    const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
+    const float lx = dx > 0 ? kCell - P.lx : P.lx, ly = dy > 0 ? kCell - P.ly : P.ly, lz = dz > 0 ? kCell - P.lz : P.lz;
+    float lb = 0.f;
+    if (dx != 0) lb += lx * lx * 0.99999f - margin;
+    if (dy != 0) lb += ly * ly * 0.99999f - margin;
+    if (dz != 0) lb += lz * lz * 0.99999f - margin;
+    return lb;
 }
 
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
@@ -947,9 +1003,12 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // (<= 168: the compiler keeps more values instead of recomputing them; for scans that do not fill three waves per SIMD).
 // SPLIT (G == 2): the two sub-lanes of a query do not deal the neighbour voxels between them but share every bucket, ten
 // points each.
-template <int BLOCK, int G, int OCC, bool SPLIT>
+// LAT (G == 1, built at two waves per SIMD): the latency-oriented build for scans that do not fill the machine beyond that
+// (<= 131 072 points on 256 CUs) - two neighbour voxels per round (visit_two).
+template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
     static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
+    static_assert(!LAT || G == 1, "the latency-oriented build serves one lane per query");
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
@@ -974,7 +1033,16 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     while (__any(L.todo != 0u)) {
         // which of the 27 neighbours could still hold something within the margin of the current minimum
         L.todo = cull_todo(L, cull, margin);
-        if (L.todo) {
+        if (LAT) {
+            if (L.todo) {
+                const int s1 = __ffs(L.todo) - 1;
+                L.todo &= L.todo - 1u;
+                const bool has2 = L.todo != 0u;
+                const int s2 = has2 ? __ffs(L.todo) - 1 : s1;
+                L.todo &= L.todo - 1u;  // (0 stays 0; a second voxel that the first one's result rules out is dropped here - cull_todo would)
+                visit_two(L.q, L.t, m, s1, s2, has2, has2 ? voxel_lower_bound(L.q, s2, margin) : 0.f, margin);
+            }
+        } else if (L.todo) {
             const int s = __ffs(L.todo) - 1;
             L.todo &= L.todo - 1u;
             visit_bucket<SPLIT ? 2 : 1>(L.q, L.t, m, s, margin, SPLIT ? sub : 0);

@@ -8,6 +8,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <mutex>
+#include <thread>
+
 #include "kicp_aql.hpp"
 #include "kicp_internal.hpp"
 #include "kicp_kernels.hpp"
@@ -103,6 +107,7 @@ struct kicp_reg {
     int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
     int occupancy = 4;        // variant 3: waves per SIMD the kernel is compiled for (4 default | 3)
+    int latency_kernel = 1;   // variant 3, one lane per query: the two-voxels-per-round build (0 never | 1 scans <= kLatencyMaxPoints | 2 always)
     int split_buckets = 1;    // variant 3 with two sub-lanes per query: the pair shares every bucket (1 default) | deals the voxels (0)
     int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
@@ -183,6 +188,7 @@ int normalized_block(int b) { return (b == 64 || b == 256 || b == 512) ? b : 128
 // Sub-lanes per query of variant 3.  Small scans are latency bound (few waves, each lane's chain of dependent bucket
 // visits decides the kernel time): spreading a query's neighbour voxels over 2-4 lanes shortens that chain.  Large
 // scans already fill the machine and only pay for the extra waves.
+constexpr size_t kLatencyMaxPoints = 131072;  // two waves per SIMD on 256 CUs
 int lanes_for(const kicp_reg *r, size_t n) {
     if (r->lanes_per_query > 0) return r->lanes_per_query;
     return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
@@ -218,10 +224,10 @@ const AqlKernel *aql_lookup(kicp_reg *r, int key, const char *demangled_prefix) 
     return r->aql_kernels[key] = k.usable ? &k : nullptr;
 }
 // the names below must agree with tools/aql_kernel_names.py (tests/test_host.py checks them against build/kicp_reg.hsaco)
-const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split) {
+const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split, bool lat) {
     char name[128];
-    std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s>(", b, g, occ, split ? "true" : "false");
-    return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0), name);
+    std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s, %s>(", b, g, occ, split ? "true" : "false", lat ? "true" : "false");
+    return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0) + (lat ? 2 : 0), name);
 }
 const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
@@ -248,12 +254,15 @@ int launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
         const int b = effective_block(r, p.n), g = lanes_for(r, p.n);
         // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
         // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
-        const int occ = (r->occupancy == 3 && b != 512) ? 3 : 4;
+        // the latency-oriented build (two neighbour voxels per round, two waves per SIMD): scans of one lane per query that
+        // leave the machine at most two waves per SIMD anyway
+        const bool lat = g == 1 && b != 512 && (r->latency_kernel == 2 || (r->latency_kernel == 1 && p.n <= kLatencyMaxPoints));
+        const int occ = lat ? 2 : ((r->occupancy == 3 && b != 512) ? 3 : 4);
         const bool split = g == 2 && r->split_buckets;
         // While HIP work may be pending on the handle's stream (a frame upload, a mirror refresh, a clear) the kernel goes
         // through the stream, ordered behind it; once the host has that pass's result the stream is known to be idle.
         if (allow_aql && r->use_aql && !r->stream_dirty) {
-            if (const AqlKernel *k = aql_kernel_for(r, b, g, occ, split)) {
+            if (const AqlKernel *k = aql_kernel_for(r, b, g, occ, split, lat)) {
                 // Fences of the packet.  Acquire: agent scope - the kernel start invalidates the vector / scalar L1s and the
                 // XCDs' L2 lines of device memory, so everything earlier kernels released and every DMA the host has waited
                 // for is seen; it is what makes a kernarg slot re-read from host memory, too (no acquire: stale arguments).
@@ -281,7 +290,11 @@ int launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
         else if (b == 256) KICP_G32(256, G, SPLIT); \
         else KICP_G32(128, G, SPLIT);               \
     } while (0)
-        if (g == 1 && b == 512) hipLaunchKernelGGL((k_pass_gather32<512, 1, 4, false>), dim3(grid), dim3(512), 0, r->stream, p);  // experiment: one workgroup per CU
+        if (lat) {
+            if (b == 64) hipLaunchKernelGGL((k_pass_gather32<64, 1, 2, false, true>), dim3(grid), dim3(64), 0, r->stream, p);
+            else if (b == 256) hipLaunchKernelGGL((k_pass_gather32<256, 1, 2, false, true>), dim3(grid), dim3(256), 0, r->stream, p);
+            else hipLaunchKernelGGL((k_pass_gather32<128, 1, 2, false, true>), dim3(grid), dim3(128), 0, r->stream, p);
+        } else if (g == 1 && b == 512) hipLaunchKernelGGL((k_pass_gather32<512, 1, 4, false>), dim3(grid), dim3(512), 0, r->stream, p);  // experiment: one workgroup per CU
         else if (g == 1) KICP_G32_BLOCKS(1, false);
         else if (split) KICP_G32_BLOCKS(2, true);
         else if (g == 2) KICP_G32_BLOCKS(2, false);
@@ -1051,6 +1064,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
+    else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
@@ -1090,6 +1104,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "occupancy") return reg->occupancy;
+    if (k == "latency_kernel") return reg->latency_kernel;
     if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
     if (k == "aql") return reg->use_aql;
@@ -1141,6 +1156,65 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
         if (out_iterations) out_iterations[k] = st.iterations;
     }
     return worst;
+}
+int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_map *map, size_t count, const double *const *d_frames_xyz,
+                                    const size_t *n, const double *last_poses_qt, const double *rel_odoms_qt, double max_correspondence_distance,
+                                    double *out_poses_qt, int *out_iterations) {
+    KICP_TRACE_CALL();
+    if (!regs || lanes == 0 || !map) return fail(KICP_ERR_ARG, "null argument");
+    if (count && (!d_frames_xyz || !n || !last_poses_qt || !rel_odoms_qt || !out_poses_qt)) return fail(KICP_ERR_ARG, "null argument");
+    for (size_t t = 0; t < lanes; ++t) {
+        if (!regs[t] || regs[t]->device != regs[0]->device) return fail(KICP_ERR_ARG, "the lanes' handles must exist and live on one device");
+        for (size_t u = 0; u < t; ++u)
+            if (regs[u] == regs[t]) return fail(KICP_ERR_ARG, "every lane needs a handle of its own");
+        if (regs[t]->comm || regs[t]->allreduce_fn || regs[t]->shm || regs[t]->d_p2p_table)
+            return fail(KICP_ERR_ARG, "independent scans are not sharded: detach the multi-GPU exchange from the lanes' handles");
+    }
+    for (size_t k = 0; k < count; ++k)
+        if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
+    // the map's HBM copy is brought up to date HERE, once: the lanes then only read it
+    if (int rc = set_device(regs[0]->device)) return rc;
+    if (!kicp_map_empty(map)) {
+        if (int rc = map_sync(map, regs[0]->device, regs[0]->stream)) return rc;
+        HIP_TRY(hipStreamSynchronize(regs[0]->stream));
+    }
+    lanes = std::min(lanes, std::max<size_t>(count, 1));
+    // Small scans: one launch per pass while several lanes are in flight.  A resident kernel waits for its host, which waits for
+    // the rows of ALL its workgroups - with several such kernels on the device, workgroups of one may have to wait for CUs held by
+    // the others, and only the give-up time-out would untangle that.
+    std::vector<int> resident(lanes);
+    for (size_t t = 0; t < lanes; ++t) {
+        resident[t] = regs[t]->small_resident;
+        if (lanes > 1) regs[t]->small_resident = 0;
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> worst{KICP_OK}, failed{KICP_OK};
+    std::string failure;
+    std::mutex failure_lock;
+    auto lane = [&](size_t t) {
+        kicp_stats st;
+        for (;;) {
+            const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= count || failed.load(std::memory_order_relaxed) < 0) return;
+            const int rc = run_registration(regs[t], map, d_frames_xyz[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, max_correspondence_distance,
+                                            out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
+            if (rc < 0) {
+                std::lock_guard<std::mutex> hold(failure_lock);
+                if (failed.load() == KICP_OK) failed = rc, failure = kicp_last_error();  // (the message is per thread: carry it over)
+                return;
+            }
+            int seen = worst.load();
+            while (rc > seen && !worst.compare_exchange_weak(seen, rc)) {}
+            if (out_iterations) out_iterations[k] = st.iterations;
+        }
+    };
+    std::vector<std::thread> others;
+    for (size_t t = 1; t < lanes; ++t) others.emplace_back(lane, t);
+    lane(0);
+    for (auto &th : others) th.join();
+    for (size_t t = 0; t < lanes; ++t) regs[t]->small_resident = resident[t];
+    if (failed.load() < 0) return fail(failed.load(), failure);
+    return worst.load();
 }
 int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
                   const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
@@ -1416,14 +1490,16 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
     for (int b : {64, 128, 256}) {
         for (int occ : {4, 3}) {
             for (int g : {1, 2, 4}) {
-                std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, false>(\n", b, g, occ);
+                std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, false, false>(\n", b, g, occ);
                 all += name;
             }
-            std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 2, %d, true>(\n", b, occ);
+            std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 2, %d, true, false>(\n", b, occ);
             all += name;
         }
+        std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 1, 2, false, true>(\n", b);
+        all += name;
     }
-    all += "void kicp::k_pass_gather32<512, 1, 4, false>(\n";
+    all += "void kicp::k_pass_gather32<512, 1, 4, false, false>(\n";
     for (int b : {256, 512, 1024})
         for (int g : {1, 2, 4}) {
             std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(\n", b, g);

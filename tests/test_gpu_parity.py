@@ -21,7 +21,8 @@ SUM_RTOL = 1e-10
 # with four (what very small scans run)
 # (pass kernel, workgroup size[, sub-lanes per query[, bucket sharing]])
 VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 64, 1), (3, 128, 1), (3, 256, 1), (3, 64, 4), (3, 256, 4),
-            (3, 64, 2, 1), (3, 128, 2, 1), (3, 256, 2, 1), (3, 64, 2, 0), (3, 256, 2, 0)]
+            (3, 64, 2, 1), (3, 128, 2, 1), (3, 256, 2, 1), (3, 64, 2, 0), (3, 256, 2, 0),
+            (3, 64, 1, None, 2), (3, 128, 1, None, 2), (3, 256, 1, None, 2)]  # (.., 2): the two-voxels-per-round build
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +46,7 @@ def test_reference_build_is_present():
     ref()
 
 
-def _reg(kernel, block, lanes=None, split=None, **kw):
+def _reg(kernel, block, lanes=None, split=None, latency=None, **kw):
     reg = K.KinematicRegistration(**kw)
     reg.set_option("pass_kernel", kernel)
     reg.set_option("block", block)
@@ -53,6 +54,8 @@ def _reg(kernel, block, lanes=None, split=None, **kw):
         reg.set_option("lanes_per_query", lanes)
     if split is not None:
         reg.set_option("split_buckets", split)
+    if latency is not None:
+        reg.set_option("latency_kernel", latency)
     return reg
 
 
@@ -368,6 +371,37 @@ def test_batch_call_equals_a_loop_of_single_calls(case1):
     b2 = reg.prepare_batch([empty, frames[0]], [items[0][1], items[0][1]], [items[0][2], items[0][2]])
     out2 = reg.ComputeRobotMotionBatch(b2, gmap, tau)
     assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES and np.isnan(out2[0]).any() and np.array_equal(out2[1], single[0])
+
+
+def test_concurrent_lanes_equal_the_sequential_batch(case1):
+    """kicp_register_device_concurrent (independent scans, several in flight, one host thread and one handle per lane): every
+    pose and iteration count equals the sequential batch's, bit for bit, for 1, 2, 3 and 8 lanes, with scans of both the
+    small-scan and the generic path mixed; the argument checks."""
+    cfg, scans, gmap, omap = case1
+    tau = cfg.first_frame_tau()
+    rng = np.random.default_rng(3)
+    items = []
+    for k in range(40):
+        s = scans[k % 3]
+        rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(rng.uniform(-0.15, 0.15), 0.0, np.deg2rad(rng.uniform(-1.0, 1.0))))
+        items.append((s["frame"][:(900 if k % 5 == 0 else len(s["frame"]))], s["last_pose"], rel))
+    frames = [K.DeviceFrame(f) for f, _, _ in items]
+    regs = [K.KinematicRegistration() for _ in range(8)]
+    batch = regs[0].prepare_batch(frames, [i[1] for i in items], [i[2] for i in items])
+    want, want_it = regs[0].ComputeRobotMotionBatch(batch, gmap, tau).copy(), batch.iterations.copy()
+    assert max(want_it) > 2 and min(want_it) >= 1
+    for lanes in (1, 2, 3, 8):
+        batch.out[:] = 0.0
+        batch.iterations[:] = 0
+        out = regs[0].ComputeRobotMotionConcurrent(regs[1:lanes], batch, gmap, tau)
+        assert np.array_equal(out, want) and np.array_equal(batch.iterations, want_it), lanes
+    with pytest.raises(K.KicpError) as e:  # a handle may serve one lane only
+        regs[0].ComputeRobotMotionConcurrent([regs[1], regs[1]], batch, gmap, tau)
+    assert e.value.code == K.KICP_ERR_ARG
+    # a frame without points: the warning code comes back, the other scans are unaffected
+    b2 = regs[0].prepare_batch([K.DeviceFrame(np.zeros((0, 3))), frames[1], frames[2]], [items[0][1], items[1][1], items[2][1]], [items[0][2], items[1][2], items[2][2]])
+    out2 = regs[0].ComputeRobotMotionConcurrent(regs[1:3], b2, gmap, tau)
+    assert regs[0].last_status == K.KICP_WARN_NO_CORRESPONDENCES and np.isnan(out2[0]).any() and np.array_equal(out2[1:], want[1:3])
 
 
 def test_aql_dispatch_equals_hip_launch(case1):

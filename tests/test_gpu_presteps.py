@@ -7,6 +7,7 @@ import pytest
 
 import kinematic_icp_amd as K
 from kinematic_icp_amd import synthetic as syn
+from boundary_case import boundary_frame, EXT, REL
 from oracle import okicp, rkicp
 
 pytestmark = pytest.mark.gpu
@@ -99,3 +100,35 @@ def test_presteps_feed_registration_without_leaving_the_gpu(raw):
     src = okicp.voxel_downsample(okicp.voxel_downsample(okicp.se3_act(ext, frame), 0.5), 1.5)
     ref = okicp.KinematicRegistration().ComputeRobotMotion(src, omap, s["last_pose"], s["rel_odom"], cfg.first_frame_tau())
     np.testing.assert_allclose(a, ref, rtol=0, atol=1e-9)
+
+
+def test_decisions_next_to_a_boundary_equal_the_reference_builds():
+    """points the reference build's deskew puts within 1e-12 / 1e-11 / 1e-9 m of max_range, min_range or a
+    face of the 0.5 * voxel_size grid are cropped / kept / deduplicated by the device exactly as by the reference build."""
+    if not rkicp.available():
+        pytest.skip("oracle/_ref not built")
+    max_range, min_range, v = 30.0, 3.0, 0.5
+    ext, rel = EXT, REL
+    raw, ts, kind = boundary_frame(rel, ext, max_range, min_range, v, (1e-12, 1e-11, 1e-9))
+    # where the reference build really put them
+    d = rkicp.preprocess(raw, ts, rel, 1e300, -1.0, True)
+    r = np.sqrt((d * d).sum(axis=1))
+    off = np.minimum(np.abs(r - max_range), np.abs(r - min_range))[kind == 0]
+    assert (off < 3e-9).all() and (off[:48] < 3e-12).all() and (off[:48] > 2e-13).all()  # the 1e-12 groups sit where intended
+    base = rkicp.se3_act(ext, d)
+    g = base[kind == 2] / v
+    face_off = np.abs(g - np.rint(g)).min(axis=1) * v
+    assert (face_off[:36] < 3e-12).all() and (face_off[:36] > 2e-13).all()
+    ref_kept = rkicp.preprocess(raw, ts, rel, max_range, min_range, True)
+    ref_base = rkicp.se3_act(ext, ref_kept)
+    ref_down = rkicp.voxel_downsample(ref_base, v)
+    n_ring = int((kind == 0).sum())
+    assert n_ring // 2 - 12 < len(ref_kept) - int((kind != 0).sum()) < n_ring // 2 + 12  # about half of the ring points fall on either side
+    assert len(ref_down) < len(ref_kept)  # some boundary points were on the + side and lost to their companion
+    pre = K.PreSteps()
+    n = pre.Preprocess(raw, ts, rel, ext, max_range, min_range, 1, dst=0)
+    assert n == len(ref_kept)
+    np.testing.assert_allclose(pre.download(0), ref_base, rtol=0, atol=1e-11)  # the same points survive, in the same order
+    nd = pre.VoxelDownsample(0, v, 1)
+    assert nd == len(ref_down)
+    np.testing.assert_allclose(pre.download(1), ref_down, rtol=0, atol=1e-11)

@@ -84,6 +84,23 @@ def test_host_drop_in_preprocess_matches_the_oracle(tmp_path):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
 
 
+def test_host_drop_in_preprocess_next_to_the_crop_radii_equals_the_reference_build(tmp_path):
+    """The host twin runs the reference's operation sequence on the host libm, so on points the reference build's deskew puts
+    within 1e-12 m of max_range / min_range (tests/boundary_case.py) it keeps the very same points, bit for bit."""
+    from oracle import rkicp
+    if not rkicp.available():
+        pytest.skip("oracle/_ref not built")
+    from boundary_case import boundary_frame, EXT, REL
+    exe = str(tmp_path / "host_filter")
+    _build_host_filter(exe)
+    raw, ts, kind = boundary_frame(REL, EXT, 30.0, 3.0, 0.5, (1e-12, 1e-11, 1e-9))
+    np.ascontiguousarray(raw).tofile(tmp_path / "p.bin"), ts.tofile(tmp_path / "t.bin"), REL.tofile(tmp_path / "r.bin")
+    got = np.frombuffer(subprocess.check_output([exe, "preprocess", str(tmp_path / "p.bin"), str(tmp_path / "t.bin"), str(tmp_path / "r.bin"), "30", "3", "1"]),
+                        dtype=np.float64).reshape(-1, 3)
+    want = rkicp.preprocess(raw, ts, REL, 30.0, 3.0, True)
+    assert 0 < len(want) < len(raw) and np.array_equal(got, want)
+
+
 def test_host_drop_in_threshold_reproduces_the_reference_builds_sequence(tmp_path):
     """kinematic_icp::CorrespondenceThreshold of the drop-in headers (host scalar code, SURVEY.md section 8f row 4) on the error
     sequence frozen in tests/golden/ref_outputs.npz: the taus the reference build's CorrespondenceThreshold.cpp returned."""
