@@ -467,6 +467,10 @@ class PreSteps:
             _lib.kicp_pre_destroy(self._h)
             self._h = None
 
+    def last_max_probe(self):
+        """Largest robin-hood displacement the last VoxelDownsample's replay saw (kicp_pre_last_max_probe)."""
+        return int(lib().kicp_pre_last_max_probe(self._h))
+
     def Preprocess(self, frame, timestamps, relative_motion, lidar_to_base, max_range, min_range, deskew, dst=0):
         a, p = _d(frame)
         t, tp = _d(timestamps if timestamps is not None else np.zeros(0))

@@ -307,15 +307,57 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     hipStream_t st = nullptr;
     UpdateParams up{};
     DevMapCounters c{};
-    for (int attempt = 0;; ++attempt) {
-        // ... and <= n new table entries without leaving the probing regime: re-hash (on the device) when the table is short
-        if ((map->dev.n_entries + n) * 2 > mr.live_slots)
-            if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
+    auto bind = [&]() {
         const size_t slots = mr.live_slots, bucket_cap = mr.pool_doubles / (static_cast<size_t>(cap) * 3);
         up.m = DevMap{mr.d_table, mr.d_keys64, static_cast<uint32_t>(slots - 1), mr.d_pool, mr.d_pool16, cap, map->host.count_bits(), static_cast<uint32_t>(bucket_cap),
                       map->host.voxel_size(), map->host.max_distance(), mr.d_free_list, mr.d_cnt, mr.d_seg_start, mr.d_ctr};
         up.in = d_points, up.n = static_cast<uint32_t>(n), up.pose = pose, up.world = mr.d_world, up.slot_of = mr.d_slot_of, up.order = mr.d_order;
         up.touched = mr.d_touched;
+    };
+    // steps 3, 4 and the far-voxel sweep; `touched_bound`: the number of touched voxels, or an upper bound of it (the kernels
+    // read the exact number on the device)
+    auto enqueue_apply = [&](size_t touched_bound) {
+        hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
+        if (touched_bound <= 16384 && cap <= kApplyMaxPoints)  // a frame's worth of voxels: one wave each; bulk insertions: one thread each (kicp_mapdev.hpp steps 4 / 4b)
+            hipLaunchKernelGGL(k_up_apply, dim3(static_cast<uint32_t>((touched_bound + kApplyWaves - 1) / kApplyWaves)), dim3(64 * kApplyWaves), 0, st, up);
+        else
+            hipLaunchKernelGGL(k_up_apply_thread, dim3(static_cast<uint32_t>((touched_bound + 63) / 64)), dim3(64), 0, st, up);
+        if (remove_origin)
+            hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((mr.live_slots / 4 + 255) / 256, 8192))), dim3(256), 0, st, up.m,
+                               remove_origin[0], remove_origin[1], remove_origin[2]);
+    };
+    // ... and <= n new table entries without leaving the probing regime: re-hash (on the device) when the table is short
+    if ((map->dev.n_entries + n) * 2 > mr.live_slots)
+        if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
+    // Every touched voxel that holds no point yet - a fresh entry or a halo entry that existed before - may become occupied in
+    // k_up_apply and then adds up to 26 halo entries of its own; the update only goes ahead with that head-room (load factor
+    // <= 0.75 in the worst case, so that no probe sequence can run away).  With room for the worst case - every point a new voxel
+    // with 26 new neighbours - nothing has to be asked of the device in between and the update is ONE queue of kernels behind
+    // one synchronisation; a claim step that gives up (voxel coordinate out of range) turns the later steps into no-ops.
+    if (n <= 16384 && (map->dev.n_entries + 27ull * n) * 4 <= mr.live_slots * 3ull) {
+        bind();
+        HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
+        hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
+        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
+        enqueue_apply(n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        map->device_ahead = true;
+        map->dev = c;
+        if (c.error == 3) return fail(KICP_ERR_CAPACITY, "device-side map update: voxel table full");
+        if (c.error == 1) {  // (see below: the host map takes over)
+            map->host_updates_only = true;
+            return host_fallback();
+        }
+        if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
+        map->last_update_on_device = 1;
+        return KICP_OK;
+    }
+    for (int attempt = 0;; ++attempt) {
+        if (attempt == 0 && (map->dev.n_entries + n) * 2 > mr.live_slots)
+            if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
+        bind();
         HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
         hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
         hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
@@ -331,25 +373,14 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
             map->dev = c;
             return host_fallback();
         }
-        // Every touched voxel that holds no point yet - a fresh entry or a halo entry that existed before - may become
-        // occupied in k_up_apply and then adds up to 26 halo entries of its own: only continue with that head-room
-        // (load factor <= 0.75 in the worst case, so that no probe sequence can run away).
         map->dev = c;
-        if ((c.n_entries + 26ull * c.may_occupy) * 4 <= slots * 3) break;
+        if ((c.n_entries + 26ull * c.may_occupy) * 4 <= mr.live_slots * 3ull) break;
         if (attempt) return fail(KICP_ERR_CAPACITY, "device-side map update found no room after a re-hash");
         // Too tight.  The entries just claimed are still plain halo entries without an occupied neighbour, so a re-hash drops
         // them together with the per-slot counters of this attempt; then claim again in the larger table.
         if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
     }
-    const size_t slots = mr.live_slots;
-    hipLaunchKernelGGL(k_up_scatter, dim3(grid), dim3(256), 0, st, up);
-    if (c.touched <= 16384 && cap <= kApplyMaxPoints)  // a frame's worth of voxels: one wave each; bulk insertions: one thread each (kicp_mapdev.hpp steps 4 / 4b)
-        hipLaunchKernelGGL(k_up_apply, dim3((c.touched + kApplyWaves - 1) / kApplyWaves), dim3(64 * kApplyWaves), 0, st, up);
-    else
-        hipLaunchKernelGGL(k_up_apply_thread, dim3((c.touched + 63) / 64), dim3(64), 0, st, up);
-    if (remove_origin)
-        hipLaunchKernelGGL(k_up_remove, dim3(static_cast<uint32_t>(std::min<size_t>((slots / 4 + 255) / 256, 8192))), dim3(256), 0, st, up.m,
-                           remove_origin[0], remove_origin[1], remove_origin[2]);
+    enqueue_apply(c.touched);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

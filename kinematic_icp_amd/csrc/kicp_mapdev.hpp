@@ -104,6 +104,14 @@ static __global__ __launch_bounds__(256) void k_build_keys64(const Slot *table, 
     }
 }
 
+// The later steps of an update that the claim step gave up on (a voxel coordinate out of the packable range: error 1; table
+// full: 3) do nothing - with a single host synchronisation per update the host only learns of it at the end.  (Error 2 is
+// raised inside step 4 itself and is not a reason for its other waves to stop.)
+__device__ __forceinline__ bool claim_failed(const DevMap &m) {
+    const uint32_t err = m.ctr->error;
+    return err == 1u || err == 3u;
+}
+
 // 1. transform, find/claim the voxel's slot, count the voxel's new points
 static __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -127,19 +135,33 @@ static __global__ __launch_bounds__(256) void k_up_claim(const UpdateParams p) {
 // 2. exclusive scan of the touched voxels' counts -> group starts; counts are zeroed to serve as fill cursors.  Also counts
 //    the touched voxels that hold no point yet (fresh entries and halo entries alike): each of them may become occupied
 //    in step 4 and then insert up to 26 halo entries of its own - the head-room the host checks before going on.
+//    One workgroup; a frame's worth of touched voxels (<= 8 192) is ONE chunk: every thread fetches its eight voxels' counts
+//    up front - the loads of a chunk are independent of the carry, so their latency is paid once, not once per 1 024 voxels
+//    (12 us -> ~4 us per frame-sized update).
+constexpr int kScanPerThread = 8;
 static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    // (runs even when the claim step gave up: it leaves the per-slot counters clean)
     const uint32_t n_touched = p.m.ctr->touched;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     uint32_t may_become_occupied = 0;
     __syncthreads();
-    for (uint32_t j0 = 0; j0 < n_touched; j0 += 1024) {
-        const uint32_t j = j0 + threadIdx.x;
-        uint32_t h = 0, c = 0;
-        if (j < n_touched) h = p.touched[j], c = p.m.cnt[h], may_become_occupied += val_count(p.m.table[h].val, p.m.cbits) == 0u ? 1u : 0u;
-        uint32_t incl = c;
+    for (uint32_t j0 = 0; j0 < n_touched; j0 += 1024 * kScanPerThread) {
+        // thread t owns the kScanPerThread consecutive voxels from j0 + t * kScanPerThread
+        const uint32_t first = j0 + threadIdx.x * kScanPerThread;
+        uint32_t h[kScanPerThread], c[kScanPerThread];
+#pragma unroll
+        for (int u = 0; u < kScanPerThread; ++u) h[u] = first + u < n_touched ? p.touched[first + u] : kNoSlot;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < kScanPerThread; ++u) {
+            c[u] = 0;
+            if (h[u] != kNoSlot) c[u] = p.m.cnt[h[u]], may_become_occupied += val_count(p.m.table[h[u]].val, p.m.cbits) == 0u ? 1u : 0u;
+            mine += c[u];
+        }
+        uint32_t incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(incl, off, 64);
@@ -149,7 +171,12 @@ static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
         __syncthreads();
         uint32_t before = s_carry;
         for (int w = 0; w < wave; ++w) before += s_wave[w];
-        if (j < n_touched) p.m.seg_start[h] = before + incl - c, p.m.cnt[h] = 0;
+        uint32_t at = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < kScanPerThread; ++u) {
+            if (h[u] != kNoSlot) p.m.seg_start[h[u]] = at, p.m.cnt[h[u]] = 0;
+            at += c[u];
+        }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = before + incl;
         __syncthreads();
@@ -162,7 +189,7 @@ static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
 // 3. scatter the point indices into their voxel's group (any order; the apply step walks a group by ascending index)
 static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+    if (i >= p.n || claim_failed(p.m)) return;
     const uint32_t h = p.slot_of[i];
     if (h == kNoSlot) return;
     p.order[p.m.seg_start[h] + atomicAdd(p.m.cnt + h, 1u)] = i;
@@ -181,7 +208,7 @@ static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const Upda
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * kApplyWaves + wave;
     const DevMap &m = p.m;
-    if (t >= m.ctr->touched) return;  // (wave-uniform)
+    if (t >= m.ctr->touched || claim_failed(m)) return;  // (wave-uniform)
     const uint32_t h = p.touched[t];
     const uint32_t g = m.cnt[h], start = m.seg_start[h];
     Slot &e = m.table[h];
@@ -261,7 +288,7 @@ static __global__ __launch_bounds__(64 * kApplyWaves) void k_up_apply(const Upda
 static __global__ __launch_bounds__(64) void k_up_apply_thread(const UpdateParams p) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     const DevMap &m = p.m;
-    if (t >= m.ctr->touched) return;
+    if (t >= m.ctr->touched || claim_failed(m)) return;
     const uint32_t h = p.touched[t];
     const uint32_t g = m.cnt[h], start = m.seg_start[h];
     m.cnt[h] = 0;  // leave the per-slot scratch clean for the next update
@@ -332,6 +359,7 @@ static __global__ __launch_bounds__(64) void k_up_apply_thread(const UpdateParam
 //    the entries that exist are looked at, and only the occupied ones touch the point pool.  (Sweeping the slots themselves
 //    took 0.7 ms per update on cfg2's 2M-slot table - the largest single item of a frame's map update.)
 static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double ox, double oy, double oz) {
+    if (claim_failed(m)) return;
     const uint32_t slots = m.mask + 1;
     const double max_distance2 = m.max_distance * m.max_distance;
     const ulonglong2 *keys2 = reinterpret_cast<const ulonglong2 *>(m.keys64);
