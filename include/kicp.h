@@ -296,10 +296,13 @@ int kicp_reg_comm_destroy(kicp_reg *reg);
 int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name);
 int kicp_reg_shm_destroy(kicp_reg *reg);
 /* One-shot exchange over peer mappings: no collective library, no host shared segment.  Every
- * rank (one process per GPU) owns a mailbox in its HBM; the last workgroup of every pass kernel writes the rank's 24 exact
- * limb totals - tagged - into ALL ranks' mailboxes (the peers' through IPC mappings: stores over xGMI), collects the
- * nranks slots of its own mailbox, adds them in rank order (integers: bit-identical on every rank) and hands the totals
- * to its host, which solves.  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
+ * rank (one process per GPU) owns a mailbox in its HBM.  The pass kernel's first reduction level ends in groups of 32
+ * workgroups; the last workgroup of every group writes the group's row of 24 exact limb sums - tagged - into ALL ranks'
+ * mailboxes (the peers' through IPC mappings: stores over xGMI), and the last workgroup of group 0 adds the rows of all
+ * ranks' groups as they arrive in its own mailbox (integers, fixed order: bit-identical on every rank) and hands the totals
+ * to its host, which solves - no second reduction level, no collective.  (A launch of more than 32 groups - 262 144 lanes
+ * per rank - reduces on two levels and sends one row.  Option "p2p_rows" = 0, on EVERY rank, selects round 2's format: the
+ * launch's last workgroup exchanges the rank's totals.)  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
  * transport), every rank calls kicp_reg_p2p_connect with the nranks handles in rank order; a barrier between connect and
  * the first registration, and before kicp_reg_p2p_destroy, is the caller's.  nranks <= KICP_P2P_MAX_RANKS.
  * Recovery contract: the ranks stay in step only while every exchange completes on every rank.  When a registration fails

@@ -98,11 +98,21 @@ struct SolveParams {
     int32_t p2p_nranks, p2p_rank;
     uint32_t p2p_tag;     // 1..65535 (step % 65535 + 1); double-buffered by p2p_parity, so a stale slot can never match
     uint32_t p2p_parity;  // step & 1
+    // mode 6: as 5 without the second reduction level - the last workgroup of every first-level group writes the group's row
+    // into every rank's mailbox itself, and the last workgroup of group 0 adds ALL ranks' group rows (its own rank's included,
+    // in rank and group order) as they arrive.  For launches of at most kP2pMaxGroups groups; a larger launch reduces on two
+    // levels as mode 5 does and sends its total as a single row (mode 7), so ranks on either side of the limit still pair up.
     long long p2p_timeout_ticks;  // 100 MHz ticks a rank waits for its peers' slots (derived from the host's KICP_WAIT_TIMEOUT_S)
 };
 // a rank's mailbox: [2 parities][nranks][kP2pWords] tagged words; a 64-bit total travels as two tagged 32-bit halves
 constexpr int kP2pWords = 2 * 24;
 constexpr int kP2pMaxRanks = 16;
+// ... followed by the area of mode 6: [2 parities][nranks][kP2pMaxGroups] rows of 24 tagged words (value << 16 | tag, like the
+// rows of mode 4) - the first-level GROUP rows of every rank, written by the groups' last workgroups themselves
+constexpr int kP2pMaxGroups = 32;  // <= 1024 workgroups per rank and launch; larger launches exchange totals (mode 5)
+constexpr int kP2pCountWord = 23;  // word of a row that carries the sender's group count (padding in the single-GPU layout)
+KICP_HD size_t p2p_rows_offset(int nranks) { return 2 * static_cast<size_t>(nranks) * kP2pWords; }
+KICP_HD size_t p2p_box_words(int nranks) { return p2p_rows_offset(nranks) + 2 * static_cast<size_t>(nranks) * kP2pMaxGroups * 24; }
 
 // Wave-uniform numbers of the pre-selection over the 16-bit mirror, computed once per call on the host (search_params()).
 struct SearchParams {
@@ -491,6 +501,74 @@ __device__ __forceinline__ long long p2p_exchange(const SolveParams &f, long lon
     return sum;
 }
 
+// mode 6, the last workgroup of group 0 (wave 0): add every rank's group rows out of this rank's mailbox.  Lanes r < nranks first
+// learn rank r's group count (word kP2pCountWord of its row 0); then all rows are fetched the way sum_rows_tagged does it - 48
+// lanes, 16 loads each in flight, 32 rows per round over the flattened (rank, group) index - and re-fetched until every word
+// carries the tag.  Returns the node-wide totals in lanes 0..23; lane kNumLimbs + 1 is set to 1 when a row did not arrive in time.
+__device__ __forceinline__ long long p2p_collect_rows(const SolveParams &f, int lane) {
+    const uint32_t nr = static_cast<uint32_t>(f.p2p_nranks), tag = f.p2p_tag;
+    const unsigned long long *box = f.p2p_peers[f.p2p_rank] + p2p_rows_offset(f.p2p_nranks) +
+                                    static_cast<size_t>(f.p2p_parity) * nr * kP2pMaxGroups * kReduceWords;
+    const long long t0 = wall_clock64();
+    int late = 0;
+    uint32_t count = 0;
+    if (static_cast<uint32_t>(lane) < nr) {
+        for (;;) {
+            const unsigned long long got = __hip_atomic_load(box + static_cast<size_t>(lane) * kP2pMaxGroups * kReduceWords + kP2pCountWord, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((static_cast<uint32_t>(got) & 0xFFFFu) == tag) {
+                count = min(static_cast<uint32_t>(got >> 16), static_cast<uint32_t>(kP2pMaxGroups));
+                break;
+            }
+            if (wall_clock64() - t0 > f.p2p_timeout_ticks) {
+                late = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    late = __any(late) ? 1 : 0;
+    uint32_t widest = count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) widest = max(widest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(widest), off, 64)));
+    long long sum = 0;
+    const int word = lane % kReduceWords;
+    const uint32_t phase = static_cast<uint32_t>(lane / kReduceWords);  // lanes 0..23 take the even rows of a round, 24..47 the odd ones
+    for (uint32_t v0 = 0; v0 < nr * widest && !late; v0 += kGroup) {
+        for (;;) {
+            bool ok = true;
+            long long part = 0;
+            unsigned long long t[kGroup / 2];
+#pragma unroll
+            for (int u = 0; u < kGroup / 2; ++u) {
+                const uint32_t v = v0 + phase + 2 * u, r = v / widest, j = v % widest;  // (widest >= 1 here)
+                const uint32_t rows_of_r = static_cast<uint32_t>(__shfl(static_cast<int>(count), static_cast<int>(min(r, nr - 1u)), 64));  // (every lane takes part)
+                const bool want = lane < 2 * kReduceWords && r < nr && j < rows_of_r;
+                t[u] = want ? __hip_atomic_load(box + (static_cast<size_t>(r) * kP2pMaxGroups + j) * kReduceWords + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : static_cast<unsigned long long>(tag);
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup / 2; ++u) {
+                ok = ok && (static_cast<uint32_t>(t[u]) & 0xFFFFu) == tag;
+                part += static_cast<long long>(t[u]) >> 16;
+            }
+            if (__all(ok)) {
+                sum += part;
+                break;
+            }
+            if (wall_clock64() - t0 > f.p2p_timeout_ticks) {
+                late = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    sum += __shfl_down(sum, kReduceWords, 64);
+    if (lane == kP2pCountWord) sum = 0;  // (the counts are not part of the payload)
+    if (lane == kNumLimbs + 1) sum = late;
+    return sum;
+}
+
 // Sum of a 32-bit value over the wave with DPP adds only (no LDS crossbar): inclusive scan inside each row of 16 lanes
 // (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of row 0 / 2 is added to every lane of
 // row 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).  LANE 63 holds the wave total.
@@ -543,7 +621,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
-    if (p.sol.mode == 4) {
+    if (p.sol.mode == 4 || p.sol.mode == 6) {
         // Tagged rows: no store acknowledgement is awaited anywhere.  The ticket only elects the group's reader; whether
         // a row has landed is visible in the row itself.  Values: limbs < 2^40 (the top limb is a small signed number
         // within the documented range), so value << 16 | tag fits a word, and so does the sum of a group's 32 rows.
@@ -567,9 +645,26 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         do {
             total = sum_rows_tagged(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
         } while (!__all(ok));
-        if (lane < kReduceWords)
-            __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(g) * kReduceWords + lane, (static_cast<unsigned long long>(total) << 16) | tag,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.sol.mode == 4) {
+            if (lane < kReduceWords)
+                __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(g) * kReduceWords + lane, (static_cast<unsigned long long>(total) << 16) | tag,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        // mode 6: the group's row goes into EVERY rank's mailbox (over xGMI for the peers'), tagged with the step
+        const SolveParams &f = p.sol;
+        if (lane < kReduceWords) {
+            const unsigned long long value = lane == kP2pCountWord ? static_cast<unsigned long long>(ngroups) : static_cast<unsigned long long>(total);
+            const unsigned long long w = (value << 16) | f.p2p_tag;
+            const size_t at = p2p_rows_offset(f.p2p_nranks) + ((static_cast<size_t>(f.p2p_parity) * f.p2p_nranks + f.p2p_rank) * kP2pMaxGroups + g) * kReduceWords + lane;
+            for (int r = 0; r < f.p2p_nranks; ++r) __hip_atomic_store(f.p2p_peers[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (g != 0) return;
+        // group 0's last workgroup collects for this rank and hands the node-wide totals to its host (as mode 5 does)
+        const long long all = p2p_collect_rows(f, lane);
+        if (lane < kReduceWords) __hip_atomic_store(f.pub_words + lane, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(f.pub_seq, f.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     if (lane < kNumSums) {
@@ -603,11 +698,35 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     }
     // ---- last workgroup of the launch ------------------------------------------------------------------------
     if (p.sol.mode == 5) total = p2p_exchange(p.sol, total, lane);
+    if (p.sol.mode == 7) {
+        // Group rows are what the ranks exchange (mode 6), but this launch has more groups than a rank's share of the mailbox
+        // holds: its total travels as ONE row.  A row's words carry 48 bits, so the limb sums are brought back into limb range
+        // first (lane 3i + j: limb j of sum i).
+        const SolveParams &f = p.sol;
+        const int i3 = 3 * (min(lane, kNumLimbs - 1) / 3);
+        const unsigned long long a = static_cast<unsigned long long>(__shfl(total, i3, 64)), b = static_cast<unsigned long long>(__shfl(total, i3 + 1, 64));
+        const long long c = __shfl(total, i3 + 2, 64);
+        I128 t{a, 0ll};
+        i128_add(t, I128{b << 40, static_cast<long long>(b >> 24)});  // (the two lower limb sums are non-negative)
+        t.hi += c << 16;
+        long long l[3];
+        i128_to_limbs(t, l);
+        const int j = lane % 3;
+        long long word = j == 0 ? l[0] : (j == 1 ? l[1] : l[2]);
+        if (lane >= kNumLimbs) word = lane == kNumLimbs ? (total != 0 ? 1 : 0) : 0;  // the range flag as 0 / 1
+        if (lane < kReduceWords) {
+            const unsigned long long value = lane == kP2pCountWord ? 1ull : static_cast<unsigned long long>(word);
+            const unsigned long long w = (value << 16) | f.p2p_tag;
+            const size_t at = p2p_rows_offset(f.p2p_nranks) + ((static_cast<size_t>(f.p2p_parity) * f.p2p_nranks + f.p2p_rank) * kP2pMaxGroups) * kReduceWords + lane;
+            for (int r = 0; r < f.p2p_nranks; ++r) __hip_atomic_store(f.p2p_peers[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        total = p2p_collect_rows(f, lane);
+    }
     if (lane < kReduceWords) st->reduce[lane] = total;
     long long limbs[kNumLimbs + 1];
 #pragma unroll
     for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
-    if (p.sol.mode == 2 || p.sol.mode == 5) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
+    if (p.sol.mode == 2 || p.sol.mode == 5 || p.sol.mode == 7) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
         if (lane < kReduceWords) __hip_atomic_store(p.sol.pub_words + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(p.sol.pub_seq, p.sol.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -130,6 +130,8 @@ struct kicp_reg {
     // one-shot exchange over peer mappings (kicp_reg_p2p_*): this rank's mailbox in its own HBM (fine-grained), the peers'
     // mailboxes as IPC mappings, and the table of all of them the pass kernel reads
     unsigned long long *p2p_box = nullptr;
+    int p2p_rows = 1;  // peer mailboxes, wire format (the same on every rank): 1 the first-level group rows themselves - a launch of more than
+                       // kP2pMaxGroups groups sends its total as one row -, 2 always that single row, 0 the totals as tagged halves (round 2's)
     void *p2p_mapped[kP2pMaxRanks] = {};
     unsigned long long **d_p2p_table = nullptr;
     unsigned long long p2p_step = 0;  // exchanges issued so far (same on every rank)
@@ -832,7 +834,11 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         for (int it = 0; it < max_it; ++it) {
             ++passes_run;
             const bool rows_mode = !multi && !p2p && r->group_rows != 0;
-            sp.pass = it, sp.pose0 = loop.T, sp.mode = multi ? 3 : (p2p ? 5 : (rows_mode ? 4 : 2));
+            const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
+            // peer mailboxes: the groups' rows travel themselves when the launch has few enough of them (one reduction level less)
+            // (every rank must use the same wire format - option "p2p_rows" - but may be on either side of the group limit)
+            const bool p2p_rows = p2p && r->p2p_rows == 1 && groups <= static_cast<size_t>(kP2pMaxGroups);  // (2: always the single row - tests)
+            sp.pass = it, sp.pose0 = loop.T, sp.mode = multi ? 3 : (p2p ? (p2p_rows ? 6 : (r->p2p_rows ? 7 : 5)) : (rows_mode ? 4 : 2));
             if (p2p) {  // every rank issues the same sequence of exchanges: the step number doubles as tag and buffer parity
                 const unsigned long long step = r->p2p_step++;
                 sp.p2p_peers = r->d_p2p_table, sp.p2p_nranks = r->nranks, sp.p2p_rank = r->rank;
@@ -855,11 +861,12 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
                 sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
                 sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
             }
-            const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
             if (rows_mode) {
                 if (int rc = ensure_rows(r, groups)) return rc;
                 if (int rc = next_tag(r, &sp.tag)) return rc;
                 sp.pub_rows = r->d_rows;
+            } else if (p2p_rows) {
+                if (int rc = next_tag(r, &sp.tag)) return rc;  // (the workgroups' rows inside a group are tagged like mode 4's)
             }
             const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
             if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
@@ -1008,6 +1015,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (const char *env = std::getenv("KICP_SMALL")) r->use_small = std::atoi(env) != 0;
     if (const char *env = std::getenv("KICP_SMALL_RESIDENT")) r->small_resident = std::atoi(env) != 0;
     if (const char *env = std::getenv("KICP_SMALL_CMD")) r->small_cmd = std::atoi(env) != 0;
+    if (const char *env = std::getenv("KICP_P2P_ROWS")) r->p2p_rows = std::atoi(env) == 2 ? 2 : (std::atoi(env) != 0 ? 1 : 0);
     *out = r;
     return KICP_OK;
 }
@@ -1064,6 +1072,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
+    else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
     else if (k == "timing") reg->timing = static_cast<int>(value);
@@ -1104,6 +1113,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "occupancy") return reg->occupancy;
+    if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
     if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
@@ -1438,7 +1448,7 @@ int kicp_reg_p2p_export(kicp_reg *reg, int nranks, int rank, char handle[KICP_P2
     if (reg->comm || reg->shm || reg->allreduce_fn) return fail(KICP_ERR_ARG, "another exchange is already attached");
     kicp_reg_p2p_destroy(reg);
     if (int rc = set_device(reg->device)) return rc;
-    const size_t bytes = 2 * static_cast<size_t>(nranks) * kP2pWords * sizeof(unsigned long long);
+    const size_t bytes = p2p_box_words(nranks) * sizeof(unsigned long long);  // totals area (mode 5) + group-row area (mode 6)
     // fine-grained: stores arriving from a peer GPU must be visible to a wave that is polling (no stale L2 line)
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&reg->p2p_box), bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {

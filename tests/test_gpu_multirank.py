@@ -170,12 +170,24 @@ def _p2p_worker(rank, world, barrier, handles, q):
         barrier.wait()
         reg.p2p_connect([handles[r] for r in range(world)])
         barrier.wait()
-        out = _run_cases(reg, world, rank)
+        out = _run_cases(reg, world, rank)  # default wire format: every first-level group's row goes to every rank
         # a second round on the same mailboxes (tags and buffer parity keep advancing), then the plain path after a detach
         out2 = _run_cases(reg, world, rank)
+        # more, smaller workgroups = more group rows per rank; a rank that sends its total as one row (what a launch beyond the
+        # mailbox's row limit does) pairs up with ranks that send group rows; round 2's totals-as-halves format
+        reg.set_option("block", 64), reg.set_option("lanes_per_query", 4)
+        out3 = _run_cases(reg, world, rank)
+        reg.set_option("block", 256), reg.set_option("lanes_per_query", 0)
+        if rank == 0:
+            reg.set_option("p2p_rows", 2)
+        out4 = _run_cases(reg, world, rank)
+        barrier.wait()
+        reg.set_option("p2p_rows", 0)
+        out5 = _run_cases(reg, world, rank)
         barrier.wait()
         reg.p2p_destroy()
-        assert all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(out, out2))
+        for other in (out2, out3, out4, out5):
+            assert all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(out, other))
         q.put((rank, out, None))
     except Exception as e:  # noqa: BLE001
         import traceback
