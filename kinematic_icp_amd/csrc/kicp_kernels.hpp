@@ -582,11 +582,16 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
     return v;
 }
 
-template <int BLOCK>
-__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag) {
+// `row_tag` (tagged-row modes): the tag of this pass - p.sol.tag for a kernel that runs one pass, tag0 + pass for the resident
+// kernel.  `gave_up` (resident kernel): this workgroup saw no command in time and hands over empty sums; the group row's flag
+// word counts such workgroups in its upper half (kGaveUpUnit each) so that the host repeats the pass in a fresh launch.
+constexpr unsigned long long kGaveUpUnit = 1ull << 16;
+// ROWS_ONLY: the caller only ever runs mode 4 (the resident kernel): none of the other hand-offs is compiled in.
+template <int BLOCK, bool ROWS_ONLY = false>
+__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag, uint32_t row_tag, int gave_up = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
-    if (p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
+    if (!ROWS_ONLY && p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
         if (p.sol.mode == 4 && wave == 0 && blockIdx.x % kGroup == 0 && lane < kReduceWords)
             __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(blockIdx.x / kGroup) * kReduceWords + lane, static_cast<unsigned long long>(p.sol.tag),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -621,18 +626,19 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
-    if (p.sol.mode == 4 || p.sol.mode == 6) {
+    if (ROWS_ONLY || p.sol.mode == 4 || p.sol.mode == 6) {
         // Tagged rows: no store acknowledgement is awaited anywhere.  The ticket only elects the group's reader; whether
         // a row has landed is visible in the row itself.  Values: limbs < 2^40 (the top limb is a small signed number
         // within the documented range), so value << 16 | tag fits a word, and so does the sum of a group's 32 rows.
-        const unsigned long long tag = p.sol.tag;
+        const unsigned long long tag = row_tag;
         if (lane < kNumSums) {
             long long l[3];
             i128_to_limbs(t, l);
 #pragma unroll
             for (int j = 0; j < 3; ++j) st_sc1(row + 3 * lane + j, (static_cast<unsigned long long>(l[j]) << 16) | tag);
         } else if (lane < kNumSums + 3) {
-            st_sc1(row + kNumLimbs + (lane - kNumSums), ((lane == kNumSums ? static_cast<unsigned long long>(range_error) : 0ull) << 16) | tag);
+            st_sc1(row + kNumLimbs + (lane - kNumSums),
+                   ((lane == kNumSums ? static_cast<unsigned long long>(range_error) + (gave_up ? kGaveUpUnit : 0ull) : 0ull) << 16) | tag);
         }
         unsigned int ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -645,7 +651,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         do {
             total = sum_rows_tagged(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
         } while (!__all(ok));
-        if (p.sol.mode == 4) {
+        if (ROWS_ONLY || p.sol.mode == 4) {
             if (lane < kReduceWords)
                 __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(g) * kReduceWords + lane, (static_cast<unsigned long long>(total) << 16) | tag,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
         }
     }
     if (BLOCK > 64) __syncthreads();
-    finish_pass<BLOCK>(acc, p, s_red, &s_flag);
+    finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1124,16 +1130,12 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // points each.
 // LAT (G == 1, built at two waves per SIMD): the latency-oriented build for scans that do not fill the machine beyond that
 // (<= 131 072 points on 256 CUs) - two neighbour voxels per round (visit_two).
-template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
-__global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
-    static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
-    static_assert(!LAT || G == 1, "the latency-oriented build serves one lane per query");
-    KICP_PASS_SHARED(BLOCK)
-    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
-    const Pose T = load_pose(p);
+// the search and the exact phase of one pass for lane `tid` of workgroup blockIdx.x; `acc` receives the lane's terms
+template <int BLOCK, int G, bool SPLIT, bool LAT>
+__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc) {
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
-    const uint32_t gt = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t gt = blockIdx.x * BLOCK + tid;
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
     const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
@@ -1179,10 +1181,19 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
         best3_merge(L.t, o);
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
-    Acc acc{};  // (declared here, not at the top: 28 registers that would otherwise stay live through the search)
     if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t);
+}
+template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
+__global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
+    static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
+    static_assert(!LAT || G == 1, "the latency-oriented build serves one lane per query");
+    KICP_PASS_SHARED(BLOCK)
+    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
+    const Pose T = load_pose(p);
+    Acc acc{};
+    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc);
     if (BLOCK > 64) __syncthreads();
-    finish_pass<BLOCK>(acc, p, s_red, &s_flag);
+    finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }
 
 // ------------------------------------------------------------------------------------------------------------

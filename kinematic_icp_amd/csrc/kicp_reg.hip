@@ -159,6 +159,8 @@ struct kicp_reg {
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
+    int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
+    int last_resident_passes = 0; // passes of the last call that a resident launch of the GENERIC kernel served (get-only "resident_passes")
     int small_prev_iters = 2;     // iterations of the previous small-path call: a scan that converged at once makes the next launch leave after its first pass
     long long *d_trace = nullptr; // option "small_trace": device buffer of the kernel's per-pass wall-clock stamps
     double trace_host_us = 0.0, trace_dev_us = 0.0, trace_first_us = 0.0;  // host: rows seen -> command sent; device: command sent -> rows seen; launch -> first rows
@@ -231,6 +233,7 @@ const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split, 
     std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s, %s>(", b, g, occ, split ? "true" : "false", lat ? "true" : "false");
     return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0) + (lat ? 2 : 0), name);
 }
+const AqlKernel *aql_resident_kernel_for(kicp_reg *r) { return aql_lookup(r, -7, "void kicp::k_pass_resident<256, 2, true>("); }
 const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
     if (wave) std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(", block);
@@ -490,6 +493,7 @@ struct SmallPlan {
     uint32_t grid = 0;
     int block = 256, g = 1;
     bool wave = false;
+    bool generic = false, lat = false;  // generic: the generic pass kernel, resident (k_pass_resident); rows = group rows
 };
 SmallPlan small_plan(const kicp_reg *r, size_t n) {
     SmallPlan pl;
@@ -505,8 +509,19 @@ SmallPlan small_plan(const kicp_reg *r, size_t n) {
     }
     pl.g = lanes_for(r, n), pl.block = r->small_block;
     const size_t lanes = n * static_cast<size_t>(pl.g);
-    if (lanes > static_cast<size_t>(kSmallMaxLanes)) return pl;
-    pl.grid = static_cast<uint32_t>((lanes + pl.block - 1) / pl.block);
+    if (lanes <= static_cast<size_t>(kSmallMaxLanes)) {
+        pl.grid = static_cast<uint32_t>((lanes + pl.block - 1) / pl.block);
+        return pl;
+    }
+    // larger scans: the generic kernel, resident while every workgroup fits on the device at once (one lane per query)
+    // (the latency-oriented build only: with 235 VGPRs it keeps everything in registers across the pass loop, the four-waves-per-
+    // SIMD build does not; two workgroups per CU)
+    pl.lat = r->latency_kernel != 0;
+    if (!pl.lat || !r->resident_generic || r->lanes_per_query > 1 || normalized_block(r->block) != 256 || r->occupancy != 4 ||
+        n > kLatencyMaxPoints * static_cast<size_t>(std::max(1, r->num_cus)) / 256)
+        return pl;  // (explicit kernel-shape options keep the plain kernel they name)
+    pl.generic = true, pl.g = 1, pl.block = 256;
+    pl.grid = static_cast<uint32_t>((n + 255) / 256);
     return pl;
 }
 int ensure_cmd(kicp_reg *r) {
@@ -565,7 +580,7 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
     const int b = pl.block, g = pl.g;
     const uint32_t grid = pl.grid;
     if (r->use_aql && !r->stream_dirty) {
-        if (const AqlKernel *k = aql_small_kernel_for(r, b, g, pl.wave)) {
+        if (const AqlKernel *k = pl.generic ? aql_resident_kernel_for(r) : aql_small_kernel_for(r, b, g, pl.wave)) {
             if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &sp, sizeof sp, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
                 r->last_via_aql = true;
                 return KICP_OK;
@@ -582,7 +597,8 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
         else if (g == 2) hipLaunchKernelGGL((k_pass_small<B, 2>), dim3(grid), dim3(B), 0, r->stream, sp); \
         else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
     } while (0)
-    if (b == 1024) KICP_SMALL(1024);
+    if (pl.generic) hipLaunchKernelGGL((k_pass_resident<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else if (b == 1024) KICP_SMALL(1024);
     else if (b == 512) KICP_SMALL(512);
     else KICP_SMALL(256);
 #undef KICP_SMALL
@@ -687,13 +703,21 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
               kicp_stats *stats) {
     const int max_it = r->cfg.max_num_iterations;
     const uint32_t grid = pl.grid;
-    if (int rc = ensure_rows(r, grid)) return rc;
+    // generic plan: a launch that will not stay goes out as the plain pass kernel (launch_pass, its own grid)
+    const size_t groups_resident = (grid + kGroup - 1) / kGroup, groups_plain = (pass_grid(r, n) + kGroup - 1) / kGroup;
+    if (pl.generic) {
+        if (int rc = ensure_partials(r, std::max<uint32_t>(grid, pass_grid(r, n)))) return rc;
+        if (int rc = ensure_rows(r, std::max(groups_resident, groups_plain))) return rc;
+    } else if (int rc = ensure_rows(r, grid)) {
+        return rc;
+    }
     if (int rc = ensure_cmd(r)) return rc;
     SmallParams sp{};
     PassParams &pp = sp.p;
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
+    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);  // 100 MHz wall clock
     HostLoop loop;
@@ -713,11 +737,25 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
         r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
         sp.trace = r->d_trace;
         auto t_sent = std::chrono::steady_clock::now();
-        if (int rc = launch_small(r, sp, pl)) return rc;
+        const bool plain = pl.generic && cnt == 1;
+        const int iter_at_launch = loop.iter;
+        if (plain) {
+            pp.sol.tag = sp.tag0;
+            if (int rc = launch_pass(r, pp, true)) return rc;
+        } else if (int rc = launch_small(r, sp, pl)) {
+            return rc;
+        }
         for (uint32_t k = 0; k < cnt; ++k) {
             long long words[kReduceWords];
             bool gave_up = false;
-            const int rc_rows = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up);
+            int rc_rows;
+            if (pl.generic) {
+                rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words);
+                gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 16) != 0ull;  // workgroups that left without a command (kGaveUpUnit each)
+                words[kNumLimbs] &= 0xFFFFll;
+            } else {
+                rc_rows = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up);
+            }
             const auto t_rows = std::chrono::steady_clock::now();
             if (r->d_trace) {
                 const double us = std::chrono::duration<double, std::micro>(t_rows - t_sent).count();
@@ -748,10 +786,11 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             }
             if (finished) break;
         }
+        if (pl.generic && !plain) r->last_resident_passes += loop.iter - iter_at_launch;
     }
     pose_to(loop.T, out_pose_qt);
     if (stats) stats->iterations = loop.iter, stats->converged = loop.converged, stats->beta = loop.beta;
-    r->last_small = pl.wave ? 2 : 1;
+    r->last_small = pl.generic ? 0 : (pl.wave ? 2 : 1);
     r->small_prev_iters = loop.iter;
     if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
     return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
@@ -786,7 +825,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     // their sequence word; the default tagged-row hand-offs and the small-scan path have no such limit)
     if (max_it > 0x7FFF && (!r->host_solve || r->group_rows == 0 || multi || p2p))
         return fail(KICP_ERR_ARG, "max_num_iterations > 32767 with a single-record hand-off (host_solve = 0, group_rows = 0, RCCL / callback / peer-mailbox exchange)");
-    r->last_small = 0;
+    r->last_small = 0, r->last_resident_passes = 0;
     if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0) {
         const SmallPlan pl = small_plan(r, n);
         if (pl.grid) return run_small(r, map, d_frame, n, pl, T0, tau, out_pose_qt, stats);
@@ -1072,6 +1111,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
+    else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
@@ -1113,6 +1153,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
     if (k == "occupancy") return reg->occupancy;
+    if (k == "resident_generic") return reg->resident_generic;
+    if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
     if (k == "split_buckets") return reg->split_buckets;
@@ -1519,6 +1561,7 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
         std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(\n", b);
         all += name;
     }
+    all += "void kicp::k_pass_resident<256, 2, true>(\n";
     if (out && cap) {
         const size_t n = std::min(cap - 1, all.size());
         std::memcpy(out, all.data(), n);

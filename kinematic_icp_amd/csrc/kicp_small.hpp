@@ -81,6 +81,7 @@ __device__ __forceinline__ uint32_t fresh_tid() {
 // afresh).  Ends in a workgroup barrier.
 constexpr int kCmdReplicas = 64;         // copies of the command line ...
 constexpr int kCmdStrideWords = 544;     // ... 4352 bytes apart (4 KiB + 256 B), so that the pollers spread over memory channels
+template <bool MARK_ROWS = true>
 __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
     if ((tid >> 6) == 0) {
         const int lane = tid & 63;
@@ -100,7 +101,7 @@ __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t ti
             if ((ctrl >> 8) == want && ((ctrl & 0xFFull) == kCmdContinue || (ctrl & 0xFFull) == kCmdStop)) break;
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
-                if (lane < kSmallRowWords)
+                if (MARK_ROWS && lane < kSmallRowWords)
                     __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + lane,
                                        ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
@@ -216,6 +217,42 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[6])))};
         // (no barrier here: wave 0 reaches its next poll only through the two barriers of the next pass's epilogue)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_pass_resident: the GENERIC pass kernel (one lane per query, kicp_kernels.hpp) resident for the iterations of a call - scans
+// too large for the kernels above but small enough for every workgroup to be on the device at once (<= 512 workgroups of the
+// latency-oriented build, <= 1024 of the four-waves-per-SIMD build on 256 CUs).  Same search, same exact sums, same reduction:
+// tagged workgroup rows, a ticket per group of 32, the group's row to the host (finish_pass, mode 4) - with tag0 + pass as the
+// tag of pass `pass`.  What a pass after the first saves is the launch (doorbell -> packet -> dispatch of 2 048 waves, ~5 us)
+// against a polled command (~1.3 us).  A workgroup that sees no command in time hands over an EMPTY row marked kGaveUpUnit
+// for the pass it will not run - through the same group protocol, so the host finds the mark in the group's row - and leaves.
+template <int BLOCK, int OCC, bool LAT>
+__global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams /* read through fresh_args() */) {
+    __shared__ int s_red[BLOCK / 64][kWaveLimbs];
+    __shared__ int s_flag;
+    __shared__ unsigned long long s_cmd[kCmdWords];
+    Pose T = fresh_args().p.sol.pose0;
+    int gave_up = 0;  // (wave-uniform) no command arrived in time: this round only hands over the marked empty row
+    for (uint32_t pass = 0;; ++pass) {
+        const SmallParams &sp = fresh_args();
+        uint32_t tid = fresh_tid();
+        if (tid == 0) s_flag = 0;
+        Acc acc{};
+        if (!gave_up) gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc);
+        __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
+        finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up);
+        if (gave_up || pass + 1 >= sp.max_passes) return;
+        if (!await_command<false>(sp, fresh_tid(), pass, s_cmd)) {
+            if (static_cast<uint32_t>(s_cmd[7]) == kCmdStop) return;
+            gave_up = 1;
+            continue;
+        }
+        T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
+                 uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[6])))};
     }
 }
 

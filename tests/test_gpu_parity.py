@@ -373,6 +373,66 @@ def test_batch_call_equals_a_loop_of_single_calls(case1):
     assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES and np.isnan(out2[0]).any() and np.array_equal(out2[1], single[0])
 
 
+def test_resident_generic_kernel_equals_the_plain_launches(case1):
+    """Scans beyond the small-scan kernels (here 16 384 points) keep the generic kernel RESIDENT for a call's later iterations
+    (k_pass_resident, commands through the BAR): bits, iteration counts and per-iteration statistics equal one launch per
+    iteration (option small = 0) and the oracle; adaptive and forced residency; more iterations than one launch serves; a
+    host that is late with a command (the workgroups leave, the marked group rows make the host launch afresh); tag wrap."""
+    cfg, scans, gmap, omap = case1
+    tau = cfg.first_frame_tau()
+    rels = [syn.pose_mul(s["rel_odom"], syn.planar_pose(0.2, 0.0, np.deg2rad(1.5))) for s in scans]
+    frames = [K.DeviceFrame(s["frame"]) for s in scans]
+    plain = K.KinematicRegistration()
+    plain.set_option("small", 0)
+    want = [plain.ComputeRobotMotion(f, gmap, s["last_pose"], rel, tau) for f, s, rel in zip(frames, scans, rels)]
+    iters = []
+    for f, s, rel, w in zip(frames, scans, rels, want):
+        np.testing.assert_allclose(w, okicp.KinematicRegistration().ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau), rtol=0, atol=POSE_TOL)
+        plain.ComputeRobotMotion(f, gmap, s["last_pose"], rel, tau)
+        iters.append(plain.last_stats.iterations)
+    assert min(iters) > 2
+    for resident in (1, 2):
+        reg = K.KinematicRegistration()
+        reg.set_option("small_resident", resident)
+        for rounds in range(2):
+            for f, s, rel, w, k in zip(frames, scans, rels, want, iters):
+                got = reg.ComputeRobotMotion(f, gmap, s["last_pose"], rel, tau)
+                assert np.array_equal(got, w) and reg.last_stats.iterations == k
+                assert reg.get_option("small_active") == 0.0 and reg.get_option("resident_passes") >= k - 1  # (adaptive: the first pass may be a plain launch)
+        # a scan that converges at once right after: no resident launch is wasted on it when adaptive
+        easy = reg.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], scans[0]["rel_odom"], tau)
+        assert np.array_equal(easy, plain.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], scans[0]["rel_odom"], tau))
+    # never converging: max_num_iterations reached, 60 > the 48 passes one launch serves
+    for max_it in (1, 2, 60):
+        kw = dict(max_num_iteration=max_it, convergence_criterion=0.0)
+        a, b = K.KinematicRegistration(**kw), K.KinematicRegistration(**kw)
+        b.set_option("small", 0), a.set_option("small_resident", 2)
+        assert np.array_equal(a.ComputeRobotMotion(frames[1], gmap, scans[1]["last_pose"], rels[1], tau), b.ComputeRobotMotion(frames[1], gmap, scans[1]["last_pose"], rels[1], tau))
+        assert a.last_stats.iterations == b.last_stats.iterations == max_it
+        assert a.get_option("resident_passes") == (max_it if max_it > 1 else 0)  # (a launch that can serve one pass only goes out as the plain kernel)
+    # a late host
+    reg = K.KinematicRegistration()
+    reg.set_option("small_resident", 2), reg.set_option("small_timeout_us", 200.0)
+    for cmd in (1, 0):
+        reg.set_option("small_cmd", cmd)
+        for stall in (2000.0, 150.0, 260.0):
+            before = reg.get_option("small_relaunches")
+            reg.set_option("debug_stall_us", stall)
+            assert np.array_equal(reg.ComputeRobotMotion(frames[2], gmap, scans[2]["last_pose"], rels[2], tau), want[2]) and reg.last_stats.iterations == iters[2]
+            if stall == 2000.0:
+                assert reg.get_option("small_relaunches") == before + 1
+    assert np.array_equal(reg.ComputeRobotMotion(frames[2], gmap, scans[2]["last_pose"], rels[2], tau), want[2])
+    # the 16-bit tag wraps inside a reserved range
+    reg.set_option("debug_tag", 65535 - 12)
+    for _ in range(6):
+        assert np.array_equal(reg.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], rels[0], tau), want[0])
+    assert reg.get_option("debug_tag") < 1000
+    # explicit kernel-shape options keep the plain kernels
+    shaped = K.KinematicRegistration()
+    shaped.set_option("lanes_per_query", 2)
+    assert np.array_equal(shaped.ComputeRobotMotion(frames[0], gmap, scans[0]["last_pose"], rels[0], tau), want[0]) and shaped.get_option("resident_passes") == 0.0
+
+
 def test_concurrent_lanes_equal_the_sequential_batch(case1):
     """kicp_register_device_concurrent (independent scans, several in flight, one host thread and one handle per lane): every
     pose and iteration count equals the sequential batch's, bit for bit, for 1, 2, 3 and 8 lanes, with scans of both the

@@ -64,7 +64,7 @@ def test_every_aql_kernel_name_exists_in_the_embedded_code_object():
     checked = 0
     for b in blocks:
         m = re.search(r"\.name:\s+(\S+)", b)
-        if m and any(k in m.group(1) for k in ("k_pass_gather32", "k_pass_small", "k_pass_wave")):
+        if m and any(k in m.group(1) for k in ("k_pass_gather32", "k_pass_small", "k_pass_wave", "k_pass_resident")):
             assert re.search(r"\.private_segment_fixed_size:\s+0\b", b), m.group(1)
             checked += 1
     assert checked >= len(wanted)
