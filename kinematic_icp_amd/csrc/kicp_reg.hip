@@ -1234,10 +1234,13 @@ int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_ma
     // Small scans: one launch per pass while several lanes are in flight.  A resident kernel waits for its host, which waits for
     // the rows of ALL its workgroups - with several such kernels on the device, workgroups of one may have to wait for CUs held by
     // the others, and only the give-up time-out would untangle that.
-    std::vector<int> resident(lanes);
+    // Large scans: the four-waves-per-SIMD build.  The latency-oriented build trades occupancy for a shorter chain per wave - two
+    // workgroups per CU, which ONE scan of <= 131 072 points cannot exceed anyway, but which leaves no room for a second scan's
+    // workgroups next to the first's (measured: 94k instead of 137k scans/s with four lanes on cfg2).
+    std::vector<int> resident(lanes), latency(lanes);
     for (size_t t = 0; t < lanes; ++t) {
-        resident[t] = regs[t]->small_resident;
-        if (lanes > 1) regs[t]->small_resident = 0;
+        resident[t] = regs[t]->small_resident, latency[t] = regs[t]->latency_kernel;
+        if (lanes > 1) regs[t]->small_resident = 0, regs[t]->latency_kernel = 0;
     }
     std::atomic<size_t> next{0};
     std::atomic<int> worst{KICP_OK}, failed{KICP_OK};
@@ -1264,7 +1267,7 @@ int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_ma
     for (size_t t = 1; t < lanes; ++t) others.emplace_back(lane, t);
     lane(0);
     for (auto &th : others) th.join();
-    for (size_t t = 0; t < lanes; ++t) regs[t]->small_resident = resident[t];
+    for (size_t t = 0; t < lanes; ++t) regs[t]->small_resident = resident[t], regs[t]->latency_kernel = latency[t];
     if (failed.load() < 0) return fail(failed.load(), failure);
     return worst.load();
 }

@@ -23,9 +23,15 @@ ap.add_argument("--lanes", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--multi", action="store_true")
 ap.add_argument("--count", type=int, default=512)
 ap.add_argument("--repeats", type=int, default=5)
+ap.add_argument("--with-torch", action="store_true", help="initialise torch's HIP context in the process first (what bench.py has)")
+ap.add_argument("--scans", type=int, default=4, help="distinct scans cycled through")
 args = ap.parse_args()
 
-cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=4)
+if args.with_torch:
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(8, device="cuda").sum().item()
+cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=args.scans)
 gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
 ident = np.array([0, 0, 0, 1.0, 0, 0, 0])
 syn.build_map_points(scene, cfg, lambda pts: gmap.UpdateDevice(K.DeviceFrame(pts), ident), gmap.num_points, rng)
@@ -35,8 +41,8 @@ frames = [K.DeviceFrame(s["frame"]) for s in scans]
 extra = syn.planar_pose(0.2, 0.0, np.deg2rad(1.5)) if args.multi else syn.planar_pose(0.0, 0.0, 0.0)
 rels = [syn.pose_mul(s["rel_odom"], extra) for s in scans]
 regs = [K.KinematicRegistration() for _ in range(max(args.lanes))]
-batch = regs[0].prepare_batch([frames[i % 4] for i in range(args.count)], [scans[i % 4]["last_pose"] for i in range(args.count)],
-                              [rels[i % 4] for i in range(args.count)])
+batch = regs[0].prepare_batch([frames[i % len(scans)] for i in range(args.count)], [scans[i % len(scans)]["last_pose"] for i in range(args.count)],
+                              [rels[i % len(scans)] for i in range(args.count)])
 want = regs[0].ComputeRobotMotionBatch(batch, gmap, tau).copy()
 out = {"workload": args.workload, "multi": args.multi, "count": args.count, "iterations_mean": float(batch.iterations.mean())}
 best = []
@@ -54,4 +60,5 @@ for lanes in args.lanes:
         best.append(time.perf_counter() - t0)
     assert np.array_equal(got, want)
     out["lanes_%d_scans_per_s" % lanes] = round(args.count / min(best), 1)
+    out["lanes_%d_median" % lanes] = round(args.count / float(np.median(best)), 1)
 print(json.dumps(out))
