@@ -329,10 +329,13 @@ __device__ __forceinline__ void search_global(const MapView &m, const Query &q, 
 
 constexpr uint32_t kNoIndex32 = 0xFFFFFFFFu;
 // exact fp64 evaluation of one candidate from the HBM pool
+__device__ __forceinline__ double exact_d2_of(double tx, double ty, double tz, const Query &q) {
+    const double dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+    return dx * dx + dy * dy + dz * dz;
+}
 __device__ __forceinline__ double exact_d2(const MapView &m, uint32_t gidx, const Query &q) {
     const double *t = m.pool + static_cast<size_t>(gidx) * 3;
-    const double dx = t[0] - q.x, dy = t[1] - q.y, dz = t[2] - q.z;
-    return dx * dx + dy * dy + dz * dz;
+    return exact_d2_of(t[0], t[1], t[2], q);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -925,8 +928,15 @@ struct Lane {
 constexpr float kCell = 65536.f;  // one voxel in mirror units
 
 // the transformed point T * source[i] and its voxel (PointToVoxel); recomputed where needed rather than kept in registers
-__device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const Pose &T, uint32_t i) {
+// (`kept`: the latency-oriented build has the registers to keep the query and the two source coordinates the Jacobian needs
+// through the search, and so starts its exact phase without re-reading the source point: -0.5 us per cfg2 scan)
+struct KeptQuery {
+    Query q;
+    double sx, sy;
+};
+__device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const Pose &T, uint32_t i, KeptQuery *kept = nullptr) {
     const double sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
+    if (kept) kept->sx = sx, kept->sy = sy;
     double rx, ry, rz;
     quat_rotate(T, sx, sy, sz, rx, ry, rz);
     q.x = rx + T.tx, q.y = ry + T.ty, q.z = rz + T.tz;
@@ -939,13 +949,14 @@ __device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, con
 // plus 4.2e-6 D for the fp32 squares / sums and the 5 mantissa bits dropped for the integer tournament.  sp.margin_u covers
 // the errors of BOTH candidates of a decision with 10 % to spare, for D up to the acceptance bound (and never farther than
 // the 27-voxel neighbourhood reaches, D <= 12 voxel sizes^2): computed on the host (search_params()).
-__device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const Pose &T, uint32_t i, bool valid) {
+__device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const Pose &T, uint32_t i, bool valid, KeptQuery *kept = nullptr) {
     const SearchParams &sp = p.search;
     L.i = valid ? i : kNoIndex32;
     L.q.slot0 = 0u, L.todo = 0u;
     L.t = Best3{sp.bound_u, sp.bound_u, sp.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
     Query q;
-    make_query_of(q, p, T, valid ? i : 0u);
+    make_query_of(q, p, T, valid ? i : 0u, kept);
+    if (kept) kept->q = q;
     const double vs = p.map.voxel_size;
     L.q.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
     L.q.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
@@ -1090,34 +1101,44 @@ __device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float 
 
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
-__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t) {
+__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t, const KeptQuery *kept = nullptr) {
     if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
-    make_query_of(q, p, T, i);
+    if (kept) q = kept->q;
+    else make_query_of(q, p, T, i);
     const double bound = p.search.bound;
     double best = bound;
     uint32_t best_idx = kNoIndex32;
+    double wx = 0.0, wy = 0.0, wz = 0.0;  // the winner's coordinates, as far as they have passed through registers already
+    bool have_winner = false;
     if (t.b3 - t.b1 <= margin && p.dbg != 9) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
         search_global(m, q, best, best_idx);
     } else {
-        const double d1 = exact_d2(m, t.i1, q);
-        if (d1 < best) best = d1, best_idx = t.i1;
+        const double *c1 = m.pool + static_cast<size_t>(t.i1) * 3;
+        const double x1 = c1[0], y1 = c1[1], z1 = c1[2];
+        const double d1 = exact_d2_of(x1, y1, z1, q);
+        if (d1 < best) best = d1, best_idx = t.i1, wx = x1, wy = y1, wz = z1, have_winner = true;
         if (t.b2 - t.b1 <= margin && t.i2 != kNoIndex32) {
-            const double d2 = exact_d2(m, t.i2, q);
+            const double *c2 = m.pool + static_cast<size_t>(t.i2) * 3;
+            const double x2 = c2[0], y2 = c2[1], z2 = c2[2];
+            const double d2 = exact_d2_of(x2, y2, z2, q);
             // the reference keeps the FIRST candidate (in visiting order) whose NORM attains the strict minimum: the later of
             // the two only replaces the earlier when its rounded square root is smaller (closer_by_norm)
             if (d2 < bound) {
-                if (best_idx == kNoIndex32) best = d2, best_idx = t.i2;
-                else if (t.o2 < t.o1 ? !closer_by_norm(d1, d2) : closer_by_norm(d2, d1)) best = d2, best_idx = t.i2;
+                if (best_idx == kNoIndex32 || (t.o2 < t.o1 ? !closer_by_norm(d1, d2) : closer_by_norm(d2, d1)))
+                    best = d2, best_idx = t.i2, wx = x2, wy = y2, wz = z2, have_winner = true;
             }
         }
     }
     if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
-        const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
-        // the untransformed source point again (L1 / L2 hit): cheaper than registers kept live through the search
-        accumulate(acc, T, p.src[3 * i], p.src[3 * i + 1], q.x, q.y, q.z, tp[0], tp[1], tp[2]);
+        if (!have_winner) {  // (found by the exact search)
+            const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
+            wx = tp[0], wy = tp[1], wz = tp[2];
+        }
+        // the untransformed source point again (L1 / L2 hit) unless the build kept it: cheaper than registers kept live through the search
+        accumulate(acc, T, kept ? kept->sx : p.src[3 * i], kept ? kept->sy : p.src[3 * i + 1], q.x, q.y, q.z, wx, wy, wz);
     }
 }
 
@@ -1140,7 +1161,8 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
     const int sub = static_cast<int>(gt % G);
     const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
     Lane L;
-    start_lane(L, p, T, i, valid);
+    KeptQuery kept;
+    start_lane(L, p, T, i, valid, LAT ? &kept : nullptr);
     if (G > 1 && !SPLIT) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
         uint32_t rest = L.todo, mine = 0u;
         for (int r = 0; rest; ++r) {
@@ -1181,7 +1203,7 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
         best3_merge(L.t, o);
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
-    if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t);
+    if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t, LAT ? &kept : nullptr);
 }
 template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
