@@ -3,6 +3,7 @@
 // at run time, caller-supplied all-reduce).
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <rccl/rccl.h>  // declarations only; the library is bound at run time (see CommApi)
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -1263,8 +1264,17 @@ int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_ma
             if (out_iterations) out_iterations[k] = st.iterations;
         }
     };
+    // The helper threads must not inherit a caller's pinning: a caller bound to one core (OMP_PROC_BIND binds the initial thread
+    // of many a process) would have all lanes spin on that core.  Asking for every CPU leaves what the cpuset allows.
+    auto unpinned_lane = [&](size_t t) {
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
+        (void)sched_setaffinity(0, sizeof all, &all);
+        lane(t);
+    };
     std::vector<std::thread> others;
-    for (size_t t = 1; t < lanes; ++t) others.emplace_back(lane, t);
+    for (size_t t = 1; t < lanes; ++t) others.emplace_back(unpinned_lane, t);
     lane(0);
     for (auto &th : others) th.join();
     for (size_t t = 0; t < lanes; ++t) regs[t]->small_resident = resident[t], regs[t]->latency_kernel = latency[t];
