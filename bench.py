@@ -306,24 +306,6 @@ def main():
         for i in range(k_host):
             reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
         host_rate = k_host / (time.perf_counter() - t1)
-    # informational, never `value`: INDEPENDENT scans with four in flight (kicp_register_device_concurrent: one handle, HSA
-    # queue and host thread per lane) - what the device does when a workload has several scans to offer at a time (robots
-    # sharing a map, replayed logs).  The reference's sequential pipeline cannot use it, hence not the headline.
-    conc_rate, conc_lanes = None, 4
-    if world == 1 and not use_comm:
-        lanes = [K.KinematicRegistration(device=device) for _ in range(conc_lanes - 1)]
-        cb = reg.prepare_batch([frames[i % len(scans)] for i in range(512)], [scans[i % len(scans)]["last_pose"] for i in range(512)],
-                               [rel_single[i % len(scans)] for i in range(512)])
-        seq = reg.ComputeRobotMotionBatch(cb, gmap, tau).copy()
-        reg.ComputeRobotMotionConcurrent(lanes, cb, gmap, tau)
-        best = []
-        for _ in range(6):
-            t1 = time.perf_counter()
-            got = reg.ComputeRobotMotionConcurrent(lanes, cb, gmap, tau)
-            best.append(time.perf_counter() - t1)
-        assert np.array_equal(got, seq), "concurrent lanes must return the sequential poses bit for bit"
-        conc_rate = 512 / float(np.median(best))
-        del lanes
     pass_kernel = int(reg.get_option("pass_kernel"))
     if exchange:
         release(reg, comm)
@@ -434,6 +416,11 @@ def main():
     #      (stamped with the commit it was taken at) where rocprofv3 cannot run.
     kernel_sub = {0: "k_pass_gather32", 1: "k_pass_small", 2: "k_pass_wave"}[small_kind]
     traffic, traffic_src = (None, "not measured (--no-pmc)") if (args.no_pmc or world != 1) else _pmc_traffic(args.workload, kernel_sub)
+    # informational, never `value`: INDEPENDENT scans with four in flight (kicp_register_device_concurrent: one handle, HSA queue
+    # and host thread per lane) - what the device does when a workload has several scans to offer at a time (robots sharing a
+    # map, replayed logs).  The reference's sequential pipeline cannot use it, hence not the headline.
+    conc_lanes = 4
+    conc_rate = _concurrent_rate(args.workload, conc_lanes, len(scans)) if (world == 1 and not use_comm) else None
     prof = _profile_counters(args.workload, world)
     if traffic is None and prof and prof.get("hbm_bytes_per_launch"):
         traffic = float(prof["hbm_bytes_per_launch"])
@@ -504,8 +491,11 @@ def main():
                                                       "(Registration.hpp:39-43): upload over PCIe inside the call"},
         "value_concurrent_independent_scans": None if conc_rate is None else
         {"scans_per_s": round(conc_rate, 1), "lanes": conc_lanes,
-         "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each); "
-                 "a throughput mode the reference's sequential pipeline cannot use - never the headline" % conc_lanes},
+         "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each), "
+                 "512 per call, median of 5 calls, measured by tools/bench_concurrent.py in a process of its own after everything timed here "
+                 "(this process pins its OpenMP teams for the CPU baseline, which together with torch's thread pool holds four polling "
+                 "lanes back: 89k instead of 137k scans/s on cfg2); a throughput mode the reference's sequential pipeline cannot use - "
+                 "never the headline" % conc_lanes},
         "roofline": roof,
         "cpu_baseline": cpu,
     }
@@ -590,6 +580,19 @@ def _cpu_baseline(args, cfg, scans, rels, tau, omap, map_points, okicp, rkicp):
                     "sample": "%d calls of the oracle port on the same %d scans (oracle/_ref not present); threads tried %s, best reported"
                               % (port_n, len(scans), counts), "single_thread_value": round(port[1], 3)})
     return res
+
+
+def _concurrent_rate(workload, lanes, n_scans):
+    """scans/s of tools/bench_concurrent.py (its own process, without this one's OpenMP pinning), or None"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_PROC_BIND", "OMP_PLACES")}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_concurrent.py"), "--workload", workload, "--lanes", str(lanes),
+                              "--scans", str(n_scans)], env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return float(json.loads(line)["lanes_%d_median" % lanes])
+    except Exception:  # noqa: BLE001  (informational figure: a failure here must not cost the bench line)
+        return None
 
 
 def _pmc_traffic(workload, kernel_sub, calls=200):

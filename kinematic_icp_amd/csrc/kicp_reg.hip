@@ -1273,10 +1273,10 @@ int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_ma
         (void)sched_setaffinity(0, sizeof all, &all);
         lane(t);
     };
-    std::vector<std::thread> others;
-    for (size_t t = 1; t < lanes; ++t) others.emplace_back(unpinned_lane, t);
-    lane(0);
-    for (auto &th : others) th.join();
+    // (every lane on a thread of its own, also lane 0: the caller's thread may be pinned next to the runtime's helper threads)
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < lanes; ++t) threads.emplace_back(unpinned_lane, t);
+    for (auto &th : threads) th.join();
     for (size_t t = 0; t < lanes; ++t) regs[t]->small_resident = resident[t], regs[t]->latency_kernel = latency[t];
     if (failed.load() < 0) return fail(failed.load(), failure);
     return worst.load();
