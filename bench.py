@@ -49,6 +49,7 @@ import time
 # (the default passive policy): spinning ones eat the container's CPU quota and slowed the 1-thread sample 10x.
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # (libgomp spins without end by default once its threads are bound)
 
 import numpy as np  # noqa: E402
 
@@ -492,10 +493,8 @@ def main():
         "value_concurrent_independent_scans": None if conc_rate is None else
         {"scans_per_s": round(conc_rate, 1), "lanes": conc_lanes,
          "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each), "
-                 "512 per call, median of 5 calls, measured by tools/bench_concurrent.py in a process of its own after everything timed here "
-                 "(this process pins its OpenMP teams for the CPU baseline, which together with torch's thread pool holds four polling "
-                 "lanes back: 89k instead of 137k scans/s on cfg2); a throughput mode the reference's sequential pipeline cannot use - "
-                 "never the headline" % conc_lanes},
+                 "512 per call, median of 5 calls, measured by tools/bench_concurrent.py in a process of its own after everything timed here; "
+                 "a throughput mode the reference's sequential pipeline cannot use - never the headline" % conc_lanes},
         "roofline": roof,
         "cpu_baseline": cpu,
     }

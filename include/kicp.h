@@ -186,8 +186,9 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
 /* The same queue of INDEPENDENT registrations with `lanes` of them in flight: lane t drives handle regs[t] (its own stream,
  * AQL queue and hand-off buffers; options and config are taken from each handle, except that for the duration of the call
  * small scans are not kept resident and large scans use the four-waves-per-SIMD kernel, which leaves room for the other
- * lanes' workgroups) from a host thread of its own (started for the call, unpinned: they do not inherit the caller's CPU
- * affinity; the calling thread sleeps until they are done), scans are
+ * lanes' workgroups) from a host thread of its own (a pool the library starts on first use and keeps, unpinned - they do not
+ * inherit the caller's CPU affinity; the calling thread sleeps until the lanes are done; one concurrent call at a time uses the
+ * pool), scans are
  * dealt to the lanes first come, first served.  This is a THROUGHPUT mode for workloads that have independent scans -
  * several robots localising in one map, replayed logs - and nothing the reference's sequential pipeline can use: a scan's
  * initial guess there is the previous scan's result.  Every pose is bit-equal to what kicp_register_device returns for that

@@ -149,7 +149,7 @@ def test_bench_launch_path_with_two_ranks_on_one_gpu():
            "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans-per-step", "4",
            "--workload", "cfg1", "--comm", "shm", "--pg-backend", "gloo", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[-12000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
