@@ -89,6 +89,13 @@ def _callback_worker(rank, world, port, host_solve, q):
         q.put((rank, [], repr(e) + "\n" + traceback.format_exc()))
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _spawn(target, world, extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -108,7 +115,7 @@ def _spawn(target, world, extra):
 
 @pytest.mark.parametrize("world,host_solve", [(2, 1), (3, 1), (2, 0)])
 def test_callback_allreduce_across_processes(world, host_solve):
-    results = _spawn(_callback_worker, world, (29600 + world * 7 + host_solve, host_solve))
+    results = _spawn(_callback_worker, world, (_free_port(), host_solve))
     ref = _single_process_results()
     for r in range(world):
         for (pose, iters), (pose1, iters1) in zip(results[r], ref):
@@ -146,10 +153,11 @@ def test_rccl_allreduce_two_gpus():
 def test_bench_launch_path_with_two_ranks_on_one_gpu():
     env = dict(os.environ, KICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans-per-step", "4",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans-per-step", "4",
            "--workload", "cfg1", "--comm", "shm", "--pg-backend", "gloo", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-12000:]
+    # (on failure: the first rank's own traceback first - the other rank only reports the closed connection)
+    assert p.returncode == 0, "\n".join([l for l in p.stderr.splitlines() if "[rank0]" in l][-40:]) + "\n...\n" + p.stderr[-6000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
