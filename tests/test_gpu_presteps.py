@@ -66,6 +66,24 @@ def test_voxel_downsample_matches_oracle(raw):
     assert e.value.code == K.KICP_ERR_CAPACITY
 
 
+def test_large_uploads_arrive_intact():
+    """Uploads travel through the handle's pinned staging buffer in 1 MB pieces (kicp_core.hip): every byte arrives, for sizes
+    around the piece boundaries, back to back on one handle, also when a kernel that reads the destination is still queued on
+    the handle's stream."""
+    pre = K.PreSteps()
+    rng = np.random.default_rng(2)
+    for n in (87381, 87382, 131072, 43690, 300001, 87382, 5):  # 2 MB - 8 B, 2 MB + 16 B, ..., back down to one piece
+        pts = rng.normal(size=(n, 3))
+        pre.upload(0, pts)
+        np.testing.assert_array_equal(pre.download(0), pts)
+    ts = np.linspace(0.0, 1.0, 300001)
+    ident = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    for _ in range(3):  # back to back: the next upload overwrites what the previous call's kernels read
+        pts = rng.normal(size=(300001, 3))
+        assert pre.Preprocess(pts, ts, ident, ident, 1e9, -1.0, 1, dst=1) == 300001  # both arrays in one call
+        np.testing.assert_allclose(pre.download(1), pts, rtol=0, atol=1e-15)
+
+
 def test_background_download_overlaps_the_next_steps(raw):
     frame, ts, rel, ext = raw
     pre = K.PreSteps()
