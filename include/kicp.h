@@ -141,6 +141,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  resident launch from its second pass on); 2: always resident; 0: one launch per iteration.  Set 0 on
  *                  handles that register small scans from several threads at once on one device (a resident kernel holds its
  *                  CUs until its host answers; kicp_register_device_concurrent does this for its lanes)
+ *   "resident_generic" 1 (default): scans beyond the small-scan kernels and up to 131 072 points (256 CUs) keep the generic
+ *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
+ *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
+ *                  the last call that a resident launch of the generic kernel served
  *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
  *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
  *                  wave_block 0 = by scan size, default)
@@ -150,6 +154,8 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  the host then launches afresh - "small_relaunches" counts those)
  *   "bar_frame"    1 (default): kicp_register writes host frames of up to 8 192 points straight into HBM through the PCIe BAR
  *                  instead of staging them for the DMA engine; 0: always stage
+ *   "p2p_rows"     peer-mailbox exchange, wire format (the same value on every rank): 1 (default) the first-level group rows
+ *                  themselves; 0 the ranks' totals (round 2); 2 always one row per rank (what launches of more than 32 groups send)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
  *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
  *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the
