@@ -360,7 +360,14 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         bind();
         HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
         hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
-        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
+        if (n > 16384) {  // bulk: the scan over many workgroups (the number of touched voxels is only known on the device: <= n)
+            const uint32_t spans = static_cast<uint32_t>((n + kScanSpan - 1) / kScanSpan);
+            hipLaunchKernelGGL(k_up_scan_local, dim3(spans), dim3(256), 0, st, up, mr.d_order);
+            hipLaunchKernelGGL(k_up_scan_sums, dim3(1), dim3(1024), 0, st, up, mr.d_order);
+            hipLaunchKernelGGL(k_up_scan_add, dim3(grid), dim3(256), 0, st, up, mr.d_order);
+        } else {
+            hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
+        }
         HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         map->device_ahead = true;  // the table now carries the new voxels' (still empty) entries

@@ -186,6 +186,81 @@ static __global__ __launch_bounds__(1024) void k_up_scan(const UpdateParams p) {
     if (lane == 0 && may_become_occupied) atomicAdd(&p.m.ctr->may_occupy, may_become_occupied);
 }
 
+// 2b. the same scan over MANY workgroups, for bulk insertions (tens of thousands of touched voxels and more): one workgroup
+//     gathering the counts of every touched voxel is bound by its CU's address path (~400 us per 70 000 voxels, half of a bulk
+//     insertion's kernel time).  k_up_scan_local: workgroup b scans its kScanSpan voxels (offsets local to the workgroup) and leaves
+//     its total in sums[b]; k_up_scan_sums: one workgroup turns the totals into exclusive prefixes; k_up_scan_add: every voxel's
+//     offset gets its workgroup's prefix.  `sums` borrows the head of `order`, which step 3 only fills afterwards.
+constexpr uint32_t kScanSpan = 256 * kScanPerThread;  // voxels per workgroup of k_up_scan_local
+static __global__ __launch_bounds__(256) void k_up_scan_local(const UpdateParams p, uint32_t *sums) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n_touched = p.m.ctr->touched;
+    const uint32_t base = blockIdx.x * kScanSpan;
+    if (base >= n_touched) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = base + threadIdx.x * kScanPerThread;
+    uint32_t h[kScanPerThread], c[kScanPerThread], may_become_occupied = 0, mine = 0;
+#pragma unroll
+    for (int u = 0; u < kScanPerThread; ++u) h[u] = first + u < n_touched ? p.touched[first + u] : kNoSlot;
+#pragma unroll
+    for (int u = 0; u < kScanPerThread; ++u) {
+        c[u] = 0;
+        if (h[u] != kNoSlot) c[u] = p.m.cnt[h[u]], may_become_occupied += val_count(p.m.table[h[u]].val, p.m.cbits) == 0u ? 1u : 0u;
+        mine += c[u];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t at = incl - mine;
+    for (int w = 0; w < wave; ++w) at += s_wave[w];
+#pragma unroll
+    for (int u = 0; u < kScanPerThread; ++u) {
+        if (h[u] != kNoSlot) p.m.seg_start[h[u]] = at, p.m.cnt[h[u]] = 0;
+        at += c[u];
+    }
+    if (threadIdx.x == 255) sums[blockIdx.x] = at;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) may_become_occupied += __shfl_down(may_become_occupied, off, 64);
+    if (lane == 0 && may_become_occupied) atomicAdd(&p.m.ctr->may_occupy, may_become_occupied);
+}
+static __global__ __launch_bounds__(1024) void k_up_scan_sums(const UpdateParams p, uint32_t *sums) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t nblocks = (p.m.ctr->touched + kScanSpan - 1) / kScanSpan;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t c = b < nblocks ? sums[b] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (b < nblocks) sums[b] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+static __global__ __launch_bounds__(256) void k_up_scan_add(const UpdateParams p, const uint32_t *sums) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p.m.ctr->touched) return;
+    const uint32_t prefix = sums[j / kScanSpan];
+    if (prefix) p.m.seg_start[p.touched[j]] += prefix;
+}
+
 // 3. scatter the point indices into their voxel's group (any order; the apply step walks a group by ascending index)
 static __global__ __launch_bounds__(256) void k_up_scatter(const UpdateParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
