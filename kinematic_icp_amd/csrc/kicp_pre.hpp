@@ -145,6 +145,7 @@ __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y,
 // slot's winner to its own index
 static __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *p.probe_max = 0u;  // (the replay kernel, which raises it, runs after this one: no separate memset per call)
     const bool in_range = i < p.n;
     const double vs = p.voxel_size;
     int32_t vx = 0, vy = 0, vz = 0;
@@ -199,6 +200,8 @@ static __global__ __launch_bounds__(256) void k_downsample_gather(const Downsamp
     for (int w = 0; w < wave; ++w) pos += s_wave[w];
     const uint32_t i = p.order[s];
     out[3 * pos] = p.in[3 * i], out[3 * pos + 1] = p.in[3 * i + 1], out[3 * pos + 2] = p.in[3 * i + 2];
+    // leave the bucket as the next call must find it (free slots were never written): the host clears the table only once
+    p.keys[s] = kEmptyVoxelKey, p.min_index[s] = 0xFFFFFFFFu, p.order[s] = kFreeBucket, p.home_at[s] = 0xFFFFFFFFu;
 }
 
 // ---- PointCloud2 wire-format ingest ----------------------------------------------------
