@@ -254,8 +254,10 @@ int kicp_pre_preprocess_ingested(kicp_pre *pre, const double relative_motion_qt[
                                  double min_range, int deskew, int dst_buffer, size_t *out_n);
 /* Download the decoded cloud (fp64 xyz) and its normalised stamps: what PointCloud2ToEigen / ProcessTimestamps return. */
 int kicp_pre_ingested(const kicp_pre *pre, double *out_xyz, double *out_stamps, size_t cap_points, size_t *out_n, int *out_has_stamps);
-/* kiss_icp::VoxelDownsample(buffer src, voxel_size) -> buffer dst: the first point (lowest index) of every voxel, in
- * first-seen order. */
+/* kiss_icp::VoxelDownsample(buffer src, voxel_size) -> buffer dst: the first point (lowest index) of every voxel, in the
+ * ITERATION ORDER of the reference's tsl::robin_map after reserve(frame.size()) - the order the second downsample and the map
+ * update of the pipeline depend on (kiss-icp v1.2.0 core/VoxelUtils.cpp; call sites pipeline/KinematicICP.cpp:40,42).
+ * KICP_ERR_CAPACITY when a voxel coordinate leaves +-2^20 (the handle stays usable). */
 int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, int dst_buffer, size_t *out_n);
 /* Largest robin-hood displacement (in buckets) the last kicp_pre_voxel_downsample saw while replaying the reference's table
  * (0 when every probe stayed below 32).  tsl::robin_map grows its table when an insertion's probe exceeds the container's
