@@ -38,9 +38,11 @@ enum {
     KICP_WARN_NO_CORRESPONDENCES = 1, /* N_corr == 0 in some pass -> NaN pose, as the reference produces */
     KICP_ERR_HIP = -1,                /* HIP runtime / device failure (message in kicp_last_error) */
     KICP_ERR_ARG = -2,                /* bad argument */
-    KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 255, > 2^24-2 voxels, a per-point term
-                                         of the normal equations >= 2^43: source points ~2 900 km from the base frame) */
-    KICP_ERR_COMM = -4                /* RCCL failure */
+    KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 65 535, more voxels than the table's bucket
+                                         index addresses - 2^24-2 at <= 255 points per voxel -, a per-point term of the normal
+                                         equations >= 2^43: source points ~2 900 km from the base frame, a voxel coordinate beyond
+                                         +-2^20 in kicp_pre_voxel_downsample) */
+    KICP_ERR_COMM = -4                /* a multi-GPU exchange failed (RCCL, peer mailboxes, shared segment): a peer did not show up in time */
 };
 
 typedef struct kicp_map kicp_map; /* twin of kiss_icp::VoxelHashMap: host-authoritative voxel map + HBM mirror */
@@ -87,10 +89,12 @@ int kicp_map_remove_far(kicp_map *map, const double origin[3]);              /* 
 int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]); /* Update(points, origin) */
 int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose_qt[7]);  /* Update(points, pose) -- KinematicICP.cpp:79 */
 /* Update(points, pose) with the points already in HBM (e.g. a kicp_pre buffer): transform, AddPoints and
- * RemovePointsFarFromLocation run on the device - every touched voxel is processed by one thread in input order with the
- * reference's fp64 rule, so the accepted points and their order inside each voxel are exactly the sequential
- * reference's.  Table growth / clean-up (a device-side re-hash) and pool growth happen in HBM as well; the host copy is
- * refreshed lazily when a host-side call (AddPoints, kicp_map_check, ...) needs it. */
+ * RemovePointsFarFromLocation run on the device - every touched voxel's new points are judged in input order with the
+ * reference's fp64 rule (one wave per voxel for frame-sized updates, one thread per voxel for bulk insertions), so the
+ * accepted points and their order inside each voxel are exactly the sequential reference's.  Table growth / clean-up (a
+ * device-side re-hash) and pool growth happen in HBM as well; the host copy is refreshed lazily when a host-side call
+ * (AddPoints, kicp_map_check, ...) needs it.  A map that leaves +-2^20 voxels from its origin is updated by the host map
+ * from then on (same result). */
 int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
 int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU */
 /* Preferred device for BULK host-side insertions (not part of the reference API): with device >= 0, kicp_map_add_points /
