@@ -304,9 +304,10 @@ int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]); /* rank 0 creates, the cal
 int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]); /* RCCL comm on reg's device */
 int kicp_reg_comm_destroy(kicp_reg *reg);
 /* Single-node alternative without any device collective: all ranks map one POSIX shared-memory segment (`name`, created
- * by rank 0 - call it there first, e.g. before a barrier) as host-mapped pinned memory.  Each rank's pass kernel writes
- * its 24 limb words + a sequence word straight into its own slot of the segment; every rank's host polls all slots, adds
- * the integers and solves.  The "all-reduce" thus costs no more than the single-GPU hand-off (a 192-byte RCCL all-reduce
+ * by rank 0 - call it there first, e.g. before a barrier).  Each rank's 24 limb totals + a sequence word go into its own slot
+ * of the segment - written by its host, which has just added its GPU's tagged group rows exactly as in the single-GPU
+ * hand-off (default), or by the pass kernel itself ("group_rows" = 0) -; every rank's host polls all slots, adds the integers
+ * and solves.  The "all-reduce" thus costs no more than the single-GPU hand-off (a 192-byte RCCL all-reduce
  * costs tens of microseconds per ICP iteration, as long as the kernel itself).  Every rank must issue the same sequence
  * of kicp_register* calls. */
 int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name);
