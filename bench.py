@@ -210,6 +210,16 @@ def main():
 
     B = max(1, args.scans_per_step) if args.scans_per_step > 0 else 64  # (auto: fixed below, after the calibration batch)
 
+    def all_ranks_ok(err):
+        """every rank learns whether ANY rank failed and all of them raise together (this rank's own error, or a stand-in)"""
+        if use_comm:
+            t = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t.item()) > 0.0 and err is None:
+                err = K.KicpError(K.KICP_ERR_COMM, "a peer rank's registration failed")
+        if err is not None:
+            raise err
+
     def timed(reg, rels, steps, warmup, per_call=False):
         """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
         A step is ONE kicp_register_device_batch call: the library registers the step's B scans one after the other (a plain
@@ -224,14 +234,25 @@ def main():
                     run_scan(reg, i, rels)
             else:
                 reg.ComputeRobotMotionBatch(batch, gmap, tau)
-        for k in range(warmup):
-            step(k)
+        # A registration that fails on one rank (an exchange that cannot complete on this box) must not leave the ranks at
+        # different collectives: the failing rank still walks through the barriers, and all ranks leave together (all_ranks_ok).
+        err = None
+        try:
+            for k in range(warmup):
+                step(k)
+        except K.KicpError as e:
+            err = e
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
-            step(k)
+        if err is None:
+            try:
+                for k in range(steps):
+                    step(k)
+            except K.KicpError as e:
+                err = e
         barrier()
         elapsed = time.perf_counter() - t0
+        all_ranks_ok(err)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -341,8 +362,13 @@ def main():
                 exch[alt] = {"note": str(e)[:200]}
                 continue
             try:
-                for i in range(60):
-                    run_scan(reg2, i, rel_single)
+                err = None
+                try:
+                    for i in range(60):
+                        run_scan(reg2, i, rel_single)
+                except K.KicpError as e:
+                    err = e
+                all_ranks_ok(err)
                 e1 = timed(reg2, rel_single, args.steps, min(args.warmup, 2))
                 em = timed(reg2, rel_multi, args.steps, 1)
                 its = timed.last_iterations
