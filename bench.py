@@ -274,10 +274,21 @@ def main():
     # ---- one-time settling (setup, not measurement): the HIP runtime finishes its lazy initialisation (signal pools,
     #      code objects, clocks) during the first few hundred launches of a process; a ~30 ms hiccup there would
     #      otherwise land inside a short timed region.
+    #      With an exchange attached every registration is a collective, so every rank must run the SAME number of scans: the
+    #      ranks agree on "another block?" (round 3 let each rank consult its own clock; when the 0.5 s mark fell between two
+    #      ranks' checks one of them ran 50 scans more, which the peers never answered: the bounded wait of the exchange
+    #      expired 20 s later - the one-in-fifteen failure of the two-rank test).
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.5:
+    while True:
         for i in range(50):
             run_scan(reg, i, rel_single)
+        go_on = time.perf_counter() - t_settle < 0.5
+        if use_comm:
+            t = torch.tensor([1.0 if go_on else 0.0], dtype=torch.float64, device=pg_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            go_on = float(t.item()) > 0.0
+        if not go_on:
+            break
     if args.scans_per_step <= 0:
         # calibration (setup, not measurement): size the batch so that the K timed steps last >= --min-timed-s whatever K is;
         # identical on every rank (max over ranks)

@@ -123,6 +123,10 @@ int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full);
 /* ---- kinematic_icp::KinematicRegistration (registration/Registration.hpp:32-50) ------------------------- */
 int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out);
 void kicp_reg_destroy(kicp_reg *reg);
+/* KinematicRegistration(const KinematicRegistration &): the reference's struct is a plain copyable aggregate
+ * (Registration.hpp:32-50).  A new handle on the same device with the same parameters and tuning options and workspaces of
+ * its own (stream, queue, hand-off buffers).  Multi-GPU exchanges are per handle and are not carried over. */
+int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out);
 int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
 int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
 /* Backend tuning knobs (not part of the reference API):
@@ -158,6 +162,8 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  the host then launches afresh - "small_relaunches" counts those)
  *   "bar_frame"    1 (default): kicp_register writes host frames of up to 8 192 points straight into HBM through the PCIe BAR
  *                  instead of staging them for the DMA engine; 0: always stage
+ *   "fetch_upload" 1 (default): larger host frames are copied into the pinned staging buffer in 384 KB pieces and PULLED by a small
+ *                  kernel per piece (which also widens float32 frames) while the CPU copies the next piece; 0: one DMA per 1 MB piece
  *   "p2p_rows"     peer-mailbox exchange, wire format (the same value on every rank): 1 (default) the first-level group rows
  *                  themselves; 0 the ranks' totals (round 2); 2 always one row per rank (what launches of more than 32 groups send)
  *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
@@ -180,6 +186,11 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name);
  * -- Registration.hpp:39-43 / Registration.cpp:151-190.  `frame_xyz` is a HOST pointer (uploaded inside). */
 int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double last_pose_qt[7],
                   const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats);
+/* Same with the frame still float32 - the wire format of a PointCloud2, which the reference widens on the host with
+ * static_cast<double> before it registers anything (ros/src/kinematic_icp_ros/utils/RosUtils.cpp:30-39): half the bytes cross
+ * PCIe and the widening (exact) happens on the device, so the result is bit-equal to kicp_register on the widened frame. */
+int kicp_register_f32(kicp_reg *reg, kicp_map *map, const float *frame_xyz_f32, size_t n, const double last_pose_qt[7],
+                      const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats);
 /* Same, but the frame is already in HBM: `d_frame_xyz` is a DEVICE pointer on the handle's device
  * (e.g. the output of an on-device pre-step, or a torch tensor's data_ptr()). */
 int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],

@@ -76,11 +76,13 @@ _SIGNATURES = {
     "kicp_map_last_upload": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_reg_create": (C.c_int, [C.POINTER(RegConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "kicp_reg_destroy": (None, [C.c_void_p]),
+    "kicp_reg_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "kicp_reg_get_config": (C.c_int, [C.c_void_p, C.POINTER(RegConfig)]),
     "kicp_reg_set_config": (C.c_int, [C.c_void_p, C.POINTER(RegConfig)]),
     "kicp_reg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "kicp_reg_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "kicp_register": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
+    "kicp_register_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_register_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, C.c_double, _dp, C.POINTER(Stats)]),
     "kicp_register_device_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _dp, _dp,
                                              C.c_double, _dp, C.POINTER(C.c_int)]),
@@ -308,6 +310,20 @@ class KinematicRegistration:
             _lib.kicp_reg_destroy(self._h)
             self._h = None
 
+    def copy(self):
+        """KinematicRegistration(const KinematicRegistration &): the reference's struct is copyable (Registration.hpp:32-50);
+        same parameters and tuning options, workspaces of its own (kicp_reg_clone)."""
+        h = C.c_void_p()
+        _check(lib().kicp_reg_clone(self._h, C.byref(h)))
+        other = object.__new__(KinematicRegistration)
+        other._h, other.device = h, self.device
+        other.last_stats, other.last_status = Stats(), 0
+        other._stats_ref = C.byref(other.last_stats)
+        other._out = np.zeros(7, dtype=np.float64)
+        other._out_p = C.cast(other._out.ctypes.data, _dp)
+        other._cb = None
+        return other
+
     # the reference exposes its five parameters as public mutable fields (Registration.hpp:45-49)
     def _cfg(self):
         c = RegConfig()
@@ -339,6 +355,11 @@ class KinematicRegistration:
         if isinstance(frame, DeviceFrame):
             rc = _lib.kicp_register_device(self._h, voxel_map._h, frame.ptr, frame.n, lp, ro, max_correspondence_distance,
                                            self._out_p, self._stats_ref)
+        elif isinstance(frame, np.ndarray) and frame.dtype == np.float32:
+            # float32 xyz as a PointCloud2 carries it: widened on the device (kicp_register_f32), half the bytes over PCIe
+            a = np.ascontiguousarray(frame)
+            rc = _lib.kicp_register_f32(self._h, voxel_map._h, a.ctypes.data, a.size // 3, lp, ro, max_correspondence_distance,
+                                        self._out_p, self._stats_ref)
         else:
             a, p = _d(frame)
             rc = _lib.kicp_register(self._h, voxel_map._h, p, a.size // 3, lp, ro, max_correspondence_distance,

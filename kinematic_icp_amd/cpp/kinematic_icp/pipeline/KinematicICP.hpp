@@ -14,6 +14,7 @@
 #include <kiss_icp/core/VoxelUtils.hpp>
 #include <sophus/se3.hpp>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "kinematic_icp/correspondence_threshold/CorrespondenceThreshold.hpp"
@@ -60,8 +61,37 @@ public:
 #endif
     }
     ~KinematicICP() { kicp_pre_destroy(pre_); }
-    KinematicICP(const KinematicICP &) = delete;
-    KinematicICP &operator=(const KinematicICP &) = delete;
+    // copyable and movable like the reference's class (every member is held by value there, KinematicICP.hpp:100-108): a copy owns
+    // a deep copy of the map, a registration handle of its own and its own pre-step workspace
+    KinematicICP(const KinematicICP &o)
+        : last_pose_(o.last_pose_),
+          registration_(o.registration_),
+          correspondence_threshold_(o.correspondence_threshold_),
+          config_(o.config_),
+          preprocessor_(o.preprocessor_),
+          local_map_(o.local_map_) {
+#ifndef KICP_HOST_PRESTEPS
+        kicp_bridge::check(kicp_pre_create(kicp_bridge::default_device(), &pre_), "KinematicICP");
+#endif
+    }
+    KinematicICP(KinematicICP &&o) noexcept
+        : last_pose_(o.last_pose_),
+          registration_(std::move(o.registration_)),
+          correspondence_threshold_(o.correspondence_threshold_),
+          config_(o.config_),
+          preprocessor_(o.preprocessor_),
+          local_map_(std::move(o.local_map_)),
+          pre_(o.pre_) {
+        o.pre_ = nullptr;
+    }
+    KinematicICP &operator=(KinematicICP o) noexcept {  // copy / move and swap
+        std::swap(last_pose_, o.last_pose_);
+        registration_ = std::move(o.registration_);
+        std::swap(correspondence_threshold_, o.correspondence_threshold_), std::swap(config_, o.config_), std::swap(preprocessor_, o.preprocessor_);
+        local_map_ = std::move(o.local_map_);
+        std::swap(pre_, o.pre_);
+        return *this;
+    }
 
     // pipeline/KinematicICP.cpp:48-85
     Vector3dVectorTuple RegisterFrame(const std::vector<Eigen::Vector3d> &frame, const std::vector<double> &timestamps,
@@ -140,6 +170,15 @@ protected:
         Vector3dVectorTuple result{Vector3dVector(n_frame), Vector3dVector()};
         auto &frame = std::get<0>(result);
         kicp_bridge::check(kicp_pre_download_begin_into(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size()), "download");
+        // From here on the backend's helper thread holds a pointer into `frame`: should any later step throw, the download is
+        // collected (and dropped) before `result` is destroyed, so nothing is ever copied into freed memory.
+        struct DownloadGuard {
+            kicp_pre *pre;
+            bool armed = true;
+            ~DownloadGuard() {
+                if (armed) (void)kicp_pre_download_finish(pre, 0, nullptr, 0, nullptr);
+            }
+        } guard{pre_};
         size_t n_down = 0, n_source = 0;
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
         kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
@@ -155,6 +194,7 @@ protected:
         auto &source = std::get<1>(result);
         source.resize(n_source);
         kicp_bridge::check(kicp_pre_download(pre_, 2, source.empty() ? nullptr : source.front().data(), source.size(), nullptr), "download");
+        guard.armed = false;
         kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size(), nullptr), "download");
         return result;  // built in place: no copy of the clouds on the way out
     }

@@ -41,7 +41,7 @@ struct VoxelHashMap {
         const_iterator cend() const { return end(); }
         const_iterator find(const Voxel &v) const {
             const auto &items = snapshot();
-            const auto it = index_.find(pack(v));
+            const auto it = index_.find(Key{v.x(), v.y(), v.z()});
             return it == index_.end() ? items.end() : items.begin() + static_cast<std::ptrdiff_t>(it->second);
         }
         size_t count(const Voxel &v) const { return find(v) == end() ? 0u : 1u; }
@@ -55,10 +55,17 @@ struct VoxelHashMap {
     private:
         friend struct VoxelHashMap;
         explicit MapView(const VoxelHashMap *owner) : owner_(owner) {}
-        static uint64_t pack(const Voxel &v) {
-            return (static_cast<uint64_t>(static_cast<uint32_t>(v.x())) * 0x9E3779B97F4A7C15ull) ^
-                   (static_cast<uint64_t>(static_cast<uint32_t>(v.y())) << 32 | static_cast<uint32_t>(v.z()));
-        }
+        // the index is keyed on the voxel itself (the reference's std::hash<Voxel>, kiss-icp v1.2.0 core/VoxelUtils.hpp, and
+        // component-wise equality): two voxels can share a hash, never an entry
+        struct Key {
+            int x, y, z;
+            bool operator==(const Key &o) const { return x == o.x && y == o.y && z == o.z; }
+        };
+        struct KeyHash {
+            size_t operator()(const Key &k) const {
+                return static_cast<size_t>((static_cast<uint32_t>(k.x) * 73856093u) ^ (static_cast<uint32_t>(k.y) * 19349669u) ^ (static_cast<uint32_t>(k.z) * 83492791u));
+            }
+        };
         // Pointcloud() lists the voxels one after another; a voxel's points are recognised by PointToVoxel (VoxelUtils.hpp)
         const std::vector<value_type> &snapshot() const {
             if (seen_ == owner_->version_) return items_;
@@ -68,7 +75,7 @@ struct VoxelHashMap {
             for (const auto &p : points) {
                 const Voxel v(static_cast<int>(std::floor(p.x() / vs)), static_cast<int>(std::floor(p.y() / vs)), static_cast<int>(std::floor(p.z() / vs)));
                 if (items_.empty() || items_.back().first.x() != v.x() || items_.back().first.y() != v.y() || items_.back().first.z() != v.z()) {
-                    index_[pack(v)] = items_.size();
+                    index_[Key{v.x(), v.y(), v.z()}] = items_.size();
                     items_.emplace_back(v, mapped_type{});
                 }
                 items_.back().second.push_back(p);
@@ -78,7 +85,7 @@ struct VoxelHashMap {
         }
         const VoxelHashMap *owner_;
         mutable std::vector<value_type> items_;
-        mutable std::unordered_map<uint64_t, size_t> index_;
+        mutable std::unordered_map<Key, size_t, KeyHash> index_;
         mutable uint64_t seen_ = ~uint64_t(0);
     };
 

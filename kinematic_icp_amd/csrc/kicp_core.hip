@@ -46,6 +46,20 @@ int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream) {
     const size_t want = bytes + bytes / 2 + (1u << 20);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.p), want, hipHostMallocDefault));
     hs.cap = want;
+    hs.dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&hs.dev), hs.p, 0) != hipSuccess) hs.dev = nullptr, (void)hipGetLastError();
+    return KICP_OK;
+}
+// a transfer that fills the staging buffer itself (kicp_register's pipelined frame upload): wait for the previous user, make room;
+// stage_end records the event that guards the buffer against the next one
+int stage_begin(HostStage &hs, size_t bytes, hipStream_t stream) {
+    if (int rc = stage_wait(hs)) return rc;
+    return stage_reserve(hs, bytes, stream);
+}
+int stage_end(HostStage &hs, hipStream_t stream) {
+    if (!hs.done) HIP_TRY(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(hs.done, stream));
+    hs.pending = true;
     return KICP_OK;
 }
 constexpr size_t kStagePiece = 1u << 20;

@@ -59,17 +59,20 @@ inline int set_device(int device) {
 // pinned staging buffer for uploads of pageable caller memory (see staged_upload)
 struct HostStage {
     unsigned char *p = nullptr;
+    unsigned char *dev = nullptr;  // the same memory as a kernel sees it (nullptr: not mapped on this platform)
     size_t cap = 0;
     hipEvent_t done = nullptr;  // recorded behind the last asynchronous copy that reads the buffer
     bool pending = false;       // such a copy may still be in flight: wait on `done` before writing the buffer again
     void release() {
         if (done) hipEventSynchronize(done), hipEventDestroy(done);
         if (p) hipHostFree(p);
-        p = nullptr, cap = 0, done = nullptr, pending = false;
+        p = nullptr, dev = nullptr, cap = 0, done = nullptr, pending = false;
     }
 };
 // (policy and implementation: kicp_core.hip)
 int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream);
+int stage_begin(HostStage &hs, size_t bytes, hipStream_t stream);
+int stage_end(HostStage &hs, hipStream_t stream);
 int staged_upload(HostStage &hs, size_t offset, void *dst, const void *src, size_t bytes, hipStream_t stream);
 int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hipStream_t stream);
 

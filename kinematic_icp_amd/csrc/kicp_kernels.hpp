@@ -589,9 +589,20 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
 // kernel.  `gave_up` (resident kernel): this workgroup saw no command in time and hands over empty sums; the group row's flag
 // word counts such workgroups in its upper half (kGaveUpUnit each) so that the host repeats the pass in a fresh launch.
 constexpr unsigned long long kGaveUpUnit = 1ull << 16;
+// A group's reader gives a row this long to land (100 MHz ticks = 2 s: rows arrive within microseconds of the ticket that
+// announced them; anything longer is a lost workgroup).  It then hands over what it has, marked kLostRowUnit in the flag word, and
+// the host repeats the pass (resident kernel) or fails the call - instead of a wave spinning on the device for ever.
+constexpr unsigned long long kLostRowUnit = 1ull << 8;
+constexpr long long kRowWaitTicks = 200000000ll;
 // ROWS_ONLY: the caller only ever runs mode 4 (the resident kernel): none of the other hand-offs is compiled in.
+// `parity` (resident kernel: pass & 1): workgroup rows, tickets and the groups' host rows are double-buffered by pass parity, so
+// that what a workgroup writes for pass k + 1 - in particular the marked empty row of a workgroup that gave up waiting for the
+// command of pass k + 1 - can never land on a row of pass k that its reader (the group's last workgroup, the host) has not
+// consumed yet.  The buffer of parity (k + 1) & 1 last held pass k - 1, whose rows the host had added before it sent the command
+// that started pass k.
 template <int BLOCK, bool ROWS_ONLY = false>
-__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag, uint32_t row_tag, int gave_up = 0) {
+__device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s_red)[kWaveLimbs], int *s_flag, uint32_t row_tag, int gave_up = 0,
+                                            uint32_t parity = 0u) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
     if (!ROWS_ONLY && p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
@@ -628,7 +639,9 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             i128_add_limb_sums(t, s_red[w][kTermLimbs * lane], s_red[w][kTermLimbs * lane + 1], s_red[w][kTermLimbs * lane + 2], s_red[w][kTermLimbs * lane + 3]);
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
-    unsigned long long *row = p.partials + static_cast<size_t>(b) * kReduceWords;
+    unsigned long long *const rows0 = p.partials + (ROWS_ONLY ? static_cast<size_t>(parity) * nblocks * kReduceWords : 0u);
+    unsigned int *const tickets0 = p.tickets + (ROWS_ONLY ? static_cast<size_t>(parity) * ngroups * kTicketStride : 0u);
+    unsigned long long *row = rows0 + static_cast<size_t>(b) * kReduceWords;
     if (ROWS_ONLY || p.sol.mode == 4 || p.sol.mode == 6) {
         // Tagged rows: no store acknowledgement is awaited anywhere.  The ticket only elects the group's reader; whether
         // a row has landed is visible in the row itself.  Values: limbs < 2^40 (the top limb is a small signed number
@@ -644,20 +657,28 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
                    ((lane == kNumSums ? static_cast<unsigned long long>(range_error) + (gave_up ? kGaveUpUnit : 0ull) : 0ull) << 16) | tag);
         }
         unsigned int ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) ticket = __hip_atomic_fetch_add(tickets0 + static_cast<size_t>(g) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __shfl(ticket, 0, 64);
         const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
         if (ticket != group_size - 1) return;
-        if (lane == 0) __hip_atomic_store(p.tickets + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(tickets0 + static_cast<size_t>(g) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long total;
         bool ok;
-        do {
-            total = sum_rows_tagged(p.partials + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
-        } while (!__all(ok));
+        total = sum_rows_tagged(rows0 + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
+        if (!__all(ok)) {  // (rare: a row still on its way) re-read, bounded by wall-clock time
+            const long long t0 = wall_clock64();
+            bool lost = false;
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                total = sum_rows_tagged(rows0 + static_cast<size_t>(g) * kGroup * kReduceWords, group_size, lane, static_cast<uint32_t>(tag), ok);
+                lost = wall_clock64() - t0 > kRowWaitTicks;
+            } while (!__all(ok) && !lost);
+            if (!__all(ok)) total = lane == kNumLimbs ? static_cast<long long>(kLostRowUnit) : 0ll;  // nothing of an incomplete sum is handed on
+        }
         if (ROWS_ONLY || p.sol.mode == 4) {
             if (lane < kReduceWords)
-                __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(g) * kReduceWords + lane, (static_cast<unsigned long long>(total) << 16) | tag,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(ROWS_ONLY ? parity * ngroups : 0u) + g) * kReduceWords + lane,
+                                   (static_cast<unsigned long long>(total) << 16) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
         // mode 6: the group's row goes into EVERY rank's mailbox (over xGMI for the peers'), tagged with the step
@@ -1173,7 +1194,9 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
         L.todo = mine;
     }
     float cull = L.t.b1;  // running minimum shared by the G sub-lanes (culling only)
+    uint32_t rounds = 0u;  // (wave-uniform; read by the dbg 10 census only)
     while (__any(L.todo != 0u)) {
+        ++rounds;
         // which of the 27 neighbours could still hold something within the margin of the current minimum
         L.todo = cull_todo(L, cull, margin);
         if (LAT) {
@@ -1204,6 +1227,9 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
     if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t, LAT ? &kept : nullptr);
+    // dbg 10 (bench.py's latency model): no correspondences are formed; the "count" sum carries the number of visiting rounds
+    // this WAVE ran - its chain of dependent bucket visits - from lane 0 (as rounds x 2^40: limb 1 holds bits 21..41, limb 2 the rest)
+    if (p.dbg == 10 && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
 }
 template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {

@@ -98,6 +98,7 @@ struct kicp_reg {
     // small host frames skip the DMA engine altogether: the CPU writes them through the PCIe BAR into host-visible HBM
     double *bar_frame = nullptr;  // (the same address on both sides)
     int use_bar_frame = 1;        // option "bar_frame"
+    int fetch_frames = 1;         // option "fetch_upload": larger host frames are pulled by the GPU out of the staging buffer piece by piece (1) | DMA engine (0)
     bool bar_frame_tried = false;
     // options
     int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather
@@ -378,6 +379,47 @@ int ensure_frame(kicp_reg *r, size_t n) {
     r->frame_cap = want;
     return KICP_OK;
 }
+// A piece of a host frame, read by the GPU straight out of the handle's pinned staging buffer (host-mapped memory, over PCIe) and
+// written as fp64 into the device frame: float32 sources are widened on the way - static_cast<double>(float) is exact, i.e. what
+// the reference's host-side conversion produces (ros/src/kinematic_icp_ros/utils/RosUtils.cpp:30-39).  16 bytes per lane and load.
+template <typename T>
+__global__ __launch_bounds__(256) void k_fetch_frame(const T *__restrict__ staged, double *__restrict__ dst, uint32_t count) {
+    constexpr uint32_t kPer = 16 / sizeof(T);  // scalars per 16-byte load
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * kPer;
+    if (i + kPer <= count) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(staged + i));
+        T v[kPer];
+        __builtin_memcpy(v, &w, 16);
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) dst[i + k] = static_cast<double>(v[k]);
+    } else {
+        for (uint32_t k = i; k < count; ++k) dst[k] = static_cast<double>(staged[k]);
+    }
+}
+// Upload of a whole host frame (`n` points of T = double | float) into r->d_frame: the calling thread copies the caller's memory
+// into the pinned staging buffer piece by piece and launches k_fetch_frame behind each piece, so the GPU pulls piece k over PCIe
+// while the CPU copies piece k + 1.  One kernel launch per piece costs the host ~3 us where a hipMemcpyAsync costs ~10
+// (profiles/r03_time_presteps.txt), and nothing but the copy itself is left on the calling thread.
+constexpr size_t kFetchPiece = 384u << 10;  // bytes of caller memory per piece (a multiple of 16)
+template <typename T>
+int fetch_upload(kicp_reg *r, const T *src, size_t n) {
+    const size_t bytes = n * 3 * sizeof(T);
+    if (int rc = stage_begin(r->stage, bytes, r->stream)) return rc;
+    if (!r->stage.dev) return fail(KICP_ERR_HIP, "the staging buffer is not mapped into the device's address space");
+    const unsigned char *from = reinterpret_cast<const unsigned char *>(src);
+    for (size_t off = 0; off < bytes; off += kFetchPiece) {
+        const size_t len = std::min(kFetchPiece, bytes - off);
+        std::memcpy(r->stage.p + off, from + off, len);
+        const uint32_t count = static_cast<uint32_t>(len / sizeof(T));
+        const uint32_t grid = static_cast<uint32_t>((len + 4095) / 4096);  // 256 lanes x 16 bytes
+        hipLaunchKernelGGL(k_fetch_frame<T>, dim3(grid), dim3(256), 0, r->stream, reinterpret_cast<const T *>(r->stage.dev + off),
+                           r->d_frame + off / sizeof(T), count);
+    }
+    HIP_TRY(hipGetLastError());
+    return stage_end(r->stage, r->stream);
+}
+
 // enqueue the collective between the limb reduction and the solve (multi-GPU only)
 int enqueue_allreduce(kicp_reg *r) {
     long long *buf = r->d_state->reduce;
@@ -432,14 +474,14 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
 }
 
 // mode 4: add the tagged rows of the `groups` first-level groups as they arrive (word = value << 16 | tag)
-int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kReduceWords]) {
+int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kReduceWords], size_t first_row = 0) {
     for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
     const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
     unsigned drained = 0;
     unsigned long long spins = 0;
     const Deadline deadline;
     for (size_t g = 0; g < groups; ++g) {
-        const unsigned long long *row = r->rows + g * kReduceWords;
+        const unsigned long long *row = r->rows + (first_row + g) * kReduceWords;
         long long v[kReduceWords];
         for (;;) {
             bool ok = true;
@@ -610,7 +652,7 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
 }
 // add the rows of the `grid` workgroups as they arrive; out_words in the layout of the all-reduce payload (three 40-bit limbs
 // per sum, then the range flag).  *gave_up: a resident workgroup left without having seen the command of this pass.
-int wait_rows_small(kicp_reg *r, uint32_t grid, uint32_t tag, long long out_words[kReduceWords], bool *gave_up) {
+int wait_rows_small(kicp_reg *r, uint32_t grid, uint32_t tag, uint32_t parity, long long out_words[kReduceWords], bool *gave_up) {
     __int128 total[kNumSums] = {};
     unsigned long long flags = 0;
     const unsigned query_every = r->query_every > 0 ? static_cast<unsigned>(r->query_every) : 64u;
@@ -618,7 +660,7 @@ int wait_rows_small(kicp_reg *r, uint32_t grid, uint32_t tag, long long out_word
     unsigned long long spins = 0;
     const Deadline deadline;
     for (uint32_t g = 0; g < grid; ++g) {
-        const unsigned long long *row = r->rows + static_cast<size_t>(g) * kSmallRowWords;
+        const unsigned long long *row = r->rows + (static_cast<size_t>(parity) * grid + g) * kSmallRowWords;
         unsigned long long w[kSmallRowWords];
         // the rows land within a few microseconds of each other, and every line the device has just written misses the CPU's
         // caches: ask for the lines a few rows ahead while this row is being checked
@@ -702,16 +744,29 @@ struct HostLoop {
     }
 };
 
+// A workgroup of an earlier resident launch of the generic kernel gave up waiting for its command (k_pass_resident sets the word):
+// tickets of a give-up round that never completed - the call ended first - may be left behind.  Clear them before they are
+// counted into this call's passes.
+int clear_stale_tickets(kicp_reg *r) {
+    if (__atomic_load_n(&r->rec->reserved[0], __ATOMIC_RELAXED) == 0u || !r->d_tickets) return KICP_OK;
+    if (int rc = aql_quiesce(r)) return rc;
+    r->stream_dirty = true;
+    HIP_TRY(hipMemsetAsync(r->d_tickets, 0, (r->partial_blocks / kGroup + 2) * kTicketStride * sizeof(unsigned int), r->stream));
+    __atomic_store_n(&r->rec->reserved[0], 0u, __ATOMIC_RELAXED);
+    return KICP_OK;
+}
+
 int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const SmallPlan &pl, const Pose &T0, double tau, double out_pose_qt[7],
               kicp_stats *stats) {
     const int max_it = r->cfg.max_num_iterations;
     const uint32_t grid = pl.grid;
     // generic plan: a launch that will not stay goes out as the plain pass kernel (launch_pass, its own grid)
     const size_t groups_resident = (grid + kGroup - 1) / kGroup, groups_plain = (pass_grid(r, n) + kGroup - 1) / kGroup;
+    // (rows, tickets and host rows of a resident launch are double-buffered by pass parity: finish_pass, small_publish)
     if (pl.generic) {
-        if (int rc = ensure_partials(r, std::max<uint32_t>(grid, pass_grid(r, n)))) return rc;
-        if (int rc = ensure_rows(r, std::max(groups_resident, groups_plain))) return rc;
-    } else if (int rc = ensure_rows(r, grid)) {
+        if (int rc = ensure_partials(r, std::max<uint32_t>(2u * grid, pass_grid(r, n)))) return rc;
+        if (int rc = ensure_rows(r, std::max(2 * groups_resident, groups_plain))) return rc;
+    } else if (int rc = ensure_rows(r, 2 * static_cast<size_t>(grid))) {
         return rc;
     }
     if (int rc = ensure_cmd(r)) return rc;
@@ -720,7 +775,9 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
-    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id;
+    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
+    if (pl.generic)
+        if (int rc = clear_stale_tickets(r)) return rc;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);  // 100 MHz wall clock
     HostLoop loop;
@@ -753,11 +810,13 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             bool gave_up = false;
             int rc_rows;
             if (pl.generic) {
-                rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words);
-                gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 16) != 0ull;  // workgroups that left without a command (kGaveUpUnit each)
-                words[kNumLimbs] &= 0xFFFFll;
+                rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words, plain ? 0 : (k & 1u) * groups_resident);
+                // workgroups that left without a command (kGaveUpUnit each), or a row that never reached its group's reader
+                // (kLostRowUnit): either way this pass is run again, in a fresh launch
+                gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull;
+                words[kNumLimbs] &= 0xFFll;
             } else {
-                rc_rows = wait_rows_small(r, grid, sp.tag0 + k, words, &gave_up);
+                rc_rows = wait_rows_small(r, grid, sp.tag0 + k, k & 1u, words, &gave_up);
             }
             const auto t_rows = std::chrono::steady_clock::now();
             if (r->d_trace) {
@@ -834,6 +893,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         if (pl.grid) return run_small(r, map, d_frame, n, pl, T0, tau, out_pose_qt, stats);
     }
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
+    if (int rc = clear_stale_tickets(r)) return rc;
     if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
     if (p2p && (!r->host_solve || multi || shm)) return fail(KICP_ERR_ARG, "the peer-mailbox mode needs host_solve = 1 and no other exchange attached");
     if (p2p && r->p2p_poisoned)
@@ -921,6 +981,8 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
             }
             if (rows_mode) {
                 if (int rc = wait_rows(r, groups, sp.tag, words)) return rc;
+                if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
+                    return fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)");
                 if (shm) {  // this rank's totals go into its slot from the host side; then every rank adds all slots
                     for (int i = 0; i < kReduceWords; ++i) mine_host->words[i] = words[i];
                     __atomic_store_n(&mine_host->seq, shm_value, __ATOMIC_RELEASE);
@@ -1175,6 +1237,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
     else if (k == "bar_frame") reg->use_bar_frame = value != 0.0 ? 1 : 0;
+    else if (k == "fetch_upload") reg->fetch_frames = value != 0.0 ? 1 : 0;
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
     else if (k == "small_resident") reg->small_resident = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);  // 1 adaptive (default), 2 always, 0 never
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
@@ -1219,6 +1282,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "aql") return reg->use_aql;
     if (k == "aql_kernarg") return !reg->aql.ready ? -1.0 : (std::strcmp(reg->aql.kernarg_place(), "host memory") == 0 ? 0.0 : (std::strcmp(reg->aql.kernarg_place(), "device memory") == 0 ? 1.0 : 2.0));
     if (k == "bar_frame") return reg->bar_frame ? 1.0 : (reg->use_bar_frame ? 0.5 : 0.0);  // 1: in use; 0.5: enabled, not (yet) set up
+    if (k == "fetch_upload") return reg->fetch_frames;
     if (k == "small") return reg->use_small;
     if (k == "small_resident") return reg->small_resident;
     if (k == "small_block") return reg->small_block;
@@ -1347,10 +1411,60 @@ int kicp_register(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t 
             }
         }
         if (int rc = ensure_frame(reg, n)) return rc;
+        if (int rc = aql_quiesce(reg)) return rc;
         reg->stream_dirty = true;  // (the kernels of earlier calls have long read d_frame: the host had their results)
-        if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
+        if (reg->fetch_frames) {
+            if (int rc = fetch_upload<double>(reg, frame_xyz, n)) return rc;
+        } else if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) {
+            return rc;
+        }
     }
     return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+// ComputeRobotMotion on a frame that is still float32 - what a PointCloud2 carries on the wire (RosUtils.cpp:30-39 widens every
+// coordinate with static_cast<double> on the host before the reference ever sees it): half the bytes cross PCIe, the widening
+// happens on the device (exact, so the registration sees the very doubles the reference sees).
+int kicp_register_f32(kicp_reg *reg, kicp_map *map, const float *frame_xyz_f32, size_t n, const double last_pose_qt[7],
+                      const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7], kicp_stats *stats) {
+    KICP_TRACE_CALL();
+    if (!reg || !map || (!frame_xyz_f32 && n)) return fail(KICP_ERR_ARG, "null argument");
+    if (!kicp_map_empty(map) && n) {
+        if (int rc = set_device(reg->device)) return rc;
+        if (reg->use_bar_frame && n <= kBarFramePoints) {  // small frames: widened by the CPU on their way through the BAR
+            if (!reg->bar_frame && !reg->bar_frame_tried) {
+                reg->bar_frame_tried = true;
+                if (aql_up(reg)) reg->bar_frame = static_cast<double *>(reg->aql.alloc_bar(kBarFramePoints * 24));
+            }
+            if (reg->bar_frame) {
+                for (size_t i = 0; i < 3 * n; ++i) reg->bar_frame[i] = static_cast<double>(frame_xyz_f32[i]);
+                _mm_sfence();
+                return run_registration(reg, map, reg->bar_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+            }
+        }
+        if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+        if (int rc = ensure_frame(reg, n)) return rc;
+        if (int rc = aql_quiesce(reg)) return rc;
+        reg->stream_dirty = true;
+        if (int rc = fetch_upload<float>(reg, frame_xyz_f32, n)) return rc;
+    }
+    return run_registration(reg, map, reg->d_frame, n, last_pose_qt, rel_odom_qt, max_correspondence_distance, out_pose_qt, stats);
+}
+// KinematicRegistration(const KinematicRegistration &): the reference's struct is a plain copyable aggregate
+// (Registration.hpp:32-50).  A new handle on the same device with the same parameters and tuning options, and workspaces of its
+// own; multi-GPU exchanges (communicator, shared segment, mailboxes, callback) are per handle and are NOT carried over.
+int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
+    if (!reg || !out) return fail(KICP_ERR_ARG, "null argument");
+    kicp_reg *c = nullptr;
+    if (int rc = kicp_reg_create(&reg->cfg, reg->device, &c)) return rc;
+    c->group_rows = reg->group_rows, c->use_bar_frame = reg->use_bar_frame, c->fetch_frames = reg->fetch_frames;
+    c->pass_kernel = reg->pass_kernel, c->block = reg->block, c->loop_mode = reg->loop_mode, c->wait_mode = reg->wait_mode, c->timing = reg->timing;
+    c->query_every = reg->query_every, c->lanes_per_query = reg->lanes_per_query, c->occupancy = reg->occupancy, c->latency_kernel = reg->latency_kernel;
+    c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
+    c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
+    c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
+    c->resident_generic = reg->resident_generic;
+    *out = c;
+    return KICP_OK;
 }
 static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                      double max_correspondence_distance, double out_sums[7], long long out_words[24]);

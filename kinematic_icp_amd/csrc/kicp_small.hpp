@@ -46,7 +46,8 @@ struct SmallParams {
     unsigned long long *cmd_dev;    // kCmdReplicas copies of the command line in device memory (await_command)
     int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
     long long *trace;               // debugging aid (option "small_trace"): workgroup 0 stamps its passes here, 4 wall-clock words each
-    unsigned long long *rows;       // device view of the host-mapped rows [gridDim.x][kSmallRowWords]
+    unsigned long long *rows;       // device view of the host-mapped rows [2][gridDim.x][kSmallRowWords]: pass k writes buffer k & 1, so the
+                                    // give-up marker of pass k + 1 never lands on a row of pass k the host has not read yet
     unsigned long long seq_base;    // the command that starts pass k (k >= 1) carries sequence seq_base + k
     uint32_t tag0;                  // pass k publishes with tag tag0 + k (the host reserves the range)
     uint32_t max_passes;            // passes this launch may serve; 1 = leave after the first (no residency)
@@ -102,7 +103,7 @@ __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t ti
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
                 if (MARK_ROWS && lane < kSmallRowWords)
-                    __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + lane,
+                    __hip_atomic_store(sp.rows + (static_cast<size_t>((pass + 1u) & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + lane,
                                        ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -127,7 +128,8 @@ __device__ __forceinline__ double uniform_lane_d(double v, int l) {
 
 // workgroup sum of the lanes' terms -> one row of self-validating words in host memory
 template <int BLOCK>
-__device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &sp, uint32_t tid, uint32_t tag, int (*s_red)[kWaveLimbs], int *s_flag) {
+__device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &sp, uint32_t tid, uint32_t pass, int (*s_red)[kWaveLimbs], int *s_flag) {
+    const uint32_t tag = sp.tag0 + pass;
     const int lane = tid & 63, wave = tid >> 6;
     int limb[kWaveLimbs];
 #pragma unroll
@@ -152,7 +154,8 @@ __device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &s
     if (lane == 2 * kNumSums) word = (*s_flag & 2) ? 1ull : 0ull;
     if (lane > 2 * kNumSums) word = 0ull;
     if (lane < kSmallRowWords)
-        __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + lane, (word << 16) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(sp.rows + (static_cast<size_t>(pass & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + lane, (word << 16) | tag, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // G sub-lanes per query as in k_pass_gather32 (the neighbour voxels of a query are dealt round-robin to its sub-lanes).
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         tid = fresh_tid();
-        small_publish<BLOCK>(acc, sp, tid, sp.tag0 + pass, s_red, &s_flag);
+        small_publish<BLOCK>(acc, sp, tid, pass, s_red, &s_flag);
         if (pass + 1 >= sp.max_passes) return;
         if (!await_command(sp, tid, pass, s_cmd)) return;
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
@@ -242,11 +245,15 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
         Acc acc{};
         if (!gave_up) gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc);
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
-        finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up);
+        finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up, pass & 1u);
         if (gave_up || pass + 1 >= sp.max_passes) return;
         if (!await_command<false>(sp, fresh_tid(), pass, s_cmd)) {
             if (static_cast<uint32_t>(s_cmd[7]) == kCmdStop) return;
             gave_up = 1;
+            // tell the host that a workgroup of this launch gave up: should the call end before every workgroup has taken its ticket
+            // of the give-up round (the host stops after the pass it was waiting for), the next launch must not inherit the
+            // tickets taken so far - the host clears them when it finds this word set (run_small)
+            if (fresh_tid() == 0 && sp.p.sol.rec) __hip_atomic_store(&sp.p.sol.rec->reserved[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             continue;
         }
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
@@ -529,8 +536,8 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
             if (ln == 2 * kNumSums) word = (s_flag & 2) ? 1ull : 0ull;
             if (ln > 2 * kNumSums) word = 0ull;
             if (ln < kSmallRowWords)
-                __hip_atomic_store(sp.rows + static_cast<size_t>(blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(sp.rows + (static_cast<size_t>(pass & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;

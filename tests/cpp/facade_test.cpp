@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kinematic_icp/pipeline/KinematicICP.hpp"
@@ -62,6 +63,36 @@ int main(int argc, char **argv) {
             print_pose("pose_on_copy", reg.ComputeRobotMotion(frame, assigned, kicp_bridge::from_params(last.data()),
                                                               kicp_bridge::from_params(rel.data()), h[4]));
             printf("original_empty %d copy_points %zu\n", map.Empty() ? 1 : 0, copy.Pointcloud().size());
+            // the registration is copyable / movable like the reference's struct (Registration.hpp:32-50): a copy carries the
+            // edited public fields, registers to the same pose on a handle of its own, and outlives the original
+            kinematic_icp::KinematicRegistration *first = new kinematic_icp::KinematicRegistration(10, 1e-3, 1, true, 0.0);
+            first->max_num_iterations_ = 7;
+            kinematic_icp::KinematicRegistration copied(*first);
+            kinematic_icp::KinematicRegistration moved(std::move(*first));
+            delete first;
+            kinematic_icp::KinematicRegistration target(3, 1e-2, 1, false, 0.5);
+            target = copied;
+            printf("copied_fields %d %d %d %d %d\n", copied.max_num_iterations_, moved.max_num_iterations_, target.max_num_iterations_,
+                   target.use_adaptive_odometry_regularization_ ? 1 : 0, copied.handle() != moved.handle() && target.handle() != copied.handle() ? 1 : 0);
+            copied.max_num_iterations_ = moved.max_num_iterations_ = target.max_num_iterations_ = 10;
+            print_pose("pose_copied", copied.ComputeRobotMotion(frame, assigned, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]));
+            print_pose("pose_moved", moved.ComputeRobotMotion(frame, assigned, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]));
+            print_pose("pose_assigned", target.ComputeRobotMotion(frame, assigned, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]));
+            // float32 frame (the wire format): the same registration as on the widened doubles
+            std::vector<float> f32(frame.size() * 3);
+            std::vector<Eigen::Vector3d> widened(frame.size());
+            for (size_t i = 0; i < frame.size(); ++i)
+                for (int c = 0; c < 3; ++c) f32[3 * i + c] = static_cast<float>(frame[i][c]), widened[i][c] = static_cast<double>(f32[3 * i + c]);
+            print_pose("pose_f32", copied.ComputeRobotMotion(f32.data(), frame.size(), assigned, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]));
+            print_pose("pose_widened", copied.ComputeRobotMotion(widened, assigned, kicp_bridge::from_params(last.data()), kicp_bridge::from_params(rel.data()), h[4]));
+            // the pipeline object too (every member by value in the reference, KinematicICP.hpp:100-108)
+            kinematic_icp::pipeline::Config cfg;
+            kinematic_icp::pipeline::KinematicICP icp(cfg);
+            icp.VoxelMap().AddPoints(map_pts);
+            kinematic_icp::pipeline::KinematicICP icp_copy(icp);
+            icp.SetPose(Sophus::SE3d());
+            kinematic_icp::pipeline::KinematicICP icp_moved(std::move(icp));
+            printf("pipeline_copy %zu %zu\n", icp_copy.LocalMap().size(), icp_moved.LocalMap().size());
         } else if (mode == "pipeline") {
             const auto h = read_doubles(f, 4);  // n_frames, voxel, max_range, deskew
             kinematic_icp::pipeline::Config cfg;

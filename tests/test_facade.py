@@ -61,6 +61,16 @@ def test_facade_registration_matches_golden(tmp_path):
     assert out[3] == "iterations_after_edit 1"
     np.testing.assert_array_equal(np.array([float(x) for x in out[4].split()[1:]]), pose)  # registration against a copy of the map
     assert out[5] == "original_empty 1 copy_points %d" % m.num_points()
+    # copy / move / assignment of the registration (value semantics of the reference's struct) and of the pipeline object
+    assert out[6] == "copied_fields 7 7 7 1 1"
+    for k in (7, 8, 9):
+        np.testing.assert_array_equal(np.array([float(x) for x in out[k].split()[1:]]), pose)
+    f32_pose, widened_pose = (np.array([float(x) for x in out[k].split()[1:]]) for k in (10, 11))
+    np.testing.assert_array_equal(f32_pose, widened_pose)  # float32 on the wire, widened on the device == widened on the host
+    wide = g["a_frame"].astype(np.float32).astype(np.float64)
+    ref = okicp.KinematicRegistration().ComputeRobotMotion(wide, m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+    np.testing.assert_allclose(f32_pose, ref, rtol=0, atol=1e-9)
+    assert out[12] == "pipeline_copy %d 0" % m.num_points()
 
 
 @pytest.mark.gpu
