@@ -62,6 +62,34 @@ L2_PEAK_GBS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 MULTI_ITER_ERROR = (0.05, 0.5)  # extra odometry error of the multi-iteration workload: metres along x, degrees of yaw
 
 
+class Workload:
+    """one BASELINE configuration resident on this rank's GPU: scene, scans (this rank's shard of each), map, threshold"""
+
+    def __init__(self, K, syn, name, n_scans, device, rank, world, replicas, torch=None):
+        self.name = name
+        self.cfg, self.scene, self.scans, rng = syn.make_case(name, n_scans=min(n_scans, 8))
+        self.gmap = K.VoxelHashMap(self.cfg.voxel_size, self.cfg.max_range, self.cfg.max_points_per_voxel)
+        # the map grows through VoxelHashMap::Update(points, identity) on the GPU - the path the pipeline's map update takes
+        # (same map as the host-side AddPoints builds, tests/test_gpu_mapdev.py; seconds instead of a minute for cfg5)
+        ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+        syn.build_map_points(self.scene, self.cfg, lambda pts: self.gmap.UpdateDevice(K.DeviceFrame(pts, device=device), ident), self.gmap.num_points, rng)
+        if n_scans > 8:
+            # further scans from a generator of their own (the first eight and the map are those of every earlier round), ray-cast
+            # on the GPU by torch: dozens of distinct 131 072-point scans in seconds
+            cast = (lambda o, d: syn.raycast_torch(self.scene, o, d, "cuda")) if torch is not None else None
+            self.scans += syn.extra_scans(self.cfg, self.scene, n_scans - 8, self.cfg.seed + 1000, raycast=cast)
+        self.tau = self.cfg.first_frame_tau()
+        self.gmap.sync(device)
+        self.n_total = self.scans[0]["frame"].shape[0]
+        self.lo, self.hi = (self.n_total * rank) // world, (self.n_total * (rank + 1)) // world  # contiguous shard of this rank
+        if replicas:
+            self.lo, self.hi = 0, self.n_total
+        self.frames = [K.DeviceFrame(s["frame"][self.lo:self.hi], device=device) for s in self.scans]
+        extra = syn.planar_pose(MULTI_ITER_ERROR[0], 0.0, np.deg2rad(MULTI_ITER_ERROR[1]))
+        self.rel_single = [s["rel_odom"] for s in self.scans]
+        self.rel_multi = [syn.pose_mul(s["rel_odom"], extra) for s in self.scans]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,11 +97,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scans-per-step", type=int, default=0,
                     help="registrations per step (one batch of synthetic scans); 0 (default) = chosen after a calibration batch so that the "
-                         "timed region of the K steps lasts at least --min-timed-s, never fewer than 64")
+                         "timed region of the K steps lasts at least --min-timed-s, never fewer than 64; re-sized and re-run if the timed "
+                         "region still comes in short")
     ap.add_argument("--min-timed-s", type=float, default=0.3, help="shortest acceptable timed region (auto batch size)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic")
     ap.add_argument("--workload", default="cfg2")
-    ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
+    ap.add_argument("--scans", type=int, default=64, help="distinct synthetic scans cycled through (SURVEY.md section 8d asks for >= 50; 64 x 3.1 MB "
+                                                          "of scans + the map exceed what the caches hold)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "p2p", "torch"],
@@ -85,6 +115,8 @@ def main():
                     help="N>1: 'shard' (default, the north star) splits every scan's points across the ranks and exchanges the sums each "
                          "iteration; 'replicas' lets every rank register whole scans on its own (one robot per GPU, no exchange; weak scaling)")
     ap.add_argument("--force-comm", action="store_true", help="exercise the multi-GPU code path (all-reduce + separate solve) even with one rank")
+    ap.add_argument("--no-sharded-cfg5", action="store_true",
+                    help="N>1: skip the second sharded workload (cfg5: 500 000-point scans, 62 500 per GPU at N = 8 - where sharding can pay)")
     args = ap.parse_args()
 
     # Everything except the final JSON line goes to stderr - also what C libraries print (RCCL writes a version banner to
@@ -132,21 +164,9 @@ def main():
     pg_dev = "cuda" if args.pg_backend == "nccl" else "cpu"
 
     # ---- synthetic workload (identical on every rank: seeded) ---------------------------------------------------
-    cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=args.scans)
-    gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
-    # the map grows through VoxelHashMap::Update(points, identity) on the GPU - the path the pipeline's map update takes
-    # (same map as the host-side AddPoints builds, tests/test_gpu_mapdev.py; seconds instead of a minute for cfg5)
-    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
-    syn.build_map_points(scene, cfg, lambda pts: gmap.UpdateDevice(K.DeviceFrame(pts, device=device), ident), gmap.num_points, rng)
-    tau = cfg.first_frame_tau()
-    gmap.sync(device)
-    n_total = scans[0]["frame"].shape[0]
-    lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world  # contiguous shard of this rank
-    if replicas:
-        lo, hi = 0, n_total
-    frames = [K.DeviceFrame(s["frame"][lo:hi], device=device) for s in scans]
-    extra = syn.planar_pose(MULTI_ITER_ERROR[0], 0.0, np.deg2rad(MULTI_ITER_ERROR[1]))
-    rel_multi = [syn.pose_mul(s["rel_odom"], extra) for s in scans]
+    wl = Workload(K, syn, args.workload, max(1, args.scans), device, rank, world, replicas, torch)
+    cfg, scans, gmap, tau, n_total, lo, hi = wl.cfg, wl.scans, wl.gmap, wl.tau, wl.n_total, wl.lo, wl.hi
+    rel_single, rel_multi = wl.rel_single, wl.rel_multi
 
     def make_reg(comm, **kw):
         """a registration handle with the requested exchange attached (None: single GPU / replicas)"""
@@ -200,15 +220,16 @@ def main():
         torch.cuda.synchronize()
         K.lib().kicp_device_synchronize(device)
 
-    def run_scan(reg, i, rels, stats_out=None):
-        s = scans[i % len(scans)]
-        pose = reg.ComputeRobotMotion(frames[i % len(scans)], gmap, s["last_pose"], rels[i % len(scans)], tau)
+    def run_scan(reg, i, rels, stats_out=None, w=None):
+        w = w or wl
+        s = w.scans[i % len(w.scans)]
+        pose = reg.ComputeRobotMotion(w.frames[i % len(w.scans)], w.gmap, s["last_pose"], rels[i % len(w.scans)], w.tau)
         if stats_out is not None:
             k = reg.last_stats.iterations
             stats_out.append((k, list(reg.last_stats.pass_ms[:k])))
         return pose
 
-    B = max(1, args.scans_per_step) if args.scans_per_step > 0 else 64  # (auto: fixed below, after the calibration batch)
+    state = {"B": max(1, args.scans_per_step) if args.scans_per_step > 0 else 64}  # (auto: fixed below, after the calibration batch)
 
     def all_ranks_ok(err):
         """every rank learns whether ANY rank failed and all of them raise together (this rank's own error, or a stand-in)"""
@@ -220,20 +241,27 @@ def main():
         if err is not None:
             raise err
 
-    def timed(reg, rels, steps, warmup, per_call=False):
+    def timed(reg, rels, steps, warmup, per_call=False, w=None, B=None):
         """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
         A step is ONE kicp_register_device_batch call: the library registers the step's B scans one after the other (a plain
         loop of ComputeRobotMotion, each scan run to completion before the next starts) - what a C++ caller of the C-ABI
-        sees.  per_call=True issues the B calls from Python instead (adds the interpreter's ~3 us per call)."""
-        batch = reg.prepare_batch([frames[i % len(scans)] for i in range(B)], [scans[i % len(scans)]["last_pose"] for i in range(B)],
-                                  [rels[i % len(scans)] for i in range(B)])
+        sees.  per_call=True issues the B calls from Python instead (adds the interpreter's ~3 us per call).  The host clock is
+        read between steps (no synchronisation of any kind: a step ends when its last pose is back), for the median step."""
+        w = w or wl
+        B = B or state["B"]
+        nsc = len(w.scans)
+        # step k registers scans k*B .. (k+1)*B-1 of the cycle: with B not a multiple of the cycle every step starts elsewhere in it
+        batches = []
+        for k in range(max(1, min(steps, nsc)) if not per_call else 0):
+            idx = [(k * B + i) % nsc for i in range(B)]
+            batches.append(reg.prepare_batch([w.frames[i] for i in idx], [w.scans[i]["last_pose"] for i in idx], [rels[i] for i in idx]))
 
         def step(k):
             if per_call:
                 for i in range(k * B, (k + 1) * B):
-                    run_scan(reg, i, rels)
+                    run_scan(reg, i, rels, w=w)
             else:
-                reg.ComputeRobotMotionBatch(batch, gmap, tau)
+                reg.ComputeRobotMotionBatch(batches[k % len(batches)], w.gmap, w.tau)
         # A registration that fails on one rank (an exchange that cannot complete on this box) must not leave the ranks at
         # different collectives: the failing rank still walks through the barriers, and all ranks leave together (all_ranks_ok).
         err = None
@@ -243,11 +271,13 @@ def main():
         except K.KicpError as e:
             err = e
         barrier()
-        t0 = time.perf_counter()
+        marks = [time.perf_counter()]
+        t0 = marks[0]
         if err is None:
             try:
                 for k in range(steps):
                     step(k)
+                    marks.append(time.perf_counter())
             except K.KicpError as e:
                 err = e
         barrier()
@@ -257,10 +287,10 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        timed.last_iterations = float(np.mean(batch.iterations)) if not per_call else float("nan")  # ICP iterations per scan of this run
+        timed.last_iterations = float(np.mean(np.concatenate([b.iterations for b in batches]))) if not per_call else float("nan")  # ICP iterations per scan of this run
+        timed.last_step_s = np.diff(np.array(marks))  # this rank's clock
         return elapsed
 
-    rel_single = [s["rel_odom"] for s in scans]
     comm = args.comm if exchange else None
     comm_note = None
     try:
@@ -271,6 +301,7 @@ def main():
         comm_note = "rccl set-up failed (%s): fell back to the host shared segment" % e
         comm = args.comm = "shm"
         reg, keep = make_reg(comm)
+    rccl_ranks = int(reg.get_option("comm_ranks")) if comm == "rccl" else None
     # ---- one-time settling (setup, not measurement): the HIP runtime finishes its lazy initialisation (signal pools,
     #      code objects, clocks) during the first few hundred launches of a process; a ~30 ms hiccup there would
     #      otherwise land inside a short timed region.
@@ -278,6 +309,8 @@ def main():
     #      ranks agree on "another block?" (round 3 let each rank consult its own clock; when the 0.5 s mark fell between two
     #      ranks' checks one of them ran 50 scans more, which the peers never answered: the bounded wait of the exchange
     #      expired 20 s later - the one-in-fifteen failure of the two-rank test).
+    if world > 1 and rank == world - 1 and os.environ.get("KICP_BENCH_RANK_SKEW_S"):
+        time.sleep(float(os.environ["KICP_BENCH_RANK_SKEW_S"]))  # tests: the ranks' clocks start this far apart
     t_settle = time.perf_counter()
     while True:
         for i in range(50):
@@ -292,9 +325,20 @@ def main():
     if args.scans_per_step <= 0:
         # calibration (setup, not measurement): size the batch so that the K timed steps last >= --min-timed-s whatever K is;
         # identical on every rank (max over ranks)
-        t_cal = timed(reg, rel_single, 4, 1) / (4 * B)
-        B = int(min(8192, max(64, -(-args.min_timed_s // (max(1, args.steps) * t_cal)))))
-    elapsed = timed(reg, rel_single, args.steps, args.warmup)                 # ---- the headline number
+        t_cal = timed(reg, rel_single, 4, 1) / (4 * state["B"])
+        state["B"] = int(min(8192, max(64, -(-args.min_timed_s * 1.15 // (max(1, args.steps) * t_cal)))))
+    resized = 0
+    while True:
+        elapsed = timed(reg, rel_single, args.steps, args.warmup)             # ---- the headline number
+        step_s = timed.last_step_s.copy()
+        if args.scans_per_step > 0 or elapsed >= args.min_timed_s or state["B"] >= 8192 or resized >= 3:
+            break
+        # the timed region came in short of --min-timed-s AS MEASURED (a fresh box speeds up after the calibration batch):
+        # re-size the batch from this run's own rate and time the K steps again (identical decision on every rank: `elapsed` is
+        # the maximum over ranks)
+        state["B"] = int(min(8192, max(state["B"] + 1, -(-state["B"] * args.min_timed_s * 1.2 // elapsed))))
+        resized += 1
+    B = state["B"]
     launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp), kernel arguments in %s"
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
@@ -314,32 +358,63 @@ def main():
     for i in range(min(n_ev, 512)):
         run_scan(reg, i, rel_multi, per_call_multi)
     barrier()
-    # fixed floor of a pass, measured live: the same launch with every query switched off (launch + reduction + hand-off)
-    floor_us = None
+    # fixed floor of a pass, measured live: the same launch with every query switched off (launch + reduction + hand-off);
+    # and the census behind the latency model: visiting rounds per wave (dbg 10: the "count" sum carries every wave's rounds)
+    floor_us, rounds_per_wave = None, None
     if not use_comm and not small_active:  # (the dbg switches belong to the generic pass kernel)
         reg.set_option("dbg", 7)
         tmp = []
         for i in range(64 + 256):
             run_scan(reg, i, rel_single, tmp)
-        reg.set_option("dbg", 0)
         fl = np.array([lst[0] for _, lst in tmp[64:] if lst], dtype=np.float64)  # (pass 0: with every query off the call ends there)
         floor_us = float(fl.mean() * 1e3) if fl.size else None
+        reg.set_option("dbg", 10)
+        lanes = int(reg.get_option("lanes_per_query")) or (4 if hi - lo <= 4096 else (2 if hi - lo <= 32768 else 1))  # (0 = by scan size, as the library picks)
+        waves = -(-(hi - lo) * lanes // 64)
+        rr = []
+        max_it = reg.max_num_iterations_
+        reg.max_num_iterations_ = 1  # (the census pass carries no correspondences: there is nothing to iterate on)
+        for i in range(min(len(scans), 16)):
+            run_scan(reg, i, rel_single)
+            rr.append(reg.last_stats.n_corr[0] / waves)
+        reg.max_num_iterations_ = max_it
+        rounds_per_wave = float(np.mean(rr))
+        reg.set_option("dbg", 0)
     reg.set_option("timing", 0)
     poses = [run_scan(reg, i, rel_single) for i in range(len(scans))]
     poses_multi = [run_scan(reg, i, rel_multi) for i in range(len(scans))]
     barrier()
-    # informational, never `value`: the same calls with the scan handed over as a HOST array (upload inside)
-    host_rate = None
+    # informational, never `value`: the same calls with the scan handed over as a HOST array (upload inside), as fp64 - the
+    # reference's std::vector<Eigen::Vector3d> - and as float32, the wire format of the message the points came in
+    host_rate = host_rate_f32 = None
+    f32_pose_err = None
     if world == 1:
-        host_frames = [np.ascontiguousarray(s["frame"][lo:hi]) for s in scans]
+        nh = min(len(scans), 16)
+        host_frames = [np.ascontiguousarray(s["frame"][lo:hi]) for s in scans[:nh]]
         for i in range(8):
-            reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
+            reg.ComputeRobotMotion(host_frames[i % nh], gmap, scans[i % nh]["last_pose"], scans[i % nh]["rel_odom"], tau)
         t1 = time.perf_counter()
         k_host = min(args.steps * B, 400)
         for i in range(k_host):
-            reg.ComputeRobotMotion(host_frames[i % len(scans)], gmap, scans[i % len(scans)]["last_pose"], scans[i % len(scans)]["rel_odom"], tau)
+            reg.ComputeRobotMotion(host_frames[i % nh], gmap, scans[i % nh]["last_pose"], scans[i % nh]["rel_odom"], tau)
         host_rate = k_host / (time.perf_counter() - t1)
+        f32_frames = [f.astype(np.float32) for f in host_frames]
+        f32_poses = [reg.ComputeRobotMotion(f32_frames[i % nh], gmap, scans[i % nh]["last_pose"], scans[i % nh]["rel_odom"], tau) for i in range(8)]
+        t1 = time.perf_counter()
+        for i in range(k_host):
+            reg.ComputeRobotMotion(f32_frames[i % nh], gmap, scans[i % nh]["last_pose"], scans[i % nh]["rel_odom"], tau)
+        host_rate_f32 = k_host / (time.perf_counter() - t1)
     pass_kernel = int(reg.get_option("pass_kernel"))
+    # ---- latency model inputs: the time of one DEPENDENT load step under the pass kernel's own launch shape, far (a working set
+    #      of the map's size: probes, buckets, winners) and near (the record next to the probed key: the same line again)
+    lat_far_ns = lat_near_ns = None
+    if world == 1 and not small_active:
+        try:
+            shape = dict(workgroups=max(1, -(-(hi - lo) // 256)), block=256, steps=64, device=device)
+            lat_far_ns = K.probe_dependent_load(max(gmap.device_bytes(), 1 << 20), **shape)
+            lat_near_ns = K.probe_dependent_load(16 << 10, **shape)
+        except K.KicpError:
+            pass
     if exchange:
         release(reg, comm)
     del reg
@@ -347,22 +422,36 @@ def main():
     #      per ICP iteration on the multi-iteration workload and what the exchange adds per iteration over the same shard
     #      registered WITHOUT any exchange (a plain handle on this rank's points: the kernel and hand-off alone)
     other = {}
-    if exchange:
+    top_exchange = {}
+
+    def measure_exchanges(w, steps, B_w, headline_comm=None, headline=None):
+        """every exchange on workload `w`: scans/s, us per ICP iteration, what the exchange adds per iteration"""
         FIXED = dict(max_num_iteration=4, convergence_criterion=0.0)  # every scan runs exactly four iterations, exchange or not
 
-        def measure(reg_x, reg_fixed):
-            for i in range(60):
-                run_scan(reg_x, i, rel_single)
-            e1 = timed(reg_x, rel_single, args.steps, min(args.warmup, 2))
-            em = timed(reg_x, rel_multi, args.steps, 1)
+        def rates(reg_x, reg_fixed):
+            err = None
+            try:
+                for i in range(60):
+                    run_scan(reg_x, i, w.rel_single, w=w)
+            except K.KicpError as e:
+                err = e
+            all_ranks_ok(err)
+            e1 = timed(reg_x, w.rel_single, steps, min(args.warmup, 2), w=w, B=B_w)
+            em = timed(reg_x, w.rel_multi, steps, 1, w=w, B=B_w)
             its = timed.last_iterations
-            ef = timed(reg_fixed, rel_single, args.steps, 1)
-            return {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / its, 3),
-                    "iterations_per_scan": round(its, 3), "us_per_iteration_at_4_fixed_iterations": round(1e6 * ef / (args.steps * B) / 4.0, 3)}
+            ef = timed(reg_fixed(), w.rel_single, steps, 1, w=w, B=B_w)
+            return {"scans_per_s": round(steps * B_w / e1, 1), "us_per_iteration": round(1e6 * em / (steps * B_w) / its, 3),
+                    "iterations_per_scan": round(its, 3), "us_per_iteration_at_4_fixed_iterations": round(1e6 * ef / (steps * B_w) / 4.0, 3)}
         exch = {}
-        plain, plain_fixed = K.KinematicRegistration(device=device), K.KinematicRegistration(device=device, **FIXED)
-        exch["none (this rank's shard alone, no exchange: NOT a registration of the scan)"] = base = measure(plain, plain_fixed)
-        del plain, plain_fixed
+        plain = K.KinematicRegistration(device=device)
+        held = {}
+
+        def plain_fixed():
+            held["r"] = K.KinematicRegistration(device=device, **FIXED)
+            return held["r"]
+        exch["none (this rank's shard alone, no exchange: NOT a registration of the scan)"] = base = rates(plain, plain_fixed)
+        del plain
+        held.clear()
         for alt in ("rccl", "shm", "p2p"):
             if alt == "rccl" and (torch.cuda.device_count() < world or "KICP_BENCH_DEVICE" in os.environ):
                 exch[alt] = {"note": "skipped: RCCL needs one GPU per rank"}
@@ -373,33 +462,48 @@ def main():
                 exch[alt] = {"note": str(e)[:200]}
                 continue
             try:
-                err = None
-                try:
-                    for i in range(60):
-                        run_scan(reg2, i, rel_single)
-                except K.KicpError as e:
-                    err = e
-                all_ranks_ok(err)
-                e1 = timed(reg2, rel_single, args.steps, min(args.warmup, 2))
-                em = timed(reg2, rel_multi, args.steps, 1)
-                its = timed.last_iterations
-                release(reg2, alt)
-                del reg2
-                reg3, keep3 = make_reg(alt, **FIXED)
-                ef = timed(reg3, rel_single, args.steps, 1)
-                fixed_us = 1e6 * ef / (args.steps * B) / 4.0
-                exch[alt] = {"scans_per_s": round(args.steps * B / e1, 1), "us_per_iteration": round(1e6 * em / (args.steps * B) / its, 3),
-                             "iterations_per_scan": round(its, 3), "us_per_iteration_at_4_fixed_iterations": round(fixed_us, 3),
-                             # what the exchange adds to an iteration of this rank's shard (both sides run exactly four iterations per scan)
-                             "exchange_us_per_iteration": round(fixed_us - base["us_per_iteration_at_4_fixed_iterations"], 3)}
-                release(reg3, alt)
-                del reg3
+                def fixed_handle():
+                    release(held.pop("x"), alt)
+                    held["f"], held["k"] = make_reg(alt, **FIXED)
+                    return held["f"]
+                held["x"] = reg2
+                ranks_seen = int(reg2.get_option("comm_ranks")) if alt == "rccl" else None
+                r = rates(reg2, fixed_handle)
+                r["exchange_us_per_iteration"] = round(r["us_per_iteration_at_4_fixed_iterations"] - base["us_per_iteration_at_4_fixed_iterations"], 3)
+                if ranks_seen is not None:
+                    r["rccl_ranks"] = ranks_seen
+                exch[alt] = r
+                release(held.pop("f"), alt)
+                held.clear()
             except K.KicpError as e:
                 exch[alt] = {"note": str(e)[:200]}
+                held.clear()
+        return exch
+
+    sharded_cfg5 = None
+    if exchange:
+        exch = measure_exchanges(wl, args.steps, B)
         other["exchanges"] = exch
+        for alt in ("rccl", "shm", "p2p"):
+            top_exchange["value_" + alt] = exch.get(alt, {}).get("scans_per_s")
+        top_exchange["value_" + comm] = None  # (filled with the headline below: the same exchange, the contract's timed region)
         for alt in ("shm", "p2p"):  # (kept under their round-2 names too)
             if "scans_per_s" in exch.get(alt, {}):
                 other[alt + "_scans_per_s"] = exch[alt]["scans_per_s"]
+        if world > 1 and not args.no_sharded_cfg5 and args.workload != "cfg5":
+            # the workload where sharding the points can pay: cfg5's 500 000-point scans fill the machine (VALU-bound pass of ~56 us
+            # on one GPU); 62 500 points per GPU at N = 8
+            try:
+                w5 = Workload(K, syn, "cfg5", 4, device, rank, world, False, torch)
+                steps5 = max(3, min(args.steps, 10))
+                ex5 = measure_exchanges(w5, steps5, 32)
+                sharded_cfg5 = {"workload": "cfg5: %d-pt scan vs %d-pt / %d-voxel map, voxel %.2f m; %d points per GPU; %d steps of 32 scans"
+                                            % (w5.n_total, w5.gmap.num_points(), w5.gmap.num_voxels(), w5.cfg.voxel_size, w5.hi - w5.lo, steps5),
+                                "value_rccl": ex5.get("rccl", {}).get("scans_per_s"), "value_shm": ex5.get("shm", {}).get("scans_per_s"),
+                                "value_p2p": ex5.get("p2p", {}).get("scans_per_s"), "exchanges": ex5}
+                del w5
+            except (K.KicpError, MemoryError) as e:
+                sharded_cfg5 = {"note": str(e)[:300]}
     if use_comm:  # all GPU work is done: tear the process group down before rank 0's CPU-only epilogue
         dist.barrier()
         dist.destroy_process_group()
@@ -414,8 +518,11 @@ def main():
     oreg = okicp.KinematicRegistration(max_num_threads=0)
     balgo_pass, bmin_pass, iters_ref, iters_ref_multi, max_pose_err = [], [], [], [], 0.0
     vox_keys, vox_counts = _voxel_census(map_points, cfg.voxel_size)
+    n_check = min(len(scans), 16)  # (the checker is the slow side: every scan's pose is compared on the multi-iteration workload, a sample carries the byte counts)
     for rels, ps, it_out, count in ((rel_single, poses, iters_ref, True), (rel_multi, poses_multi, iters_ref_multi, False)):
-        for s, rel, pose in zip(scans, rels, ps):
+        for k_scan, (s, rel, pose) in enumerate(zip(scans, rels, ps)):
+            if k_scan >= n_check and count:
+                continue
             ref = oreg.ComputeRobotMotion(s["frame"], omap, s["last_pose"], rel, tau, count_work=count)
             st = oreg.last_stats
             it_out.append(st.iterations)
@@ -429,6 +536,12 @@ def main():
             q = okicp.se3_act(okicp.se3_mul(s["last_pose"], rel), s["frame"])
             v_touched, m_touched = _touched(q, cfg.voxel_size, vox_keys, vox_counts)
             bmin_pass.append(12 * n_total + 12 * m_touched + 16 * v_touched)
+    if world == 1 and host_rate_f32 is not None:  # the float32 entry point against the checker on the widened frames
+        f32_pose_err = 0.0
+        for i in range(min(4, len(f32_poses))):
+            wide = f32_frames[i].astype(np.float64)
+            ref = oreg.ComputeRobotMotion(wide, omap, scans[i]["last_pose"], scans[i]["rel_odom"], tau)
+            f32_pose_err = max(f32_pose_err, float(np.max(np.abs(f32_poses[i] - ref))))
     share = 1 if replicas else world  # each rank's launch covers its shard
     bytes_per_launch = float(np.mean(balgo_pass)) / share
     bmin_per_launch = float(np.mean(bmin_pass)) / share
@@ -445,10 +558,12 @@ def main():
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if pass_ms.size else None
     pass_ms_multi = np.array([ms for _, lst in per_call_multi for ms in lst], dtype=np.float64)
 
-    cpu = None if args.no_cpu_baseline else _cpu_baseline(args, cfg, scans, rel_single, tau, omap, map_points, okicp, rkicp)
+    cpu = None if args.no_cpu_baseline else _cpu_baseline(args, cfg, scans[:8], rel_single[:8], tau, omap, map_points, okicp, rkicp)
 
     n_scans_timed = args.steps * B
     value = (world if replicas else 1) * n_scans_timed / elapsed  # replicas: every rank completed its own scans
+    if exchange:
+        top_exchange["value_" + comm] = round(value, 2)
     # ---- HBM traffic of the pass kernel, measured in THIS run: one rocprofv3 --pmc pass per counter over a bare loop of the
     #      same registrations (tools/prof_target.py), after everything timed is over.  Falls back to the committed profile
     #      (stamped with the commit it was taken at) where rocprofv3 cannot run.
@@ -458,21 +573,40 @@ def main():
     # and host thread per lane) - what the device does when a workload has several scans to offer at a time (robots sharing a
     # map, replayed logs).  The reference's sequential pipeline cannot use it, hence not the headline.
     conc_lanes = 4
-    conc_rate = _concurrent_rate(args.workload, conc_lanes, len(scans)) if (world == 1 and not use_comm) else None
+    conc_rate = _concurrent_rate(args.workload, conc_lanes, min(len(scans), 8)) if (world == 1 and not use_comm) else None
     prof = _profile_counters(args.workload, world)
     if traffic is None and prof and prof.get("hbm_bytes_per_launch"):
         traffic = float(prof["hbm_bytes_per_launch"])
         traffic_src = "%s; in-run measurement unavailable: %s" % (prof.get("source"), traffic_src)
     t_kernel = kernel_us * 1e-6
     traffic_gbs = None if (traffic is None or not pass_ms.size) else traffic / t_kernel / 1e9
+    # ---- the bound this kernel CAN be held to: its waves' chains of dependent accesses on top of the fixed floor.  A wave's chain:
+    #      source point -> probe of the own voxel's slot -> per visiting round [bucket record (the line just probed: near) -> the
+    #      bucket's points (far)] -> the winner's fp64 point (far).  Rounds per wave are counted by the kernel itself (dbg 10),
+    #      the price of a dependent step by kicp_probe_dependent_load under the same launch shape, the floor by the same launch
+    #      with every query switched off.
+    latency = None
+    if floor_us is not None and rounds_per_wave is not None and lat_far_ns and lat_near_ns and pass_ms.size:
+        far_steps = 3.0 + rounds_per_wave
+        bound_us = floor_us + (far_steps * lat_far_ns + rounds_per_wave * lat_near_ns) * 1e-3
+        latency = {"floor_us": round(floor_us, 2), "rounds_per_wave": round(rounds_per_wave, 3), "dependent_far_steps_per_wave": round(far_steps, 3),
+                   "dependent_near_steps_per_wave": round(rounds_per_wave, 3), "far_step_ns": round(lat_far_ns, 1), "near_step_ns": round(lat_near_ns, 1),
+                   "far_working_set_bytes": int(gmap.device_bytes()), "latency_bound_us": round(bound_us, 2),
+                   "what": "latency_bound_us = floor_us + (3 + rounds) x far_step_ns + rounds x near_step_ns: the pass cannot end before its slowest "
+                           "wave has walked source point -> probe -> rounds x (bucket record, bucket) -> winner; far / near step = "
+                           "kicp_probe_dependent_load (every lane of the same launch shape chasing its own chain through a buffer of the map's "
+                           "size / 16 KB), rounds = mean visiting rounds per wave counted by the kernel (dbg 10), floor = the same launch with "
+                           "every query off.  frac_latency = latency_bound_us / kernel_avg_us (1 = at the bound)"}
     roof = {"bound": "hbm", "achieved": None if traffic_gbs is None else round(traffic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 4),
+            "frac_latency": None if latency is None else round(latency["latency_bound_us"] / kernel_us, 4),
+            "latency_model": latency,
             "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
             "kernel": "fused association+accumulation pass (%s)" % kernel_sub, "kernel_avg_us": round(kernel_us, 2),
             "kernel_time_source": kernel_time_source, "launches_timed": int(pass_ms.size),
             "what": "achieved = HBM bytes the pass kernel moved per launch (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) / its "
                     "average duration; frac = achieved / 8 TB/s.  The kernel is bound by its waves' dependent-load chains and a fixed launch + "
-                    "reduction floor, not by HBM: see time_split_us and counters",
+                    "reduction floor, not by HBM: frac_latency holds it to THAT bound (latency_model), time_split_us and counters show the rest",
             "algorithmic": {"bytes_per_launch": round(bytes_per_launch),
                             "GBps": None if achieved is None else round(achieved, 1),
                             "ratio_to_hbm_peak": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -488,6 +622,7 @@ def main():
             "time_split_us": None if floor_us is None else {"fixed_floor_launch_reduction_handoff": round(floor_us, 2),
                                                             "query_work": round(kernel_us - floor_us, 2)},
             "counters": prof or None}
+    med_step = float(np.median(step_s)) if step_s.size else float("nan")
     out = {
         "metric": "scans/sec (ICP registration only), 128k-pt scan vs 1M-pt map",
         "value": round(value, 2),
@@ -502,15 +637,20 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
-                               "(mean %.2f per scan, reference %.2f); one step = one kicp_register_device_batch call = %d scans registered one after the other"
+                               "(mean %.2f per scan, reference %.2f); one step = one kicp_register_device_batch call = %d scans registered one after the other; "
+                               "%d distinct scans cycled"
                                % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(), cfg.voxel_size, tau, iters_gpu,
-                                  float(np.mean(iters_ref)), B),
-                   "scans_per_step": B, "ms_per_scan": round(1e3 * elapsed / n_scans_timed, 5), "timed_region_s": round(elapsed, 4),
+                                  float(np.mean(iters_ref)), B, len(scans)),
+                   "scans_per_step": B, "distinct_scans": len(scans), "ms_per_scan": round(1e3 * elapsed / n_scans_timed, 5), "timed_region_s": round(elapsed, 4),
+                   "batch_resized_after_short_timed_region": resized,
+                   "ms_per_step_median": round(1e3 * med_step, 5),
+                   "ms_per_step_min_max": [round(1e3 * float(step_s.min()), 5), round(1e3 * float(step_s.max()), 5)] if step_s.size else None,
                    "points_per_gpu": hi - lo,
                    "scans_per_s_one_python_call_per_scan": round((world if replicas else 1) * n_scans_timed / elapsed_py, 2),
                    "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
                                   (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
                    "pass_kernel": pass_kernel, "launch_path": launch_path, "max_pose_abs_diff_vs_oracle": max_pose_err,
+                   "poses_checked_against_the_oracle": len(iters_ref_multi) + len(iters_ref),
                    "multi_iteration": {
                        "workload": "same scans, odometry error +%.2f m / +%.1f deg: %.2f ICP iterations per scan (reference %.2f)"
                                    % (MULTI_ITER_ERROR[0], MULTI_ITER_ERROR[1], iters_gpu_multi, float(np.mean(iters_ref_multi))),
@@ -520,18 +660,27 @@ def main():
                        "pass_kernel_avg_us": round(float(pass_ms_multi.mean() * 1e3), 2) if pass_ms_multi.size else None},
                    "scans_per_s_with_host_input_incl_pcie": None if host_rate is None else round(host_rate, 1), **other,
                    **({"comm_note": comm_note} if comm_note else {})},
+        "value_median_step": None if not np.isfinite(med_step) else
+        {"scans_per_s": round((world if replicas else 1) * B / med_step, 2), "ms_per_step": round(1e3 * med_step, 5),
+         "what": "the median of the %d timed steps (rank 0's clock between steps; `value` is the contract's K steps / elapsed)" % args.steps},
         "value_multi_iteration": {"scans_per_s": round((world if replicas else 1) * n_scans_timed / elapsed_multi, 2),
                                   "iterations_per_scan": None if not np.isfinite(iters_gpu_multi) else round(iters_gpu_multi, 3),
                                   "us_per_iteration": None if not np.isfinite(iters_gpu_multi) else round(1e6 * elapsed_multi / n_scans_timed / iters_gpu_multi, 3),
                                   "what": "the same scans with +%.2f m / +%.1f deg odometry error, same steps and batch" % MULTI_ITER_ERROR},
         "value_host_vector_input": None if host_rate is None else
         {"scans_per_s": round(host_rate, 1), "what": "kicp_register with the scan handed over as a HOST array, the reference's own signature "
-                                                      "(Registration.hpp:39-43): upload over PCIe inside the call"},
+                                                      "(Registration.hpp:39-43): upload over PCIe inside the call",
+         "scans_per_s_float32": None if host_rate_f32 is None else round(host_rate_f32, 1),
+         "float32_what": "kicp_register_f32: the same scans as float32 xyz (what the PointCloud2 carried, RosUtils.cpp:30-39), widened on the device",
+         "float32_max_pose_abs_diff_vs_oracle_on_widened_frames": f32_pose_err},
         "value_concurrent_independent_scans": None if conc_rate is None else
         {"scans_per_s": round(conc_rate, 1), "lanes": conc_lanes,
          "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each), "
                  "512 per call, median of 5 calls, measured by tools/bench_concurrent.py in a process of its own after everything timed here; "
                  "a throughput mode the reference's sequential pipeline cannot use - never the headline" % conc_lanes},
+        **top_exchange,
+        **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
+        **({"sharded_cfg5": sharded_cfg5} if sharded_cfg5 is not None else {}),
         "roofline": roof,
         "cpu_baseline": cpu,
     }

@@ -36,6 +36,8 @@ extern "C" {
 enum {
     KICP_OK = 0,
     KICP_WARN_NO_CORRESPONDENCES = 1, /* N_corr == 0 in some pass -> NaN pose, as the reference produces */
+    KICP_WARN_TABLE_ORDER = 2,        /* kicp_pre_voxel_downsample: the survivors are the reference's, but a robin-hood probe exceeded the
+                                         limit at which tsl::robin_map re-hashes mid-way: their ORDER may differ (kicp_pre_set_probe_limit) */
     KICP_ERR_HIP = -1,                /* HIP runtime / device failure (message in kicp_last_error) */
     KICP_ERR_ARG = -2,                /* bad argument */
     KICP_ERR_CAPACITY = -3,           /* a documented limit exceeded (max_points_per_voxel > 65 535, more voxels than the table's bucket
@@ -280,6 +282,10 @@ int kicp_pre_voxel_downsample(kicp_pre *pre, int src_buffer, double voxel_size, 
  * or beyond the limit of the robin-map the reference was built against means the ORDER of that output may differ from the
  * reference's (the set of survivors never does). */
 unsigned int kicp_pre_last_max_probe(const kicp_pre *pre);
+/* The probe length beyond which the reference's container grows its table (default 128 = robin-map 0.6.x, what Ubuntu 22.04 ships
+ * and USE_SYSTEM_TSL-ROBIN-MAP picks up; 8192 for robin-map 1.x; also KICP_ROBIN_PROBE_LIMIT in the environment).  A downsample whose
+ * replay sees a longer probe returns KICP_WARN_TABLE_ORDER (> 0: the output is complete, its order is not vouched for). */
+int kicp_pre_set_probe_limit(kicp_pre *pre, unsigned int limit);
 int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
 int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 /* The same download in the background: _begin queues the copy of the buffer's current contents on a stream of its own
@@ -297,6 +303,14 @@ const double *kicp_pre_device_ptr(const kicp_pre *pre, int buffer, size_t *out_n
  * embedded code object, newline separated (tests check each against build/kicp_reg.hsaco, so a change of the compiler's
  * mangling or of a template signature fails a CPU test instead of silently disabling the path).  Returns the bytes needed. */
 size_t kicp_aql_kernel_names(char *out, size_t cap);
+
+/* Diagnostic behind bench.py's latency model: `workgroups` x `block` lanes each walk their own chain of `steps` DEPENDENT loads
+ * through a random cyclic permutation of the 128-byte lines of a `working_set_bytes` buffer (the pass kernel's situation: a
+ * wave's step costs the slowest of its 64 lanes' accesses, with the whole launch's accesses in flight around it).  Returns the
+ * time per dependent step (whole-launch duration / steps, best of three warm launches, HIP events). */
+int kicp_probe_dependent_load(int device, size_t working_set_bytes, int workgroups, int block, int steps, double *out_ns_per_step);
+/* Bytes of HBM the map's device copy occupies (table + fp64 pool + 16-bit mirror); 0 before the first upload. */
+size_t kicp_map_device_bytes(const kicp_map *map);
 
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */
 int kicp_device_malloc(int device, size_t bytes, void **out_dptr);

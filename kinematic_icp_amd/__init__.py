@@ -25,6 +25,7 @@ COMM_ID_BYTES = 128
 
 KICP_OK = 0
 KICP_WARN_NO_CORRESPONDENCES = 1
+KICP_WARN_TABLE_ORDER = 2
 KICP_ERR_HIP, KICP_ERR_ARG, KICP_ERR_CAPACITY, KICP_ERR_COMM = -1, -2, -3, -4
 
 
@@ -99,6 +100,7 @@ _SIGNATURES = {
     "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_last_max_probe": (C.c_uint, [C.c_void_p]),
+    "kicp_pre_set_probe_limit": (C.c_int, [C.c_void_p, C.c_uint]),
     "kicp_pre_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t]),
     "kicp_pre_download": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kicp_pre_download_begin": (C.c_int, [C.c_void_p, C.c_int]),
@@ -119,6 +121,8 @@ _SIGNATURES = {
     "kicp_reg_p2p_destroy": (C.c_int, [C.c_void_p]),
     "kicp_reg_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "kicp_aql_kernel_names": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "kicp_probe_dependent_load": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "kicp_map_device_bytes": (C.c_size_t, [C.c_void_p]),
 }
 
 
@@ -167,6 +171,13 @@ def _pose_ptr(a):
     elif arr is not a:
         ptr._keep = arr  # a converted temporary must outlive the call
     return ptr
+
+
+def probe_dependent_load(working_set_bytes, workgroups=512, block=256, steps=64, device=0):
+    """ns per dependent load step of `workgroups` x `block` lanes walking a random chain through `working_set_bytes` (kicp.h)"""
+    out = C.c_double(0.0)
+    _check(lib().kicp_probe_dependent_load(device, int(working_set_bytes), workgroups, block, steps, C.byref(out)))
+    return out.value
 
 
 def device_count():
@@ -260,6 +271,9 @@ class VoxelHashMap:
 
     def sync(self, device=0):
         _check(lib().kicp_map_sync(self._h, device))
+
+    def device_bytes(self):
+        return lib().kicp_map_device_bytes(self._h)
 
     def last_upload(self):
         """(bytes sent by the last mirror upload, True if it was a full re-send rather than a delta)."""
@@ -488,6 +502,10 @@ class PreSteps:
             _lib.kicp_pre_destroy(self._h)
             self._h = None
 
+    def set_probe_limit(self, limit):
+        """probe length at which the reference's tsl::robin_map grows its table (128: robin-map 0.6.x, default; 8192: 1.x)"""
+        _check(lib().kicp_pre_set_probe_limit(self._h, int(limit)))
+
     def last_max_probe(self):
         """Largest robin-hood displacement the last VoxelDownsample's replay saw (kicp_pre_last_max_probe)."""
         return int(lib().kicp_pre_last_max_probe(self._h))
@@ -528,7 +546,7 @@ class PreSteps:
 
     def VoxelDownsample(self, src, voxel_size, dst):
         n = C.c_size_t()
-        _check(lib().kicp_pre_voxel_downsample(self._h, src, voxel_size, dst, C.byref(n)))
+        self.last_status = _check(lib().kicp_pre_voxel_downsample(self._h, src, voxel_size, dst, C.byref(n)))  # KICP_WARN_TABLE_ORDER: see kicp.h
         return n.value
 
     def upload(self, buffer, points):

@@ -39,8 +39,15 @@ inline int default_device() {
     return device;
 }
 // The reference's core throws nothing; a backend failure must not return garbage silently.
-inline void check(int rc, const char *what) {
+inline int check(int rc, const char *what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + kicp_last_error());
+    return rc;  // (> 0: a warning code of include/kicp.h; the result still follows the reference's convention)
+}
+// a warning the reference has no channel for: once per process on stderr
+inline void warn_once(const char *message) {
+    static bool said = false;
+    if (!said) std::fprintf(stderr, "[kicp] warning: %s\n", message);
+    said = true;
 }
 // KICP_TRACE=1: host-side sections of the drop-in headers report their wall time on stderr, next to the library's own
 // per-call lines (debugging aid; a getenv once per process otherwise)

@@ -180,8 +180,9 @@ protected:
             }
         } guard{pre_};
         size_t n_down = 0, n_source = 0;
-        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
-        kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
+        const int order1 = kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
+        const int order2 = kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
+        if (order1 == KICP_WARN_TABLE_ORDER || order2 == KICP_WARN_TABLE_ORDER) kicp_bridge::warn_once(kicp_last_error());
         trace.lap("registration");
         const double tau = correspondence_threshold_.ComputeThreshold();
         const auto new_pose = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,

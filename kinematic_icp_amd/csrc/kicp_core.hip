@@ -1,5 +1,7 @@
 // kicp_core.hip -- shared host-side plumbing of libkicp_amd.so: error state, tracing switch, the staging policy for caller
 // memory, version / device queries and the raw device-memory helpers of include/kicp.h.
+#include <dlfcn.h>
+
 #include "kicp_internal.hpp"
 
 namespace kicp {
@@ -12,6 +14,36 @@ bool env_flag(const char *name) {
     return e && *e && *e != '0';
 }
 const bool g_trace = env_flag("KICP_TRACE");
+
+// roctx ranges (SURVEY.md section 5 "tracing"): libroctx64 is bound with dlopen the first time a range is opened, so that nothing
+// links against the profiler's library; a process without it simply gets no ranges
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *nm : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so.1"}) {
+            if (void *h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+            }
+        }
+        push = nullptr, pop = nullptr;
+    }
+};
+Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+const bool g_roctx = env_flag("KICP_ROCTX");
+void roctx_push(const char *name) {
+    if (roctx().push) roctx().push(name);
+}
+void roctx_pop() {
+    if (roctx().pop) roctx().pop();
+}
 
 std::string &last_error() {
     thread_local std::string g_error;
@@ -107,7 +139,56 @@ int staged_download(HostStage &hs, void *dst, const void *src, size_t bytes, hip
 using namespace kicp;
 using namespace kicp::host;
 
+// every lane walks its own chain of dependent loads through a random cyclic permutation of 128-byte lines (diagnostic: the
+// latency model of bench.py prices the pass kernel's chain of dependent accesses with what THIS box measures)
+static __global__ void k_chase(const uint32_t *__restrict__ next, uint32_t lines, int steps, uint32_t *__restrict__ sink) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = static_cast<uint32_t>((static_cast<unsigned long long>(gid) * 2654435761ull) % lines) * 32u;
+    for (int s = 0; s < steps; ++s) i = next[i];
+    sink[gid] = i;
+}
+
 extern "C" {
+
+int kicp_probe_dependent_load(int device, size_t working_set_bytes, int workgroups, int block, int steps, double *out_ns_per_step) {
+    if (!out_ns_per_step || workgroups <= 0 || block <= 0 || block > 1024 || steps <= 0 || working_set_bytes < 256) return fail(KICP_ERR_ARG, "bad argument");
+    if (int rc = set_device(device)) return rc;
+    const size_t lines = std::min<size_t>(working_set_bytes / 128, 0x7FFFFFFu);
+    std::vector<uint32_t> perm(lines), next(lines * 32, 0u);
+    for (size_t k = 0; k < lines; ++k) perm[k] = static_cast<uint32_t>(k);
+    unsigned long long x = 0x9E3779B97F4A7C15ull;  // splitmix64: the same permutation on every box
+    for (size_t k = lines - 1; k > 0; --k) {
+        x += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull, z ^= z >> 31;
+        std::swap(perm[k], perm[z % (k + 1)]);
+    }
+    for (size_t k = 0; k < lines; ++k) next[static_cast<size_t>(perm[k]) * 32] = perm[(k + 1) % lines] * 32u;
+    uint32_t *d_next = nullptr, *d_sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t lanes = static_cast<size_t>(workgroups) * block;
+    hipError_t e = hipMalloc(&d_next, next.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_sink, lanes * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_next, next.data(), next.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best = 0.f;
+    for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) {  // (the first launch warms the caches as far as the working set lets it)
+        hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(k_chase, dim3(workgroups), dim3(block), 0, nullptr, d_next, static_cast<uint32_t>(lines), steps, d_sink);
+        hipEventRecord(e1, nullptr);
+        e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(d_next), hipFree(d_sink);
+    if (e != hipSuccess) return fail(KICP_ERR_HIP, std::string("kicp_probe_dependent_load: ") + hipGetErrorString(e));
+    *out_ns_per_step = static_cast<double>(best) * 1.0e6 / steps;
+    return KICP_OK;
+}
 
 
 const char *kicp_last_error(void) { return last_error().c_str(); }

@@ -45,6 +45,9 @@ public:
     // ---- hand-over with the device-side maintenance (kicp_mapdev.hpp) ---------------------------------------------------
     const std::vector<uint32_t> &free_list() const { return free_; }
     size_t num_entries() const { return n_entries_; }
+    // a voxel beyond the range the device-side maintenance can pack (+-(2^20 - 1), one voxel of head-room for the neighbours) has
+    // been occupied since the last Clear(): updates of this map belong on the host (kicp_map.hip::map_update_device)
+    bool has_far_voxel() const { return has_far_voxel_; }
     // make room so that `extra_entries` more table entries keep the load factor <= 0.25 (re-hashes if necessary)
     void ReserveEntries(size_t extra_entries) {
         size_t want = table_.size();
@@ -94,6 +97,7 @@ public:
         pool16_.clear();
         free_.clear();
         n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
+        has_far_voxel_ = false;
         ++epoch_;
     }
 
@@ -124,6 +128,8 @@ public:
                 touch_slot(static_cast<size_t>(s)), touch_bucket(bucket);
             } else {
                 if (n_voxels_ + 1 > max_buckets(cb_)) return false;
+                constexpr int32_t kFar = (1 << 20) - 1;
+                if (vx <= -kFar || vx >= kFar || vy <= -kFar || vy >= kFar || vz <= -kFar || vz >= kFar) has_far_voxel_ = true;
                 const uint32_t bucket = alloc_bucket();
                 double *b = &pool_[static_cast<size_t>(bucket) * cap_ * 3];
                 b[0] = px, b[1] = py, b[2] = pz;
@@ -337,6 +343,7 @@ private:
     std::vector<MirrorPoint> pool16_;
     std::vector<uint32_t> free_;
     size_t n_buckets_hi_ = 0, n_voxels_ = 0, n_points_ = 0;
+    bool has_far_voxel_ = false;
     size_t n_entries_ = 0, n_dead_ = 0;  // table entries (occupied + halo); halo entries with no occupied neighbour left
     std::vector<uint8_t> slot_flag_, bucket_flag_;
     std::vector<uint32_t> dirty_slots_, dirty_buckets_;

@@ -26,17 +26,32 @@ namespace host {
 // KICP_TRACE=1 in the environment: every traced C-ABI call reports its wall time on stderr (debugging aid)
 bool env_flag(const char *name);
 extern const bool g_trace;
+// KICP_ROCTX=1: the same calls open a roctx range (libroctx64, bound at run time), so that a rocprofv3 --marker-trace run shows
+// pre-steps, registration passes and map updates as named spans around their kernels
+extern const bool g_roctx;
+void roctx_push(const char *name);
+void roctx_pop();
 struct TraceScope {
     const char *name;
     std::chrono::steady_clock::time_point t0;
     explicit TraceScope(const char *n) : name(n) {
         if (g_trace) t0 = std::chrono::steady_clock::now();
+        if (g_roctx) roctx_push(n);
     }
     ~TraceScope() {
+        if (g_roctx) roctx_pop();
         if (g_trace) std::fprintf(stderr, "[kicp] %-32s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 #define KICP_TRACE_CALL() ::kicp::host::TraceScope trace_scope_(__func__)
+struct RoctxScope {  // a named span inside a call (one ICP pass: dispatch -> rows -> solve)
+    explicit RoctxScope(const char *n) {
+        if (g_roctx) roctx_push(n);
+    }
+    ~RoctxScope() {
+        if (g_roctx) roctx_pop();
+    }
+};
 
 // last error message of the calling thread (kicp_last_error) and the one way to report a failure
 std::string &last_error();

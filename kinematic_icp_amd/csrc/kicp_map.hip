@@ -295,7 +295,9 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         if (remove_origin) map->host.RemovePointsFarFromLocation(remove_origin);
         return KICP_OK;
     };
-    if (n == 0 || n > 0x7FFFFFF0ull / 3 || map->host_updates_only) return host_fallback();
+    // (a map that holds a voxel the packed keys cannot express - through host-side AddPoints, or inherited by a clone - stays on
+    //  the host: the device kernels would alias its key)
+    if (n == 0 || n > 0x7FFFFFF0ull / 3 || map->host_updates_only || map->host.has_far_voxel()) return host_fallback();
     if (int rc = set_device(device)) return rc;
     if (int rc = map_sync(map, device, nullptr)) return rc;
     const uint32_t cap = map->host.cap();
@@ -444,6 +446,7 @@ int kicp_map_clone(const kicp_map *map, kicp_map **out) {
     kicp_map *c = new kicp_map(map->host.voxel_size(), map->host.max_distance(), map->host.cap());
     c->host = map->host;  // table, pools, free list, counters; the copy's mirror starts empty and uploads on first use
     c->bulk_device = map->bulk_device;
+    c->host_updates_only = map->host_updates_only;
     *out = c;
     return KICP_OK;
 }
@@ -573,6 +576,12 @@ int kicp_map_sync(kicp_map *map, int device) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     if (int rc = set_device(device)) return rc;
     return map_sync(map, device, nullptr);
+}
+size_t kicp_map_device_bytes(const kicp_map *map) {
+    if (!map || !map->mirror.d_table) return 0;
+    const DeviceMirror &mr = map->mirror;
+    const size_t buckets = map->device_ahead ? map->dev.n_buckets_hi : map->host.buckets_in_use_hi();
+    return mr.live_slots * sizeof(Slot) + buckets * (static_cast<size_t>(map->host.cap()) * 24 + static_cast<size_t>(map->host.cap16()) * sizeof(MirrorPoint));
 }
 int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full) {
     if (!map || !bytes || !was_full) return fail(KICP_ERR_ARG, "null argument");

@@ -18,6 +18,11 @@ struct kicp_pre {
     double *d_in = nullptr, *d_ts = nullptr, *d_staged = nullptr;
     uint32_t *d_flags = nullptr, *d_block_counts = nullptr, *d_misc = nullptr;  // misc: [0] total, [1] error, [2] largest robin-hood displacement of the last downsample
     uint32_t last_max_probe = 0;
+    // longest probe the reference's tsl::robin_map tolerates before it grows its table instead (kicp_pre_set_probe_limit)
+    uint32_t probe_limit = [] {
+        const char *e = std::getenv("KICP_ROBIN_PROBE_LIMIT");
+        return e && *e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 128u;
+    }();
     unsigned char *d_table = nullptr;  // downsampling table: keys | min_index | order | home_at, 20 B per bucket (kicp_pre.hpp)
     size_t cap_n = 0, table_slots = 0;
     bool table_clean = false;  // every byte of d_table is 0xFF (what a downsample needs to find; its gather step leaves it so)
@@ -283,9 +288,22 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     HIP_TRY(hipGetLastError());
     const int rc = pre_finish(p, dst, out_n);
     p->table_clean = rc == KICP_OK;
+    if (rc == KICP_OK && p->last_max_probe > p->probe_limit) {
+        // The survivors are the reference's; their ORDER is only the reference's while its robin_map never grew mid-way, which it
+        // does when a probe exceeds the container's limit - a re-hash the parallel replay does not model.  Say so instead of
+        // handing out an order that may differ (the points are in place, the caller decides).
+        last_error() = "VoxelDownsample: a robin-hood probe of " + std::to_string(p->last_max_probe) + " buckets exceeds the limit of " +
+                       std::to_string(p->probe_limit) + " at which tsl::robin_map grows its table: the output ORDER may differ from the reference's";
+        return KICP_WARN_TABLE_ORDER;
+    }
     return rc;
 }
 unsigned int kicp_pre_last_max_probe(const kicp_pre *p) { return p ? p->last_max_probe : 0u; }
+int kicp_pre_set_probe_limit(kicp_pre *p, unsigned int limit) {
+    if (!p || limit == 0u) return fail(KICP_ERR_ARG, "bad argument");
+    p->probe_limit = limit;
+    return KICP_OK;
+}
 int kicp_pre_upload(kicp_pre *p, int buffer, const double *xyz, size_t n) {
     KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS || (!xyz && n)) return fail(KICP_ERR_ARG, "bad argument");

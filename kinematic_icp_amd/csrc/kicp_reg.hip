@@ -44,6 +44,7 @@ struct CommApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // (optional: diagnostics only)
     bool load(std::string &err) {
         if (handle) return true;
         // prefer an RCCL that is already in the process (e.g. the one torch.distributed loaded)
@@ -62,6 +63,7 @@ struct CommApi {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(handle, "ncclCommCount"));
         if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
             err = "librccl lacks an expected symbol";
             return false;
@@ -806,6 +808,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             return rc;
         }
         for (uint32_t k = 0; k < cnt; ++k) {
+            const RoctxScope pass_span("icp pass: rows -> solve -> command");
             long long words[kReduceWords];
             bool gave_up = false;
             int rc_rows;
@@ -934,6 +937,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         loop.T = T0;
         int passes_run = 0;
         for (int it = 0; it < max_it; ++it) {
+            const RoctxScope pass_span("icp pass: launch -> rows -> solve");
             ++passes_run;
             const bool rows_mode = !multi && !p2p && r->group_rows != 0;
             const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
@@ -1282,6 +1286,11 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "aql") return reg->use_aql;
     if (k == "aql_kernarg") return !reg->aql.ready ? -1.0 : (std::strcmp(reg->aql.kernarg_place(), "host memory") == 0 ? 0.0 : (std::strcmp(reg->aql.kernarg_place(), "device memory") == 0 ? 1.0 : 2.0));
     if (k == "bar_frame") return reg->bar_frame ? 1.0 : (reg->use_bar_frame ? 0.5 : 0.0);  // 1: in use; 0.5: enabled, not (yet) set up
+    if (k == "comm_ranks") {  // ranks the attached RCCL communicator itself reports (ncclCommCount); 0: none attached
+        int count = 0;
+        if (reg->comm && g_comm.CommCount && g_comm.CommCount(reg->comm, &count) == ncclSuccess) return count;
+        return reg->comm ? reg->nranks : 0;
+    }
     if (k == "fetch_upload") return reg->fetch_frames;
     if (k == "small") return reg->use_small;
     if (k == "small_resident") return reg->small_resident;

@@ -237,3 +237,51 @@ def make_case(cfg_name, n_scans=1, order="ring", scene=None, rng=None):
         last = pose_mul(guess, pose_inverse(rel))
         scans.append(dict(frame=np.ascontiguousarray(pts), last_pose=last, rel_odom=rel, true_pose=true_pose))
     return cfg, scene, scans, rng
+
+
+def raycast_torch(scene, origin, dirs, device="cuda"):
+    """Scene.raycast with the arithmetic done by torch on `device` (fp64, the same slab test box by box): what bench.py uses to
+    produce dozens of distinct scans in seconds.  Not bit-compared with the numpy version anywhere: the scans it makes are
+    inputs, checked against the oracle like any other."""
+    import torch
+    with torch.no_grad():
+        d = torch.as_tensor(np.ascontiguousarray(dirs), dtype=torch.float64, device=device)
+        o = torch.as_tensor(np.asarray(origin, dtype=np.float64), device=device)
+        inv = 1.0 / d
+        lo = torch.tensor([-scene.half, -scene.half, 0.0], dtype=torch.float64, device=device)
+        hi = torch.tensor([scene.half, scene.half, scene.height], dtype=torch.float64, device=device)
+        inf = torch.full_like(d, float("inf"))
+        t = torch.where(d > 0, (hi - o) * inv, torch.where(d < 0, (lo - o) * inv, inf)).min(dim=1).values
+        for b in scene.boxes:
+            bl = torch.as_tensor(b[:3], dtype=torch.float64, device=device)
+            bh = torch.as_tensor(b[3:], dtype=torch.float64, device=device)
+            t0, t1 = (bl - o) * inv, (bh - o) * inv
+            tn = torch.nan_to_num(torch.minimum(t0, t1), nan=-float("inf")).max(dim=1).values
+            tf = torch.nan_to_num(torch.maximum(t0, t1), nan=float("inf")).min(dim=1).values
+            hit = (tn <= tf) & (tn > 0) & (tn < t)
+            t = torch.where(hit, tn, t)
+        return t.cpu().numpy()
+
+
+def extra_scans(cfg, scene, n, seed, order="ring", raycast=None):
+    """`n` more scans of `scene` in the manner of make_case (same pose / initial-guess distributions), from a generator of their
+    own - so that asking for more scans leaves the first ones and the map built after them unchanged.  `raycast(origin, dirs)`
+    replaces Scene.raycast (e.g. raycast_torch)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    dirs = beam_directions(cfg.n_beams, cfg.n_az, cfg.elev_deg, cfg.az_span_deg, order)
+    scans = []
+    for _ in range(n):
+        true_pose = planar_pose(rng.uniform(-2.0, 2.0), rng.uniform(-2.0, 2.0), rng.uniform(-np.pi, np.pi))
+        R = quat_to_matrix(true_pose[:4])
+        origin_w = true_pose[4:] + R @ np.array([0.0, 0.0, cfg.sensor_height])
+        dirs_w = dirs @ R.T
+        t = (raycast or scene.raycast)(origin_w, dirs_w)
+        t = t + rng.normal(0.0, 0.01, size=t.shape)
+        pts = dirs * t[:, None] + np.array([0.0, 0.0, cfg.sensor_height])
+        dd = rng.uniform(0.02, 0.10) * cfg.voxel_size * rng.choice([-1.0, 1.0])
+        dth = np.deg2rad(rng.uniform(0.04, 0.2)) * rng.choice([-1.0, 1.0])
+        guess = pose_mul(true_pose, planar_pose(dd, 0.0, dth))
+        rel = planar_pose(rng.uniform(0.2, 0.6), 0.0, np.deg2rad(rng.uniform(-3.0, 3.0)))
+        last = pose_mul(guess, pose_inverse(rel))
+        scans.append(dict(frame=np.ascontiguousarray(pts), last_pose=last, rel_odom=rel, true_pose=true_pose))
+    return scans

@@ -218,7 +218,11 @@ struct Voxel {
     int32_t x, y, z;
     bool operator==(const Voxel &o) const { return x == o.x && y == o.y && z == o.z; }
 };
-inline Voxel operator+(const Voxel &a, const Voxel &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+// (Eigen::Vector3i addition is plain int addition.  After a pass without correspondences the pose is NaN, PointToVoxel(NaN) is
+//  INT_MIN on x86, and the reference's `voxel + shift` overflows - which the compiled reference wraps.  `make -C oracle asan`
+//  found it; the wrap is spelled out here so that the restatement has defined behaviour with the same result.)
+inline int32_t wrap_add(int32_t a, int32_t b) { return static_cast<int32_t>(static_cast<uint32_t>(a) + static_cast<uint32_t>(b)); }
+inline Voxel operator+(const Voxel &a, const Voxel &b) { return {wrap_add(a.x, b.x), wrap_add(a.y, b.y), wrap_add(a.z, b.z)}; }
 inline Voxel point_to_voxel(const V3 &p, double voxel_size) {
     return {static_cast<int>(std::floor(p.x / voxel_size)), static_cast<int>(std::floor(p.y / voxel_size)),
             static_cast<int>(std::floor(p.z / voxel_size))};

@@ -58,7 +58,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        # OKICP_LIB: another build of the same sources (`make -C oracle asan`: the restatement under ASan + UBSan)
+        L = C.CDLL(os.environ.get("OKICP_LIB") or _LIB_PATH)
         L.okicp_map_create.restype = C.c_void_p
         L.okicp_map_create.argtypes = [C.c_double, C.c_double, C.c_uint]
         L.okicp_map_destroy.argtypes = [C.c_void_p]

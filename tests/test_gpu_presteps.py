@@ -150,3 +150,31 @@ def test_decisions_next_to_a_boundary_equal_the_reference_builds():
     nd = pre.VoxelDownsample(0, v, 1)
     assert nd == len(ref_down)
     np.testing.assert_allclose(pre.download(1), ref_down, rtol=0, atol=1e-11)
+
+
+def test_a_probe_beyond_the_containers_limit_is_reported_not_hidden():
+    """Adversarial frame for the reference's table: voxel x-coordinates that are multiples of the bucket count make every key's
+    ideal bucket depend on (y, z) alone, so a column of such voxels piles up in ONE run of buckets and the last insertions walk
+    hundreds of buckets.  tsl::robin_map would grow its table at that point (probe > 128 in 0.6.x, > 8192 in 1.x) and re-insert
+    everything - an order the parallel replay does not model.  The survivors are still exactly the reference's first-per-voxel
+    points; the call says KICP_WARN_TABLE_ORDER instead of vouching for their order; with the limit of robin-map 1.x (or an
+    ordinary frame) it does not."""
+    import kinematic_icp_amd as K
+    n = 300
+    buckets = 1024  # reserve(300) -> ceil(300 / 0.5) = 600 -> 1024 buckets
+    vox = np.stack([np.arange(n) * buckets - 150 * buckets, np.full(n, 7), np.full(n, -3)], 1)
+    pts = (vox + 0.25) * 0.5 + np.random.default_rng(5).uniform(0.0, 0.2, (n, 3))
+    pre = K.PreSteps()
+    pre.upload(0, pts)
+    assert pre.VoxelDownsample(0, 0.5, 1) == n
+    assert pre.last_max_probe() >= n - 2 and pre.last_status == K.KICP_WARN_TABLE_ORDER
+    assert "ORDER" in K.lib().kicp_last_error().decode()
+    got = pre.download(1)
+    np.testing.assert_array_equal(got[np.argsort(got[:, 0])], pts[np.argsort(pts[:, 0])])  # every voxel's first (here: only) point
+    pre.set_probe_limit(8192)
+    assert pre.VoxelDownsample(0, 0.5, 1) == n and pre.last_status == K.KICP_OK
+    # an ordinary frame never comes near either limit
+    pre.set_probe_limit(128)
+    pre.upload(0, np.random.default_rng(6).uniform(-50, 50, (20000, 3)))
+    pre.VoxelDownsample(0, 0.5, 1)
+    assert pre.last_status == K.KICP_OK and pre.last_max_probe() < 64
