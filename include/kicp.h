@@ -155,6 +155,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
  *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
  *                  the last call that a resident launch of the generic kernel served
+ *   "batch_resident" 1 (default): kicp_register_device_batch keeps that resident kernel on the device ACROSS the scans of a batch (the
+ *                  scans are still registered strictly one after the other; what starts a scan's first pass is a polled command
+ *                  instead of a dispatch; the batch's scan table travels with the launch); 0: every scan of a batch is a call of its
+ *                  own.  "batch_resident_passes" (read only): passes served that way so far
  *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
  *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
  *                  wave_block 0 = by scan size, default)
@@ -286,6 +290,21 @@ unsigned int kicp_pre_last_max_probe(const kicp_pre *pre);
  * and USE_SYSTEM_TSL-ROBIN-MAP picks up; 8192 for robin-map 1.x; also KICP_ROBIN_PROBE_LIMIT in the environment).  A downsample whose
  * replay sees a longer probe returns KICP_WARN_TABLE_ORDER (> 0: the output is complete, its order is not vouched for). */
 int kicp_pre_set_probe_limit(kicp_pre *pre, unsigned int limit);
+/* The pre-steps of one frame as ONE call behind one host synchronisation (pipeline/KinematicICP.cpp:54-62): Preprocess +
+ * transform_points into buffer 0, VoxelDownsample(buffer 0, voxel_a) into buffer 1, VoxelDownsample(buffer 1, voxel_b) into
+ * buffer 2 - the results of kicp_pre_preprocess[_ingested] + two kicp_pre_voxel_downsample calls, element for element; each
+ * step's survivor count stays on the device as the next step's input count.  out_counts = {points of buffer 0, 1, 2}.
+ * out_frame_xyz (nullable; room for every INPUT point, cap_points >= n): buffer 0 starts travelling there in the background as
+ * soon as it is complete - collect it with kicp_pre_download_finish(pre, 0, ...), whose out_n is out_counts[0]; the first
+ * out_counts[0] points are the frame.  kicp_pre_frame: host input as kicp_pre_preprocess; kicp_pre_frame_ingested: the cloud
+ * of the last kicp_pre_ingest (kicp_pre_ingested_count points).  May return KICP_WARN_TABLE_ORDER like the downsample. */
+int kicp_pre_frame(kicp_pre *pre, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                   const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range, int deskew,
+                   double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points, size_t out_counts[3]);
+int kicp_pre_frame_ingested(kicp_pre *pre, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
+                            double min_range, int deskew, double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points,
+                            size_t out_counts[3]);
+size_t kicp_pre_ingested_count(const kicp_pre *pre);
 int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
 int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 /* The same download in the background: _begin queues the copy of the buffer's current contents on a stream of its own
@@ -309,7 +328,8 @@ size_t kicp_aql_kernel_names(char *out, size_t cap);
  * wave's step costs the slowest of its 64 lanes' accesses, with the whole launch's accesses in flight around it).  Returns the
  * time per dependent step (whole-launch duration / steps, best of three warm launches, HIP events). */
 int kicp_probe_dependent_load(int device, size_t working_set_bytes, int workgroups, int block, int steps, double *out_ns_per_step);
-/* Bytes of HBM the map's device copy occupies (table + fp64 pool + 16-bit mirror); 0 before the first upload. */
+/* Bytes of the map's device copy a query can touch: table entries (occupied + halo, 128 B each) and the occupied voxels' buckets
+ * (fp64 pool + 16-bit mirror), without the head-room around them; 0 before the first upload. */
 size_t kicp_map_device_bytes(const kicp_map *map);
 
 /* ---- device memory helpers for callers without a HIP runtime binding of their own ------------------------ */

@@ -98,6 +98,10 @@ _SIGNATURES = {
     "kicp_pre_ingest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp, _dp, _dp]),
     "kicp_pre_preprocess_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "kicp_pre_frame": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp, C.c_size_t,
+                                 C.POINTER(C.c_size_t)]),
+    "kicp_pre_frame_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kicp_pre_ingested_count": (C.c_size_t, [C.c_void_p]),
     "kicp_pre_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_last_max_probe": (C.c_uint, [C.c_void_p]),
     "kicp_pre_set_probe_limit": (C.c_int, [C.c_void_p, C.c_uint]),
@@ -543,6 +547,30 @@ class PreSteps:
         xyz, st = np.empty((n.value, 3)), np.empty(n.value)
         _check(lib().kicp_pre_ingested(self._h, xyz.ctypes.data_as(_dp), st.ctypes.data_as(_dp), n.value, C.byref(n), C.byref(has)))
         return xyz, (st if has.value else None)
+
+    def Frame(self, frame, timestamps, relative_motion, lidar_to_base, max_range, min_range, deskew, voxel_a, voxel_b, want_frame=True):
+        """kicp_pre_frame / kicp_pre_frame_ingested (frame=None: the ingested cloud): Preprocess + the two downsamples behind one
+        synchronisation.  Returns (counts, preprocessed frame or None)."""
+        _, r = _d(relative_motion)
+        _, e = _d(lidar_to_base)
+        counts = (C.c_size_t * 3)()
+        if frame is None:
+            n_in = lib().kicp_pre_ingested_count(self._h)
+            out = np.empty((n_in, 3), dtype=np.float64) if want_frame else None
+            self.last_status = _check(lib().kicp_pre_frame_ingested(self._h, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
+                                                                    out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts))
+        else:
+            a, p = _d(frame)
+            t, tp = _d(timestamps if timestamps is not None else np.zeros(0))
+            n_in = a.size // 3
+            out = np.empty((n_in, 3), dtype=np.float64) if want_frame else None
+            self.last_status = _check(lib().kicp_pre_frame(self._h, p, n_in, tp, t.size, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
+                                                           out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts))
+        if want_frame and n_in:
+            n = C.c_size_t()
+            _check(lib().kicp_pre_download_finish(self._h, 0, out.ctypes.data_as(_dp), n_in, C.byref(n)))
+            out = out[:counts[0]]
+        return [int(c) for c in counts], out
 
     def VoxelDownsample(self, src, voxel_size, dst):
         n = C.c_size_t()

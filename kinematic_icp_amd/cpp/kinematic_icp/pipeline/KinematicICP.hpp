@@ -101,11 +101,19 @@ public:
         double rel_lidar[7], ext[7];
         kicp_bridge::to_params(relative_odometry_in_lidar, rel_lidar);
         kicp_bridge::to_params(lidar_to_base, ext);
-        size_t n_frame = 0;
-        kicp_bridge::check(kicp_pre_preprocess(pre_, kicp_bridge::xyz(frame), frame.size(), timestamps.data(), timestamps.size(), rel_lidar,
-                                               ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, 0, &n_frame),
-                           "Preprocess");
-        return RegisterPreprocessed(n_frame, relative_odometry);
+        // Preprocess + transform_points + the two VoxelDownsamples as ONE backend call behind one host synchronisation; the
+        // preprocessed frame (a return value nothing on the device waits for) travels back while the downsamples run
+        Vector3dVectorTuple result{Vector3dVector(frame.size()), Vector3dVector()};
+        auto &out_frame = std::get<0>(result);
+        DownloadGuard guard{pre_};
+        size_t counts[3] = {0, 0, 0};
+        const int order = kicp_bridge::check(
+            kicp_pre_frame(pre_, kicp_bridge::xyz(frame), frame.size(), timestamps.data(), timestamps.size(), rel_lidar, ext, config_.max_range, config_.min_range,
+                           config_.deskew ? 1 : 0, config_.voxel_size * 0.5, config_.voxel_size * 1.5, out_frame.empty() ? nullptr : out_frame.front().data(),
+                           out_frame.size(), counts),
+            "Preprocess + VoxelDownsample");
+        if (order == KICP_WARN_TABLE_ORDER) kicp_bridge::warn_once(kicp_last_error());
+        return RegisterChained(result, guard, counts, relative_odometry);
 #else
         const auto preprocessed_frame = preprocessor_.Preprocess(frame, timestamps, relative_odometry_in_lidar);
         Vector3dVector preprocessed_frame_in_base(preprocessed_frame.size());
@@ -138,11 +146,16 @@ public:
         double rel_lidar[7], ext[7];
         kicp_bridge::to_params(relative_odometry_in_lidar, rel_lidar);
         kicp_bridge::to_params(lidar_to_base, ext);
-        size_t n_frame = 0;
-        kicp_bridge::check(kicp_pre_preprocess_ingested(pre_, rel_lidar, ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, 0,
-                                                        &n_frame),
-                           "Preprocess");
-        return RegisterPreprocessed(n_frame, relative_odometry);
+        Vector3dVectorTuple result{Vector3dVector(kicp_pre_ingested_count(pre_)), Vector3dVector()};
+        auto &out_frame = std::get<0>(result);
+        DownloadGuard guard{pre_};
+        size_t counts[3] = {0, 0, 0};
+        const int order = kicp_bridge::check(
+            kicp_pre_frame_ingested(pre_, rel_lidar, ext, config_.max_range, config_.min_range, config_.deskew ? 1 : 0, config_.voxel_size * 0.5,
+                                    config_.voxel_size * 1.5, out_frame.empty() ? nullptr : out_frame.front().data(), out_frame.size(), counts),
+            "Preprocess + VoxelDownsample");
+        if (order == KICP_WARN_TABLE_ORDER) kicp_bridge::warn_once(kicp_last_error());
+        return RegisterChained(result, guard, counts, relative_odometry);
     }
 #endif
 
@@ -160,30 +173,22 @@ public:
 
 protected:
 #ifndef KICP_HOST_PRESTEPS
-    // pipeline/KinematicICP.cpp:56-84 from the preprocessed frame (pre_ buffer 0) on: downsample twice, register, update
-    // the threshold and the map - all on the device; only the two returned clouds come back to the host.
-    Vector3dVectorTuple RegisterPreprocessed(size_t n_frame, const Sophus::SE3d &relative_odometry) {
-        kicp_bridge::Trace trace("downsample");
-        // The preprocessed frame is a return value nothing on the device waits for: its 3 MB travel in the background, and a
-        // helper thread of the backend moves them into the result vector while this thread goes on with the pipeline.
-        // (Real Eigen leaves a default-constructed Vector3d uninitialised, so sizing the vector costs the allocation only.)
-        Vector3dVectorTuple result{Vector3dVector(n_frame), Vector3dVector()};
+    // From the moment the backend's helper thread holds a pointer into the result's frame vector: should any later step throw,
+    // the download is collected (and dropped) before the vector is destroyed, so nothing is ever copied into freed memory.
+    struct DownloadGuard {
+        kicp_pre *pre;
+        bool armed = true;
+        ~DownloadGuard() {
+            if (armed) (void)kicp_pre_download_finish(pre, 0, nullptr, 0, nullptr);
+        }
+    };
+    // pipeline/KinematicICP.cpp:65-84 from the pre-steps' three buffers on (0: preprocessed frame, 1: first downsample - what goes
+    // into the map, 2: second downsample - the registration source): register, update the threshold and the map - all on the
+    // device; only the two returned clouds come back to the host.
+    Vector3dVectorTuple RegisterChained(Vector3dVectorTuple &result, DownloadGuard &guard, const size_t counts[3], const Sophus::SE3d &relative_odometry) {
+        kicp_bridge::Trace trace("registration");
         auto &frame = std::get<0>(result);
-        kicp_bridge::check(kicp_pre_download_begin_into(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size()), "download");
-        // From here on the backend's helper thread holds a pointer into `frame`: should any later step throw, the download is
-        // collected (and dropped) before `result` is destroyed, so nothing is ever copied into freed memory.
-        struct DownloadGuard {
-            kicp_pre *pre;
-            bool armed = true;
-            ~DownloadGuard() {
-                if (armed) (void)kicp_pre_download_finish(pre, 0, nullptr, 0, nullptr);
-            }
-        } guard{pre_};
-        size_t n_down = 0, n_source = 0;
-        const int order1 = kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 0, config_.voxel_size * 0.5, 1, &n_down), "VoxelDownsample");
-        const int order2 = kicp_bridge::check(kicp_pre_voxel_downsample(pre_, 1, config_.voxel_size * 1.5, 2, &n_source), "VoxelDownsample");
-        if (order1 == KICP_WARN_TABLE_ORDER || order2 == KICP_WARN_TABLE_ORDER) kicp_bridge::warn_once(kicp_last_error());
-        trace.lap("registration");
+        const size_t n_down = counts[1], n_source = counts[2];
         const double tau = correspondence_threshold_.ComputeThreshold();
         const auto new_pose = registration_.ComputeRobotMotionDevice(kicp_pre_device_ptr(pre_, 2, nullptr), n_source, local_map_, last_pose_,
                                                                      relative_odometry, tau);
@@ -196,8 +201,9 @@ protected:
         source.resize(n_source);
         kicp_bridge::check(kicp_pre_download(pre_, 2, source.empty() ? nullptr : source.front().data(), source.size(), nullptr), "download");
         guard.armed = false;
-        kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.empty() ? nullptr : frame.front().data(), frame.size(), nullptr), "download");
-        return result;  // built in place: no copy of the clouds on the way out
+        if (!frame.empty()) kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.front().data(), frame.size(), nullptr), "download");
+        frame.resize(counts[0]);  // (the landing area held every input point; shrinking costs nothing)
+        return std::move(result);  // built in place: no copy of the clouds on the way out
     }
 #endif
     Sophus::SE3d last_pose_;

@@ -955,8 +955,9 @@ struct KeptQuery {
     Query q;
     double sx, sy;
 };
-__device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const Pose &T, uint32_t i, KeptQuery *kept = nullptr) {
-    const double sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
+// (`src`: the scan's points - p.src, or the scan a resident kernel was told to take up next, kicp_small.hpp)
+__device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, KeptQuery *kept = nullptr) {
+    const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
     if (kept) kept->sx = sx, kept->sy = sy;
     double rx, ry, rz;
     quat_rotate(T, sx, sy, sz, rx, ry, rz);
@@ -970,13 +971,13 @@ __device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, con
 // plus 4.2e-6 D for the fp32 squares / sums and the 5 mantissa bits dropped for the integer tournament.  sp.margin_u covers
 // the errors of BOTH candidates of a decision with 10 % to spare, for D up to the acceptance bound (and never farther than
 // the 27-voxel neighbourhood reaches, D <= 12 voxel sizes^2): computed on the host (search_params()).
-__device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const Pose &T, uint32_t i, bool valid, KeptQuery *kept = nullptr) {
+__device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, bool valid, KeptQuery *kept = nullptr) {
     const SearchParams &sp = p.search;
     L.i = valid ? i : kNoIndex32;
     L.q.slot0 = 0u, L.todo = 0u;
     L.t = Best3{sp.bound_u, sp.bound_u, sp.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
     Query q;
-    make_query_of(q, p, T, valid ? i : 0u, kept);
+    make_query_of(q, p, src, T, valid ? i : 0u, kept);
     if (kept) kept->q = q;
     const double vs = p.map.voxel_size;
     L.q.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
@@ -1122,13 +1123,14 @@ __device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float 
 
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
-__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const Pose &T, uint32_t i, const Best3 &t, const KeptQuery *kept = nullptr) {
+__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, const Best3 &t,
+                                                       const KeptQuery *kept = nullptr) {
     if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
     if (kept) q = kept->q;
-    else make_query_of(q, p, T, i);
+    else make_query_of(q, p, src, T, i);
     const double bound = p.search.bound;
     double best = bound;
     uint32_t best_idx = kNoIndex32;
@@ -1159,7 +1161,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
             wx = tp[0], wy = tp[1], wz = tp[2];
         }
         // the untransformed source point again (L1 / L2 hit) unless the build kept it: cheaper than registers kept live through the search
-        accumulate(acc, T, kept ? kept->sx : p.src[3 * i], kept ? kept->sy : p.src[3 * i + 1], q.x, q.y, q.z, wx, wy, wz);
+        accumulate(acc, T, kept ? kept->sx : src[3 * i], kept ? kept->sy : src[3 * i + 1], q.x, q.y, q.z, wx, wy, wz);
     }
 }
 
@@ -1173,17 +1175,18 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // LAT (G == 1, built at two waves per SIMD): the latency-oriented build for scans that do not fill the machine beyond that
 // (<= 131 072 points on 256 CUs) - two neighbour voxels per round (visit_two).
 // the search and the exact phase of one pass for lane `tid` of workgroup blockIdx.x; `acc` receives the lane's terms
+// (`src`, `n`: the scan - p.src / p.n for a kernel that serves one call, the current scan of a resident kernel that serves a batch)
 template <int BLOCK, int G, bool SPLIT, bool LAT>
-__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc) {
+__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n) {
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     const uint32_t gt = blockIdx.x * BLOCK + tid;
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
-    const bool valid = i < p.n && p.dbg != 7 && p.dbg != 8;
+    const bool valid = i < n && p.dbg != 7 && p.dbg != 8;
     Lane L;
     KeptQuery kept;
-    start_lane(L, p, T, i, valid, LAT ? &kept : nullptr);
+    start_lane(L, p, src, T, i, valid, LAT ? &kept : nullptr);
     if (G > 1 && !SPLIT) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
         uint32_t rest = L.todo, mine = 0u;
         for (int r = 0; rest; ++r) {
@@ -1226,7 +1229,7 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
         best3_merge(L.t, o);
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
-    if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t, LAT ? &kept : nullptr);
+    if (sub == 0) resolve_and_accumulate(acc, p, src, T, L.i, L.t, LAT ? &kept : nullptr);
     // dbg 10 (bench.py's latency model): no correspondences are formed; the "count" sum carries the number of visiting rounds
     // this WAVE ran - its chain of dependent bucket visits - from lane 0 (as rounds x 2^40: limb 1 holds bits 21..41, limb 2 the rest)
     if (p.dbg == 10 && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     Acc acc{};
-    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc);
+    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }

@@ -580,8 +580,12 @@ int kicp_map_sync(kicp_map *map, int device) {
 size_t kicp_map_device_bytes(const kicp_map *map) {
     if (!map || !map->mirror.d_table) return 0;
     const DeviceMirror &mr = map->mirror;
-    const size_t buckets = map->device_ahead ? map->dev.n_buckets_hi : map->host.buckets_in_use_hi();
-    return mr.live_slots * sizeof(Slot) + buckets * (static_cast<size_t>(map->host.cap()) * 24 + static_cast<size_t>(map->host.cap16()) * sizeof(MirrorPoint));
+    // what a query can touch: the table's entries (occupied + halo) and the buckets of the occupied voxels, not the head-room
+    // around them
+    const size_t entries = map->device_ahead ? map->dev.n_entries : map->host.num_entries();
+    const size_t voxels = map->device_ahead ? map->dev.n_voxels : map->host.num_voxels();
+    (void)mr;
+    return entries * sizeof(Slot) + voxels * (static_cast<size_t>(map->host.cap()) * 24 + static_cast<size_t>(map->host.cap16()) * sizeof(MirrorPoint));
 }
 int kicp_map_last_upload(const kicp_map *map, size_t *bytes, int *was_full) {
     if (!map || !bytes || !was_full) return fail(KICP_ERR_ARG, "null argument");

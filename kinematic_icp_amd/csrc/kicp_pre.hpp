@@ -132,7 +132,17 @@ struct DownsampleParams {
     uint32_t *block_counts;    // occupied buckets per 256-slot block
     uint32_t *error;           // set when a voxel coordinate leaves the 21-bit packable range
     uint32_t *probe_max;       // largest robin-hood displacement the replay saw (atomicMax; see replay_cluster)
+    // chained pre-steps (kicp_pre_frame_*): the input count is the previous step's survivor count, still on the device; n and mask
+    // above are then unused, the launch is sized for an upper bound and every kernel derives the reference's bucket count itself
+    const uint32_t *n_dev;
+    uint32_t *probe_max_sticky;  // nullable: the chain's second downsample must not reset the first one's figure
 };
+__device__ __forceinline__ uint32_t ds_count(const DownsampleParams &p) { return p.n_dev ? *p.n_dev : p.n; }
+__device__ __forceinline__ uint32_t ds_mask(const DownsampleParams &p, uint32_t n) {
+    if (!p.n_dev) return p.mask;
+    const uint32_t buckets = reference_bucket_count_u32(n);
+    return buckets ? buckets - 1u : 0u;
+}
 
 __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y, int32_t z, bool &ok) {
     const int lim = 1 << 20;
@@ -145,8 +155,9 @@ __device__ __forceinline__ unsigned long long pack_voxel21(int32_t x, int32_t y,
 // slot's winner to its own index
 static __global__ __launch_bounds__(256) void k_downsample_claim(const DownsampleParams p) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *p.probe_max = 0u;  // (the replay kernel, which raises it, runs after this one: no separate memset per call)
-    const bool in_range = i < p.n;
+    if (i == 0 && !p.probe_max_sticky) *p.probe_max = 0u;  // (the replay kernel, which raises it, runs after this one: no separate memset per call)
+    const uint32_t n = ds_count(p), mask = ds_mask(p, n);
+    const bool in_range = i < n;
     const double vs = p.voxel_size;
     int32_t vx = 0, vy = 0, vz = 0;
     if (in_range)
@@ -162,11 +173,11 @@ static __global__ __launch_bounds__(256) void k_downsample_claim(const Downsampl
         *p.error = 1u;
         return;
     }
-    uint32_t slot = reference_voxel_hash(vx, vy, vz) & p.mask;
+    uint32_t slot = reference_voxel_hash(vx, vy, vz) & mask;
     for (;;) {
         const unsigned long long seen = atomicCAS(p.keys + slot, kEmptyVoxelKey, key);
         if (seen == kEmptyVoxelKey || seen == key) break;
-        slot = (slot + 1) & p.mask;
+        slot = (slot + 1) & mask;
     }
     atomicMin(p.min_index + slot, i);
 }
@@ -174,13 +185,14 @@ static __global__ __launch_bounds__(256) void k_downsample_claim(const Downsampl
 // pass 2: one thread per bucket; heads of clusters replay them; every thread counts its bucket for the compaction
 static __global__ __launch_bounds__(256) void k_downsample_replay(const DownsampleParams p) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = ds_count(p), mask = ds_mask(p, n);
     bool occupied = false;
-    if (s <= p.mask) {
+    if (n != 0u && s <= mask) {
         occupied = p.keys[s] != kEmptyVoxelKey;
-        if (occupied && p.keys[(s - 1u) & p.mask] == kEmptyVoxelKey) {
+        if (occupied && p.keys[(s - 1u) & mask] == kEmptyVoxelKey) {
             uint32_t len = 1u;
-            while (p.keys[(s + len) & p.mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
-            const uint32_t probe = replay_cluster(p.keys, p.min_index, p.order, p.home_at, p.mask, s, len);
+            while (p.keys[(s + len) & mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
+            const uint32_t probe = replay_cluster(p.keys, p.min_index, p.order, p.home_at, mask, s, len);
             if (probe >= 32u) atomicMax(p.probe_max, probe);  // (short probes are the rule: only the rare long one touches the counter)
         }
     }
@@ -191,7 +203,8 @@ static __global__ __launch_bounds__(256) void k_downsample_gather(const Downsamp
     __shared__ uint32_t s_wave[4];
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool occupied = s <= p.mask && p.keys[s] != kEmptyVoxelKey;
+    const uint32_t n = ds_count(p), mask = ds_mask(p, n);
+    const bool occupied = n != 0u && s <= mask && p.keys[s] != kEmptyVoxelKey;
     const unsigned long long ballot = __ballot(occupied);
     if (lane == 0) s_wave[wave] = static_cast<uint32_t>(__popcll(ballot));
     __syncthreads();

@@ -30,6 +30,7 @@ struct kicp_pre {
     unsigned char *d_raw = nullptr;
     size_t raw_cap = 0;
     mutable HostStage stage;  // pinned staging for transfers from / to caller memory
+    hipEvent_t chain_ready = nullptr;  // chained pre-steps: buffer 0 is complete (its background download may start)
     // background download of one buffer (kicp_pre_download_begin / _finish): its own stream, pinned landing area and event
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
@@ -126,8 +127,9 @@ int kicp_pre_create(int device, kicp_pre **out) {
     kicp_pre *p = new kicp_pre;
     p->device = device;
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&p->d_misc, 16);
-    if (e == hipSuccess) e = hipMemset(p->d_misc, 0, 16);
+    if (e == hipSuccess) e = hipMalloc(&p->d_misc, 32);  // [0] total [1] error [2] longest probe [3] - [4..6] the chained pre-steps' three counts
+    if (e == hipSuccess) e = hipMemset(p->d_misc, 0, 32);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->chain_ready, hipEventDisableTiming);
     if (e != hipSuccess) {
         kicp_pre_destroy(p);
         return fail(KICP_ERR_HIP, std::string("kicp_pre_create: ") + hipGetErrorString(e));
@@ -154,6 +156,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     }
     if (p->copy_stream) hipStreamSynchronize(p->copy_stream), hipStreamDestroy(p->copy_stream);
     if (p->copy_done) hipEventDestroy(p->copy_done);
+    if (p->chain_ready) hipEventDestroy(p->chain_ready);
     if (p->copy_host) hipHostFree(p->copy_host);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
@@ -298,6 +301,115 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     }
     return rc;
 }
+static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after);
+static void copy_worker(kicp_pre *p);
+// ---- the whole pre-step chain of one frame behind ONE host synchronisation (KinematicICP.cpp:54-62) ------------------------
+// What d_in / d_ts hold (n_in points: an uploaded frame or an ingested cloud) is preprocessed into buffer 0, buffer 0 is
+// downsampled into buffer 1 at `voxel_a`, buffer 1 into buffer 2 at `voxel_b`.  The survivor count of each step stays on the
+// device and is the next step's input count (every launch is sized for n_in, every kernel derives the reference's bucket count
+// from the real count itself); the three counts come back together at the end.  Buffer 0 - the preprocessed frame the pipeline
+// returns - starts travelling to `out_frame_xyz` (room for n_in points; may be nullptr) as soon as it is complete, on the
+// download stream, while the downsamples run.
+static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
+                           double min_range, double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points, size_t counts[3]) {
+    counts[0] = counts[1] = counts[2] = 0;
+    p->buf_n[0] = p->buf_n[1] = p->buf_n[2] = 0;
+    if (n_in == 0) return KICP_OK;
+    if (!(voxel_a > 0.0) || !(voxel_b > 0.0)) return fail(KICP_ERR_ARG, "bad voxel size");
+    for (int b = 0; b < 3; ++b)
+        if (int rc = pre_ensure_buf(p, b, n_in)) return rc;
+    const size_t slots_up = reference_bucket_count(n_in);
+    if (slots_up > p->table_slots || slots_up > 0x80000000ull || n_in > slots_up / 2) return fail(KICP_ERR_CAPACITY, "frame too large for the downsampling table");
+    const uint32_t grid = static_cast<uint32_t>((n_in + 255) / 256), sgrid = static_cast<uint32_t>((slots_up + 255) / 256);
+    uint32_t *cnt = p->d_misc + 4;
+    PreprocessParams pp{};
+    pp.in = p->d_in, pp.timestamps = p->d_ts, pp.n = static_cast<uint32_t>(n_in), pp.deskew = do_deskew ? 1 : 0;
+    const Pose rel = pose_from(relative_motion_qt);
+    pose_log(rel, pp.omega);
+    pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
+    pp.max_range = max_range, pp.min_range = min_range;
+    pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
+    hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, p->stream, pp);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, cnt + 0);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, static_cast<const double *>(p->d_staged), static_cast<const uint32_t *>(p->d_flags),
+                       static_cast<const uint32_t *>(p->d_block_counts), static_cast<uint32_t>(n_in), p->buf[0]);
+    if (out_frame_xyz) {  // buffer 0 is complete behind this point: its download overlaps the downsamples (n_in points: an upper bound)
+        HIP_TRY(hipEventRecord(p->chain_ready, p->stream));
+        if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
+        if (int rc = download_begin_impl(p, 0, n_in, p->chain_ready)) return rc;
+        if (!p->copy_thread.joinable()) p->copy_thread = std::thread(copy_worker, p);
+        {
+            std::lock_guard<std::mutex> lock(p->copy_mutex);
+            p->copy_dst = out_frame_xyz, p->copy_dst_points = cap_points, p->copy_state = 1;
+        }
+        p->copy_cv.notify_all();
+    }
+    // the table's arrays laid out for the LARGEST table this handle can hold: every layout agrees on "all bytes 0xFF = clean"
+    if (!p->table_clean) HIP_TRY(hipMemsetAsync(p->d_table, 0xFF, p->table_slots * 20, p->stream));
+    p->table_clean = false;
+    DownsampleParams dp{};
+    dp.keys = reinterpret_cast<unsigned long long *>(p->d_table);
+    dp.min_index = reinterpret_cast<uint32_t *>(p->d_table + p->table_slots * 8);
+    dp.order = dp.min_index + p->table_slots, dp.home_at = dp.order + p->table_slots;
+    dp.block_counts = p->d_block_counts, dp.error = p->d_misc + 1, dp.probe_max = p->d_misc + 2;
+    for (int stage = 0; stage < 2; ++stage) {
+        dp.in = p->buf[stage], dp.voxel_size = stage == 0 ? voxel_a : voxel_b, dp.n_dev = cnt + stage;
+        dp.probe_max_sticky = stage == 0 ? nullptr : dp.probe_max;
+        hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
+        hipLaunchKernelGGL(k_downsample_replay, dim3(sgrid), dim3(256), 0, p->stream, dp);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, cnt + stage + 1);
+        hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, static_cast<const uint32_t *>(p->d_block_counts), p->buf[stage + 1]);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t misc[8] = {};
+    HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->last_max_probe = misc[2];
+    if (misc[1]) {
+        HIP_TRY(hipMemsetAsync(p->d_misc + 1, 0, 4, p->stream));
+        return fail(KICP_ERR_CAPACITY, "a voxel coordinate left the +-2^20 range of the downsampling table");
+    }
+    p->table_clean = true;
+    for (int b = 0; b < 3; ++b) counts[b] = p->buf_n[b] = misc[4 + b];
+    if (out_frame_xyz) p->copy_n = counts[0];  // (what _finish reports; the copy itself moved the upper bound)
+    if (p->last_max_probe > p->probe_limit) {
+        last_error() = "VoxelDownsample: a robin-hood probe of " + std::to_string(p->last_max_probe) + " buckets exceeds the limit of " +
+                       std::to_string(p->probe_limit) + " at which tsl::robin_map grows its table: the output ORDER may differ from the reference's";
+        return KICP_WARN_TABLE_ORDER;
+    }
+    return KICP_OK;
+}
+int kicp_pre_frame_ingested(kicp_pre *p, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range, int deskew,
+                            double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points, size_t out_counts[3]) {
+    KICP_TRACE_CALL();
+    if (!p || !relative_motion_qt || !lidar_to_base_qt || !out_counts) return fail(KICP_ERR_ARG, "bad argument");
+    if (!p->ingested) return fail(KICP_ERR_ARG, "no ingested cloud: call kicp_pre_ingest first");
+    if (out_frame_xyz && cap_points < p->ingested_n) return fail(KICP_ERR_ARG, "the frame's landing area must hold every ingested point");
+    if (int rc = set_device(p->device)) return rc;
+    return pre_frame_chain(p, p->ingested_n, deskew && p->ingested_stamps, relative_motion_qt, lidar_to_base_qt, max_range, min_range, voxel_a, voxel_b,
+                           out_frame_xyz, cap_points, out_counts);
+}
+int kicp_pre_frame(kicp_pre *p, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps, const double relative_motion_qt[7],
+                   const double lidar_to_base_qt[7], double max_range, double min_range, int deskew, double voxel_a, double voxel_b, double *out_frame_xyz,
+                   size_t cap_points, size_t out_counts[3]) {
+    KICP_TRACE_CALL();
+    if (!p || (!frame_xyz && n) || !relative_motion_qt || !lidar_to_base_qt || !out_counts) return fail(KICP_ERR_ARG, "bad argument");
+    const bool do_deskew = deskew && n_timestamps != 0;
+    if (do_deskew && (!timestamps || n_timestamps < n)) return fail(KICP_ERR_ARG, "one timestamp per point is required for deskewing");
+    if (out_frame_xyz && cap_points < n) return fail(KICP_ERR_ARG, "the frame's landing area must hold every input point");
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (int rc = set_device(p->device)) return rc;
+    if (n) {
+        if (int rc = pre_ensure(p, n)) return rc;
+        p->ingested = false;
+        if (int rc = stage_reserve(p->stage, n * 32, p->stream)) return rc;
+        if (int rc = staged_upload(p->stage, 0, p->d_in, frame_xyz, n * 24, p->stream)) return rc;
+        if (do_deskew)
+            if (int rc = staged_upload(p->stage, n * 24, p->d_ts, timestamps, n * 8, p->stream)) return rc;
+    }
+    return pre_frame_chain(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, voxel_a, voxel_b, out_frame_xyz, cap_points, out_counts);
+}
+size_t kicp_pre_ingested_count(const kicp_pre *p) { return (p && p->ingested) ? p->ingested_n : 0; }
 unsigned int kicp_pre_last_max_probe(const kicp_pre *p) { return p ? p->last_max_probe : 0u; }
 int kicp_pre_set_probe_limit(kicp_pre *p, unsigned int limit) {
     if (!p || limit == 0u) return fail(KICP_ERR_ARG, "bad argument");
@@ -327,10 +439,15 @@ int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap
 }
 // Background download: the copy runs on its own stream while the caller goes on with the next steps (downsampling,
 // registration, map update), and lands in pinned memory; _finish waits for it and hands the points over.
+// `n`: points to copy; `after`: an event on the pre-step stream the copy has to wait for (nullptr: the buffer is final already)
+static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after);
 int kicp_pre_download_begin(kicp_pre *p, int buffer) {
     KICP_TRACE_CALL();
     if (!p || buffer < 0 || buffer >= KICP_PRE_BUFFERS) return fail(KICP_ERR_ARG, "bad argument");
     if (int rc = set_device(p->device)) return rc;
+    return download_begin_impl(p, buffer, p->buf_n[buffer], nullptr);
+}
+static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after) {
     if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
     if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
     if (p->copy_buffer >= 0) {  // an earlier download nobody collected: let it (and the helper thread's copy) finish first
@@ -342,14 +459,16 @@ int kicp_pre_download_begin(kicp_pre *p, int buffer) {
         lock.unlock();
         HIP_TRY(hipStreamSynchronize(p->copy_stream));
     }
-    const size_t n = p->buf_n[buffer], bytes = n * 24;
+    const size_t bytes = n * 24;
     if (bytes > p->copy_cap) {
         if (p->copy_host) HIP_TRY(hipHostFree(p->copy_host));
         p->copy_host = nullptr, p->copy_cap = 0;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->copy_host), bytes + bytes / 2 + (1u << 20), hipHostMallocDefault));
         p->copy_cap = bytes + bytes / 2 + (1u << 20);
     }
-    // the buffer's contents are final: every call that fills a buffer returns only after its kernels have finished
+    // the buffer's contents are final (every call that fills a buffer returns only after its kernels have finished) - or will be
+    // once `after` has happened on the pre-step stream
+    if (after) HIP_TRY(hipStreamWaitEvent(p->copy_stream, after, 0));
     if (bytes) HIP_TRY(hipMemcpyAsync(p->copy_host, p->buf[buffer], bytes, hipMemcpyDeviceToHost, p->copy_stream));
     HIP_TRY(hipEventRecord(p->copy_done, p->copy_stream));
     p->copy_buffer = buffer, p->copy_n = n;

@@ -166,6 +166,10 @@ struct kicp_reg {
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
     int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
+    int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
+    ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
+    size_t scans_cap = 0;
+    unsigned long long batch_resident_passes = 0;  // passes served that way so far (get-only "batch_resident_passes")
     int last_resident_passes = 0; // passes of the last call that a resident launch of the GENERIC kernel served (get-only "resident_passes")
     int small_prev_iters = 2;     // iterations of the previous small-path call: a scan that converged at once makes the next launch leave after its first pass
     long long *d_trace = nullptr; // option "small_trace": device buffer of the kernel's per-pass wall-clock stamps
@@ -1085,6 +1089,134 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     return rc;
 }
 
+// kicp_register_device_batch with the generic pass kernel RESIDENT ACROSS THE SCANS of the batch.  The scans are still registered
+// strictly one after the other - scan k + 1's first pass is only started when scan k's last solve is done, as a loop of
+// ComputeRobotMotion calls would -, but what starts a pass is a command polled by a kernel that is already on the device
+// (~1.5 us) instead of a dispatch of 2 048 waves (~4.5 us), for pass 0 of a scan as for its later passes (run_small).  The launch
+// carries the table of the batch's scans (pointer, size); kCmdNewScan moves the kernel on to the next entry.
+// Returns 1 when the batch (from scan `first` on) is not one for this path - the caller then runs the plain loop -, else a
+// kicp status; *done = scans completed.  On a give-up of the kernel (a workgroup that saw no command in time) the scan in
+// hand and the rest are left to the plain loop, too.
+constexpr uint32_t kBatchMaxPasses = 1024;  // passes (= tags) one launch may serve
+int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
+                       const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
+    *done = 0;
+    const int max_it = r->cfg.max_num_iterations;
+    if (!r->batch_resident || !r->resident_generic || count < 2 || max_it <= 0 || kicp_map_empty(map)) return 1;
+    if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
+          r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0))
+        return 1;
+    size_t n_max = 0;
+    for (size_t k = 0; k < count; ++k) {
+        const SmallPlan pl = small_plan(r, n[k]);
+        if (!pl.generic) return 1;  // (small scans have their own kernels; larger ones than the device holds at once take the plain kernel)
+        n_max = std::max(n_max, n[k]);
+    }
+    if (int rc = set_device(r->device)) return rc;
+    const uint64_t epoch_before = map->mirror.synced_epoch;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    if (map->mirror.synced_epoch != epoch_before) r->stream_dirty = true;
+    const uint32_t grid = static_cast<uint32_t>((n_max + 255) / 256);
+    const size_t groups = (grid + kGroup - 1) / kGroup;
+    if (int rc = ensure_partials(r, 2u * grid)) return rc;
+    if (int rc = ensure_rows(r, 2 * groups)) return rc;
+    if (int rc = ensure_cmd(r)) return rc;
+    if (int rc = clear_stale_tickets(r)) return rc;
+    if (count > r->scans_cap) {
+        if (int rc = aql_quiesce(r)) return rc;
+        if (r->d_scans) HIP_TRY(hipFree(r->d_scans));
+        r->d_scans = nullptr, r->scans_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_scans), (count + count / 2 + 64) * sizeof(ScanRef)));
+        r->scans_cap = count + count / 2 + 64;
+    }
+    {
+        // (the previous batch's kernel has left: the host had its last rows and sent STOP; a launch that is still draining is
+        //  ordered before this copy's consumer by the queue / stream)
+        std::vector<ScanRef> table(count);
+        for (size_t k = 0; k < count; ++k) table[k] = ScanRef{d_frames[k], n[k]};
+        if (int rc = aql_quiesce(r)) return rc;
+        r->stream_dirty = true;
+        HIP_TRY(hipMemcpyAsync(r->d_scans, table.data(), count * sizeof(ScanRef), hipMemcpyHostToDevice, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
+        r->stream_dirty = false;
+    }
+    SmallPlan pl;
+    pl.generic = true, pl.lat = true, pl.g = 1, pl.block = 256, pl.grid = grid;
+    SmallParams sp{};
+    PassParams &pp = sp.p;
+    pp.src = d_frames[0], pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.search = search_params(tau, map->mirror.view.voxel_size);
+    pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
+    pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
+    sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
+    sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
+    sp.scans = r->d_scans;
+    uint32_t pass = 0, budget = 0;  // pass index inside the current launch; passes that launch may serve (0: none in flight)
+    auto stop_kernel = [&](const Pose &T) {
+        if (budget && pass < budget) send_command(r, sp.seq_base + pass, kCmdStop, T);
+        budget = 0;
+    };
+    r->last_small = 0, r->last_resident_passes = 0;
+    for (size_t k = 0; k < count; ++k) {
+        HostLoop loop;
+        loop.T = pose_mul(pose_from(last_poses_qt + 7 * k), pose_from(rel_odoms_qt + 7 * k));  // Registration.cpp:156
+        kicp_stats st;
+        std::memset(&st, 0, sizeof st);
+        bool finished = false, first_pass = true;
+        while (!finished) {
+            if (budget == 0 || pass >= budget) {  // no kernel on the device (any more): launch, starting on this scan with this pose
+                // (a launch that has served all its passes has left by itself)
+                const uint32_t cnt = kBatchMaxPasses;
+                if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
+                pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
+                sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(k);
+                r->cmd_seq += cnt;
+                sp.trace = r->d_trace;
+                if (int rc = launch_small(r, sp, pl)) return rc;
+                pass = 0, budget = cnt;
+            } else {
+                if (r->debug_stall_us > 0.0) {  // tests: be late once (the kernel gives up, the plain loop takes over)
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < r->debug_stall_us) {
+                    }
+                    r->debug_stall_us = 0.0;
+                }
+                send_command(r, sp.seq_base + pass, first_pass ? kCmdNewScan : kCmdContinue, loop.T);
+            }
+            first_pass = false;
+            long long words[kReduceWords];
+            if (int rc = wait_rows(r, groups, sp.tag0 + pass, words, (pass & 1u) * groups)) {
+                ++pass;
+                stop_kernel(loop.T);
+                return rc;
+            }
+            const bool gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull;
+            words[kNumLimbs] &= 0xFFll;
+            ++pass;
+            if (gave_up) {  // (part of) the kernel has left: this scan and the rest go through the plain loop
+                ++r->small_relaunches;
+                stop_kernel(loop.T);
+                *done = k;
+                return KICP_OK;
+            }
+            ++r->batch_resident_passes;
+            finished = loop.step(r, words, &st);
+        }
+        pose_to(loop.T, out_poses_qt + 7 * k);
+        if (out_iterations) out_iterations[k] = loop.iter;
+        r->small_prev_iters = loop.iter;
+        *done = k + 1;
+        if (loop.nan_flag == 2) {
+            stop_kernel(loop.T);
+            return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
+        }
+        if (loop.nan_flag) *worst = std::max(*worst, static_cast<int>(KICP_WARN_NO_CORRESPONDENCES));
+    }
+    Pose ident{0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
+    stop_kernel(ident);
+    return KICP_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1195,6 +1327,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->cmd) hipHostFree(reg->cmd);
     if (reg->bar_frame) reg->aql.free_bar(reg->bar_frame);
     if (reg->d_trace) hipFree(reg->d_trace);
+    if (reg->d_scans) hipFree(reg->d_scans);
     if (reg->cmd_bar) reg->aql.free_bar(reg->cmd_bar);
     else if (reg->d_cmd_copies) hipFree(reg->d_cmd_copies);
     reg->stage.release();
@@ -1235,6 +1368,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
+    else if (k == "batch_resident") reg->batch_resident = value != 0.0;
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
@@ -1279,6 +1413,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "occupancy") return reg->occupancy;
     if (k == "resident_generic") return reg->resident_generic;
     if (k == "resident_passes") return reg->last_resident_passes;
+    if (k == "batch_resident") return reg->batch_resident;
+    if (k == "batch_resident_passes") return static_cast<double>(reg->batch_resident_passes);
     if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
     if (k == "split_buckets") return reg->split_buckets;
@@ -1329,8 +1465,15 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
     if (count && (!d_frames_xyz || !n || !last_poses_qt || !rel_odoms_qt || !out_poses_qt)) return fail(KICP_ERR_ARG, "null argument");
     int worst = KICP_OK;
     kicp_stats st;
-    for (size_t k = 0; k < count; ++k) {
+    for (size_t k = 0; k < count; ++k)
         if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
+    size_t first = 0;
+    if (reg && map) {  // the generic kernel resident across the batch's scans, where the batch is one for it
+        const int rc = run_batch_resident(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
+                                          out_iterations, &first, &worst);
+        if (rc < 0) return rc;
+    }
+    for (size_t k = first; k < count; ++k) {
         const int rc = run_registration(reg, map, d_frames_xyz[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, max_correspondence_distance,
                                         out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
         if (rc < 0) return rc;
@@ -1471,7 +1614,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
-    c->resident_generic = reg->resident_generic;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident;
     *out = c;
     return KICP_OK;
 }

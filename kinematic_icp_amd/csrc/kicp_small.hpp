@@ -27,7 +27,14 @@ constexpr int kSmallMaxGroups = 64;      // workgroups of one launch = rows the 
 constexpr int kSmallRowWords = 16;       // 14 sum words (two 48-bit halves per sum) + flag word + spare = two 64-byte lines
 constexpr uint32_t kSmallMaxPasses = 48; // passes one launch may serve (bounds the tags reserved per launch)
 constexpr int kCmdWords = 8;
-enum : uint32_t { kCmdContinue = 1u, kCmdStop = 2u };
+// kCmdNewScan (the generic kernel resident across the scans of a batch): like kCmdContinue, and the pass it starts is pass 0 of the
+// NEXT scan of the launch's scan table (SmallParams::scans)
+enum : uint32_t { kCmdContinue = 1u, kCmdStop = 2u, kCmdNewScan = 3u };
+// one scan of a batch as the resident kernel sees it
+struct ScanRef {
+    const double *src;   // device pointer, AoS xyz fp64
+    unsigned long long n;
+};
 constexpr unsigned long long kSmallGaveUp = 2ull;  // flag-word bit: the workgroup saw no command in time and left
 
 // 64-bit fold of the seven pose words of a command (host and device)
@@ -52,6 +59,8 @@ struct SmallParams {
     uint32_t tag0;                  // pass k publishes with tag tag0 + k (the host reserves the range)
     uint32_t max_passes;            // passes this launch may serve; 1 = leave after the first (no residency)
     long long timeout_ticks;        // 100 MHz wall-clock ticks a workgroup waits for a command before it gives up
+    const ScanRef *scans;           // k_pass_resident serving a batch: the batch's scans (device memory, written before the launch);
+    uint32_t scan0, pad2_;          // the launch starts on scans[scan0], every kCmdNewScan moves on to the next.  nullptr: p.src / p.n
 };
 
 // Between the passes of a resident kernel NOTHING but the pose, the pass counter and the lane id is worth a register: the
@@ -78,12 +87,12 @@ __device__ __forceinline__ uint32_t fresh_tid() {
 // blockIdx % kCmdReplicas with agent-scope loads, lanes 0..7 one word each).  Who fills them:
 //   relay = 1: wave 0 of workgroup 0 polls the host line (ONE PCIe reader) and stores what it finds into every copy;
 //   relay = 0: the host writes the copies itself through the PCIe BAR (the line lives in host-visible fine-grained HBM).
-// false: STOP, or no command in time (the rows of the pass that will not run are then marked so that the host launches
-// afresh).  Ends in a workgroup barrier.
+// Returns the command's opcode; 0: no command in time (the rows of the pass that will not run are then marked so that the host
+// launches afresh).  Ends in a workgroup barrier.
 constexpr int kCmdReplicas = 64;         // copies of the command line ...
 constexpr int kCmdStrideWords = 544;     // ... 4352 bytes apart (4 KiB + 256 B), so that the pollers spread over memory channels
 template <bool MARK_ROWS = true>
-__device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
+__device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
     if ((tid >> 6) == 0) {
         const int lane = tid & 63;
         const unsigned long long want = sp.seq_base + pass + 1;
@@ -99,7 +108,7 @@ __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t ti
 #pragma unroll
             for (int k = 0; k < 7; ++k) pose[k] = __shfl(w, k, 64);
             ctrl = __shfl(w, 7, 64) ^ cmd_fold(pose);
-            if ((ctrl >> 8) == want && ((ctrl & 0xFFull) == kCmdContinue || (ctrl & 0xFFull) == kCmdStop)) break;
+            if ((ctrl >> 8) == want && (ctrl & 0xFFull) >= kCmdContinue && (ctrl & 0xFFull) <= kCmdNewScan) break;
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
                 if (MARK_ROWS && lane < kSmallRowWords)
@@ -117,7 +126,7 @@ __device__ __forceinline__ bool await_command(const SmallParams &sp, uint32_t ti
         if (lane == 7) s_cmd[7] = ctrl & 0xFFull;
     }
     __syncthreads();
-    return static_cast<uint32_t>(s_cmd[7]) == kCmdContinue;
+    return static_cast<uint32_t>(s_cmd[7]);  // kCmdContinue / kCmdStop / kCmdNewScan; 0: no command in time
 }
 // value of a double in lane l, wave-uniform
 __device__ __forceinline__ double uniform_lane_d(double v, int l) {
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
             const int sub = static_cast<int>(gt % G);
             const float margin = p.search.margin_u;
             Lane L;
-            start_lane(L, p, T, i, i < p.n);
+            start_lane(L, p, p.src, T, i, i < p.n);
             if (G > 1) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
                 uint32_t rest = L.todo, mine = 0u;
                 for (int r = 0; rest; ++r) {
@@ -208,13 +217,13 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
                 o.i1 = __shfl_xor(L.t.i1, off, 64), o.i2 = __shfl_xor(L.t.i2, off, 64), o.o1 = __shfl_xor(L.t.o1, off, 64), o.o2 = __shfl_xor(L.t.o2, off, 64);
                 best3_merge(L.t, o);
             }
-            if (sub == 0) resolve_and_accumulate(acc, p, T, L.i, L.t);
+            if (sub == 0) resolve_and_accumulate(acc, p, p.src, T, L.i, L.t);
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         tid = fresh_tid();
         small_publish<BLOCK>(acc, sp, tid, pass, s_red, &s_flag);
         if (pass + 1 >= sp.max_passes) return;
-        if (!await_command(sp, tid, pass, s_cmd)) return;
+        if (await_command(sp, tid, pass, s_cmd) != kCmdContinue) return;
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
@@ -238,17 +247,30 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
     __shared__ unsigned long long s_cmd[kCmdWords];
     Pose T = fresh_args().p.sol.pose0;
     int gave_up = 0;  // (wave-uniform) no command arrived in time: this round only hands over the marked empty row
+    uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0)));  // (a batch: index into sp.scans of the scan this pass belongs to)
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         uint32_t tid = fresh_tid();
         if (tid == 0) s_flag = 0;
+        const bool stamp = sp.trace != nullptr && tid == 0 && pass == 1;  // option "small_trace": every workgroup stamps its second pass, [workgroup][4]
+        if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
         Acc acc{};
-        if (!gave_up) gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc);
+        if (!gave_up) {
+            const double *src = sp.p.src;
+            uint32_t n = sp.p.n;
+            if (sp.scans) src = sp.scans[scan].src, n = static_cast<uint32_t>(sp.scans[scan].n);  // (uniform: scalar loads)
+            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc, src, n);
+        }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 1] = wall_clock64();  // every wave's search is done
         finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up, pass & 1u);
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();  // row stored (a group's last workgroup: group row sent)
         if (gave_up || pass + 1 >= sp.max_passes) return;
-        if (!await_command<false>(sp, fresh_tid(), pass, s_cmd)) {
-            if (static_cast<uint32_t>(s_cmd[7]) == kCmdStop) return;
+        const uint32_t op = await_command<false>(sp, fresh_tid(), pass, s_cmd);
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();  // next command seen
+        if (op == kCmdNewScan) scan = static_cast<uint32_t>(uniform_i(static_cast<int>(scan + 1u)));
+        if (op != kCmdContinue && op != kCmdNewScan) {
+            if (op == kCmdStop) return;
             gave_up = 1;
             // tell the host that a workgroup of this launch gave up: should the call end before every workgroup has taken its ticket
             // of the give-up round (the host stops after the pass it was waiting for), the next launch must not inherit the
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         }
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;
-        if (!await_command(sp, tid, pass, s_cmd)) return;
+        if (await_command(sp, tid, pass, s_cmd) != kCmdContinue) return;
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),

@@ -32,6 +32,18 @@ inline size_t reference_bucket_count(size_t n) {
     return buckets;
 }
 
+// the same for a count that fits 32 bits, host + device (the chained pre-steps size the table on the device, from a count that
+// never visits the host in between: kicp_pre.hpp)
+KICP_HD uint32_t reference_bucket_count_u32(uint32_t n) {
+    const float want = ceilf(static_cast<float>(n) / 0.5f);
+    uint32_t buckets = 0u;
+    if (want > 0.f) {
+        buckets = 1u;
+        while (static_cast<float>(buckets) < want && buckets < 0x80000000u) buckets <<= 1;
+    }
+    return buckets;
+}
+
 // One cluster (slots head .. head+len-1, cyclic) of the claimed table -> the reference's arrangement of the same keys.
 // keys / min_index are read-only here; order / home_at are written inside the cluster only.  order[] must be kFreeBucket
 // on entry.  Host + device.

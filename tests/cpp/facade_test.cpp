@@ -204,6 +204,37 @@ int main(int argc, char **argv) {
                 print_pose("pose", icp.pose());
             }
             printf("map %zu\n", icp.LocalMap().size());
+        } else if (mode == "pipeline_timed_raw") {  // the same frames as 16-byte PointCloud2 records (x y z t, FLOAT32): IngestCloud + RegisterIngestedFrame in the clock
+            const auto h = read_doubles(f, 4);
+            kinematic_icp::pipeline::Config cfg;
+            cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
+            kinematic_icp::pipeline::KinematicICP icp(cfg);
+            const auto ext = read_doubles(f, 7);
+            const kicp_cloud_layout layout{16, 0, 4, 8, KICP_FIELD_FLOAT32, 12};
+            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+                const auto n = read_doubles(f, 1);
+                const size_t np = static_cast<size_t>(n[0]);
+                const auto xyz = read_doubles(f, np * 3), stamps = read_doubles(f, np);
+                const auto delta = read_doubles(f, 7);
+                std::vector<float> msg(np * 4);  // (the message as it arrives from the driver: outside the clock)
+                for (size_t i = 0; i < np; ++i)
+                    msg[4 * i] = static_cast<float>(xyz[3 * i]), msg[4 * i + 1] = static_cast<float>(xyz[3 * i + 1]), msg[4 * i + 2] = static_cast<float>(xyz[3 * i + 2]),
+                              msg[4 * i + 3] = static_cast<float>(stamps[i]);
+                const auto t0 = std::chrono::steady_clock::now();
+                double ms = 0.0;
+                size_t n_deskewed = 0, n_source = 0;
+                {
+                    (void)icp.IngestCloud(msg.data(), np, layout);
+                    const auto [deskewed, source] = icp.RegisterIngestedFrame(kicp_bridge::from_params(ext.data()), kicp_bridge::from_params(delta.data()));
+                    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    n_deskewed = deskewed.size(), n_source = source.size();
+                }
+                const double ms_with_free = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                printf("frame %d ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, ms, ms_with_free, n_deskewed,
+                       n_source, kicp_map_last_update_on_device(icp.VoxelMap().handle()));
+                print_pose("pose", icp.pose());
+            }
+            printf("map %zu\n", icp.LocalMap().size());
         }
     } catch (const std::exception &e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -222,3 +222,41 @@ def test_copies_of_a_registration_handle_are_independent():
     twin.max_num_iterations_ = 1
     twin.ComputeRobotMotion(src - np.array([0.03, 0, 0]), maps[0], I, I, 0.5)
     assert twin.last_stats.iterations == 1
+
+
+def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop():
+    """kicp_register_device_batch keeps the generic kernel on the device across the scans of a batch ("batch_resident"): scans of
+    different sizes and iteration counts, the zero-correspondence scan in the middle, a kernel that gives up half-way (the plain
+    loop takes over) - all bit-equal to one call per scan."""
+    maps, src = _big_world(n_map=60000, n_src=20000, seed=21)
+    g = maps[0]
+    shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03]
+    sizes = [20000, 12000, 9000, 20000, 15000, 10000]
+    frames = [src[:k] - np.array([d, 0.0, 0.0]) for k, d in zip(sizes, shifts)]
+    frames[4] = np.full((9000, 3), 400.0)  # no correspondence at all
+    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(6)]
+    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(6)]
+    dev = [K.DeviceFrame(f, device=0) for f in frames]
+    plain = _reg({"batch_resident": 0}, **CFG)
+    b0 = plain.prepare_batch(dev, lasts, rels)
+    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    assert plain.get_option("batch_resident_passes") == 0.0 and plain.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+    reg = _reg({}, **CFG)
+    b1 = reg.prepare_batch(dev, lasts, rels)
+    for _ in range(3):
+        got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+        assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
+        assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+    assert reg.get_option("batch_resident_passes") >= 3 * (sum(b0.iterations) - 10) and max(b0.iterations[:4]) >= 2
+    for k, f in enumerate(frames[:4]):  # ... and to the oracle
+        o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(f, maps[1], lasts[k], rels[k], 0.5)
+        np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
+    # the kernel gives up waiting for a late host: the scan in hand and the rest run through the plain loop, same bits
+    reg.set_option("small_timeout_us", 300.0), reg.set_option("debug_stall_us", 3000.0)
+    before = reg.get_option("small_relaunches")
+    got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+    assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
+    assert reg.get_option("small_relaunches") == before + 1
+    reg.set_option("small_timeout_us", 20000.0)
+    got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+    assert np.array_equal(got, want, equal_nan=True)

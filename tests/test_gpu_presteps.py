@@ -178,3 +178,36 @@ def test_a_probe_beyond_the_containers_limit_is_reported_not_hidden():
     pre.upload(0, np.random.default_rng(6).uniform(-50, 50, (20000, 3)))
     pre.VoxelDownsample(0, 0.5, 1)
     assert pre.last_status == K.KICP_OK and pre.last_max_probe() < 64
+
+
+@pytest.mark.parametrize("deskew", [0, 1])
+@pytest.mark.parametrize("source", ["host", "ingested"])
+def test_the_chained_frame_call_equals_the_separate_calls(deskew, source):
+    """kicp_pre_frame / kicp_pre_frame_ingested: Preprocess + two downsamples behind one synchronisation, the counts never leaving the
+    device in between - element for element what Preprocess -> VoxelDownsample -> VoxelDownsample give, the background copy of the
+    preprocessed frame included; also on an empty frame, a frame the crop empties, and with the table reused across calls."""
+    import kinematic_icp_amd as K
+    rng = np.random.default_rng(31 + deskew)
+    ext = np.concatenate([[0, 0, np.sin(0.05), np.cos(0.05)], [0.3, 0.0, 0.9]])
+    rel = syn.planar_pose(0.3, 0.0, 0.02)
+    pre, sep = K.PreSteps(), K.PreSteps()
+    for n, max_range in ((40000, 60.0), (0, 60.0), (5000, 60.0), (3000, 1e-3), (40000, 25.0)):
+        pts = (rng.uniform(-50, 50, (n, 3)) * np.array([1.0, 1.0, 0.1])).astype(np.float32).astype(np.float64)
+        ts = np.linspace(0.0, 1.0, n).astype(np.float32).astype(np.float64) if n else np.zeros(0)
+        if source == "ingested":
+            rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<f4")])
+            rec["x"], rec["y"], rec["z"], rec["t"] = pts[:, 0], pts[:, 1], pts[:, 2], ts
+            for h in (pre, sep):
+                h.Ingest(rec.tobytes(), n, 16, 0, 4, 8, 7, 12)
+            counts, frame = pre.Frame(None, None, rel, ext, max_range, 0.5, deskew, 0.5, 1.5)
+            n0 = sep.PreprocessIngested(rel, ext, max_range, 0.5, deskew, 0)
+        else:
+            counts, frame = pre.Frame(pts, ts, rel, ext, max_range, 0.5, deskew, 0.5, 1.5)
+            n0 = sep.Preprocess(pts, ts, rel, ext, max_range, 0.5, deskew, 0)
+        n1 = sep.VoxelDownsample(0, 0.5, 1)
+        n2 = sep.VoxelDownsample(1, 1.5, 2)
+        assert counts == [n0, n1, n2], (n, max_range)
+        if n:
+            np.testing.assert_array_equal(frame, sep.download(0))
+        for b in (0, 1, 2):
+            np.testing.assert_array_equal(pre.download(b), sep.download(b))

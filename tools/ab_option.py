@@ -26,6 +26,7 @@ ap.add_argument("--fixed", action="append", default=[], help="name=value options
 ap.add_argument("--multi", action="store_true")
 ap.add_argument("--blocks", type=int, default=40)
 ap.add_argument("--calls", type=int, default=250)
+ap.add_argument("--batch", action="store_true", help="a block is ONE kicp_register_device_batch call of --calls scans (what bench.py times)")
 args = ap.parse_args()
 
 cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=4)
@@ -52,12 +53,19 @@ for reg in regs:
     poses.append(pose)
 K.lib().kicp_device_synchronize(0)
 us = [[] for _ in regs]
+batches = [reg.prepare_batch([frames[i % 4] for i in range(args.calls)], [scans[i % 4]["last_pose"] for i in range(args.calls)],
+                             [rels[i % 4] for i in range(args.calls)]) for reg in regs] if args.batch else None
 for b in range(args.blocks):
     for j, reg in enumerate(regs):
         t0 = time.perf_counter()
-        for i in range(args.calls):
-            reg.ComputeRobotMotion(frames[i % 4], gmap, scans[i % 4]["last_pose"], rels[i % 4], tau)
+        if args.batch:
+            reg.ComputeRobotMotionBatch(batches[j], gmap, tau)
+        else:
+            for i in range(args.calls):
+                reg.ComputeRobotMotion(frames[i % 4], gmap, scans[i % 4]["last_pose"], rels[i % 4], tau)
         us[j].append((time.perf_counter() - t0) / args.calls * 1e6)
+if args.batch:
+    poses = [b.out.copy() for b in batches]
 out = {"workload": args.workload, "multi": args.multi, "iterations": regs[0].last_stats.iterations,
        "same_pose": bool(all(np.array_equal(p, poses[0]) for p in poses))}
 for v, u in zip(labels, us):

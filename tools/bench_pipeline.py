@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--max-range", type=float, default=100.0)
     ap.add_argument("--deskew", type=int, default=1)
     ap.add_argument("--oracle-frames", type=int, default=5)
+    ap.add_argument("--mode", default="raw", choices=["raw", "vectors"],
+                    help="raw (default): every frame arrives as a PointCloud2-style buffer of 16-byte records (x y z t, FLOAT32) and goes through "
+                         "IngestCloud + RegisterIngestedFrame - 2.1 MB over PCIe, decoded on the GPU; vectors: the reference's own signature, "
+                         "std::vector<Eigen::Vector3d> + std::vector<double> (4.2 MB)")
     ap.add_argument("--dump", default="", help="only write the input file for tests/cpp/facade_test (e.g. to run it under rocprofv3)")
     ap.add_argument("--check", default="", help="output of `facade_test pipeline_timed <dump>` to analyse instead of running it here")
     a = ap.parse_args()
@@ -46,8 +50,9 @@ def main():
         wl = syn.pose_mul(poses[-1], ext)
         R = syn.quat_to_matrix(wl[:4])
         t = scene.raycast(wl[4:], dirs @ R.T) + rng.normal(0, 0.01, len(dirs))
-        frames.append(dirs * t[:, None])
-        stamps.append(np.linspace(0.0, 1.0, len(dirs)))
+        # coordinates and stamps as a PointCloud2 carries them (FLOAT32): both modes and the oracle see the same values
+        frames.append((dirs * t[:, None]).astype(np.float32).astype(np.float64))
+        stamps.append(np.linspace(0.0, 1.0, len(dirs)).astype(np.float32).astype(np.float64))
         deltas.append(syn.pose_mul(delta_true, syn.planar_pose(0.01 * (-1) ** k, 0.0, np.deg2rad(0.1))))
     with tempfile.TemporaryDirectory() as td:
         f = a.dump or os.path.join(td, "pipe.bin")
@@ -58,12 +63,12 @@ def main():
                 np.array([float(len(fr))]).tofile(fh)
                 np.ascontiguousarray(fr).tofile(fh), st.tofile(fh), dl.tofile(fh)
         if a.dump:
-            print(test_facade.build_facade(), "pipeline_timed", f)
+            print(test_facade.build_facade(), "pipeline_timed_raw" if a.mode == "raw" else "pipeline_timed", f)
             return
         if a.check:
             out = open(a.check).read().splitlines()
         else:
-            out = subprocess.check_output([test_facade.build_facade(), "pipeline_timed", f], text=True).splitlines()
+            out = subprocess.check_output([test_facade.build_facade(), "pipeline_timed_raw" if a.mode == "raw" else "pipeline_timed", f], text=True).splitlines()
     ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
     ondev = np.array([int(l.split()[-1]) for l in out if l.startswith("frame")])
     ms_free = np.array([float(l.split()[4].strip("(")) for l in out if l.startswith("frame")])
@@ -71,6 +76,7 @@ def main():
         if not l.startswith("pose"):
             print(l)
     steady = ms[len(ms) // 2:]
+    print("mode %s: %s" % (a.mode, "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 records" if a.mode == "raw" else "RegisterFrame on fp64 vectors"))
     print("GPU RegisterFrame: median %.3f ms (second half; %.3f ms incl. freeing the returned clouds), first %.1f ms, map updates on device %d/%d" %
           (np.median(steady), np.median(ms_free[len(ms) // 2:]), ms[0], ondev.sum(), len(ondev)))
     gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
