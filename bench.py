@@ -342,6 +342,9 @@ def main():
     launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp), kernel arguments in %s"
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
+    if reg.get_option("batch_resident_passes") > 0:
+        launch_path += ("; inside a batch the generic kernel stays RESIDENT across its scans (one launch per batch call, every pass started by a "
+                        "command the kernel polls: option batch_resident)")
     small_kind = int(reg.get_option("small_active"))  # 0 generic pass kernel; small-scan path (kicp_small.hpp): 1 sub-lanes per query, 2 one wave per query
     small_active = small_kind > 0
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
@@ -407,12 +410,18 @@ def main():
     pass_kernel = int(reg.get_option("pass_kernel"))
     # ---- latency model inputs: the time of one DEPENDENT load step under the pass kernel's own launch shape, far (a working set
     #      of the map's size: probes, buckets, winners) and near (the record next to the probed key: the same line again)
-    lat_far_ns = lat_near_ns = None
+    #      UNLOADED - one wave per CU, so that what is measured is latency and nothing queues: no wave of the pass can take a
+    #      dependent step faster than that, whatever else the machine is doing - and, for information, under the pass kernel's own
+    #      launch shape with every lane chasing a line of its own (which is bandwidth bound: 131 072 random lines per step)
+    lat_far_ns = lat_near_ns = lat_far_loaded_ns = lat_near_loaded_ns = None
     if world == 1 and not small_active:
         try:
+            ws = max(gmap.device_bytes(), 1 << 20)
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            idle = dict(workgroups=cus, block=64, steps=256, device=device)
             shape = dict(workgroups=max(1, -(-(hi - lo) // 256)), block=256, steps=64, device=device)
-            lat_far_ns = K.probe_dependent_load(max(gmap.device_bytes(), 1 << 20), **shape)
-            lat_near_ns = K.probe_dependent_load(16 << 10, **shape)
+            lat_far_ns, lat_near_ns = K.probe_dependent_load(ws, **idle), K.probe_dependent_load(16 << 10, **idle)
+            lat_far_loaded_ns, lat_near_loaded_ns = K.probe_dependent_load(ws, **shape), K.probe_dependent_load(16 << 10, **shape)
         except K.KicpError:
             pass
     if exchange:
@@ -591,12 +600,16 @@ def main():
         bound_us = floor_us + (far_steps * lat_far_ns + rounds_per_wave * lat_near_ns) * 1e-3
         latency = {"floor_us": round(floor_us, 2), "rounds_per_wave": round(rounds_per_wave, 3), "dependent_far_steps_per_wave": round(far_steps, 3),
                    "dependent_near_steps_per_wave": round(rounds_per_wave, 3), "far_step_ns": round(lat_far_ns, 1), "near_step_ns": round(lat_near_ns, 1),
+                   "far_step_ns_under_the_kernels_launch_shape": None if lat_far_loaded_ns is None else round(lat_far_loaded_ns, 1),
+                   "near_step_ns_under_the_kernels_launch_shape": None if lat_near_loaded_ns is None else round(lat_near_loaded_ns, 1),
                    "far_working_set_bytes": int(gmap.device_bytes()), "latency_bound_us": round(bound_us, 2),
-                   "what": "latency_bound_us = floor_us + (3 + rounds) x far_step_ns + rounds x near_step_ns: the pass cannot end before its slowest "
-                           "wave has walked source point -> probe -> rounds x (bucket record, bucket) -> winner; far / near step = "
-                           "kicp_probe_dependent_load (every lane of the same launch shape chasing its own chain through a buffer of the map's "
-                           "size / 16 KB), rounds = mean visiting rounds per wave counted by the kernel (dbg 10), floor = the same launch with "
-                           "every query off.  frac_latency = latency_bound_us / kernel_avg_us (1 = at the bound)"}
+                   "what": "latency_bound_us = floor_us + (3 + rounds) x far_step_ns + rounds x near_step_ns: the pass cannot end before a wave "
+                           "has walked source point -> probe -> rounds x (bucket record, bucket) -> winner, and no wave takes a dependent step "
+                           "faster than the UNLOADED machine does: far / near step = kicp_probe_dependent_load with one wave per CU, every lane "
+                           "chasing its own chain through a buffer of the map's size / of 16 KB (the same probe under the kernel's own launch "
+                           "shape - 131 072 lanes, a random line each: bandwidth, not latency - is given beside it); rounds = mean visiting "
+                           "rounds per wave counted by the kernel (dbg 10); floor = the same launch with every query off (launch, reduction, "
+                           "hand-off; HIP events).  frac_latency = latency_bound_us / kernel_avg_us (1 = at the bound)"}
     roof = {"bound": "hbm", "achieved": None if traffic_gbs is None else round(traffic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 4),
             "frac_latency": None if latency is None else round(latency["latency_bound_us"] / kernel_us, 4),
