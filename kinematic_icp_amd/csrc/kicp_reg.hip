@@ -1106,22 +1106,30 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
           r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0))
         return 1;
-    size_t n_max = 0;
-    for (size_t k = 0; k < count; ++k) {
-        const SmallPlan pl = small_plan(r, n[k]);
-        if (!pl.generic) return 1;  // (small scans have their own kernels; larger ones than the device holds at once take the plain kernel)
-        n_max = std::max(n_max, n[k]);
-    }
+    // one kind of kernel serves the whole batch: the generic one (scans beyond the small-scan kernels, up to what the device holds at
+    // once) or one wave per query (scans of up to kWaveMaxPoints points); anything else - or a mix - takes the plain loop
+    size_t n_max = 0, n_min = ~size_t(0);
+    for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
+    if (n_min == 0) return 1;
+    SmallPlan pl = small_plan(r, n_max);
+    const SmallPlan pl_min = small_plan(r, n_min);
+    if (!(pl.generic && pl_min.generic) && !(pl.wave && pl_min.wave && pl.grid)) return 1;
     if (int rc = set_device(r->device)) return rc;
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
     if (map->mirror.synced_epoch != epoch_before) r->stream_dirty = true;
-    const uint32_t grid = static_cast<uint32_t>((n_max + 255) / 256);
+    const bool wave = pl.wave;
+    const uint32_t grid = wave ? pl.grid : static_cast<uint32_t>((n_max + 255) / 256);
     const size_t groups = (grid + kGroup - 1) / kGroup;
-    if (int rc = ensure_partials(r, 2u * grid)) return rc;
-    if (int rc = ensure_rows(r, 2 * groups)) return rc;
+    if (wave) {
+        if (int rc = ensure_rows(r, 2 * static_cast<size_t>(grid))) return rc;
+    } else {
+        if (int rc = ensure_partials(r, 2u * grid)) return rc;
+        if (int rc = ensure_rows(r, 2 * groups)) return rc;
+    }
     if (int rc = ensure_cmd(r)) return rc;
-    if (int rc = clear_stale_tickets(r)) return rc;
+    if (!wave)
+        if (int rc = clear_stale_tickets(r)) return rc;
     if (count > r->scans_cap) {
         if (int rc = aql_quiesce(r)) return rc;
         if (r->d_scans) HIP_TRY(hipFree(r->d_scans));
@@ -1140,8 +1148,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
         r->stream_dirty = false;
     }
-    SmallPlan pl;
-    pl.generic = true, pl.lat = true, pl.g = 1, pl.block = 256, pl.grid = grid;
+    if (!wave) pl.generic = true, pl.lat = true, pl.g = 1, pl.block = 256, pl.grid = grid;
     SmallParams sp{};
     PassParams &pp = sp.p;
     pp.src = d_frames[0], pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
@@ -1156,7 +1163,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         if (budget && pass < budget) send_command(r, sp.seq_base + pass, kCmdStop, T);
         budget = 0;
     };
-    r->last_small = 0, r->last_resident_passes = 0;
+    r->last_small = wave ? 2 : 0, r->last_resident_passes = 0;
     for (size_t k = 0; k < count; ++k) {
         HostLoop loop;
         loop.T = pose_mul(pose_from(last_poses_qt + 7 * k), pose_from(rel_odoms_qt + 7 * k));  // Registration.cpp:156
@@ -1185,13 +1192,14 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
             }
             first_pass = false;
             long long words[kReduceWords];
-            if (int rc = wait_rows(r, groups, sp.tag0 + pass, words, (pass & 1u) * groups)) {
+            bool gave_up = false;
+            if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + pass, pass & 1u, words, &gave_up)
+                              : wait_rows(r, groups, sp.tag0 + pass, words, (pass & 1u) * groups)) {
                 ++pass;
                 stop_kernel(loop.T);
                 return rc;
             }
-            const bool gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull;
-            words[kNumLimbs] &= 0xFFll;
+            if (!wave) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
             ++pass;
             if (gave_up) {  // (part of) the kernel has left: this scan and the rest go through the plain loop
                 ++r->small_relaunches;

@@ -371,17 +371,23 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
     __shared__ int s_flag;
     __shared__ unsigned long long s_cmd[kCmdWords];
     Pose T = fresh_args().p.sol.pose0;
-    // this wave's query (wave-uniform) and its source point: the same for every pass of the call, so it is read once
+    // this wave's query (wave-uniform) and its source point: the same for every pass of a scan, so it is read once per scan
+    // (a launch that serves a batch - sp.scans - moves on to the next scan on kCmdNewScan)
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    {
-        const SmallParams &sp0 = fresh_args();
-        const uint32_t q0 = blockIdx.x * kWaves + (fresh_tid() >> 6);
-        if (q0 < sp0.p.n) sx = sp0.p.src[3 * q0], sy = sp0.p.src[3 * q0 + 1], sz = sp0.p.src[3 * q0 + 2];
-    }
+    uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0))), n_scan = 0u;
+    bool new_scan = true;
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         const PassParams &p = sp.p;
         const MapView &m = p.map;
+        if (new_scan) {
+            const double *src = sp.scans ? sp.scans[scan].src : p.src;
+            n_scan = sp.scans ? static_cast<uint32_t>(sp.scans[scan].n) : p.n;
+            const uint32_t q0 = blockIdx.x * kWaves + (fresh_tid() >> 6);
+            sx = sy = sz = 0.0;
+            if (q0 < n_scan) sx = src[3 * q0], sy = src[3 * q0 + 1], sz = src[3 * q0 + 2];
+            new_scan = false;
+        }
         uint32_t tid = fresh_tid();
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
         bool accepted = false;
         double term_value = 0.0;  // lane k < 6: the k-th term of this wave's correspondence (lane 6: the count)
-        if (qi < p.n) {
+        if (qi < n_scan) {
             const SearchParams &sq = p.search;
             const float margin = sq.margin_u;
             const double vs = m.voxel_size;
@@ -563,7 +569,9 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         }
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;
-        if (await_command(sp, tid, pass, s_cmd) != kCmdContinue) return;
+        const uint32_t op = await_command(sp, tid, pass, s_cmd);
+        if (op != kCmdContinue && op != kCmdNewScan) return;
+        if (op == kCmdNewScan) scan = static_cast<uint32_t>(uniform_i(static_cast<int>(scan + 1u))), new_scan = true;
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),

@@ -260,3 +260,39 @@ def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop():
     reg.set_option("small_timeout_us", 20000.0)
     got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
+    """the same for scans of at most 4 096 points (one wave per query, k_pass_wave): sizes that differ inside one launch, a scan
+    without correspondences, a give-up half-way; a batch that mixes small and large scans takes the plain loop"""
+    maps, src = _big_world(n_map=60000, n_src=20000, seed=23)
+    g = maps[0]
+    sizes, shifts = [3000, 1080, 4000, 700, 2048], [0.02, -0.04, 0.0, 0.06, 0.03]
+    frames = [src[i * 100:i * 100 + k] - np.array([d, 0.0, 0.0]) for i, (k, d) in enumerate(zip(sizes, shifts))]
+    frames[3] = np.full((700, 3), -300.0)
+    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(5)]
+    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(5)]
+    dev = [K.DeviceFrame(f, device=0) for f in frames]
+    plain = _reg({"batch_resident": 0}, **CFG)
+    b0 = plain.prepare_batch(dev, lasts, rels)
+    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    reg = _reg({}, **CFG)
+    b1 = reg.prepare_batch(dev, lasts, rels)
+    for _ in range(3):
+        got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+        assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
+    assert reg.get_option("batch_resident_passes") >= 3 * (sum(b0.iterations) - 10) and reg.get_option("small_active") == 2.0
+    for k in (0, 1, 2, 4):
+        o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
+        np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
+    reg.set_option("small_timeout_us", 300.0), reg.set_option("debug_stall_us", 3000.0)
+    before = reg.get_option("small_relaunches")
+    got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+    assert np.array_equal(got, want, equal_nan=True) and reg.get_option("small_relaunches") == before + 1
+    reg.set_option("small_timeout_us", 20000.0)
+    # small and large scans in one batch: no kernel serves both - the plain loop runs, same results
+    mixed = [dev[0], K.DeviceFrame(src[:12000] - np.array([0.02, 0, 0]), device=0), dev[2]]
+    bm0, bm1 = plain.prepare_batch(mixed, lasts[:3], rels[:3]), reg.prepare_batch(mixed, lasts[:3], rels[:3])
+    served = reg.get_option("batch_resident_passes")
+    assert np.array_equal(reg.ComputeRobotMotionBatch(bm1, g, 0.5), plain.ComputeRobotMotionBatch(bm0, g, 0.5))
+    assert reg.get_option("batch_resident_passes") == served

@@ -209,3 +209,29 @@ def test_voxel_coordinates_beyond_the_device_keys_range_fall_back_to_the_host():
     assert reg.last_stats.iterations == oreg.last_stats.iterations
     g.Clear()
     assert g.UpdateDevice(K.DeviceFrame(base), okicp.IDENTITY)  # a cleared map goes back to device-side updates
+
+
+def test_far_voxels_that_arrive_through_the_host_or_a_copy_keep_updates_on_the_host():
+    """the host fallback must also hold for a map whose far voxels did not come from a device update - inserted by
+    host-side AddPoints, or inherited by a copy (VoxelHashMap(const VoxelHashMap&) = kicp_map_clone): the packed keys of the
+    device kernels would alias such a voxel."""
+    rng = np.random.default_rng(18)
+    vs = 0.01
+    near = rng.uniform(-1.0, 1.0, (6000, 3)) * np.array([1.0, 1.0, 0.2])
+    far = near[:500] + np.array([11000.0, 0.0, 0.0])      # voxel x ~ 1.1e6 > 2^20
+    g, o = K.VoxelHashMap(vs, 20000.0, 20), okicp.VoxelHashMap(vs, 20000.0, 20)
+    g.AddPoints(far), o.AddPoints(far)                     # (fewer than 4 096 points: host-side insertion)
+    twin = g.copy()
+    for m in (g, twin):
+        assert not m.UpdateDevice(K.DeviceFrame(near), okicp.IDENTITY)   # stays on the host ...
+    o.Update(near, okicp.IDENTITY)
+    for m in (g, twin):
+        assert (m.num_points(), m.num_voxels()) == (o.num_points(), o.num_voxels()) and m.check() == 0   # ... with the reference's result
+    nn_g, d_g = g.GetClosestNeighbor(far[:50] + 0.001)
+    nn_o, d_o = o.GetClosestNeighbor(far[:50] + 0.001)
+    assert np.array_equal(nn_g, nn_o) and np.array_equal(d_g, d_o)
+    # a device-side update that itself meets a far point sets the flag; the copy taken afterwards carries it
+    h = K.VoxelHashMap(vs, 20000.0, 20)
+    assert h.UpdateDevice(K.DeviceFrame(near), okicp.IDENTITY)
+    assert not h.UpdateDevice(K.DeviceFrame(far), okicp.IDENTITY)
+    assert not h.copy().UpdateDevice(K.DeviceFrame(near + 0.5), okicp.IDENTITY)
