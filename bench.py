@@ -342,9 +342,10 @@ def main():
     launch_path = ("direct AQL dispatch on the handle's own HSA queue (kicp_aql.hpp), kernel arguments in %s"
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
-    if reg.get_option("batch_resident_passes") > 0:
-        launch_path += ("; inside a batch the generic kernel stays RESIDENT across its scans (one launch per batch call, every pass started by a "
-                        "command the kernel polls: option batch_resident)")
+    resident_batch = reg.get_option("batch_resident_passes") > 0
+    if resident_batch:
+        launch_path += ("; inside a batch the pass kernel stays RESIDENT across the batch's scans (one launch per batch call, every pass - a scan's first "
+                        "one included - started by a command the kernel polls: option batch_resident)")
     small_kind = int(reg.get_option("small_active"))  # 0 generic pass kernel; small-scan path (kicp_small.hpp): 1 sub-lanes per query, 2 one wave per query
     small_active = small_kind > 0
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
@@ -616,6 +617,11 @@ def main():
             "latency_model": latency,
             "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
             "kernel": "fused association+accumulation pass (%s)" % kernel_sub, "kernel_avg_us": round(kernel_us, 2),
+            "kernel_in_the_timed_region": None if not resident_batch else
+            {"kernel": "k_pass_resident (generic scans) / k_pass_wave (small scans): the same pass code, resident across the scans of one "
+                       "kicp_register_device_batch call - ONE dispatch per step, so a kernel trace of this command shows it with an average duration "
+                       "of about ms_per_step, and %s with the per-pass duration quoted here (the event-timed calls, one launch per pass)" % kernel_sub,
+             "us_per_pass_wall_clock": round(1e6 * elapsed / n_scans_timed / max(iters_gpu, 1e-9), 3)},
             "kernel_time_source": kernel_time_source, "launches_timed": int(pass_ms.size),
             "what": "achieved = HBM bytes the pass kernel moved per launch (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) / its "
                     "average duration; frac = achieved / 8 TB/s.  The kernel is bound by its waves' dependent-load chains and a fixed launch + "
@@ -844,7 +850,7 @@ def _profile_counters(workload, world):
     not been profiled: nothing is borrowed from another configuration."""
     if world != 1:
         return None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (rnd, workload))) as f:
                 d = json.load(f)

@@ -22,7 +22,8 @@ struct Roctx {
     int (*push)(const char *) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        for (const char *nm : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so.1"}) {
+        // (rocprofv3 listens to the rocprofiler-sdk flavour of the library; the roctracer one is what older tools hook)
+        for (const char *nm : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}) {
             if (void *h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) {
                 push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
                 pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));

@@ -88,18 +88,42 @@ static __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *block_cou
     if (threadIdx.x == 0) *total = s_carry;
 }
 
+// Offset of this workgroup's survivors = the sum of the counts of the workgroups before it, added up by the workgroup itself
+// (256 threads, a strided share each): for the grids of a frame (<= kFusedScanBlocks workgroups) that is a few loads per thread
+// and saves the separate scan kernel - a launch of one workgroup whose ~5 us were pure latency, three times per frame.  The last
+// workgroup also leaves the grand total in *total.  `raw` == 0: the counts have been scanned already (k_scan_blocks: larger grids).
+constexpr uint32_t kFusedScanBlocks = 4096;
+__device__ __forceinline__ uint32_t block_offset(const uint32_t *counts, int raw, uint32_t *total) {
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_offset;
+    const uint32_t b = blockIdx.x;
+    if (!raw) return counts[b];
+    uint32_t sum = 0u;
+    for (uint32_t i = threadIdx.x; i < b; i += 256u) sum += counts[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_offset = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (total && b == gridDim.x - 1u) *total = s_offset + counts[b];
+    }
+    __syncthreads();
+    return s_offset;
+}
 // order-preserving compaction: survivor i goes to block_offset + (number of survivors before it in its block)
-static __global__ __launch_bounds__(256) void k_compact(const double *staged, const uint32_t *flags, const uint32_t *block_offsets, uint32_t n,
-                                                 double *out) {
+static __global__ __launch_bounds__(256) void k_compact(const double *staged, const uint32_t *flags, const uint32_t *block_counts, int raw, uint32_t *total,
+                                                 uint32_t n, double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool keep = i < n && flags[i] != 0u;
     const unsigned long long ballot = __ballot(keep);
     if (lane == 0) s_wave[wave] = static_cast<uint32_t>(__popcll(ballot));
+    const uint32_t offset = block_offset(block_counts, raw, total);  // (its barriers also publish s_wave)
     __syncthreads();
     if (!keep) return;
-    uint32_t pos = block_offsets[blockIdx.x] + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
+    uint32_t pos = offset + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
     for (int w = 0; w < wave; ++w) pos += s_wave[w];
     out[3 * pos] = staged[3 * i], out[3 * pos + 1] = staged[3 * i + 1], out[3 * pos + 2] = staged[3 * i + 2];
 }
@@ -199,7 +223,7 @@ static __global__ __launch_bounds__(256) void k_downsample_replay(const Downsamp
     block_count_store(occupied, p.block_counts);
 }
 // pass 3: survivors in ascending bucket index (the reference's iteration order)
-static __global__ __launch_bounds__(256) void k_downsample_gather(const DownsampleParams p, const uint32_t *block_offsets, double *out) {
+static __global__ __launch_bounds__(256) void k_downsample_gather(const DownsampleParams p, const uint32_t *block_counts, int raw, uint32_t *total, double *out) {
     __shared__ uint32_t s_wave[4];
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,9 +231,10 @@ static __global__ __launch_bounds__(256) void k_downsample_gather(const Downsamp
     const bool occupied = n != 0u && s <= mask && p.keys[s] != kEmptyVoxelKey;
     const unsigned long long ballot = __ballot(occupied);
     if (lane == 0) s_wave[wave] = static_cast<uint32_t>(__popcll(ballot));
+    const uint32_t offset = block_offset(block_counts, raw, total);
     __syncthreads();
     if (!occupied) return;
-    uint32_t pos = block_offsets[blockIdx.x] + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
+    uint32_t pos = offset + static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
     for (int w = 0; w < wave; ++w) pos += s_wave[w];
     const uint32_t i = p.order[s];
     out[3 * pos] = p.in[3 * i], out[3 * pos + 1] = p.in[3 * i + 1], out[3 * pos + 2] = p.in[3 * i + 2];
@@ -228,10 +253,13 @@ struct IngestParams {
     uint32_t off_x, off_y, off_z, off_t;
     int32_t stamp_type;  // 0 none, 6 UINT32, 7 FLOAT32, 8 FLOAT64 (sensor_msgs::msg::PointField datatype codes)
     int32_t transform;   // 0: identity (what LidarOdometryServer.cpp:203 passes)
+    int32_t aligned;     // every field sits at a multiple of its size (base pointer, point_step and offsets): plain loads instead of byte-wise ones
     Pose T;
     double *out_xyz;
     double *out_stamps;
     unsigned long long *minmax;  // [0] min, [1] max of the stamps as order-preserving integer keys
+    unsigned long long *block_minmax;  // nullable: [gridDim.x][2] extrema per workgroup instead of two atomics per workgroup on ONE pair of words
+                                       // (512 workgroups queueing on them were 10 of this kernel's 15 us); k_normalize_stamps folds them
 };
 
 template <typename T>
@@ -252,15 +280,20 @@ KICP_HD double ordered_value(unsigned long long k) {
     return v;
 }
 
+template <typename T>
+__device__ __forceinline__ T load_field(const unsigned char *p, bool aligned) {
+    return aligned ? *reinterpret_cast<const T *>(p) : load_unaligned<T>(p);
+}
 static __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
     __shared__ unsigned long long s_min[4], s_max[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long kmin = ~0ull, kmax = 0ull;
+    const bool al = p.aligned != 0;  // (wave-uniform: the usual PointCloud2 layouts are naturally aligned)
     if (i < p.n) {
         const unsigned char *rec = p.raw + static_cast<size_t>(i) * p.point_step;
-        double x = static_cast<double>(load_unaligned<float>(rec + p.off_x));
-        double y = static_cast<double>(load_unaligned<float>(rec + p.off_y));
-        double z = static_cast<double>(load_unaligned<float>(rec + p.off_z));
+        double x = static_cast<double>(load_field<float>(rec + p.off_x, al));
+        double y = static_cast<double>(load_field<float>(rec + p.off_y, al));
+        double z = static_cast<double>(load_field<float>(rec + p.off_z, al));
         if (p.transform) {
             double rx, ry, rz;
             quat_rotate(p.T, x, y, z, rx, ry, rz);
@@ -269,9 +302,9 @@ static __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
         p.out_xyz[3 * i] = x, p.out_xyz[3 * i + 1] = y, p.out_xyz[3 * i + 2] = z;
         if (p.stamp_type) {
             double stamp;
-            if (p.stamp_type == 6) stamp = static_cast<double>(load_unaligned<uint32_t>(rec + p.off_t));
-            else if (p.stamp_type == 7) stamp = static_cast<double>(load_unaligned<float>(rec + p.off_t));
-            else stamp = load_unaligned<double>(rec + p.off_t);
+            if (p.stamp_type == 6) stamp = static_cast<double>(load_field<uint32_t>(rec + p.off_t, al));
+            else if (p.stamp_type == 7) stamp = static_cast<double>(load_field<float>(rec + p.off_t, al));
+            else stamp = load_field<double>(rec + p.off_t, al);
             // TimeStampHandler.cpp:60-63,73-78: floor(log10(uint64(round(stamp))) + 1) > 10  <=>  round(stamp) >= 1e10
             if (round(stamp) >= 1e10) stamp *= 1e-9;
             p.out_stamps[i] = stamp;
@@ -288,14 +321,38 @@ static __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) kmin = s_min[w] < kmin ? s_min[w] : kmin, kmax = s_max[w] > kmax ? s_max[w] : kmax;
-        atomicMin(p.minmax, kmin), atomicMax(p.minmax + 1, kmax);
+        if (p.block_minmax) p.block_minmax[2 * blockIdx.x] = kmin, p.block_minmax[2 * blockIdx.x + 1] = kmax;
+        else atomicMin(p.minmax, kmin), atomicMax(p.minmax + 1, kmax);
     }
 }
 // TimeStampHandler.cpp:121-128: (t - min) / (max - min), the same two fp64 operations
-static __global__ __launch_bounds__(256) void k_normalize_stamps(double *stamps, uint32_t n, const unsigned long long *minmax) {
+// (`block_minmax` != nullptr: the extrema are still spread over k_ingest's workgroups - every workgroup folds the `nblocks` pairs
+//  itself, workgroup 0 leaves the result in minmax[] for the host)
+static __global__ __launch_bounds__(256) void k_normalize_stamps(double *stamps, uint32_t n, unsigned long long *minmax, const unsigned long long *block_minmax,
+                                                          uint32_t nblocks) {
+    __shared__ unsigned long long s_lo[4], s_hi[4];
+    unsigned long long klo, khi;
+    if (block_minmax) {
+        klo = ~0ull, khi = 0ull;
+        for (uint32_t b = threadIdx.x; b < nblocks; b += 256u) {
+            const unsigned long long a = block_minmax[2 * b], c = block_minmax[2 * b + 1];
+            klo = a < klo ? a : klo, khi = c > khi ? c : khi;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long a = __shfl_xor(klo, off, 64), c = __shfl_xor(khi, off, 64);
+            klo = a < klo ? a : klo, khi = c > khi ? c : khi;
+        }
+        if ((threadIdx.x & 63) == 0) s_lo[threadIdx.x >> 6] = klo, s_hi[threadIdx.x >> 6] = khi;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) klo = s_lo[w] < klo ? s_lo[w] : klo, khi = s_hi[w] > khi ? s_hi[w] : khi;
+        if (blockIdx.x == 0 && threadIdx.x == 0) minmax[0] = klo, minmax[1] = khi;
+    } else {
+        klo = minmax[0], khi = minmax[1];
+    }
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double lo = ordered_value(minmax[0]), hi = ordered_value(minmax[1]);
+    const double lo = ordered_value(klo), hi = ordered_value(khi);
     stamps[i] = (stamps[i] - lo) / (hi - lo);
 }
 

@@ -46,7 +46,7 @@ struct kicp_pre {
     double *copy_dst = nullptr;
     size_t copy_dst_points = 0;
     hipError_t copy_error = hipSuccess;
-    unsigned long long *d_minmax = nullptr;
+    unsigned long long *d_minmax = nullptr, *d_block_minmax = nullptr;
     size_t ingested_n = 0;
     bool ingested = false, ingested_stamps = false;
 };
@@ -93,8 +93,10 @@ int pre_finish(kicp_pre *p, int dst, size_t *out_n) {
 int pre_compact(kicp_pre *p, const double *staged, size_t n, int dst, size_t *out_n) {
     const uint32_t grid = static_cast<uint32_t>((n + 255) / 256);
     if (int rc = pre_ensure_buf(p, dst, n)) return rc;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, p->d_flags, p->d_block_counts, static_cast<uint32_t>(n), p->buf[dst]);
+    const int raw = grid <= kFusedScanBlocks ? 1 : 0;  // (frame-sized grids: every workgroup adds up the counts before it itself)
+    if (!raw) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, p->d_misc);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, staged, static_cast<const uint32_t *>(p->d_flags), static_cast<const uint32_t *>(p->d_block_counts), raw,
+                       p->d_misc, static_cast<uint32_t>(n), p->buf[dst]);
     HIP_TRY(hipGetLastError());
     return pre_finish(p, dst, out_n);
 }
@@ -143,7 +145,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
-    hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax);
+    hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax), hipFree(p->d_block_minmax);
     p->stage.release();
     if (p->copy_thread.joinable()) {  // the helper thread finishes the job it has, then leaves
         {
@@ -208,19 +210,31 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
         p->raw_cap = bytes + bytes / 4 + 4096;
     }
     if (!p->d_minmax) HIP_TRY(hipMalloc(&p->d_minmax, 16));
-    const unsigned long long init[2] = {~0ull, 0ull};
-    HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
+    const uint32_t grid_in = static_cast<uint32_t>((n_points + 255) / 256);
+    if (!(st != 0 && grid_in <= kFusedScanBlocks)) {  // (the atomics of larger grids start from the identity; frame-sized ones fold per-workgroup extrema)
+        const unsigned long long init[2] = {~0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
+    }
     if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, p->stream)) return rc;
     IngestParams ip{};
     ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
     ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
     ip.transform = sensor_pose_qt ? 1 : 0;
+    ip.aligned = (L.point_step % 4 == 0 && L.offset_x % 4 == 0 && L.offset_y % 4 == 0 && L.offset_z % 4 == 0 &&
+                  (st == 0 || (L.offset_stamp % stamp_bytes == 0 && L.point_step % stamp_bytes == 0))) ? 1 : 0;  // (d_raw itself is 256-byte aligned)
     if (sensor_pose_qt) ip.T = pose_from(sensor_pose_qt);
     ip.out_xyz = p->d_in, ip.out_stamps = p->d_ts, ip.minmax = p->d_minmax;
     const uint32_t grid = static_cast<uint32_t>((n_points + 255) / 256);
+    // the stamps' extrema per workgroup, folded by the normalisation kernel (frame-sized grids; d_block_counts has room for them:
+    // >= cap / 256 + 2 words of 4 bytes... so they get a buffer of their own)
+    ip.block_minmax = nullptr;
+    if (st != 0 && grid <= kFusedScanBlocks) {
+        if (!p->d_block_minmax) HIP_TRY(hipMalloc(&p->d_block_minmax, static_cast<size_t>(kFusedScanBlocks) * 16));
+        ip.block_minmax = p->d_block_minmax;
+    }
     hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, p->stream, ip);
     if (st != 0) {
-        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, p->stream, p->d_ts, ip.n, p->d_minmax);
+        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, p->stream, p->d_ts, ip.n, p->d_minmax, static_cast<const unsigned long long *>(ip.block_minmax), grid);
         unsigned long long mm[2];
         HIP_TRY(hipMemcpyAsync(mm, p->d_minmax, 16, hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
@@ -286,8 +300,9 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     const uint32_t grid = static_cast<uint32_t>((n + 255) / 256), sgrid = static_cast<uint32_t>((slots + 255) / 256);
     hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
     hipLaunchKernelGGL(k_downsample_replay, dim3(sgrid), dim3(256), 0, p->stream, dp);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, p->d_misc);
-    hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, p->d_block_counts, p->buf[dst]);
+    const int raw = sgrid <= kFusedScanBlocks ? 1 : 0;
+    if (!raw) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, p->d_misc);
+    hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, static_cast<const uint32_t *>(p->d_block_counts), raw, p->d_misc, p->buf[dst]);
     HIP_TRY(hipGetLastError());
     const int rc = pre_finish(p, dst, out_n);
     p->table_clean = rc == KICP_OK;
@@ -330,9 +345,10 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     pp.max_range = max_range, pp.min_range = min_range;
     pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
     hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, p->stream, pp);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, cnt + 0);
+    const int raw_c = grid <= kFusedScanBlocks ? 1 : 0, raw_g = sgrid <= kFusedScanBlocks ? 1 : 0;
+    if (!raw_c) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, cnt + 0);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, static_cast<const double *>(p->d_staged), static_cast<const uint32_t *>(p->d_flags),
-                       static_cast<const uint32_t *>(p->d_block_counts), static_cast<uint32_t>(n_in), p->buf[0]);
+                       static_cast<const uint32_t *>(p->d_block_counts), raw_c, cnt + 0, static_cast<uint32_t>(n_in), p->buf[0]);
     if (out_frame_xyz) {  // buffer 0 is complete behind this point: its download overlaps the downsamples (n_in points: an upper bound)
         HIP_TRY(hipEventRecord(p->chain_ready, p->stream));
         if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
@@ -357,8 +373,9 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         dp.probe_max_sticky = stage == 0 ? nullptr : dp.probe_max;
         hipLaunchKernelGGL(k_downsample_claim, dim3(grid), dim3(256), 0, p->stream, dp);
         hipLaunchKernelGGL(k_downsample_replay, dim3(sgrid), dim3(256), 0, p->stream, dp);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, cnt + stage + 1);
-        hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, static_cast<const uint32_t *>(p->d_block_counts), p->buf[stage + 1]);
+        if (!raw_g) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, sgrid, cnt + stage + 1);
+        hipLaunchKernelGGL(k_downsample_gather, dim3(sgrid), dim3(256), 0, p->stream, dp, static_cast<const uint32_t *>(p->d_block_counts), raw_g, cnt + stage + 1,
+                           p->buf[stage + 1]);
     }
     HIP_TRY(hipGetLastError());
     uint32_t misc[8] = {};

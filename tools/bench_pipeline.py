@@ -77,8 +77,8 @@ def main():
             print(l)
     steady = ms[len(ms) // 2:]
     print("mode %s: %s" % (a.mode, "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 records" if a.mode == "raw" else "RegisterFrame on fp64 vectors"))
-    print("GPU RegisterFrame: median %.3f ms (second half; %.3f ms incl. freeing the returned clouds), first %.1f ms, map updates on device %d/%d" %
-          (np.median(steady), np.median(ms_free[len(ms) // 2:]), ms[0], ondev.sum(), len(ondev)))
+    print("GPU RegisterFrame: median %.3f ms (second half; %.3f ms incl. freeing the returned clouds; p10 %.3f, min %.3f), first %.1f ms, map updates on device %d/%d" %
+          (np.median(steady), np.median(ms_free[len(ms) // 2:]), np.percentile(steady, 10), steady.min(), ms[0], ondev.sum(), len(ondev)))
     gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
     if a.oracle_frames:
         from oracle import okicp
