@@ -168,18 +168,35 @@ def main():
     cfg, scans, gmap, tau, n_total, lo, hi = wl.cfg, wl.scans, wl.gmap, wl.tau, wl.n_total, wl.lo, wl.hi
     rel_single, rel_multi = wl.rel_single, wl.rel_multi
 
+    def all_ranks_ok(err):
+        """every rank learns whether ANY rank failed and all of them raise together (this rank's own error, or a stand-in)"""
+        if use_comm:
+            t = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t.item()) > 0.0 and err is None:
+                err = K.KicpError(K.KICP_ERR_COMM, "a peer rank's registration failed")
+        if err is not None:
+            raise err
+
     def make_reg(comm, **kw):
         """a registration handle with the requested exchange attached (None: single GPU / replicas)"""
         reg = K.KinematicRegistration(device=device, **kw)  # reference defaults (KinematicICP.hpp:51-56) unless asked otherwise
         keep = []
         if comm == "shm":
             name = "kicp_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
-            if rank == 0:
-                reg.shm_init(world, 0, name)  # removes a stale segment of that name, creates, zeroes and publishes the new one
-            dist.barrier()
-            if rank != 0:
-                reg.shm_init(world, rank, name)
-            dist.barrier()
+            err = None
+            try:
+                if rank == 0:
+                    reg.shm_init(world, 0, name)  # removes a stale segment of that name, creates, zeroes and publishes the new one
+            except K.KicpError as e:
+                err = e
+            all_ranks_ok(err)
+            try:
+                if rank != 0:
+                    reg.shm_init(world, rank, name)
+            except K.KicpError as e:
+                err = e
+            all_ranks_ok(err)
         elif comm == "rccl":
             uid = torch.zeros(K.COMM_ID_BYTES, dtype=torch.uint8, device=pg_dev)
             if rank == 0:
@@ -187,10 +204,22 @@ def main():
             dist.broadcast(uid, 0)
             reg.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
         elif comm == "p2p":
-            mine = torch.frombuffer(bytearray(reg.p2p_export(world, rank)), dtype=torch.uint8).to(pg_dev)
+            # (a set-up step that fails on ONE rank - an IPC handle that cannot be opened - must not leave the others at a barrier:
+            #  every rank learns of it and all of them raise together)
+            err, handle = None, b"\0" * K.P2P_HANDLE_BYTES
+            try:
+                handle = reg.p2p_export(world, rank)
+            except K.KicpError as e:
+                err = e
+            mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(pg_dev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
-            reg.p2p_connect([bytes(t.cpu().numpy().tobytes()) for t in every])
+            all_ranks_ok(err)
+            try:
+                reg.p2p_connect([bytes(t.cpu().numpy().tobytes()) for t in every])
+            except K.KicpError as e:
+                err = e
+            all_ranks_ok(err)
             dist.barrier()
         elif comm == "torch":
             def allreduce(ptr, count, stream):
@@ -230,16 +259,6 @@ def main():
         return pose
 
     state = {"B": max(1, args.scans_per_step) if args.scans_per_step > 0 else 64}  # (auto: fixed below, after the calibration batch)
-
-    def all_ranks_ok(err):
-        """every rank learns whether ANY rank failed and all of them raise together (this rank's own error, or a stand-in)"""
-        if use_comm:
-            t = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            if float(t.item()) > 0.0 and err is None:
-                err = K.KicpError(K.KICP_ERR_COMM, "a peer rank's registration failed")
-        if err is not None:
-            raise err
 
     def timed(reg, rels, steps, warmup, per_call=False, w=None, B=None):
         """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
