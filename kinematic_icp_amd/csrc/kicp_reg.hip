@@ -1173,7 +1173,8 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         while (!finished) {
             if (budget == 0 || pass >= budget) {  // no kernel on the device (any more): launch, starting on this scan with this pose
                 // (a launch that has served all its passes has left by itself)
-                const uint32_t cnt = kBatchMaxPasses;
+                // (tags are reserved per launch: no more than the rest of the batch can use)
+                const uint32_t cnt = static_cast<uint32_t>(std::min<unsigned long long>(kBatchMaxPasses, static_cast<unsigned long long>(count - k) * static_cast<unsigned long long>(max_it)));
                 if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
                 pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
                 sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(k);

@@ -296,3 +296,25 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     served = reg.get_option("batch_resident_passes")
     assert np.array_equal(reg.ComputeRobotMotionBatch(bm1, g, 0.5), plain.ComputeRobotMotionBatch(bm0, g, 0.5))
     assert reg.get_option("batch_resident_passes") == served
+
+
+@pytest.mark.parametrize("n_src", [1500, 9000])
+def test_a_batch_longer_than_one_resident_launch_serves(n_src):
+    """a resident launch serves at most 1 024 passes (= tags): a batch of 320 scans x ~4 iterations is relaunched on the way, in the
+    middle of a scan if that is where the budget ends - same bits as one call per scan (wave-per-query and generic kernel)"""
+    maps, src = _big_world(n_map=60000, n_src=20000, seed=29)
+    g = maps[0]
+    rng = np.random.default_rng(7)
+    base = [K.DeviceFrame(src[i * 50:i * 50 + n_src] - np.array([0.04 + 0.01 * i, 0.0, 0.0]), device=0) for i in range(4)]
+    count = 320
+    dev = [base[i % 4] for i in range(count)]
+    lasts = [syn.planar_pose(rng.uniform(-0.02, 0.02), 0.0, rng.uniform(-0.002, 0.002)) for _ in range(count)]
+    rels = [syn.planar_pose(rng.uniform(-0.01, 0.01), 0.0, 0.0005) for _ in range(count)]
+    four = dict(CFG, max_num_iteration=4, convergence_criterion=0.0)  # every scan runs exactly four iterations
+    plain, reg = _reg({"batch_resident": 0}, **four), _reg({}, **four)
+    b0, b1 = plain.prepare_batch(dev, lasts, rels), reg.prepare_batch(dev, lasts, rels)
+    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+    assert sum(b0.iterations) == 1280  # more passes than one launch's budget of 1 024
+    assert np.array_equal(got, want) and list(b1.iterations) == list(b0.iterations)
+    assert reg.get_option("batch_resident_passes") == sum(b0.iterations)
