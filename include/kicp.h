@@ -98,6 +98,13 @@ int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const doubl
  * (AddPoints, kicp_map_check, ...) needs it.  A map that leaves +-2^20 voxels from its origin is updated by the host map
  * from then on (same result). */
 int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
+/* The same update in two halves (round 4): _begin queues the update's kernels and returns WITHOUT waiting for them, so that the caller
+ * can do host-side work that does not touch the map meanwhile (the drop-in RegisterFrame collects the frame's two returned clouds);
+ * kicp_map_update_finish waits and takes the result over (host fallback included).  d_points_xyz stays borrowed until then.  Only
+ * frame-sized updates into a table with room for the worst case are actually deferred; every other case runs to completion inside
+ * _begin.  Any other call on the map finishes a pending update first, so forgetting _finish costs nothing but the overlap. */
+int kicp_map_update_pose_device_begin(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
+int kicp_map_update_finish(kicp_map *map);
 int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU */
 /* Preferred device for BULK host-side insertions (not part of the reference API): with device >= 0, kicp_map_add_points /
  * kicp_map_update_origin / kicp_map_update_pose calls of 4096 points or more stage their points into HBM and insert them

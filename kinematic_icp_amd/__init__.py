@@ -66,6 +66,8 @@ _SIGNATURES = {
     "kicp_map_update_origin": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
     "kicp_map_update_pose": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp]),
     "kicp_map_update_pose_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _dp]),
+    "kicp_map_update_pose_device_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _dp]),
+    "kicp_map_update_finish": (C.c_int, [C.c_void_p]),
     "kicp_map_last_update_on_device": (C.c_int, [C.c_void_p]),
     "kicp_map_set_device": (C.c_int, [C.c_void_p, C.c_int]),
     "kicp_map_num_points": (C.c_size_t, [C.c_void_p]),
@@ -246,6 +248,16 @@ class VoxelHashMap:
         the GPU, False if the host fallback (table or pool growth) was taken."""
         _, q = _d(pose)
         _check(lib().kicp_map_update_pose_device(self._h, device_frame.device, device_frame.ptr, device_frame.n, q))
+        return bool(lib().kicp_map_last_update_on_device(self._h))
+
+    def UpdateDeviceBegin(self, device_frame, pose):
+        """kicp_map_update_pose_device_begin: the update's kernels are queued, nothing is waited for (UpdateFinish, or any other
+        call on the map, collects it); the frame must stay alive and unchanged until then"""
+        _, q = _d(pose)
+        _check(lib().kicp_map_update_pose_device_begin(self._h, device_frame.device, device_frame.ptr, device_frame.n, q))
+
+    def UpdateFinish(self):
+        _check(lib().kicp_map_update_finish(self._h))
         return bool(lib().kicp_map_last_update_on_device(self._h))
 
     def num_points(self):

@@ -194,7 +194,8 @@ protected:
                                                                      relative_odometry, tau);
         trace.lap("threshold + map update");
         correspondence_threshold_.UpdateOdometryError((last_pose_ * relative_odometry).inverse() * new_pose);
-        local_map_.UpdateDevice(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose);
+        // (the map update's kernels run while this thread collects the two returned clouds: nothing below touches the map or buffer 1)
+        local_map_.UpdateDeviceBegin(kicp_pre_device_ptr(pre_, 1, nullptr), n_down, new_pose);
         last_pose_ = new_pose;
         trace.lap("collect results");
         auto &source = std::get<1>(result);
@@ -203,6 +204,8 @@ protected:
         guard.armed = false;
         if (!frame.empty()) kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.front().data(), frame.size(), nullptr), "download");
         frame.resize(counts[0]);  // (the landing area held every input point; shrinking costs nothing)
+        trace.lap("map update: wait");
+        local_map_.UpdateFinish();
         return std::move(result);  // built in place: no copy of the clouds on the way out
     }
 #endif

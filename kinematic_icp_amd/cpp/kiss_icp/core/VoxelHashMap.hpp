@@ -130,6 +130,14 @@ struct VoxelHashMap {
         ++version_;
         kicp_bridge::check(kicp_map_update_pose_device(handle_, device_, d_points_xyz, n, p), "VoxelHashMap::Update");
     }
+    // the same in two halves: Begin queues the update and returns without waiting, Finish collects it (kicp.h); backend extension
+    void UpdateDeviceBegin(const double *d_points_xyz, size_t n, const Sophus::SE3d &pose) {
+        double p[7];
+        kicp_bridge::to_params(pose, p);
+        ++version_;
+        kicp_bridge::check(kicp_map_update_pose_device_begin(handle_, device_, d_points_xyz, n, p), "VoxelHashMap::Update");
+    }
+    void UpdateFinish() { kicp_bridge::check(kicp_map_update_finish(handle_), "VoxelHashMap::Update"); }
     void AddPoints(const std::vector<Eigen::Vector3d> &points) {
         ++version_;
         kicp_bridge::check(kicp_map_add_points(handle_, kicp_bridge::xyz(points), points.size()), "VoxelHashMap::AddPoints");

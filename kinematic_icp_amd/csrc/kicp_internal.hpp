@@ -111,6 +111,7 @@ struct DeviceMirror {
     uint32_t *d_cnt = nullptr, *d_seg_start = nullptr, *d_free_list = nullptr;
     DevMapCounters *d_ctr = nullptr;
     size_t aux_slots = 0, free_cap = 0;
+    DevMapCounters *h_ctr = nullptr;  // pinned landing area of the counters (an update whose end the caller collects later)
     double *d_world = nullptr;
     uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
     size_t upd_cap = 0;
@@ -134,6 +135,14 @@ struct kicp_map {
     // a voxel coordinate beyond +-2^20 was seen: the packed keys of the device-side maintenance cannot hold it, so this map's
     // updates stay on the host from now on (until Clear); registration and queries on the device are unaffected
     bool host_updates_only = false;
+    // kicp_map_update_pose_device_begin: the update's kernels and the copy of its counters are queued, nothing has been waited for;
+    // kicp_map_update_finish (or any other call on the map) collects it.  The points stay borrowed until then (host fallback).
+    bool pending_update = false;
+    const double *pending_points = nullptr;
+    size_t pending_n = 0;
+    kicp::Pose pending_pose{};
+    double pending_origin[3] = {0.0, 0.0, 0.0};
+    bool pending_has_origin = false;
     // preferred device for bulk host-side insertions (kicp_map_set_device; -1 = none: host insertion) and their staging
     int bulk_device = -1;
     double *d_bulk = nullptr;
@@ -146,5 +155,6 @@ namespace host {
 // make the HBM mirror on `device` current / bring the host copy up to date after device-side updates (kicp_map.hip)
 int map_sync(kicp_map *map, int device, hipStream_t stream);
 int ensure_host_current(kicp_map *map);
+int map_finish_pending(kicp_map *map);  // collect an update begun with kicp_map_update_pose_device_begin (no-op without one)
 }  // namespace host
 }  // namespace kicp

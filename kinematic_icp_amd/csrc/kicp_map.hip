@@ -20,6 +20,7 @@ void free_mirror(DeviceMirror &mr) {
         hipFree(mr.d_keys64), hipFree(mr.d_cnt), hipFree(mr.d_seg_start), hipFree(mr.d_free_list), hipFree(mr.d_ctr);
         hipFree(mr.d_world), hipFree(mr.d_slot_of), hipFree(mr.d_order), hipFree(mr.d_touched);
         hipFree(mr.d_pc), hipFree(mr.d_pc_blocks);
+        if (mr.h_ctr) hipHostFree(mr.h_ctr);
         mr.stage.release();
     }
     mr = DeviceMirror{};
@@ -93,6 +94,7 @@ namespace kicp {
 namespace host {
 
 int map_sync(kicp_map *map, int device, hipStream_t stream) {
+    if (int rc = map_finish_pending(map)) return rc;
     DeviceMirror &mr = map->mirror;
     HostMap &h = map->host;
     if (map->device_ahead) {
@@ -168,6 +170,7 @@ int map_sync(kicp_map *map, int device, hipStream_t stream) {
 
 // bring the host copy up to date after device-side updates: same layouts, so this is a plain download
 int ensure_host_current(kicp_map *map) {
+    if (int rc = map_finish_pending(map)) return rc;
     if (!map->device_ahead) return KICP_OK;
     TraceScope trace_scope_("  (host copy refreshed from HBM)");
     DeviceMirror &mr = map->mirror;
@@ -277,7 +280,8 @@ int device_rehash(kicp_map *map, size_t extra_entries) {
 // VoxelHashMap::Update(points, pose) = transform + AddPoints + RemovePointsFarFromLocation(pose.translation) with the points
 // already in HBM.  Runs on the device, table growth and pool growth included; only degenerate calls (no points) take the
 // host path.  `remove_origin` == nullptr: AddPoints only (no pruning); otherwise the origin of the pruning step.
-int map_update_device(kicp_map *map, int device, const double *d_points, size_t n, const Pose &pose, const double *remove_origin) {
+int map_update_device(kicp_map *map, int device, const double *d_points, size_t n, const Pose &pose, const double *remove_origin, bool defer = false) {
+    if (int rc = map_finish_pending(map)) return rc;
     DeviceMirror &mr = map->mirror;
     map->last_update_on_device = 0;
     auto host_fallback = [&]() -> int {
@@ -343,6 +347,18 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
         enqueue_apply(n);
         HIP_TRY(hipGetLastError());
+        if (defer) {
+            // the caller collects the end of this update later (kicp_map_update_finish, or whatever it calls on the map next):
+            // the counters land in pinned memory, nothing is waited for here
+            if (!mr.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&mr.h_ctr), sizeof(DevMapCounters), hipHostMallocDefault));
+            HIP_TRY(hipMemcpyAsync(mr.h_ctr, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+            map->device_ahead = true;
+            map->pending_update = true, map->pending_points = d_points, map->pending_n = n, map->pending_pose = pose;
+            map->pending_has_origin = remove_origin != nullptr;
+            if (remove_origin) map->pending_origin[0] = remove_origin[0], map->pending_origin[1] = remove_origin[1], map->pending_origin[2] = remove_origin[2];
+            map->last_update_on_device = 1;  // (corrected by the finish step should the host have to take the update over)
+            return KICP_OK;
+        }
         HIP_TRY(hipMemcpyAsync(&c, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         map->device_ahead = true;
@@ -399,6 +415,30 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     return KICP_OK;
 }
 
+}  // namespace
+namespace kicp {
+namespace host {
+// The end of an update begun with defer = true: wait for its kernels, take the counters over, and - should the claim step have met
+// a voxel the packed keys cannot express - let the host map redo the update from the (still borrowed) points.
+int map_finish_pending(kicp_map *map) {
+    if (!map->pending_update) return KICP_OK;
+    map->pending_update = false;
+    DeviceMirror &mr = map->mirror;
+    if (int rc = set_device(mr.device)) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    const DevMapCounters c = *mr.h_ctr;
+    map->dev = c;
+    if (c.error == 3) return fail(KICP_ERR_CAPACITY, "device-side map update: voxel table full");
+    if (c.error == 1) {
+        map->host_updates_only = true;
+        return map_update_device(map, mr.device, map->pending_points, map->pending_n, map->pending_pose, map->pending_has_origin ? map->pending_origin : nullptr);
+    }
+    if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
+    return KICP_OK;
+}
+}  // namespace host
+}  // namespace kicp
+namespace {
 // Host-side AddPoints / Update calls with many points go through the device path when the map has a preferred device
 // (kicp_map_set_device): the points are staged into HBM and inserted there - the same map as the host insertion builds
 // (tests/test_gpu_mapdev.py), an order of magnitude faster (the host table's 128-byte slots and 27 neighbour records per
@@ -433,6 +473,7 @@ int kicp_map_create(double voxel_size, double max_distance, unsigned int max_poi
 }
 void kicp_map_destroy(kicp_map *map) {
     if (!map) return;
+    (void)map_finish_pending(map);
     if (map->d_bulk) {
         hipSetDevice(map->bulk_device >= 0 ? map->bulk_device : 0);
         hipFree(map->d_bulk);
@@ -467,6 +508,7 @@ int kicp_map_set_device(kicp_map *map, int device) {
 int kicp_map_clear(kicp_map *map) {
     KICP_TRACE_CALL();
     if (!map) return fail(KICP_ERR_ARG, "null map");
+    (void)map_finish_pending(map);  // (its kernels must have left the table before anything else is queued on it)
     map->device_ahead = false;  // whatever the device holds is obsolete now
     map->host_updates_only = false;
     map->host.Clear();
@@ -474,6 +516,7 @@ int kicp_map_clear(kicp_map *map) {
 }
 int kicp_map_empty(const kicp_map *map) {
     if (!map) return 1;
+    (void)map_finish_pending(const_cast<kicp_map *>(map));
     return (map->device_ahead ? map->dev.n_voxels == 0 : map->host.Empty()) ? 1 : 0;
 }
 int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n) {
@@ -515,13 +558,35 @@ int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_point
     const double origin[3] = {pose.tx, pose.ty, pose.tz};
     return map_update_device(map, device, d_points_xyz, n, pose, origin);
 }
-int kicp_map_last_update_on_device(const kicp_map *map) { return map ? map->last_update_on_device : 0; }
+// The same update in two halves: _begin queues its kernels (and the copy of its counters) and returns without waiting - the caller
+// goes on with host-side work that does not touch the map (the pipeline collects the frame's returned clouds) -, kicp_map_update_finish
+// waits and takes the result over.  `d_points_xyz` stays borrowed until then.  Frame-sized updates into a table with room for the
+// worst case take this route; anything else (table growth, bulk insertions, a map that lives on the host) runs to completion inside
+// _begin.  Any other call on the map finishes a pending update first.
+int kicp_map_update_pose_device_begin(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]) {
+    KICP_TRACE_CALL();
+    if (!map || (!d_points_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
+    const Pose pose = pose_from(pose_qt);
+    const double origin[3] = {pose.tx, pose.ty, pose.tz};
+    return map_update_device(map, device, d_points_xyz, n, pose, origin, true);
+}
+int kicp_map_update_finish(kicp_map *map) {
+    KICP_TRACE_CALL();
+    if (!map) return fail(KICP_ERR_ARG, "null map");
+    return map_finish_pending(map);
+}
+int kicp_map_last_update_on_device(const kicp_map *map) {
+    if (map) (void)map_finish_pending(const_cast<kicp_map *>(map));
+    return map ? map->last_update_on_device : 0;
+}
 size_t kicp_map_num_points(const kicp_map *map) {
     if (!map) return 0;
+    (void)map_finish_pending(const_cast<kicp_map *>(map));
     return map->device_ahead ? static_cast<size_t>(map->dev.n_points) : map->host.num_points();
 }
 size_t kicp_map_num_voxels(const kicp_map *map) {
     if (!map) return 0;
+    (void)map_finish_pending(const_cast<kicp_map *>(map));
     return map->device_ahead ? map->dev.n_voxels : map->host.num_voxels();
 }
 size_t kicp_map_pointcloud(const kicp_map *cmap, double *out_xyz, size_t cap_points) {

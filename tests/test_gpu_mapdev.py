@@ -181,3 +181,53 @@ def test_both_apply_kernels_build_the_reference_map():
     nn_o, d_o = o.GetClosestNeighbor(q)
     assert np.array_equal(nn_g, nn_o) and np.array_equal(d_g, d_o)   # the tie rule sees the buckets' internal order
     assert np.array_equal(sort_rows(g.Pointcloud()), sort_rows(o.Pointcloud())) and g.check() == 0
+
+
+def test_update_in_two_halves_equals_the_one_call_update():
+    """kicp_map_update_pose_device_begin / kicp_map_update_finish (what the drop-in RegisterFrame uses to overlap the map update with
+    collecting its results): the same map as the one-call update and as the sequential reference, whether the caller finishes it
+    explicitly, forgets to (the next call on the map collects it), registers against the map or clears it in between; a far point
+    met by a deferred update still ends in the host map's result."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    scene = syn.make_scene(rng, half=30.0, height=5.0, n_boxes=14, box_xy=(2.0, 6.0), box_z=(1.5, 4.0), keep_clear=3.0)
+    dirs = syn.beam_directions(16, 512, (-22.0, 6.0))
+    vs, max_range = 1.0, 25.0
+    two, one, omap = K.VoxelHashMap(vs, max_range, 20), K.VoxelHashMap(vs, max_range, 20), Checkers(vs, max_range, 20)
+    pose = syn.planar_pose(-18.0, -15.0, 0.6)
+    reg, oreg = K.KinematicRegistration(), okicp.KinematicRegistration()
+    deferred = 0
+    for k in range(14):
+        true_next = syn.pose_mul(pose, syn.planar_pose(1.8, 0.0, np.deg2rad(3.0)))
+        scan = syn.make_scan(scene, true_next, dirs, 1.0, rng)
+        scan = first_seen_downsample(scan[np.linalg.norm(scan, axis=1) < max_range], 0.5 * vs)
+        frame = K.DeviceFrame(scan)
+        two.UpdateDeviceBegin(frame, true_next)
+        if k % 3 == 0:
+            deferred += int(two.UpdateFinish())
+        elif k % 3 == 1 and k > 1:  # a registration right behind the begin: it must see the finished update
+            rel = syn.planar_pose(0.03, 0.0, np.deg2rad(0.3))
+            a = reg.ComputeRobotMotion(scan, two, true_next, rel, 3 * vs / np.sqrt(20))
+        one.UpdateDevice(frame, true_next)
+        omap.Update(scan, true_next)
+        if k % 3 == 1 and k > 1:
+            b = oreg.ComputeRobotMotion(scan, omap.o, true_next, rel, 3 * vs / np.sqrt(20))
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+        assert (two.num_points(), two.num_voxels()) == (one.num_points(), one.num_voxels()) == (omap.num_points(), omap.num_voxels()), "frame %d" % k
+        pose = true_next
+    np.testing.assert_array_equal(sort_rows(two.Pointcloud()), sort_rows(omap.Pointcloud()))
+    assert two.check() == 0 and deferred >= 3
+    # cleared while an update is pending: the map is empty afterwards, and usable
+    two.UpdateDeviceBegin(frame, true_next)
+    two.Clear()
+    assert two.Empty() and two.num_points() == 0
+    two.UpdateDeviceBegin(frame, true_next)
+    assert two.UpdateFinish() and two.num_points() > 0
+    # a point beyond the packed keys' range in a deferred update: the host map takes it over at the finish
+    far = np.concatenate([scan[:200], [[2.0e6, 0.0, 0.0]]])
+    h, ho = K.VoxelHashMap(vs, 1e7, 20), okicp.VoxelHashMap(vs, 1e7, 20)
+    h.UpdateDevice(K.DeviceFrame(scan), okicp.IDENTITY), ho.Update(scan, okicp.IDENTITY)
+    ff = K.DeviceFrame(far)
+    h.UpdateDeviceBegin(ff, okicp.IDENTITY)
+    assert not h.UpdateFinish()
+    ho.Update(far, okicp.IDENTITY)
+    assert (h.num_points(), h.num_voxels()) == (ho.num_points(), ho.num_voxels())
