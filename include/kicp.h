@@ -162,7 +162,7 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
  *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
  *                  the last call that a resident launch of the generic kernel served
- *   "batch_resident" 1 (default): kicp_register_device_batch keeps that resident kernel on the device ACROSS the scans of a batch (the
+ *   "batch_resident" 1 (default): kicp_register_device_batch - for batches of eight scans and more - keeps that resident kernel on the device ACROSS the scans of a batch (the
  *                  scans are still registered strictly one after the other; what starts a scan's first pass is a polled command
  *                  instead of a dispatch; the batch's scan table travels with the launch); 0: every scan of a batch is a call of its
  *                  own.  "batch_resident_passes" (read only): passes served that way so far

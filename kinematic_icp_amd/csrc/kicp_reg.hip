@@ -168,6 +168,7 @@ struct kicp_reg {
     int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
+    ScanRef *scans_bar = nullptr; // the same memory as the CPU writes it through the PCIe BAR (nullptr: d_scans is plain device memory)
     size_t scans_cap = 0;
     unsigned long long batch_resident_passes = 0;  // passes served that way so far (get-only "batch_resident_passes")
     int last_resident_passes = 0; // passes of the last call that a resident launch of the GENERIC kernel served (get-only "resident_passes")
@@ -1102,7 +1103,10 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
                        const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
     *done = 0;
     const int max_it = r->cfg.max_num_iterations;
-    if (!r->batch_resident || !r->resident_generic || count < 2 || max_it <= 0 || kicp_map_empty(map)) return 1;
+    // (a batch call in this mode costs ~8 us of its own - the table, the kernel's leaving, the queue drained before the next call -
+    //  against ~2.2 us saved per scan: from eight scans on it pays; measured in-process, cfg2 and cfg4, batches of 2 / 4 / 16 / 256)
+    constexpr size_t kBatchResidentMinScans = 8;
+    if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
           r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0))
         return 1;
@@ -1130,19 +1134,28 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     if (int rc = ensure_cmd(r)) return rc;
     if (!wave)
         if (int rc = clear_stale_tickets(r)) return rc;
+    // The batch's scan table.  Where the CPU can write HBM through the PCIe BAR (the kernarg ring and the command copies live there
+    // already) the table is written in place - a microsecond, no copy, no synchronisation; the launch's acquire makes it visible like
+    // the kernel arguments.  Otherwise it is copied through the stream (and waited for: ~15 us per batch call).
     if (count > r->scans_cap) {
         if (int rc = aql_quiesce(r)) return rc;
-        if (r->d_scans) HIP_TRY(hipFree(r->d_scans));
-        r->d_scans = nullptr, r->scans_cap = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_scans), (count + count / 2 + 64) * sizeof(ScanRef)));
-        r->scans_cap = count + count / 2 + 64;
+        if (r->scans_bar) r->aql.free_bar(r->scans_bar);
+        else if (r->d_scans) HIP_TRY(hipFree(r->d_scans));
+        r->d_scans = nullptr, r->scans_bar = nullptr, r->scans_cap = 0;
+        const size_t cap = count + count / 2 + 64;
+        if (aql_up(r)) r->scans_bar = static_cast<ScanRef *>(r->aql.alloc_bar(cap * sizeof(ScanRef)));
+        if (r->scans_bar) r->d_scans = r->scans_bar;
+        else HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_scans), cap * sizeof(ScanRef)));
+        r->scans_cap = cap;
     }
-    {
-        // (the previous batch's kernel has left: the host had its last rows and sent STOP; a launch that is still draining is
-        //  ordered before this copy's consumer by the queue / stream)
+    // (the previous batch's kernel has left: the host had its last rows and sent STOP before it returned)
+    if (int rc = aql_quiesce(r)) return rc;
+    if (r->scans_bar) {
+        for (size_t k = 0; k < count; ++k) r->scans_bar[k] = ScanRef{d_frames[k], n[k]};
+        _mm_sfence();
+    } else {
         std::vector<ScanRef> table(count);
         for (size_t k = 0; k < count; ++k) table[k] = ScanRef{d_frames[k], n[k]};
-        if (int rc = aql_quiesce(r)) return rc;
         r->stream_dirty = true;
         HIP_TRY(hipMemcpyAsync(r->d_scans, table.data(), count * sizeof(ScanRef), hipMemcpyHostToDevice, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
@@ -1336,7 +1349,8 @@ void kicp_reg_destroy(kicp_reg *reg) {
     if (reg->cmd) hipHostFree(reg->cmd);
     if (reg->bar_frame) reg->aql.free_bar(reg->bar_frame);
     if (reg->d_trace) hipFree(reg->d_trace);
-    if (reg->d_scans) hipFree(reg->d_scans);
+    if (reg->scans_bar) reg->aql.free_bar(reg->scans_bar);
+    else if (reg->d_scans) hipFree(reg->d_scans);
     if (reg->cmd_bar) reg->aql.free_bar(reg->cmd_bar);
     else if (reg->d_cmd_copies) hipFree(reg->d_cmd_copies);
     reg->stage.release();

@@ -73,9 +73,9 @@ def _check(reg, src, maps, last, rel, tau, cfg, how="close", via="host"):
         a = reg.ComputeRobotMotion(src.astype(np.float32), g, last, rel, tau)
         src = src.astype(np.float32).astype(np.float64)
     elif via == "batch":
-        batch = reg.prepare_batch([K.DeviceFrame(src, device=0)] * 3, [last] * 3, [rel] * 3)
+        batch = reg.prepare_batch([K.DeviceFrame(src, device=0)] * 9, [last] * 9, [rel] * 9)  # (eight and more: the kernel stays across the scans)
         poses = reg.ComputeRobotMotionBatch(batch, g, tau)
-        assert np.array_equal(poses[0], poses[1], equal_nan=True) and np.array_equal(poses[0], poses[2], equal_nan=True)
+        assert all(np.array_equal(poses[0], poses[k], equal_nan=True) for k in range(1, 9))
         a = poses[0].copy()
     else:
         a = reg.ComputeRobotMotion(src, g, last, rel, tau)
@@ -93,7 +93,7 @@ def _check(reg, src, maps, last, rel, tau, cfg, how="close", via="host"):
             # give beta = 1 / DBL_MIN there and ~1e32 in fp64 - either way a displacement weight beyond anything JTJ / N (~1) can answer
             np.testing.assert_allclose(1.0 / reg.last_stats.beta, 1.0 / oreg.last_stats.beta, rtol=1e-9, atol=2.0 ** -40)
     else:
-        assert [int(x) for x in batch.iterations] == [oreg.last_stats.iterations] * 3
+        assert [int(x) for x in batch.iterations] == [oreg.last_stats.iterations] * 9
     if r is not None:
         c = rkicp.KinematicRegistration(**cfg).ComputeRobotMotion(src, r, last, rel, tau)
         _same(a, c, how)
@@ -230,12 +230,12 @@ def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop():
     loop takes over) - all bit-equal to one call per scan."""
     maps, src = _big_world(n_map=60000, n_src=20000, seed=21)
     g = maps[0]
-    shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03]
-    sizes = [20000, 12000, 9000, 20000, 15000, 10000]
+    shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03, 0.01, -0.02, 0.04]  # (nine scans: the mode is for batches of eight and more)
+    sizes = [20000, 12000, 9000, 20000, 15000, 10000, 16000, 9500, 20000]
     frames = [src[:k] - np.array([d, 0.0, 0.0]) for k, d in zip(sizes, shifts)]
     frames[4] = np.full((9000, 3), 400.0)  # no correspondence at all
-    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(6)]
-    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(6)]
+    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(9)]
+    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(9)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
     plain = _reg({"batch_resident": 0}, **CFG)
     b0 = plain.prepare_batch(dev, lasts, rels)
@@ -267,11 +267,11 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     without correspondences, a give-up half-way; a batch that mixes small and large scans takes the plain loop"""
     maps, src = _big_world(n_map=60000, n_src=20000, seed=23)
     g = maps[0]
-    sizes, shifts = [3000, 1080, 4000, 700, 2048], [0.02, -0.04, 0.0, 0.06, 0.03]
+    sizes, shifts = [3000, 1080, 4000, 700, 2048, 512, 3500, 1900, 4096], [0.02, -0.04, 0.0, 0.06, 0.03, 0.01, -0.03, 0.05, 0.02]
     frames = [src[i * 100:i * 100 + k] - np.array([d, 0.0, 0.0]) for i, (k, d) in enumerate(zip(sizes, shifts))]
     frames[3] = np.full((700, 3), -300.0)
-    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(5)]
-    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(5)]
+    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(9)]
+    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(9)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
     plain = _reg({"batch_resident": 0}, **CFG)
     b0 = plain.prepare_batch(dev, lasts, rels)
@@ -282,7 +282,7 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
         got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
         assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
     assert reg.get_option("batch_resident_passes") >= 3 * (sum(b0.iterations) - 10) and reg.get_option("small_active") == 2.0
-    for k in (0, 1, 2, 4):
+    for k in (0, 1, 2, 4, 8):
         o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
         np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
     reg.set_option("small_timeout_us", 300.0), reg.set_option("debug_stall_us", 3000.0)
@@ -291,10 +291,10 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     assert np.array_equal(got, want, equal_nan=True) and reg.get_option("small_relaunches") == before + 1
     reg.set_option("small_timeout_us", 20000.0)
     # small and large scans in one batch: no kernel serves both - the plain loop runs, same results
-    mixed = [dev[0], K.DeviceFrame(src[:12000] - np.array([0.02, 0, 0]), device=0), dev[2]]
-    bm0, bm1 = plain.prepare_batch(mixed, lasts[:3], rels[:3]), reg.prepare_batch(mixed, lasts[:3], rels[:3])
+    mixed = [dev[0], K.DeviceFrame(src[:12000] - np.array([0.02, 0, 0]), device=0)] + dev[2:]
+    bm0, bm1 = plain.prepare_batch(mixed, lasts, rels), reg.prepare_batch(mixed, lasts, rels)
     served = reg.get_option("batch_resident_passes")
-    assert np.array_equal(reg.ComputeRobotMotionBatch(bm1, g, 0.5), plain.ComputeRobotMotionBatch(bm0, g, 0.5))
+    assert np.array_equal(reg.ComputeRobotMotionBatch(bm1, g, 0.5), plain.ComputeRobotMotionBatch(bm0, g, 0.5), equal_nan=True)
     assert reg.get_option("batch_resident_passes") == served
 
 
