@@ -569,15 +569,21 @@ class PreSteps:
         if frame is None:
             n_in = lib().kicp_pre_ingested_count(self._h)
             out = np.empty((n_in, 3), dtype=np.float64) if want_frame else None
-            self.last_status = _check(lib().kicp_pre_frame_ingested(self._h, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
-                                                                    out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts))
+            rc = lib().kicp_pre_frame_ingested(self._h, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
+                                               out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts)
         else:
             a, p = _d(frame)
             t, tp = _d(timestamps if timestamps is not None else np.zeros(0))
             n_in = a.size // 3
             out = np.empty((n_in, 3), dtype=np.float64) if want_frame else None
-            self.last_status = _check(lib().kicp_pre_frame(self._h, p, n_in, tp, t.size, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
-                                                           out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts))
+            rc = lib().kicp_pre_frame(self._h, p, n_in, tp, t.size, r, e, max_range, min_range, int(deskew), voxel_a, voxel_b,
+                                      out.ctypes.data_as(_dp) if want_frame and n_in else None, n_in, counts)
+        if rc < 0:
+            message = lib().kicp_last_error().decode(errors="replace")
+            if want_frame and n_in:  # the backend's helper thread may hold a pointer into `out`: collect (and drop) the download before the array can go
+                lib().kicp_pre_download_finish(self._h, 0, None, 0, None)
+            raise KicpError(rc, message)
+        self.last_status = rc
         if want_frame and n_in:
             n = C.c_size_t()
             _check(lib().kicp_pre_download_finish(self._h, 0, out.ctypes.data_as(_dp), n_in, C.byref(n)))
