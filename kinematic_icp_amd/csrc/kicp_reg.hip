@@ -166,6 +166,7 @@ struct kicp_reg {
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
     int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
+    int batch_depth = 2;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
     ScanRef *scans_bar = nullptr; // the same memory as the CPU writes it through the PCIe BAR (nullptr: d_scans is plain device memory)
@@ -613,20 +614,22 @@ int next_tag_range(kicp_reg *r, uint32_t count, uint32_t *first) {
     r->tag += count - 1;
     return KICP_OK;
 }
-// the command that starts pass `seq - seq_base` of the resident kernel: seven pose words, then the control word (release)
-void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &T) {
+// the command that starts pass `seq - seq_base` of the resident kernel: seven pose words, then the control word (release); it
+// travels in line seq & 1 (kicp_small.hpp).  `scan`: the scan of the launch's table the pass belongs to (batches)
+void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &T, uint32_t scan = 0u) {
     unsigned long long w[kCmdWords];
     const double v[7] = {T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz};
     std::memcpy(w, v, 7 * sizeof(double));
-    w[7] = ((seq << 8) | op) ^ cmd_fold(w);
+    w[7] = (((seq & 0xFFFFFFFFull) << 32) | (static_cast<unsigned long long>(scan) << 8) | op) ^ cmd_fold(w);
+    const size_t slot = static_cast<size_t>(seq & 1ull) * kCmdWords;
     if (r->small_cmd == 1 && r->cmd_bar) {  // straight into the copies the workgroups poll (write-combined BAR stores)
         for (int c = 0; c < kCmdReplicas; ++c)
-            for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[static_cast<size_t>(c) * kCmdStrideWords + i] = w[i];
+            for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[static_cast<size_t>(c) * kCmdStrideWords + slot + i] = w[i];
         _mm_sfence();
         return;
     }
-    for (int i = 0; i < 7; ++i) __atomic_store_n(r->cmd + i, w[i], __ATOMIC_RELAXED);
-    __atomic_store_n(r->cmd + 7, w[7], __ATOMIC_RELEASE);
+    for (int i = 0; i < 7; ++i) __atomic_store_n(r->cmd + slot + i, w[i], __ATOMIC_RELAXED);
+    __atomic_store_n(r->cmd + slot + 7, w[7], __ATOMIC_RELEASE);
 }
 int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
     const int b = pl.block, g = pl.g;
@@ -1106,7 +1109,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     // (a batch call in this mode costs ~8 us of its own - the table, the kernel's leaving, the queue drained before the next call -
     //  against ~2.2 us saved per scan: from eight scans on it pays; measured in-process, cfg2 and cfg4, batches of 2 / 4 / 16 / 256)
     constexpr size_t kBatchResidentMinScans = 8;
-    if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || max_it <= 0 || kicp_map_empty(map)) return 1;
+    if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || count > kCmdMaxScans || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
           r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0))
         return 1;
@@ -1171,30 +1174,76 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
     sp.scans = r->d_scans;
-    uint32_t pass = 0, budget = 0;  // pass index inside the current launch; passes that launch may serve (0: none in flight)
-    auto stop_kernel = [&](const Pose &T) {
-        if (budget && pass < budget) send_command(r, sp.seq_base + pass, kCmdStop, T);
-        budget = 0;
+    // Two scans of the batch are in flight at a time (option "batch_depth", 1: one).  The scans of a batch do not depend on each
+    // other - every one starts from its own pose, the map does not change -, so while the host adds, solves and answers the rows of
+    // pass k (a round trip of ~3 us over PCIe), the workgroups are already searching pass k + 1, which belongs to the OTHER scan; and
+    // a workgroup that is done with its part of a pass finds the next command waiting instead of waiting for the slowest workgroup
+    // and the host.  Passes are numbered in the order their commands go out; the command of pass k + 2 goes out when every row of
+    // pass k is in (two command lines, two row buffers, two sets of tickets, all taken in turn: kicp_small.hpp, finish_pass).
+    struct InFlight {
+        HostLoop loop;
+        kicp_stats st;
+        size_t k = 0;          // the scan
+        bool active = false;   // holds a scan that is not finished
+        bool waiting = false;  // a pass of it is out
+    };
+    const int depth = r->batch_depth >= 2 ? 2 : 1;
+    InFlight slots[2];
+    int order[2] = {0, 0}, out = 0;   // slots whose passes are out, oldest first
+    uint32_t order_pass[2] = {0u, 0u};
+    uint32_t pass = 0, budget = 0;  // next pass index inside the current launch; passes that launch may serve (0: no kernel on the device)
+    size_t next_scan = 0, front = 0;  // next scan to start; scans [0, front) are complete
+    std::vector<unsigned char> complete(count, 0);
+    bool stop_sent = false;
+    auto stop_kernel = [&]() {
+        const Pose ident{0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
+        if (budget && pass < budget && !stop_sent) send_command(r, sp.seq_base + pass, kCmdStop, ident);
+        budget = 0, stop_sent = true;
+    };
+    auto leave = [&](int rc) {  // hand back what is complete from the front; the caller's plain loop takes the rest
+        stop_kernel();
+        while (front < count && complete[front]) ++front;
+        *done = front;
+        return rc;
     };
     r->last_small = wave ? 2 : 0, r->last_resident_passes = 0;
-    for (size_t k = 0; k < count; ++k) {
-        HostLoop loop;
-        loop.T = pose_mul(pose_from(last_poses_qt + 7 * k), pose_from(rel_odoms_qt + 7 * k));  // Registration.cpp:156
-        kicp_stats st;
-        std::memset(&st, 0, sizeof st);
-        bool finished = false, first_pass = true;
-        while (!finished) {
-            if (budget == 0 || pass >= budget) {  // no kernel on the device (any more): launch, starting on this scan with this pose
-                // (a launch that has served all its passes has left by itself)
-                // (tags are reserved per launch: no more than the rest of the batch can use)
-                const uint32_t cnt = static_cast<uint32_t>(std::min<unsigned long long>(kBatchMaxPasses, static_cast<unsigned long long>(count - k) * static_cast<unsigned long long>(max_it)));
-                if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
-                pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
-                sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(k);
+    for (;;) {
+        // ---- send out what can go out ------------------------------------------------------------------------------------
+        while (out < depth) {
+            int s = -1;
+            bool starts = false;
+            for (int j = 0; j < depth && s < 0; ++j)
+                if (slots[j].active && !slots[j].waiting) s = j;
+            if (s < 0 && next_scan < count) {
+                for (int j = 0; j < depth && s < 0; ++j)
+                    if (!slots[j].active) s = j;
+                if (s >= 0) {
+                    InFlight &f = slots[s];
+                    f = InFlight{};
+                    f.k = next_scan++, f.active = true, starts = true;
+                    f.loop.T = pose_mul(pose_from(last_poses_qt + 7 * f.k), pose_from(rel_odoms_qt + 7 * f.k));  // Registration.cpp:156
+                    std::memset(&f.st, 0, sizeof f.st);
+                }
+            }
+            if (s < 0) break;  // nothing to send
+            InFlight &f = slots[s];
+            if (budget == 0 || pass >= budget) {  // no kernel on the device (any more: a launch that has served all its passes has left)
+                if (out > 0) {  // (its last passes are still being collected)
+                    if (starts) f.active = false, --next_scan;
+                    break;
+                }
+                // tags are reserved per launch: no more than the rest of the batch can use
+                unsigned long long rest = static_cast<unsigned long long>(count - next_scan) * static_cast<unsigned long long>(max_it);
+                for (int j = 0; j < depth; ++j)
+                    if (slots[j].active) rest += static_cast<unsigned long long>(std::max(1, max_it - slots[j].loop.iter));
+                const uint32_t cnt = static_cast<uint32_t>(std::min<unsigned long long>(kBatchMaxPasses, rest));
+                if (int rc = next_tag_range(r, cnt, &sp.tag0)) return leave(rc);
+                pp.sol.pose0 = f.loop.T, pp.sol.pass = f.loop.iter;
+                sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(f.k);
                 r->cmd_seq += cnt;
                 sp.trace = r->d_trace;
-                if (int rc = launch_small(r, sp, pl)) return rc;
-                pass = 0, budget = cnt;
+                if (int rc = launch_small(r, sp, pl)) return leave(rc);
+                pass = 0, budget = cnt, stop_sent = false;
             } else {
                 if (r->debug_stall_us > 0.0) {  // tests: be late once (the kernel gives up, the plain loop takes over)
                     const auto t0 = std::chrono::steady_clock::now();
@@ -1202,40 +1251,37 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
                     }
                     r->debug_stall_us = 0.0;
                 }
-                send_command(r, sp.seq_base + pass, first_pass ? kCmdNewScan : kCmdContinue, loop.T);
+                send_command(r, sp.seq_base + pass, starts ? kCmdNewScan : kCmdContinue, f.loop.T, static_cast<uint32_t>(f.k));
             }
-            first_pass = false;
-            long long words[kReduceWords];
-            bool gave_up = false;
-            if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + pass, pass & 1u, words, &gave_up)
-                              : wait_rows(r, groups, sp.tag0 + pass, words, (pass & 1u) * groups)) {
-                ++pass;
-                stop_kernel(loop.T);
-                return rc;
-            }
-            if (!wave) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
-            ++pass;
-            if (gave_up) {  // (part of) the kernel has left: this scan and the rest go through the plain loop
-                ++r->small_relaunches;
-                stop_kernel(loop.T);
-                *done = k;
-                return KICP_OK;
-            }
-            ++r->batch_resident_passes;
-            finished = loop.step(r, words, &st);
+            f.waiting = true;
+            order[out] = s, order_pass[out] = pass, ++out, ++pass;
         }
-        pose_to(loop.T, out_poses_qt + 7 * k);
-        if (out_iterations) out_iterations[k] = loop.iter;
-        r->small_prev_iters = loop.iter;
-        *done = k + 1;
-        if (loop.nan_flag == 2) {
-            stop_kernel(loop.T);
-            return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
+        if (out == 0) break;  // every scan is complete
+        // ---- the rows of the oldest pass that is out ---------------------------------------------------------------------
+        InFlight &f = slots[order[0]];
+        const uint32_t at = order_pass[0];
+        order[0] = order[1], order_pass[0] = order_pass[1], --out;
+        f.waiting = false;
+        long long words[kReduceWords];
+        bool gave_up = false;
+        if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + at, at & 1u, words, &gave_up) : wait_rows(r, groups, sp.tag0 + at, words, (at & 1u) * groups))
+            return leave(rc);
+        if (!wave) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
+        if (gave_up) {  // (part of) the kernel has left: the scans in hand and the rest go through the plain loop
+            ++r->small_relaunches;
+            return leave(KICP_OK);
         }
-        if (loop.nan_flag) *worst = std::max(*worst, static_cast<int>(KICP_WARN_NO_CORRESPONDENCES));
+        ++r->batch_resident_passes;
+        if (!f.loop.step(r, words, &f.st)) continue;
+        pose_to(f.loop.T, out_poses_qt + 7 * f.k);
+        if (out_iterations) out_iterations[f.k] = f.loop.iter;
+        r->small_prev_iters = f.loop.iter;
+        complete[f.k] = 1, f.active = false;
+        if (f.loop.nan_flag == 2) return leave(fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)"));
+        if (f.loop.nan_flag) *worst = std::max(*worst, static_cast<int>(KICP_WARN_NO_CORRESPONDENCES));
     }
-    Pose ident{0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
-    stop_kernel(ident);
+    stop_kernel();
+    *done = count;
     return KICP_OK;
 }
 
@@ -1392,6 +1438,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
+    else if (k == "batch_depth") reg->batch_depth = value >= 2.0 ? 2 : 1;
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
@@ -1437,6 +1484,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "resident_generic") return reg->resident_generic;
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
+    if (k == "batch_depth") return reg->batch_depth;
     if (k == "batch_resident_passes") return static_cast<double>(reg->batch_resident_passes);
     if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
@@ -1637,7 +1685,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth;
     *out = c;
     return KICP_OK;
 }

@@ -13,8 +13,11 @@
 //     trip through a polled line costs ~3.5 us against ~7.5 us through a launch (profiles/r02a_micro_handoff.txt); the kernel
 //     occupies <= 16 of 256 CUs and never outlives the call: it leaves on STOP, after `max_passes` passes, or when no command
 //     arrives within `timeout_ticks` (it then marks the rows of the pass it gave up on, and the host launches afresh).
-// The command line is its own flag: seven pose words and one control word = (sequence << 8 | opcode) XOR a 64-bit fold of the
-// pose words, so a torn read (some words of the previous command) cannot pass for the command the kernel is waiting for.
+// The command line is its own flag: seven pose words and one control word = (sequence << 32 | scan << 8 | opcode) XOR a 64-bit
+// fold of the pose words, so a torn read (some words of the previous command) cannot pass for the command the kernel is waiting
+// for.  There are TWO lines, taken in turn (command `seq` travels in line seq & 1): the host may send the command that starts
+// pass k + 2 as soon as it holds every row of pass k - while workgroups are still busy with pass k + 1 (run_batch_resident keeps
+// two scans of a batch in flight that way).
 // Frame and map cannot change while the call is running, so the acquire of the launch (AQL packet / HIP launch) covers all
 // passes.
 #pragma once
@@ -27,9 +30,10 @@ constexpr int kSmallMaxGroups = 64;      // workgroups of one launch = rows the 
 constexpr int kSmallRowWords = 16;       // 14 sum words (two 48-bit halves per sum) + flag word + spare = two 64-byte lines
 constexpr uint32_t kSmallMaxPasses = 48; // passes one launch may serve (bounds the tags reserved per launch)
 constexpr int kCmdWords = 8;
-// kCmdNewScan (the generic kernel resident across the scans of a batch): like kCmdContinue, and the pass it starts is pass 0 of the
-// NEXT scan of the launch's scan table (SmallParams::scans)
+// kCmdNewScan (a kernel resident across the scans of a batch): like kCmdContinue, the pass it starts being pass 0 of a scan.  Both
+// carry the index (into the launch's scan table, SmallParams::scans) of the scan the pass belongs to: a batch's scans take turns.
 enum : uint32_t { kCmdContinue = 1u, kCmdStop = 2u, kCmdNewScan = 3u };
+constexpr unsigned long long kCmdMaxScans = 1ull << 24;  // scan indices a command can carry
 // one scan of a batch as the resident kernel sees it
 struct ScanRef {
     const double *src;   // device pointer, AoS xyz fp64
@@ -49,8 +53,8 @@ KICP_HD unsigned long long cmd_fold(const unsigned long long w[7]) {
 
 struct SmallParams {
     PassParams p;                   // (p.sol.mode is not used: the host always solves; p.partials / p.tickets unused)
-    const unsigned long long *cmd;  // device view of the host-mapped command line (kCmdWords words, 64-byte aligned)
-    unsigned long long *cmd_dev;    // kCmdReplicas copies of the command line in device memory (await_command)
+    const unsigned long long *cmd;  // device view of the host-mapped command lines (2 x kCmdWords words, 64-byte aligned)
+    unsigned long long *cmd_dev;    // kCmdReplicas copies of the two command lines in device memory (await_command)
     int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
     long long *trace;               // debugging aid (option "small_trace"): workgroup 0 stamps its passes here, 4 wall-clock words each
     unsigned long long *rows;       // device view of the host-mapped rows [2][gridDim.x][kSmallRowWords]: pass k writes buffer k & 1, so the
@@ -60,7 +64,7 @@ struct SmallParams {
     uint32_t max_passes;            // passes this launch may serve; 1 = leave after the first (no residency)
     long long timeout_ticks;        // 100 MHz wall-clock ticks a workgroup waits for a command before it gives up
     const ScanRef *scans;           // k_pass_resident serving a batch: the batch's scans (device memory, written before the launch);
-    uint32_t scan0, pad2_;          // the launch starts on scans[scan0], every kCmdNewScan moves on to the next.  nullptr: p.src / p.n
+    uint32_t scan0, pad2_;          // the launch starts on scans[scan0]; later passes: the scan their command names.  nullptr: p.src / p.n
 };
 
 // Between the passes of a resident kernel NOTHING but the pose, the pass counter and the lane id is worth a register: the
@@ -98,7 +102,8 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
         const unsigned long long want = sp.seq_base + pass + 1;
         const long long t0 = wall_clock64();
         const bool relay = sp.relay != 0 && blockIdx.x == 0;
-        const unsigned long long *line = relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdStrideWords;
+        const size_t slot = static_cast<size_t>(want & 1ull) * kCmdWords;  // (the two lines of a copy are neighbours)
+        const unsigned long long *line = (relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdStrideWords) + slot;
         unsigned long long w = 0, ctrl = 0;
         for (;;) {
             if (lane < kCmdWords)
@@ -108,7 +113,7 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
 #pragma unroll
             for (int k = 0; k < 7; ++k) pose[k] = __shfl(w, k, 64);
             ctrl = __shfl(w, 7, 64) ^ cmd_fold(pose);
-            if ((ctrl >> 8) == want && (ctrl & 0xFFull) >= kCmdContinue && (ctrl & 0xFFull) <= kCmdNewScan) break;
+            if ((ctrl >> 32) == (want & 0xFFFFFFFFull) && (ctrl & 0xFFull) >= kCmdContinue && (ctrl & 0xFFull) <= kCmdNewScan) break;
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
                 if (MARK_ROWS && lane < kSmallRowWords)
@@ -120,14 +125,16 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
         if (relay && ctrl != 0ull && lane < kCmdWords) {  // pass the command on: every word is self-validating, no ordering needed
 #pragma unroll
             for (int r = 0; r < kCmdReplicas; ++r)
-                __hip_atomic_store(sp.cmd_dev + static_cast<size_t>(r) * kCmdStrideWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sp.cmd_dev + static_cast<size_t>(r) * kCmdStrideWords + slot + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane < 7) s_cmd[lane] = w;
-        if (lane == 7) s_cmd[7] = ctrl & 0xFFull;
+        if (lane == 7) s_cmd[7] = ctrl & 0xFFFFFFFFull;  // scan << 8 | opcode
     }
     __syncthreads();
-    return static_cast<uint32_t>(s_cmd[7]);  // kCmdContinue / kCmdStop / kCmdNewScan; 0: no command in time
+    return static_cast<uint32_t>(s_cmd[7]) & 0xFFu;  // kCmdContinue / kCmdStop / kCmdNewScan; 0: no command in time
 }
+// the scan index the last command named (wave-uniform)
+__device__ __forceinline__ uint32_t command_scan(const unsigned long long *s_cmd) { return static_cast<uint32_t>(uniform_i(static_cast<int>(s_cmd[7] >> 8))); }
 // value of a double in lane l, wave-uniform
 __device__ __forceinline__ double uniform_lane_d(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -268,7 +275,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
         if (gave_up || pass + 1 >= sp.max_passes) return;
         const uint32_t op = await_command<false>(sp, fresh_tid(), pass, s_cmd);
         if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();  // next command seen
-        if (op == kCmdNewScan) scan = static_cast<uint32_t>(uniform_i(static_cast<int>(scan + 1u)));
         if (op != kCmdContinue && op != kCmdNewScan) {
             if (op == kCmdStop) return;
             gave_up = 1;
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
             if (fresh_tid() == 0 && sp.p.sol.rec) __hip_atomic_store(&sp.p.sol.rec->reserved[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             continue;
         }
+        scan = command_scan(s_cmd);
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
     __shared__ unsigned long long s_cmd[kCmdWords];
     Pose T = fresh_args().p.sol.pose0;
     // this wave's query (wave-uniform) and its source point: the same for every pass of a scan, so it is read once per scan
-    // (a launch that serves a batch - sp.scans - moves on to the next scan on kCmdNewScan)
+    // (a launch that serves a batch - sp.scans - takes up the scan each command names)
     double sx = 0.0, sy = 0.0, sz = 0.0;
     uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0))), n_scan = 0u;
     bool new_scan = true;
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         if (pass + 1 >= sp.max_passes) return;
         const uint32_t op = await_command(sp, tid, pass, s_cmd);
         if (op != kCmdContinue && op != kCmdNewScan) return;
-        if (op == kCmdNewScan) scan = static_cast<uint32_t>(uniform_i(static_cast<int>(scan + 1u))), new_scan = true;
+        if (sp.scans && command_scan(s_cmd) != scan) scan = command_scan(s_cmd), new_scan = true;
         if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
