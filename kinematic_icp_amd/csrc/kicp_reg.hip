@@ -174,6 +174,7 @@ struct kicp_reg {
     unsigned long long batch_resident_passes = 0;  // passes served that way so far (get-only "batch_resident_passes")
     int last_resident_passes = 0; // passes of the last call that a resident launch of the GENERIC kernel served (get-only "resident_passes")
     int small_prev_iters = 2;     // iterations of the previous small-path call: a scan that converged at once makes the next launch leave after its first pass
+    uint32_t trace_pass = 1;      // the pass of a launch the stamps are taken on (the option's value)
     long long *d_trace = nullptr; // option "small_trace": device buffer of the kernel's per-pass wall-clock stamps
     double trace_host_us = 0.0, trace_dev_us = 0.0, trace_first_us = 0.0;  // host: rows seen -> command sent; device: command sent -> rows seen; launch -> first rows
     unsigned long long trace_n = 0, trace_first_n = 0;
@@ -579,8 +580,8 @@ SmallPlan small_plan(const kicp_reg *r, size_t n) {
 }
 int ensure_cmd(kicp_reg *r) {
     if (!r->cmd) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), 128, hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(r->cmd, 0, 128);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), kPipeSlots * kCmdWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(r->cmd, 0, kPipeSlots * kCmdWords * sizeof(unsigned long long));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
     }
     const size_t bytes = static_cast<size_t>(kCmdReplicas) * kCmdStrideWords * sizeof(unsigned long long);
@@ -615,13 +616,13 @@ int next_tag_range(kicp_reg *r, uint32_t count, uint32_t *first) {
     return KICP_OK;
 }
 // the command that starts pass `seq - seq_base` of the resident kernel: seven pose words, then the control word (release); it
-// travels in line seq & 1 (kicp_small.hpp).  `scan`: the scan of the launch's table the pass belongs to (batches)
+// travels in line seq % kPipeSlots (kicp_small.hpp).  `scan`: the scan of the launch's table the pass belongs to (batches)
 void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &T, uint32_t scan = 0u) {
     unsigned long long w[kCmdWords];
     const double v[7] = {T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz};
     std::memcpy(w, v, 7 * sizeof(double));
     w[7] = (((seq & 0xFFFFFFFFull) << 32) | (static_cast<unsigned long long>(scan) << 8) | op) ^ cmd_fold(w);
-    const size_t slot = static_cast<size_t>(seq & 1ull) * kCmdWords;
+    const size_t slot = static_cast<size_t>(seq % kPipeSlots) * kCmdWords;
     if (r->small_cmd == 1 && r->cmd_bar) {  // straight into the copies the workgroups poll (write-combined BAR stores)
         for (int c = 0; c < kCmdReplicas; ++c)
             for (int i = 0; i < kCmdWords; ++i) r->cmd_bar[static_cast<size_t>(c) * kCmdStrideWords + slot + i] = w[i];
@@ -774,9 +775,9 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     const size_t groups_resident = (grid + kGroup - 1) / kGroup, groups_plain = (pass_grid(r, n) + kGroup - 1) / kGroup;
     // (rows, tickets and host rows of a resident launch are double-buffered by pass parity: finish_pass, small_publish)
     if (pl.generic) {
-        if (int rc = ensure_partials(r, std::max<uint32_t>(2u * grid, pass_grid(r, n)))) return rc;
-        if (int rc = ensure_rows(r, std::max(2 * groups_resident, groups_plain))) return rc;
-    } else if (int rc = ensure_rows(r, 2 * static_cast<size_t>(grid))) {
+        if (int rc = ensure_partials(r, std::max<uint32_t>(kPipeSlots * grid, pass_grid(r, n)))) return rc;
+        if (int rc = ensure_rows(r, std::max(kPipeSlots * groups_resident, groups_plain))) return rc;
+    } else if (int rc = ensure_rows(r, kPipeSlots * static_cast<size_t>(grid))) {
         return rc;
     }
     if (int rc = ensure_cmd(r)) return rc;
@@ -805,7 +806,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
         pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
         sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
         r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
-        sp.trace = r->d_trace;
+        sp.trace = r->d_trace, sp.trace_pass = r->trace_pass;
         auto t_sent = std::chrono::steady_clock::now();
         const bool plain = pl.generic && cnt == 1;
         const int iter_at_launch = loop.iter;
@@ -821,13 +822,13 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             bool gave_up = false;
             int rc_rows;
             if (pl.generic) {
-                rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words, plain ? 0 : (k & 1u) * groups_resident);
+                rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words, plain ? 0 : (k % kPipeSlots) * groups_resident);
                 // workgroups that left without a command (kGaveUpUnit each), or a row that never reached its group's reader
                 // (kLostRowUnit): either way this pass is run again, in a fresh launch
                 gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull;
                 words[kNumLimbs] &= 0xFFll;
             } else {
-                rc_rows = wait_rows_small(r, grid, sp.tag0 + k, k & 1u, words, &gave_up);
+                rc_rows = wait_rows_small(r, grid, sp.tag0 + k, k % kPipeSlots, words, &gave_up);
             }
             const auto t_rows = std::chrono::steady_clock::now();
             if (r->d_trace) {
@@ -1129,10 +1130,10 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     const uint32_t grid = wave ? pl.grid : static_cast<uint32_t>((n_max + 255) / 256);
     const size_t groups = (grid + kGroup - 1) / kGroup;
     if (wave) {
-        if (int rc = ensure_rows(r, 2 * static_cast<size_t>(grid))) return rc;
+        if (int rc = ensure_rows(r, kPipeSlots * static_cast<size_t>(grid))) return rc;
     } else {
-        if (int rc = ensure_partials(r, 2u * grid)) return rc;
-        if (int rc = ensure_rows(r, 2 * groups)) return rc;
+        if (int rc = ensure_partials(r, kPipeSlots * grid)) return rc;
+        if (int rc = ensure_rows(r, kPipeSlots * groups)) return rc;
     }
     if (int rc = ensure_cmd(r)) return rc;
     if (!wave)
@@ -1174,12 +1175,13 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
     sp.scans = r->d_scans;
-    // Two scans of the batch are in flight at a time (option "batch_depth", 1: one).  The scans of a batch do not depend on each
-    // other - every one starts from its own pose, the map does not change -, so while the host adds, solves and answers the rows of
-    // pass k (a round trip of ~3 us over PCIe), the workgroups are already searching pass k + 1, which belongs to the OTHER scan; and
-    // a workgroup that is done with its part of a pass finds the next command waiting instead of waiting for the slowest workgroup
-    // and the host.  Passes are numbered in the order their commands go out; the command of pass k + 2 goes out when every row of
-    // pass k is in (two command lines, two row buffers, two sets of tickets, all taken in turn: kicp_small.hpp, finish_pass).
+    // Several scans of the batch are in flight at a time (option "batch_depth", 1 .. kPipeSlots; 1: one).  The scans of a batch do not
+    // depend on each other - every one starts from its own pose, the map does not change -, so while the host adds, solves and
+    // answers the rows of pass k (a round trip of ~3 us over PCIe), the workgroups are already searching pass k + 1, which belongs
+    // to ANOTHER scan; and a workgroup that is done with its part of a pass finds the next command waiting instead of waiting for
+    // the slowest workgroup and the host.  Passes are numbered in the order their commands go out; with depth d the command of
+    // pass k + d goes out when every row of pass k is in (kPipeSlots command lines, row buffers and sets of tickets, all taken in
+    // turn: kicp_small.hpp, finish_pass).
     struct InFlight {
         HostLoop loop;
         kicp_stats st;
@@ -1187,10 +1189,10 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         bool active = false;   // holds a scan that is not finished
         bool waiting = false;  // a pass of it is out
     };
-    const int depth = r->batch_depth >= 2 ? 2 : 1;
-    InFlight slots[2];
-    int order[2] = {0, 0}, out = 0;   // slots whose passes are out, oldest first
-    uint32_t order_pass[2] = {0u, 0u};
+    const int depth = std::min<int>(std::max(r->batch_depth, 1), kPipeSlots);
+    InFlight slots[kPipeSlots];
+    int order[kPipeSlots] = {}, out = 0;   // slots whose passes are out, oldest first
+    uint32_t order_pass[kPipeSlots] = {};
     uint32_t pass = 0, budget = 0;  // next pass index inside the current launch; passes that launch may serve (0: no kernel on the device)
     size_t next_scan = 0, front = 0;  // next scan to start; scans [0, front) are complete
     std::vector<unsigned char> complete(count, 0);
@@ -1241,7 +1243,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
                 pp.sol.pose0 = f.loop.T, pp.sol.pass = f.loop.iter;
                 sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(f.k);
                 r->cmd_seq += cnt;
-                sp.trace = r->d_trace;
+                sp.trace = r->d_trace, sp.trace_pass = r->trace_pass;
                 if (int rc = launch_small(r, sp, pl)) return leave(rc);
                 pass = 0, budget = cnt, stop_sent = false;
             } else {
@@ -1260,11 +1262,12 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         // ---- the rows of the oldest pass that is out ---------------------------------------------------------------------
         InFlight &f = slots[order[0]];
         const uint32_t at = order_pass[0];
-        order[0] = order[1], order_pass[0] = order_pass[1], --out;
+        for (int j = 1; j < out; ++j) order[j - 1] = order[j], order_pass[j - 1] = order_pass[j];
+        --out;
         f.waiting = false;
         long long words[kReduceWords];
         bool gave_up = false;
-        if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + at, at & 1u, words, &gave_up) : wait_rows(r, groups, sp.tag0 + at, words, (at & 1u) * groups))
+        if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + at, at % kPipeSlots, words, &gave_up) : wait_rows(r, groups, sp.tag0 + at, words, (at % kPipeSlots) * groups))
             return leave(rc);
         if (!wave) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
         if (gave_up) {  // (part of) the kernel has left: the scans in hand and the rest go through the plain loop
@@ -1438,7 +1441,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
-    else if (k == "batch_depth") reg->batch_depth = value >= 2.0 ? 2 : 1;
+    else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
     else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
@@ -1455,6 +1458,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&reg->d_trace), 1024 * 4 * sizeof(long long)));
             HIP_TRY(hipMemset(reg->d_trace, 0, 1024 * 4 * sizeof(long long)));
         }
+        reg->trace_pass = value >= 1.0 ? static_cast<uint32_t>(value) : 1u;  // (the value: which pass of a launch is stamped)
         reg->trace_host_us = reg->trace_dev_us = reg->trace_first_us = 0.0, reg->trace_n = reg->trace_first_n = 0;
     }
     else if (k == "small_cmd") {

@@ -15,9 +15,9 @@
 //     arrives within `timeout_ticks` (it then marks the rows of the pass it gave up on, and the host launches afresh).
 // The command line is its own flag: seven pose words and one control word = (sequence << 32 | scan << 8 | opcode) XOR a 64-bit
 // fold of the pose words, so a torn read (some words of the previous command) cannot pass for the command the kernel is waiting
-// for.  There are TWO lines, taken in turn (command `seq` travels in line seq & 1): the host may send the command that starts
-// pass k + 2 as soon as it holds every row of pass k - while workgroups are still busy with pass k + 1 (run_batch_resident keeps
-// two scans of a batch in flight that way).
+// for.  There are kPipeSlots lines, taken in turn (command `seq` travels in line seq % kPipeSlots): the host may send the command
+// that starts pass k + d (d <= kPipeSlots) as soon as it holds every row of pass k - while workgroups are still busy with the
+// passes in between (run_batch_resident keeps several scans of a batch in flight that way).
 // Frame and map cannot change while the call is running, so the acquire of the launch (AQL packet / HIP launch) covers all
 // passes.
 #pragma once
@@ -34,6 +34,7 @@ constexpr int kCmdWords = 8;
 // carry the index (into the launch's scan table, SmallParams::scans) of the scan the pass belongs to: a batch's scans take turns.
 enum : uint32_t { kCmdContinue = 1u, kCmdStop = 2u, kCmdNewScan = 3u };
 constexpr unsigned long long kCmdMaxScans = 1ull << 24;  // scan indices a command can carry
+constexpr uint32_t kPipeSlots = 4;  // command lines / row buffers / ticket sets, taken in turn by consecutive passes: passes that may be out at a time
 // one scan of a batch as the resident kernel sees it
 struct ScanRef {
     const double *src;   // device pointer, AoS xyz fp64
@@ -53,18 +54,19 @@ KICP_HD unsigned long long cmd_fold(const unsigned long long w[7]) {
 
 struct SmallParams {
     PassParams p;                   // (p.sol.mode is not used: the host always solves; p.partials / p.tickets unused)
-    const unsigned long long *cmd;  // device view of the host-mapped command lines (2 x kCmdWords words, 64-byte aligned)
-    unsigned long long *cmd_dev;    // kCmdReplicas copies of the two command lines in device memory (await_command)
+    const unsigned long long *cmd;  // device view of the host-mapped command lines (kPipeSlots x kCmdWords words, 64-byte aligned)
+    unsigned long long *cmd_dev;    // kCmdReplicas copies of the command lines in device memory (await_command)
     int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
     long long *trace;               // debugging aid (option "small_trace"): workgroup 0 stamps its passes here, 4 wall-clock words each
-    unsigned long long *rows;       // device view of the host-mapped rows [2][gridDim.x][kSmallRowWords]: pass k writes buffer k & 1, so the
+    unsigned long long *rows;       // device view of the host-mapped rows [kPipeSlots][gridDim.x][kSmallRowWords]: pass k writes buffer k % kPipeSlots, so the
                                     // give-up marker of pass k + 1 never lands on a row of pass k the host has not read yet
     unsigned long long seq_base;    // the command that starts pass k (k >= 1) carries sequence seq_base + k
     uint32_t tag0;                  // pass k publishes with tag tag0 + k (the host reserves the range)
     uint32_t max_passes;            // passes this launch may serve; 1 = leave after the first (no residency)
     long long timeout_ticks;        // 100 MHz wall-clock ticks a workgroup waits for a command before it gives up
     const ScanRef *scans;           // k_pass_resident serving a batch: the batch's scans (device memory, written before the launch);
-    uint32_t scan0, pad2_;          // the launch starts on scans[scan0]; later passes: the scan their command names.  nullptr: p.src / p.n
+    uint32_t scan0, trace_pass;     // (trace_pass: the pass of the launch that `trace` stamps)
+                                    // the launch starts on scans[scan0]; later passes: the scan their command names.  nullptr: p.src / p.n
 };
 
 // Between the passes of a resident kernel NOTHING but the pose, the pass counter and the lane id is worth a register: the
@@ -102,7 +104,7 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
         const unsigned long long want = sp.seq_base + pass + 1;
         const long long t0 = wall_clock64();
         const bool relay = sp.relay != 0 && blockIdx.x == 0;
-        const size_t slot = static_cast<size_t>(want & 1ull) * kCmdWords;  // (the two lines of a copy are neighbours)
+        const size_t slot = static_cast<size_t>(want % kPipeSlots) * kCmdWords;  // (the lines of a copy are neighbours)
         const unsigned long long *line = (relay ? sp.cmd : sp.cmd_dev + static_cast<size_t>(blockIdx.x % kCmdReplicas) * kCmdStrideWords) + slot;
         unsigned long long w = 0, ctrl = 0;
         for (;;) {
@@ -117,7 +119,7 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
                 if (MARK_ROWS && lane < kSmallRowWords)
-                    __hip_atomic_store(sp.rows + (static_cast<size_t>((pass + 1u) & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + lane,
+                    __hip_atomic_store(sp.rows + (static_cast<size_t>((pass + 1u) % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + lane,
                                        ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &s
     if (lane == 2 * kNumSums) word = (*s_flag & 2) ? 1ull : 0ull;
     if (lane > 2 * kNumSums) word = 0ull;
     if (lane < kSmallRowWords)
-        __hip_atomic_store(sp.rows + (static_cast<size_t>(pass & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + lane, (word << 16) | tag, __ATOMIC_RELAXED,
+        __hip_atomic_store(sp.rows + (static_cast<size_t>(pass % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + lane, (word << 16) | tag, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
         const SmallParams &sp = fresh_args();
         uint32_t tid = fresh_tid();
         if (tid == 0) s_flag = 0;
-        const bool stamp = sp.trace != nullptr && tid == 0 && pass == 1;  // option "small_trace": every workgroup stamps its second pass, [workgroup][4]
+        const bool stamp = sp.trace != nullptr && tid == 0 && pass == sp.trace_pass;  // option "small_trace": every workgroup stamps its second pass, [workgroup][4]
         if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
         Acc acc{};
         if (!gave_up) {
@@ -269,12 +271,12 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
             gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc, src, n);
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
-        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 1] = wall_clock64();  // every wave's search is done
-        finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up, pass & 1u);
-        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();  // row stored (a group's last workgroup: group row sent)
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 1] = wall_clock64();  // every wave's search is done
+        finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up, pass % kPipeSlots);
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 2] = wall_clock64();  // row stored (a group's last workgroup: group row sent)
         if (gave_up || pass + 1 >= sp.max_passes) return;
         const uint32_t op = await_command<false>(sp, fresh_tid(), pass, s_cmd);
-        if (sp.trace != nullptr && fresh_tid() == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();  // next command seen
+        if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 3] = wall_clock64();  // next command seen
         if (op != kCmdContinue && op != kCmdNewScan) {
             if (op == kCmdStop) return;
             gave_up = 1;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
         if (tid == 0) s_flag = 0;
         const uint32_t qi = blockIdx.x * kWaves + static_cast<uint32_t>(wave);
-        const bool stamp = sp.trace != nullptr && tid == 0 && pass == 1;  // every workgroup stamps its second pass: [workgroup][4]
+        const bool stamp = sp.trace != nullptr && tid == 0 && pass == sp.trace_pass;  // every workgroup stamps its second pass: [workgroup][4]
         if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
         bool accepted = false;
         double term_value = 0.0;  // lane k < 6: the k-th term of this wave's correspondence (lane 6: the count)
@@ -571,15 +573,15 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
             if (ln == 2 * kNumSums) word = (s_flag & 2) ? 1ull : 0ull;
             if (ln > 2 * kNumSums) word = 0ull;
             if (ln < kSmallRowWords)
-                __hip_atomic_store(sp.rows + (static_cast<size_t>(pass & 1u) * gridDim.x + blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass),
+                __hip_atomic_store(sp.rows + (static_cast<size_t>(pass % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
+        if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;
         const uint32_t op = await_command(sp, tid, pass, s_cmd);
         if (op != kCmdContinue && op != kCmdNewScan) return;
         if (sp.scans && command_scan(s_cmd) != scan) scan = command_scan(s_cmd), new_scan = true;
-        if (sp.trace != nullptr && tid == 0 && pass == 1) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
+        if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
