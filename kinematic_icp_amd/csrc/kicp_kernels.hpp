@@ -295,7 +295,31 @@ __device__ __forceinline__ bool closer_by_norm(double a, double best) {
 __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32_t count, uint32_t base_index, const Query &q,
                                             double &best, uint32_t &best_idx) {
     uint32_t k = 0;
-    for (; k + 2 <= count; k += 2) {  // two points per trip: independent loads in flight
+    // ten, then four points per trip: all of a trip's loads in flight together, then the comparisons in insertion order (a bucket of
+    // the default 20 points is two round trips to memory instead of ten)
+    for (; k + 10 <= count; k += 10) {
+        double c[30];
+#pragma unroll
+        for (int j = 0; j < 30; ++j) c[j] = p[3 * k + j];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const double dx = c[3 * j] - q.x, dy = c[3 * j + 1] - q.y, dz = c[3 * j + 2] - q.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (closer_by_norm(d2, best)) best = d2, best_idx = base_index + k + j;
+        }
+    }
+    for (; k + 4 <= count; k += 4) {
+        double c[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) c[j] = p[3 * k + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double dx = c[3 * j] - q.x, dy = c[3 * j + 1] - q.y, dz = c[3 * j + 2] - q.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (closer_by_norm(d2, best)) best = d2, best_idx = base_index + k + j;
+        }
+    }
+    for (; k + 2 <= count; k += 2) {
         const double ax = p[3 * k], ay = p[3 * k + 1], az = p[3 * k + 2];
         const double bx = p[3 * k + 3], by = p[3 * k + 4], bz = p[3 * k + 5];
         const double adx = ax - q.x, ady = ay - q.y, adz = az - q.z;
@@ -312,14 +336,16 @@ __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32
     }
 }
 
-// 27-voxel 1-NN straight from HBM/L2.  `best` enters as the acceptance bound (or DBL_MAX).
-__device__ __forceinline__ void search_global(const MapView &m, const Query &q, double &best, uint32_t &best_idx) {
+// 27-voxel 1-NN straight from HBM/L2.  `best` enters as the acceptance bound (or DBL_MAX).  `cull`: a squared distance some
+// point of the map is KNOWN to have (the pre-selected winner's, exact) - voxels that cannot hold anything that close are skipped
+// from the start; the winner is still chosen among everything that is visited, in visiting order, by the reference's rule.
+__device__ __forceinline__ void search_global(const MapView &m, const Query &q, double &best, uint32_t &best_idx, double cull = 1.7976931348623157e308) {
     Faces f;
     make_faces(f, q, m.voxel_size);
 #pragma unroll 1
     for (int s = 0; s < 27; ++s) {
         const int dx = shift_component(kShiftX, s), dy = shift_component(kShiftY, s), dz = shift_component(kShiftZ, s);
-        if (box_d2(f, dx, dy, dz) > best + f.slack) continue;  // no point in there can beat `best`
+        if (box_d2(f, dx, dy, dz) > fmin(best, cull) + f.slack) continue;  // no point in there can beat `best` (or match `cull`)
         const uint32_t val = table_lookup(m, q.vx + dx, q.vy + dy, q.vz + dz);
         if (val == kEmptyVal) continue;
         const uint32_t bucket = val_bucket(val, m.cbits);
@@ -1137,7 +1163,9 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
     double wx = 0.0, wy = 0.0, wz = 0.0;  // the winner's coordinates, as far as they have passed through registers already
     bool have_winner = false;
     if (t.b3 - t.b1 <= margin && p.dbg != 9) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
-        search_global(m, q, best, best_idx);
+        // (which needs to look no farther than the pre-selected winner's exact distance)
+        const double *c1 = m.pool + static_cast<size_t>(t.i1) * 3;
+        search_global(m, q, best, best_idx, exact_d2_of(c1[0], c1[1], c1[2], q));
     } else {
         const double *c1 = m.pool + static_cast<size_t>(t.i1) * 3;
         const double x1 = c1[0], y1 = c1[1], z1 = c1[2];
@@ -1177,10 +1205,10 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // the search and the exact phase of one pass for lane `tid` of workgroup blockIdx.x; `acc` receives the lane's terms
 // (`src`, `n`: the scan - p.src / p.n for a kernel that serves one call, the current scan of a resident kernel that serves a batch)
 template <int BLOCK, int G, bool SPLIT, bool LAT>
-__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n) {
+__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n, uint32_t block) {
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
-    const uint32_t gt = blockIdx.x * BLOCK + tid;
+    const uint32_t gt = block * BLOCK + tid;  // (`block`: which BLOCK points of the scan this workgroup takes - blockIdx.x, or a resident kernel's turn)
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
     const bool valid = i < n && p.dbg != 7 && p.dbg != 8;
@@ -1242,7 +1270,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     Acc acc{};
-    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n);
+    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n, blockIdx.x);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }

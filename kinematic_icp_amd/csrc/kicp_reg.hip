@@ -166,7 +166,8 @@ struct kicp_reg {
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
     int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
-    int batch_depth = 2;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
+    int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
+    int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
     ScanRef *scans_bar = nullptr; // the same memory as the CPU writes it through the PCIe BAR (nullptr: d_scans is plain device memory)
@@ -1103,6 +1104,7 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
 // kicp status; *done = scans completed.  On a give-up of the kernel (a workgroup that saw no command in time) the scan in
 // hand and the rest are left to the plain loop, too.
 constexpr uint32_t kBatchMaxPasses = 1024;  // passes (= tags) one launch may serve
+int depth_of(const kicp_reg *r) { return std::min<int>(std::max(r->batch_depth, 1), static_cast<int>(kPipeSlots)); }
 int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
                        const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
     *done = 0;
@@ -1112,7 +1114,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     constexpr size_t kBatchResidentMinScans = 8;
     if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || count > kCmdMaxScans || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
-          r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0))
+          r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || (r->dbg >= 2 && r->dbg <= 5) || r->dbg == 9) && r->small_resident != 0))
         return 1;
     // one kind of kernel serves the whole batch: the generic one (scans beyond the small-scan kernels, up to what the device holds at
     // once) or one wave per query (scans of up to kWaveMaxPoints points); anything else - or a mix - takes the plain loop
@@ -1170,11 +1172,14 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     PassParams &pp = sp.p;
     pp.src = d_frames[0], pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
+    pp.dbg = r->dbg;
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
     pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
     sp.scans = r->d_scans;
+    // (the workgroups' shares of a scan move on by about 0.38 of the grid per pass - far from where they were, and back only after many passes)
+    if (!wave && r->batch_rotate && depth_of(r) > 1) sp.rotate = (static_cast<uint32_t>(grid * 0.381966) | 1u) % grid;
     // Several scans of the batch are in flight at a time (option "batch_depth", 1 .. kPipeSlots; 1: one).  The scans of a batch do not
     // depend on each other - every one starts from its own pose, the map does not change -, so while the host adds, solves and
     // answers the rows of pass k (a round trip of ~3 us over PCIe), the workgroups are already searching pass k + 1, which belongs
@@ -1189,7 +1194,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         bool active = false;   // holds a scan that is not finished
         bool waiting = false;  // a pass of it is out
     };
-    const int depth = std::min<int>(std::max(r->batch_depth, 1), kPipeSlots);
+    const int depth = depth_of(r);
     InFlight slots[kPipeSlots];
     int order[kPipeSlots] = {}, out = 0;   // slots whose passes are out, oldest first
     uint32_t order_pass[kPipeSlots] = {};
@@ -1441,6 +1446,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
+    else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
@@ -1489,6 +1495,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
     if (k == "batch_depth") return reg->batch_depth;
+    if (k == "batch_rotate") return reg->batch_rotate;
     if (k == "batch_resident_passes") return static_cast<double>(reg->batch_resident_passes);
     if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
@@ -1689,7 +1696,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate;
     *out = c;
     return KICP_OK;
 }

@@ -65,6 +65,7 @@ struct SmallParams {
     uint32_t max_passes;            // passes this launch may serve; 1 = leave after the first (no residency)
     long long timeout_ticks;        // 100 MHz wall-clock ticks a workgroup waits for a command before it gives up
     const ScanRef *scans;           // k_pass_resident serving a batch: the batch's scans (device memory, written before the launch);
+    uint32_t rotate, pad3_;         // k_pass_resident: the workgroups' shares of a scan move on by this many blocks from pass to pass (below)
     uint32_t scan0, trace_pass;     // (trace_pass: the pass of the launch that `trace` stamps)
                                     // the launch starts on scans[scan0]; later passes: the scan their command names.  nullptr: p.src / p.n
 };
@@ -97,9 +98,11 @@ __device__ __forceinline__ uint32_t fresh_tid() {
 // launches afresh).  Ends in a workgroup barrier.
 constexpr int kCmdReplicas = 64;         // copies of the command line ...
 constexpr int kCmdStrideWords = 544;     // ... 4352 bytes apart (4 KiB + 256 B), so that the pollers spread over memory channels
-template <bool MARK_ROWS = true>
+// POLL_WAVE: the wave that does the waiting - wave 1 where wave 0 is still busy handing over the rows of the pass (its
+// ticket and, for the last workgroup of a group, the group's sum): the two round trips then run side by side.
+template <bool MARK_ROWS = true, int POLL_WAVE = 0>
 __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_t tid, uint32_t pass, unsigned long long *s_cmd) {
-    if ((tid >> 6) == 0) {
+    if ((tid >> 6) == POLL_WAVE) {
         const int lane = tid & 63;
         const unsigned long long want = sp.seq_base + pass + 1;
         const long long t0 = wall_clock64();
@@ -257,6 +260,11 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
     Pose T = fresh_args().p.sol.pose0;
     int gave_up = 0;  // (wave-uniform) no command arrived in time: this round only hands over the marked empty row
     uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0)));  // (a batch: index into sp.scans of the scan this pass belongs to)
+    // Which 256 points of the scan this workgroup searches moves on by `rotate` blocks with every pass.  Scans of one sensor are
+    // heavy in the same places (the same index ranges hold the rays that meet the densest part of the map), and with several passes
+    // in flight the pace is set by the workgroup that is behind: taking turns, a workgroup that had a heavy share catches up on the
+    // lighter ones that follow (the sums are exact: who searches what does not change a bit of the result).
+    uint32_t share = blockIdx.x;
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         uint32_t tid = fresh_tid();
@@ -268,14 +276,16 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
             const double *src = sp.p.src;
             uint32_t n = sp.p.n;
             if (sp.scans) src = sp.scans[scan].src, n = static_cast<uint32_t>(sp.scans[scan].n);  // (uniform: scalar loads)
-            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc, src, n);
+            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc, src, n, share);
+            share += sp.rotate;
+            if (share >= gridDim.x) share -= gridDim.x;
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 1] = wall_clock64();  // every wave's search is done
         finish_pass<BLOCK, true>(acc, sp.p, s_red, &s_flag, sp.tag0 + pass, gave_up, pass % kPipeSlots);
         if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 2] = wall_clock64();  // row stored (a group's last workgroup: group row sent)
         if (gave_up || pass + 1 >= sp.max_passes) return;
-        const uint32_t op = await_command<false>(sp, fresh_tid(), pass, s_cmd);
+        const uint32_t op = await_command<false, 1>(sp, fresh_tid(), pass, s_cmd);
         if (sp.trace != nullptr && fresh_tid() == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 3] = wall_clock64();  // next command seen
         if (op != kCmdContinue && op != kCmdNewScan) {
             if (op == kCmdStop) return;
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         }
         if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
         if (pass + 1 >= sp.max_passes) return;
-        const uint32_t op = await_command(sp, tid, pass, s_cmd);
+        const uint32_t op = await_command<true, 1>(sp, tid, pass, s_cmd);
         if (op != kCmdContinue && op != kCmdNewScan) return;
         if (sp.scans && command_scan(s_cmd) != scan) scan = command_scan(s_cmd), new_scan = true;
         if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 3] = wall_clock64();

@@ -20,6 +20,7 @@ ap.add_argument("workload", nargs="?", default="cfg2")
 ap.add_argument("--depths", type=int, nargs="+", default=[1, 2, 4])
 ap.add_argument("--pass", dest="at", type=int, default=40)
 ap.add_argument("--scans", type=int, default=128)
+ap.add_argument("--fixed", action="append", default=[], help="name=value options set on every handle")
 args = ap.parse_args()
 cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=8)
 gmap = K.VoxelHashMap(cfg.voxel_size, cfg.max_range, cfg.max_points_per_voxel)
@@ -33,6 +34,8 @@ B = args.scans
 for depth in args.depths:
     reg = K.KinematicRegistration()
     reg.set_option("batch_depth", depth)
+    for o in args.fixed:
+        reg.set_option(o.split("=")[0], float(o.split("=")[1]))
     batch = reg.prepare_batch([frames[i % 8] for i in range(B)], [scans[i % 8]["last_pose"] for i in range(B)], [scans[i % 8]["rel_odom"] for i in range(B)])
     for _ in range(5):
         reg.ComputeRobotMotionBatch(batch, gmap, tau)
@@ -61,3 +64,9 @@ for depth in args.depths:
     print("    per workgroup: search mean %.2f / p90 %.2f / max %.2f us; reduction + row mean %.2f (max %.2f) us; wait for the next command mean %.2f / p10 %.2f / max %.2f us; "
           "whole cycle mean %.2f us" % (search.mean(), np.percentile(search, 90, axis=1).mean(), search.max(axis=1).mean(), rows.mean(), rows.max(axis=1).mean(),
                                         wait.mean(), np.percentile(wait, 10, axis=1).mean(), wait.max(axis=1).mean(), (r[:, :, 3] - r[:, :, 0]).mean()))
+    slow = np.argsort(-search.mean(axis=0))[:6]
+    print("    slowest workgroups (mean search us over the calls; the stamped pass registers the same scan in every call): " +
+          ", ".join("%d: %.1f" % (int(b), search.mean(axis=0)[b]) for b in slow))
+    late = np.argsort(-r[:, :, 0].mean(axis=0))[:8]
+    print("    latest to take the pass up (mean us after the first): " + ", ".join("%d: %.1f" % (int(b), r[:, :, 0].mean(axis=0)[b]) for b in late) +
+          "; workgroups more than 2 us late: %d" % int((r[:, :, 0].mean(axis=0) > 2.0).sum()))
