@@ -145,6 +145,7 @@ struct PassParams {
     IcpState *st;
     unsigned long long *partials;  // [(grid + ceil(grid/32)) * 24] limb rows of the workgroups, then of the groups
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
+    unsigned long long *group_acc; // resident kernels: the groups' counting accumulators (finish_pass, ROWS_ONLY), zero between passes
     SolveParams sol;
     int32_t dbg;          // ablation switches for tools/gpu_dbg.py (0 = normal operation)
 };
@@ -441,6 +442,9 @@ __device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams
 // two-level modes order payload before ticket with `s_waitcnt vmcnt(0)`; mode 4 needs no ordering (tags).
 constexpr int kGroup = 32;        // workgroups per first-level group
 constexpr int kTicketStride = 32; // uint32 words between group tickets (128 B)
+constexpr int kAccStride = 32;                // 64-bit words between the groups' counting accumulators (256 B: one memory channel)
+constexpr int kAccCountShift = 56;            // a word of an accumulator: contributions so far << 56 | sum of the biased words
+constexpr long long kAccBias = 1ll << 41;     // makes a row word (|value| < 2^40) non-negative; 32 of them stay below 2^47
 
 __device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -665,6 +669,33 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             i128_add_limb_sums(t, s_red[w][kTermLimbs * lane], s_red[w][kTermLimbs * lane + 1], s_red[w][kTermLimbs * lane + 2], s_red[w][kTermLimbs * lane + 3]);
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
+    if (ROWS_ONLY) {
+        // Resident kernels (several passes in flight, the pace set by the workgroup that is behind): ONE round trip to the L2 and no
+        // reader.  Lane w < kReduceWords adds word w of the workgroup's row - biased to be non-negative, with a 1 in the count field
+        // above it - to word w of the group's accumulator.  The addition that finds the count at group size - 1 is the last one for
+        // that word: old value + own = the group's sum, which that lane hands to the host (and clears the word for the slot's next
+        // turn).  Every word is completed by whichever workgroup happened to add to it last - not necessarily the same one for all
+        // 24 - and carries the pass tag, which is how the host tells a complete row anyway (wait_rows).
+        long long l[3] = {0ll, 0ll, 0ll};
+        if (lane < kNumSums) i128_to_limbs(t, l);
+        const int from = min(lane, kNumLimbs - 1) / 3;
+        const long long a0 = __shfl(l[0], from, 64), a1 = __shfl(l[1], from, 64), a2 = __shfl(l[2], from, 64);
+        long long word = lane % 3 == 0 ? a0 : (lane % 3 == 1 ? a1 : a2);
+        if (lane >= kNumLimbs) word = lane == kNumLimbs ? static_cast<long long>(range_error) + (gave_up ? static_cast<long long>(kGaveUpUnit) : 0ll) : 0ll;
+        if (lane < kReduceWords) {
+            const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
+            unsigned long long *acc = p.group_acc + (static_cast<size_t>(parity) * ngroups + g) * kAccStride + lane;
+            const unsigned long long mine = static_cast<unsigned long long>(word + kAccBias);  // |word| < 2^40: (0, 2^42)
+            const unsigned long long old = __hip_atomic_fetch_add(acc, (1ull << kAccCountShift) + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old >> kAccCountShift) == group_size - 1u) {
+                const long long total = static_cast<long long>((old & ((1ull << kAccCountShift) - 1ull)) + mine) - static_cast<long long>(group_size) * kAccBias;
+                __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(parity) * ngroups + g) * kReduceWords + lane,
+                                   (static_cast<unsigned long long>(total) << 16) | static_cast<unsigned long long>(row_tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     unsigned long long *const rows0 = p.partials + (ROWS_ONLY ? static_cast<size_t>(parity) * nblocks * kReduceWords : 0u);
     unsigned int *const tickets0 = p.tickets + (ROWS_ONLY ? static_cast<size_t>(parity) * ngroups * kTicketStride : 0u);
     unsigned long long *row = rows0 + static_cast<size_t>(b) * kReduceWords;

@@ -88,6 +88,8 @@ struct kicp_reg {
     unsigned long long call_id = 0;
     unsigned long long *d_partials = nullptr;  // limb rows of the reduction tree
     unsigned int *d_tickets = nullptr;
+    unsigned long long *d_group_acc = nullptr;  // the resident kernels' group accumulators (finish_pass, ROWS_ONLY)
+    bool acc_dirty = false;       // a resident launch was left before all its passes were collected: accumulators / tickets may hold partial counts
     size_t partial_blocks = 0;
     // mode 4 hand-off: tagged rows of the first-level groups in host-mapped pinned memory, added up by the host
     unsigned long long *rows = nullptr, *d_rows = nullptr;  // host / device view
@@ -337,12 +339,15 @@ int ensure_partials(kicp_reg *r, size_t blocks) {
     if (int rc = aql_quiesce(r)) return rc;
     if (r->d_partials) HIP_TRY(hipFree(r->d_partials));
     if (r->d_tickets) HIP_TRY(hipFree(r->d_tickets));
-    r->d_partials = nullptr, r->d_tickets = nullptr;
+    if (r->d_group_acc) HIP_TRY(hipFree(r->d_group_acc));
+    r->d_partials = nullptr, r->d_tickets = nullptr, r->d_group_acc = nullptr;
     const size_t want = blocks + blocks / 2 + 64, groups = want / kGroup + 2;
     HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&r->d_group_acc, groups * kAccStride * sizeof(unsigned long long)));
     r->stream_dirty = true;
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, groups * kAccStride * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_partials, 0, (want + groups) * kReduceWords * sizeof(unsigned long long), r->stream));  // tag 0 = never valid
     r->partial_blocks = want;
     return KICP_OK;
@@ -756,15 +761,17 @@ struct HostLoop {
     }
 };
 
-// A workgroup of an earlier resident launch of the generic kernel gave up waiting for its command (k_pass_resident sets the word):
-// tickets of a give-up round that never completed - the call ended first - may be left behind.  Clear them before they are
-// counted into this call's passes.
+// A workgroup of an earlier resident launch of the generic kernel gave up waiting for its command (k_pass_resident sets the word),
+// or the host left a launch with passes still out: counts of a round that never completed - the call ended first - may be left
+// behind in the groups' accumulators (and tickets).  Clear them before they are counted into this call's passes.
 int clear_stale_tickets(kicp_reg *r) {
-    if (__atomic_load_n(&r->rec->reserved[0], __ATOMIC_RELAXED) == 0u || !r->d_tickets) return KICP_OK;
+    if ((__atomic_load_n(&r->rec->reserved[0], __ATOMIC_RELAXED) == 0u && !r->acc_dirty) || !r->d_tickets) return KICP_OK;
     if (int rc = aql_quiesce(r)) return rc;
     r->stream_dirty = true;
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, (r->partial_blocks / kGroup + 2) * kTicketStride * sizeof(unsigned int), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, (r->partial_blocks / kGroup + 2) * kAccStride * sizeof(unsigned long long), r->stream));
     __atomic_store_n(&r->rec->reserved[0], 0u, __ATOMIC_RELAXED);
+    r->acc_dirty = false;
     return KICP_OK;
 }
 
@@ -787,7 +794,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
-    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
+    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     if (pl.generic)
         if (int rc = clear_stale_tickets(r)) return rc;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
@@ -839,6 +846,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             }
             if (int rc = rc_rows) {
                 if (k + 1 < cnt) send_command(r, sp.seq_base + k + 1, kCmdStop, loop.T);
+                r->acc_dirty = true;
                 return rc;
             }
             if (gave_up) {  // (part of) the kernel left while this thread was away: run this pass and the rest in a fresh launch
@@ -916,7 +924,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     PassParams pp{};
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
-    pp.partials = r->d_partials, pp.tickets = r->d_tickets;
+    pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc;
     pp.dbg = r->dbg;
     SolveParams &sp = pp.sol;
     sp.pose0 = T0, sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
@@ -1174,7 +1182,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.dbg = r->dbg;
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
-    pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
+    pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
     sp.scans = r->d_scans;
@@ -1208,6 +1216,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         budget = 0, stop_sent = true;
     };
     auto leave = [&](int rc) {  // hand back what is complete from the front; the caller's plain loop takes the rest
+        if (out > 0 || rc != KICP_OK) r->acc_dirty = true;  // (passes still out will not be collected)
         stop_kernel();
         while (front < count && complete[front]) ++front;
         *done = front;
@@ -1410,6 +1419,7 @@ void kicp_reg_destroy(kicp_reg *reg) {
     reg->stage.release();
     if (reg->d_partials) hipFree(reg->d_partials);
     if (reg->d_tickets) hipFree(reg->d_tickets);
+    if (reg->d_group_acc) hipFree(reg->d_group_acc);
     if (reg->d_frame) hipFree(reg->d_frame);
     if (reg->ev0) hipEventDestroy(reg->ev0);
     if (reg->ev1) hipEventDestroy(reg->ev1);
