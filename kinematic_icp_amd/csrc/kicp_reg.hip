@@ -168,6 +168,9 @@ struct kicp_reg {
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
     int last_small = 0;           // 1 when the last registration ran on the small path
     int resident_generic = 1;     // option "resident_generic": scans beyond the small-scan kernels keep the generic kernel resident for a call's later iterations
+    int batch_queues = 4;         // option "batch_queues": large scans of a batch in flight at a time, each on a queue of its own (run_batch_queues); < 2: off
+    std::vector<kicp_reg *> batch_lanes;  // the handles those queues belong to (clones of this one, made on first use)
+    unsigned long long batch_queue_passes = 0;  // passes served that way so far (get-only "batch_queue_passes")
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
@@ -1302,6 +1305,150 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     return KICP_OK;
 }
 
+
+// kicp_register_device_batch, large scans: SEVERAL SCANS IN FLIGHT ON SEVERAL QUEUES, one host thread.  The scans of a batch do
+// not depend on each other - every one starts from its own pose, the map does not change - so the call keeps option
+// "batch_queues" (default 4) of them going at a time, each on a handle of its own (clones of the caller's, made on first use and
+// kept): own HSA queue, own reduction scratch and rows.  Every pass is an ordinary launch of the pass kernel in its
+// four-waves-per-SIMD build (the latency-oriented build fills the register file with ONE scan's waves and leaves no room for a
+// second scan's next to them); the device takes workgroups from all queues as wave slots fall free, so a pass's slow workgroups
+// no longer hold anything up - the next scan's workgroups fill the slots the fast ones have left - and the host's answer to one
+// scan's rows (add, solve, next launch: ~2 us) is hidden behind the other scans' searches.  This thread goes round the scans in
+// flight: rows complete -> Registration.cpp:119-125, 159-167, 184 on the host -> next pass or next scan.
+// What kicp_register_device_concurrent does with a host thread per lane, done by one thread that never sleeps on a lane.
+// Returns 1 when the batch is not one for this path (the caller goes on to run_batch_resident / the plain loop), else a kicp
+// status; *done = scans completed from the front.
+constexpr int kMaxBatchQueues = 8;
+struct BatchFlight {
+    kicp_reg *h = nullptr;
+    HostLoop loop;
+    PassParams pp{};
+    size_t k = 0, groups = 0;
+    bool active = false;
+    unsigned polls = 0;
+    Deadline since;
+};
+// one sweep over the rows of a flight's pass: 1 complete (sums in out_words), 0 not yet, < 0 error
+int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
+    kicp_reg *h = f.h;
+    const uint32_t tag = f.pp.sol.tag;
+    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+    for (size_t g = 0; g < f.groups; ++g) {
+        const unsigned long long *row = h->rows + g * kReduceWords;
+        for (int i = 0; i < kReduceWords; ++i) {
+            const unsigned long long w = __atomic_load_n(row + i, __ATOMIC_RELAXED);
+            if ((static_cast<uint32_t>(w) & 0xFFFFu) != tag) {
+                if (++f.polls % 256u == 0u) {
+                    if (h->last_via_aql) {
+                        if (h->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(h->aql.queue_error));
+                    } else {  // (the query makes the runtime flush commands it may still hold back, and reports device faults)
+                        const hipError_t q = hipStreamQuery(h->stream);
+                        if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                    }
+                    if (f.since.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
+                }
+                return 0;
+            }
+            out_words[i] += static_cast<long long>(w) >> 16;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 1;
+}
+int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, size_t n, double tau) {
+    kicp_reg *h = f.h;
+    const uint32_t grid = pass_grid(h, n);
+    f.groups = (grid + kGroup - 1) / kGroup;
+    if (int rc = ensure_partials(h, grid)) return rc;
+    if (int rc = ensure_rows(h, f.groups)) return rc;
+    PassParams &pp = f.pp;
+    pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = h->d_state;
+    pp.search = search_params(tau, map->mirror.view.voxel_size);
+    pp.partials = h->d_partials, pp.tickets = h->d_tickets, pp.group_acc = h->d_group_acc, pp.dbg = 0;
+    SolveParams &sp = pp.sol;
+    sp.pose0 = f.loop.T, sp.pass = f.loop.iter, sp.mode = 4, sp.max_iterations = h->cfg.max_num_iterations;
+    sp.convergence_criterion = h->cfg.convergence_criterion, sp.call_id = ++h->call_id, sp.rec = h->d_rec, sp.pub_rows = h->d_rows;
+    if (int rc = next_tag(h, &sp.tag)) return rc;
+    f.polls = 0, f.since = Deadline();
+    return launch_pass(h, pp, true);
+}
+int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
+                     const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
+    *done = 0;
+    const int queues = std::min(r->batch_queues, kMaxBatchQueues);
+    const int max_it = r->cfg.max_num_iterations;
+    if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
+    if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
+          r->wait_mode == 0 && r->dbg == 0))
+        return 1;
+    for (size_t k = 0; k < count; ++k) {  // large scans only: the small-scan kernels (kicp_small.hpp) keep their own way through a batch
+        if (n[k] == 0) return 1;
+        if (r->use_small) {
+            const SmallPlan pl = small_plan(r, n[k]);
+            if (pl.grid && !pl.generic) return 1;
+        }
+    }
+    if (int rc = set_device(r->device)) return rc;
+    const uint64_t epoch_before = map->mirror.synced_epoch;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;
+    if (map->mirror.synced_epoch != epoch_before) HIP_TRY(hipStreamSynchronize(r->stream));  // (the lanes only read the copy)
+    while (static_cast<int>(r->batch_lanes.size()) < queues) {
+        kicp_reg *c = nullptr;
+        if (int rc = kicp_reg_clone(r, &c)) return rc;
+        r->batch_lanes.push_back(c);
+    }
+    BatchFlight flights[kMaxBatchQueues];
+    for (int j = 0; j < queues; ++j) {
+        kicp_reg *h = r->batch_lanes[j];
+        h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
+        h->query_every = r->query_every, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
+        flights[j].h = h;
+    }
+    r->last_small = 0, r->last_resident_passes = 0;
+    std::vector<unsigned char> complete(count, 0);
+    size_t next_scan = 0, front = 0, finished_scans = 0;
+    auto leave = [&](int rc) {  // nothing of this call may still be running when it returns: the caller owns the frames
+        for (int j = 0; j < queues; ++j) {
+            (void)aql_quiesce(flights[j].h);
+            (void)hipStreamSynchronize(flights[j].h->stream);
+        }
+        while (front < count && complete[front]) ++front;
+        *done = front;
+        return rc;
+    };
+    while (finished_scans < count) {
+        for (int j = 0; j < queues; ++j) {
+            BatchFlight &f = flights[j];
+            if (!f.active) {
+                if (next_scan >= count) continue;
+                f.k = next_scan++, f.active = true;
+                f.loop = HostLoop();
+                f.loop.T = pose_mul(pose_from(last_poses_qt + 7 * f.k), pose_from(rel_odoms_qt + 7 * f.k));  // Registration.cpp:156
+                if (int rc = flight_launch(f, map, d_frames[f.k], n[f.k], tau)) return leave(rc);
+                continue;
+            }
+            long long words[kReduceWords];
+            const int ready = flight_rows(f, words);
+            if (ready < 0) return leave(ready);
+            if (ready == 0) continue;
+            if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
+                return leave(fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)"));
+            ++r->batch_queue_passes;
+            if (!f.loop.step(f.h, words, nullptr)) {
+                if (int rc = flight_launch(f, map, d_frames[f.k], n[f.k], tau)) return leave(rc);
+                continue;
+            }
+            pose_to(f.loop.T, out_poses_qt + 7 * f.k);
+            if (out_iterations) out_iterations[f.k] = f.loop.iter;
+            complete[f.k] = 1, f.active = false, ++finished_scans;
+            if (f.loop.nan_flag == 2) return leave(fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)"));
+            if (f.loop.nan_flag) *worst = std::max(*worst, static_cast<int>(KICP_WARN_NO_CORRESPONDENCES));
+        }
+    }
+    *done = count;
+    return KICP_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1400,6 +1547,8 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
 }
 void kicp_reg_destroy(kicp_reg *reg) {
     if (!reg) return;
+    for (kicp_reg *lane : reg->batch_lanes) kicp_reg_destroy(lane);
+    reg->batch_lanes.clear();
     hipSetDevice(reg->device);
     if (reg->comm) g_comm.CommDestroy(reg->comm);
     (void)reg->aql.drain(5.0);
@@ -1456,6 +1605,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
+    else if (k == "batch_queues") reg->batch_queues = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues);
     else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
@@ -1506,6 +1656,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "batch_resident") return reg->batch_resident;
     if (k == "batch_depth") return reg->batch_depth;
     if (k == "batch_rotate") return reg->batch_rotate;
+    if (k == "batch_queues") return reg->batch_queues;
+    if (k == "batch_queue_passes") return static_cast<double>(reg->batch_queue_passes);
     if (k == "batch_resident_passes") return static_cast<double>(reg->batch_resident_passes);
     if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
@@ -1560,7 +1712,13 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
     for (size_t k = 0; k < count; ++k)
         if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
     size_t first = 0;
-    if (reg && map) {  // the generic kernel resident across the batch's scans, where the batch is one for it
+    if (reg && map) {  // large scans: several in flight, a queue each
+        const int rc = run_batch_queues(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt, out_iterations,
+                                        &first, &worst);
+        if (rc < 0) return rc;
+        if (rc != 1 && first == count) return worst;
+    }
+    if (reg && map && first == 0) {  // a pass kernel resident across the batch's scans, where the batch is one for it
         const int rc = run_batch_resident(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
                                           out_iterations, &first, &worst);
         if (rc < 0) return rc;
@@ -1706,7 +1864,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues;
     *out = c;
     return KICP_OK;
 }

@@ -224,10 +224,12 @@ def test_copies_of_a_registration_handle_are_independent():
     assert twin.last_stats.iterations == 1
 
 
-def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop():
-    """kicp_register_device_batch keeps the generic kernel on the device across the scans of a batch ("batch_resident"): scans of
-    different sizes and iteration counts, the zero-correspondence scan in the middle, a kernel that gives up half-way (the plain
-    loop takes over) - all bit-equal to one call per scan."""
+@pytest.mark.parametrize("depth,rotate", [(1, 1), (2, 0), (3, 1), (4, 1)])
+def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop(depth, rotate):
+    """kicp_register_device_batch keeps the generic kernel on the device across the scans of a batch ("batch_resident", here without
+    the several-queues mode that large scans take by default), with `depth` scans in flight: scans of different sizes and
+    iteration counts, the zero-correspondence scan in the middle, a kernel that gives up half-way (the plain loop takes over) -
+    all bit-equal to one call per scan."""
     maps, src = _big_world(n_map=60000, n_src=20000, seed=21)
     g = maps[0]
     shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03, 0.01, -0.02, 0.04]  # (nine scans: the mode is for batches of eight and more)
@@ -237,11 +239,11 @@ def test_batch_with_the_kernel_resident_across_scans_equals_the_plain_loop():
     lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(9)]
     rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(9)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
-    plain = _reg({"batch_resident": 0}, **CFG)
+    plain = _reg({"batch_resident": 0, "batch_queues": 0}, **CFG)
     b0 = plain.prepare_batch(dev, lasts, rels)
     want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
     assert plain.get_option("batch_resident_passes") == 0.0 and plain.last_status == K.KICP_WARN_NO_CORRESPONDENCES
-    reg = _reg({}, **CFG)
+    reg = _reg({"batch_queues": 0, "batch_depth": depth, "batch_rotate": rotate}, **CFG)
     b1 = reg.prepare_batch(dev, lasts, rels)
     for _ in range(3):
         got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
@@ -273,15 +275,16 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(9)]
     rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(9)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
-    plain = _reg({"batch_resident": 0}, **CFG)
+    plain = _reg({"batch_resident": 0, "batch_queues": 0}, **CFG)
     b0 = plain.prepare_batch(dev, lasts, rels)
     want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
-    reg = _reg({}, **CFG)
+    reg = _reg({}, **CFG)  # (small scans never take the several-queues mode)
     b1 = reg.prepare_batch(dev, lasts, rels)
     for _ in range(3):
         got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
         assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
     assert reg.get_option("batch_resident_passes") >= 3 * (sum(b0.iterations) - 10) and reg.get_option("small_active") == 2.0
+    assert reg.get_option("batch_queue_passes") == 0.0
     for k in (0, 1, 2, 4, 8):
         o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
         np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
@@ -298,6 +301,46 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     assert reg.get_option("batch_resident_passes") == served
 
 
+@pytest.mark.parametrize("queues", [2, 4, 8])
+def test_batch_with_several_scans_in_flight_on_queues_of_their_own_equals_the_plain_loop(queues):
+    """kicp_register_device_batch, large scans, default: "batch_queues" scans in flight at a time, each on a handle and HSA queue
+    of its own, one host thread going round them - scans of different sizes and iteration counts, a zero-correspondence scan, a
+    change of max_num_iterations between calls (the lanes follow the caller's configuration): bit-equal to one call per scan."""
+    maps, src = _big_world(n_map=60000, n_src=20000, seed=29)
+    g = maps[0]
+    count = 19
+    sizes = [20000, 12000, 9000, 20000, 15000, 10000, 16000, 9500, 20000, 17000] * 2
+    shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03, 0.01, -0.02, 0.04, 0.06] * 2
+    frames = [src[:k] - np.array([d, 0.0, 0.0]) for k, d in zip(sizes[:count], shifts[:count])]
+    frames[6] = np.full((9000, 3), 400.0)  # no correspondence at all
+    lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(count)]
+    rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(count)]
+    dev = [K.DeviceFrame(f, device=0) for f in frames]
+    plain = _reg({"batch_resident": 0, "batch_queues": 0}, **CFG)
+    b0 = plain.prepare_batch(dev, lasts, rels)
+    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    reg = _reg({"batch_queues": queues}, **CFG)
+    b1 = reg.prepare_batch(dev, lasts, rels)
+    for _ in range(3):
+        got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+        assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
+        assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+    assert reg.get_option("batch_queue_passes") >= 3 * count and reg.get_option("batch_resident_passes") == 0.0
+    assert max(b0.iterations[:4]) >= 2
+    for k in (0, 1, 3):  # ... and to the oracle
+        o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
+        np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
+    plain.max_num_iterations_ = reg.max_num_iterations_ = 1
+    want1 = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    got1 = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+    assert np.array_equal(got1, want1, equal_nan=True) and set(b1.iterations) == {1}
+    # a batch too short for the mode (fewer than two scans per queue) goes the other ways, same bits
+    served = reg.get_option("batch_queue_passes")
+    short0, short1 = plain.prepare_batch(dev[:3], lasts[:3], rels[:3]), reg.prepare_batch(dev[:3], lasts[:3], rels[:3])
+    assert np.array_equal(reg.ComputeRobotMotionBatch(short1, g, 0.5), plain.ComputeRobotMotionBatch(short0, g, 0.5), equal_nan=True)
+    assert reg.get_option("batch_queue_passes") == served
+
+
 @pytest.mark.parametrize("n_src", [1500, 9000])
 def test_a_batch_longer_than_one_resident_launch_serves(n_src):
     """a resident launch serves at most 1 024 passes (= tags): a batch of 320 scans x ~4 iterations is relaunched on the way, in the
@@ -311,7 +354,7 @@ def test_a_batch_longer_than_one_resident_launch_serves(n_src):
     lasts = [syn.planar_pose(rng.uniform(-0.02, 0.02), 0.0, rng.uniform(-0.002, 0.002)) for _ in range(count)]
     rels = [syn.planar_pose(rng.uniform(-0.01, 0.01), 0.0, 0.0005) for _ in range(count)]
     four = dict(CFG, max_num_iteration=4, convergence_criterion=0.0)  # every scan runs exactly four iterations
-    plain, reg = _reg({"batch_resident": 0}, **four), _reg({}, **four)
+    plain, reg = _reg({"batch_resident": 0, "batch_queues": 0}, **four), _reg({"batch_queues": 0}, **four)
     b0, b1 = plain.prepare_batch(dev, lasts, rels), reg.prepare_batch(dev, lasts, rels)
     want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
     got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
