@@ -4,9 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one BATCH of --scans-per-step (default 64) ComputeRobotMotion calls (all ICP iterations of each scan; the batch
-is ONE call of the C-ABI's kicp_register_device_batch, which registers the scans strictly one after the other - what a C++
-caller sees; the rate with one Python call per scan is reported next to it in `config`) on
+One "step" = one BATCH of ComputeRobotMotion registrations (all ICP iterations of each scan; the batch is ONE call of the C-ABI's
+kicp_register_device_batch - a queue of INDEPENDENT scans against the fixed map, of which the library keeps several in flight at a
+time, every result bit-identical to registering that scan alone; the rate with ONE scan in flight at a time is reported beside it,
+top-level `value_one_scan_in_flight`, and the rate with one Python call per scan in `config`) on
 synthetic data of BASELINE.json's headline config: cfg2 = 64-beam x 2048 = 131 072-point scan vs a ~1M-point voxel map
 (voxel 1.0 m, 20 pts/voxel), default ICP parameters (max 10 iterations, 1e-3 stop, adaptive regularisation), tau =
 first-frame adaptive value.  Inputs (scans, map mirror) are resident in HBM when the timed region starts; map
@@ -58,6 +59,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCLK_GHZ = 2.4          # same guide: max engine clock 2400 MHz (the sustained clock under load is lower: the bound is optimistic)
 L2_PEAK_GBS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 MULTI_ITER_ERROR = (0.05, 0.5)  # extra odometry error of the multi-iteration workload: metres along x, degrees of yaw
 
@@ -262,9 +264,9 @@ def main():
 
     def timed(reg, rels, steps, warmup, per_call=False, w=None, B=None):
         """W untimed warm-up steps, then EXACTLY `steps` steps of B scans between barriers; max over ranks.
-        A step is ONE kicp_register_device_batch call: the library registers the step's B scans one after the other (a plain
-        loop of ComputeRobotMotion, each scan run to completion before the next starts) - what a C++ caller of the C-ABI
-        sees.  per_call=True issues the B calls from Python instead (adds the interpreter's ~3 us per call).  The host clock is
+        A step is ONE kicp_register_device_batch call on the step's B independent scans (how many of them the library has in
+        flight at a time is the handle's business: options batch_queues / batch_depth) - what a C++ caller of the C-ABI sees.
+        per_call=True issues the B calls from Python instead, one scan at a time (adds the interpreter's ~3 us per call).  The host clock is
         read between steps (no synchronisation of any kind: a step ends when its last pose is back), for the median step."""
         w = w or wl
         B = B or state["B"]
@@ -362,15 +364,38 @@ def main():
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
     resident_batch = reg.get_option("batch_resident_passes") > 0
-    if resident_batch:
+    queued_batch = reg.get_option("batch_queue_passes") > 0
+    queues = int(reg.get_option("batch_queues")) if queued_batch else 0
+    depth = int(reg.get_option("batch_depth"))
+    if queued_batch:
+        launch_path += ("; inside a batch call %d scans are in flight at a time, each on a handle and HSA queue of its own (clones of the caller's), every pass "
+                        "an ordinary launch of the pass kernel's four-waves-per-SIMD build, ONE host thread going round the scans in flight (rows complete -> "
+                        "solve -> next launch): option batch_queues" % queues)
+    elif resident_batch:
         launch_path += ("; inside a batch the pass kernel stays RESIDENT across the batch's scans (one launch per batch call, every pass - a scan's first "
-                        "one included - started by a command the kernel polls: option batch_resident)")
+                        "one included - started by a command the kernel polls: option batch_resident), with up to %d scans of the batch in flight "
+                        "(option batch_depth)" % depth)
+    in_flight = queues if queued_batch else (depth if resident_batch else 1)
+    # the same batch calls with ONE scan in flight at a time (the batch's scans strictly one after the other: what a caller gets whose
+    # next scan depends on the previous result) - informational, next to the headline
+    elapsed_serial = None
+    if in_flight > 1 and not exchange:
+        reg_serial = reg.copy()
+        reg_serial.set_option("batch_queues", 0), reg_serial.set_option("batch_depth", 1)
+        elapsed_serial = timed(reg_serial, rel_single, max(2, args.steps // 4), 1)
+        serial_steps = max(2, args.steps // 4)
+        del reg_serial
     small_kind = int(reg.get_option("small_active"))  # 0 generic pass kernel; small-scan path (kicp_small.hpp): 1 sub-lanes per query, 2 one wave per query
     small_active = small_kind > 0
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
     elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
     # ---- second pass over the same steps with HIP events around every pass-kernel launch (roofline) -------------
+    # (with several scans in flight the timed region launches the four-waves-per-SIMD build of the pass kernel: that is the build
+    #  timed here, one launch at a time, and the one the floor, the census and the PMC passes look at)
+    latency_kernel_option = reg.get_option("latency_kernel")
+    if queued_batch:
+        reg.set_option("latency_kernel", 0)
     reg.set_option("timing", 2)
     per_call, per_call_multi = [], []
     n_ev = min(args.steps * B, 2048)
@@ -404,6 +429,7 @@ def main():
         rounds_per_wave = float(np.mean(rr))
         reg.set_option("dbg", 0)
     reg.set_option("timing", 0)
+    reg.set_option("latency_kernel", latency_kernel_option)
     poses = [run_scan(reg, i, rel_single) for i in range(len(scans))]
     poses_multi = [run_scan(reg, i, rel_multi) for i in range(len(scans))]
     barrier()
@@ -630,17 +656,39 @@ def main():
                            "shape - 131 072 lanes, a random line each: bandwidth, not latency - is given beside it); rounds = mean visiting "
                            "rounds per wave counted by the kernel (dbg 10); floor = the same launch with every query off (launch, reduction, "
                            "hand-off; HIP events).  frac_latency = latency_bound_us / kernel_avg_us (1 = at the bound)"}
+    # ---- the timed region's own figure: passes overlap there (several scans in flight), so what one pass costs is wall clock per
+    #      pass, and what bounds THAT is the machine's throughput, not one wave's chain: the SIMDs' VALU issue slots.  A wave64 VALU
+    #      instruction occupies its SIMD for 4 cycles; instructions per launch from the committed counter profile (SQ_INSTS_VALU).
+    us_per_pass = 1e6 * elapsed / n_scans_timed / max(iters_gpu, 1e-9)
+    valu_issue = None
+    insts = ((prof or {}).get("raw", {}).get("SQ_INSTS_VALU", {}) or {}).get("mean_per_dispatch") if prof else None
+    if insts and world == 1:
+        simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+        bound = insts * 4.0 / (simds * SCLK_GHZ * 1e3)
+        valu_issue = {"insts_valu_per_launch": round(insts), "cycles_per_wave_instruction": 4, "simds": simds, "sclk_GHz": SCLK_GHZ,
+                      "bound_us_per_pass": round(bound, 2), "frac": round(bound / us_per_pass, 4),
+                      "what": "wave-level VALU instructions of one pass (SQ_INSTS_VALU per dispatch of the pass kernel, %s) x 4 cycles / (%d SIMDs x "
+                              "%.1f GHz): the time the machine's VALU issue slots need for one pass if they never idle; frac = that / the wall clock "
+                              "per pass of the timed region" % (prof.get("source", "profiles/"), simds, SCLK_GHZ)}
     roof = {"bound": "hbm", "achieved": None if traffic_gbs is None else round(traffic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 4),
             "frac_latency": None if latency is None else round(latency["latency_bound_us"] / kernel_us, 4),
             "latency_model": latency,
             "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
             "kernel": "fused association+accumulation pass (%s)" % kernel_sub, "kernel_avg_us": round(kernel_us, 2),
-            "kernel_in_the_timed_region": None if not resident_batch else
-            {"kernel": "k_pass_resident (generic scans) / k_pass_wave (small scans): the same pass code, resident across the scans of one "
-                       "kicp_register_device_batch call - ONE dispatch per step, so a kernel trace of this command shows it with an average duration "
-                       "of about ms_per_step, and %s with the per-pass duration quoted here (the event-timed calls, one launch per pass)" % kernel_sub,
-             "us_per_pass_wall_clock": round(1e6 * elapsed / n_scans_timed / max(iters_gpu, 1e-9), 3)},
+            "kernel_in_the_timed_region": None if not (resident_batch or queued_batch) else
+            {"kernel": ("k_pass_gather32 in its four-waves-per-SIMD build, one launch per pass on %d HSA queues at a time (one per scan in flight): a kernel "
+                        "trace of this command shows it with an average duration of about scans_in_flight x us_per_pass_wall_clock - the launches "
+                        "overlap - while kernel_avg_us above is ONE launch at a time (the event-timed calls)" % queues) if queued_batch else
+                       ("k_pass_resident (generic scans) / k_pass_wave (small scans): the same pass code, resident across the scans of one "
+                        "kicp_register_device_batch call - ONE dispatch per step, so a kernel trace of this command shows it with an average duration "
+                        "of about ms_per_step, and %s with the per-pass duration quoted here (the event-timed calls, one launch per pass)" % kernel_sub),
+             "scans_in_flight": in_flight,
+             "us_per_pass_wall_clock": round(us_per_pass, 3),
+             "kernel_avg_us_expected_in_a_trace": round(in_flight * us_per_pass, 2) if queued_batch else None,
+             "hbm_GBps_sustained": None if traffic is None else round(traffic / (us_per_pass * 1e-6) / 1e9, 1),
+             "hbm_frac_sustained": None if traffic is None else round(traffic / (us_per_pass * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+             "valu_issue": valu_issue},
             "kernel_time_source": kernel_time_source, "launches_timed": int(pass_ms.size),
             "what": "achieved = HBM bytes the pass kernel moved per launch (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) / its "
                     "average duration; frac = achieved / 8 TB/s.  The kernel is bound by its waves' dependent-load chains and a fixed launch + "
@@ -664,6 +712,7 @@ def main():
     out = {
         "metric": "scans/sec (ICP registration only), 128k-pt scan vs 1M-pt map",
         "value": round(value, 2),
+        **({} if elapsed_serial is None else {"value_one_scan_in_flight": round(serial_steps * B / elapsed_serial, 2)}),
         "unit": "scans/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -675,10 +724,13 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-beam scan vs %d-pt / %d-voxel map, voxel %.2f m, tau %.4f m, default ICP iterations "
-                               "(mean %.2f per scan, reference %.2f); one step = one kicp_register_device_batch call = %d scans registered one after the other; "
+                               "(mean %.2f per scan, reference %.2f); one step = one kicp_register_device_batch call = %d independent scans against the fixed map, %s; "
                                "%d distinct scans cycled"
                                % (cfg.name, n_total, cfg.n_beams, gmap.num_points(), gmap.num_voxels(), cfg.voxel_size, tau, iters_gpu,
-                                  float(np.mean(iters_ref)), B, len(scans)),
+                                  float(np.mean(iters_ref)), B,
+                                  ("up to %d in flight at a time (every scan's result bit-identical to registering it alone)" % in_flight) if in_flight > 1
+                                  else "registered one after the other", len(scans)),
+                   "scans_in_flight": in_flight,
                    "scans_per_step": B, "distinct_scans": len(scans), "ms_per_scan": round(1e3 * elapsed / n_scans_timed, 5), "timed_region_s": round(elapsed, 4),
                    "batch_resized_after_short_timed_region": resized,
                    "ms_per_step_median": round(1e3 * med_step, 5),
@@ -834,7 +886,7 @@ def _pmc_traffic(workload, kernel_sub, calls=200):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="kicp_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "prof_target.py"), "--workload", workload,
-               "--calls", str(calls)]
+               "--calls", str(calls)] + (["--batch", "64"] if kernel_sub == "k_pass_gather32" else [])
         try:
             r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
             vals = []

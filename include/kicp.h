@@ -162,10 +162,18 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
  *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
  *                  the last call that a resident launch of the generic kernel served
- *   "batch_resident" 1 (default): kicp_register_device_batch - for batches of eight scans and more - keeps that resident kernel on the device ACROSS the scans of a batch (the
- *                  scans are still registered strictly one after the other; what starts a scan's first pass is a polled command
- *                  instead of a dispatch; the batch's scan table travels with the launch); 0: every scan of a batch is a call of its
- *                  own.  "batch_resident_passes" (read only): passes served that way so far
+ *   "batch_queues" (default 4, 0 .. 8): kicp_register_device_batch keeps this many LARGE scans (those of the generic pass kernel) in
+ *                  flight at a time, each on a handle and HSA queue of its own; < 2: off.  "batch_queue_passes" (read only): passes
+ *                  served that way so far
+ *   "batch_resident" 1 (default): kicp_register_device_batch - for batches of eight scans and more that "batch_queues" does not
+ *                  take - keeps ONE resident kernel on the device ACROSS the scans of a batch (what starts a pass is a polled
+ *                  command naming its scan instead of a dispatch; the batch's scan table travels with the launch); 0: every scan
+ *                  of such a batch is a call of its own.  "batch_resident_passes" (read only): passes served that way so far
+ *   "batch_depth"  (default 3, 1 .. 4): scans of the batch that kernel has in flight - the host answers the rows of pass k while the
+ *                  workgroups search passes k + 1 .. k + depth - 1, which belong to other scans; 1: one scan at a time
+ *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
+ *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
+ *                  256 b .. 256 b + 255
  *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
  *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
  *                  wave_block 0 = by scan size, default)
@@ -209,11 +217,24 @@ int kicp_register_f32(kicp_reg *reg, kicp_map *map, const float *frame_xyz_f32, 
 int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz, size_t n, const double last_pose_qt[7],
                          const double rel_odom_qt[7], double max_correspondence_distance, double out_pose_qt[7],
                          kicp_stats *stats);
-/* A queue of INDEPENDENT registrations against one map (several robots on one map, replayed scans): exactly a loop of
- * kicp_register_device over `count` scans - every scan runs launch -> hand-off -> solve to completion before the next one
- * starts, nothing is overlapped - without a language binding's per-call cost in between.  Poses: count x 7 doubles.
- * `out_iterations` (nullable): ICP iterations each scan ran.  Stops at the first error (< 0); otherwise returns the
- * largest warning code seen (KICP_OK if none). */
+/* A queue of INDEPENDENT registrations against one map (several robots on one map, replayed scans), without a language
+ * binding's per-call cost in between.  Every pose is bit-equal to what kicp_register_device returns for that scan alone; the
+ * scans share nothing but the read-only map, which must not be updated during the call.  Because the scans do not depend on each
+ * other, the call keeps SEVERAL OF THEM IN FLIGHT (one host thread - the caller's - drives them all):
+ *   - scans that take the generic pass kernel (more than 4 096 points by default), batches of at least two scans per queue:
+ *     option "batch_queues" (default 4) scans at a time, each on a handle + HSA queue of its own (clones of `reg`, created on
+ *     first use and kept until kicp_reg_destroy(reg); they follow reg's configuration and kernel-shape options at every call),
+ *     every pass an ordinary launch of the four-waves-per-SIMD build; the thread goes round the scans in flight: rows complete ->
+ *     solve -> next pass or next scan;
+ *   - otherwise, batches of eight scans and more of one kind (all small, or all up to 131 072 points): ONE kernel resident across
+ *     the batch's scans ("batch_resident"), option "batch_depth" (default 3, at most 4) scans in flight - the command that starts a
+ *     pass names the scan it belongs to, and the command of pass k + depth goes out when the rows of pass k are in;
+ *   - anything else, and "batch_queues" 0 with "batch_depth" 1 or "batch_resident" 0: the scans strictly one after the other
+ *     (every scan runs launch -> hand-off -> solve to completion before the next one starts) - what a caller needs whose next
+ *     scan depends on the previous result, and what kicp_register_device gives one call at a time.
+ * Poses: count x 7 doubles.  `out_iterations` (nullable): ICP iterations each scan ran.  Returns the first error (< 0) - scans
+ * after the first one that failed are then unspecified (some of them may have completed), nothing of the call is still running
+ * on the device - otherwise the largest warning code seen (KICP_OK if none). */
 int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const double *const *d_frames_xyz, const size_t *n,
                                const double *last_poses_qt, const double *rel_odoms_qt, double max_correspondence_distance,
                                double *out_poses_qt, int *out_iterations);

@@ -412,8 +412,9 @@ class KinematicRegistration:
         return b
 
     def ComputeRobotMotionBatch(self, batch, voxel_map, max_correspondence_distance):
-        """kicp_register_device_batch: the batch's scans one after the other (a plain loop of ComputeRobotMotion inside the
-        library, nothing overlapped).  Returns the (count, 7) poses; batch.iterations holds the iteration counts."""
+        """kicp_register_device_batch: a queue of INDEPENDENT scans against one map; the library keeps several of them in flight
+        (options "batch_queues" / "batch_depth"; 0 and 1: strictly one after the other), every pose bit-equal to
+        ComputeRobotMotionDevice on that scan alone.  Returns the (count, 7) poses; batch.iterations holds the iteration counts."""
         rc = _lib.kicp_register_device_batch(self._h, voxel_map._h, batch.count, batch.ptrs, batch.ns, batch.last.ctypes.data_as(_dp),
                                              batch.rel.ctypes.data_as(_dp), max_correspondence_distance, batch.out.ctypes.data_as(_dp),
                                              batch.iterations.ctypes.data_as(C.POINTER(C.c_int)))

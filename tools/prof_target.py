@@ -1,7 +1,7 @@
 """Profiling target: N registrations of one BASELINE workload with nothing else in the process (the map is built on the
 device, which takes seconds even for cfg5's 10M points), for rocprofv3 --pmc / --kernel-trace passes.
 
-    python tools/prof_target.py --workload cfg2 --calls 300 [--multi] [--build host]
+    python tools/prof_target.py --workload cfg2 --calls 300 [--multi] [--build host] [--batch 64]
 Prints one line of JSON with the wall-clock rate and the mean pass-kernel time from HIP events (un-profiled reference).
 """
 import argparse
@@ -25,6 +25,7 @@ ap.add_argument("--multi", action="store_true", help="the multi-iteration varian
 ap.add_argument("--build", default="device", choices=["device", "host"])
 ap.add_argument("--events", action="store_true", help="HIP events around every pass (adds two event records per launch)")
 ap.add_argument("--option", action="append", default=[], help="name=value registration options")
+ap.add_argument("--batch", type=int, default=0, help="register through kicp_register_device_batch calls of this many scans (what bench.py times) instead of one call per scan")
 args = ap.parse_args()
 
 cfg, scene, scans, rng = syn.make_case(args.workload, n_scans=4)
@@ -48,11 +49,20 @@ for o in args.option:
 if args.events:
     reg.set_option("timing", 2)
 pass_ms, iters = [], []
-for i in range(50):
+for i in range(0 if args.batch > 0 else 50):  # (batch mode: only the batch's own kernel build is dispatched in this process)
     reg.ComputeRobotMotion(frames[i % 4], gmap, scans[i % 4]["last_pose"], rels[i % 4], tau)
 K.lib().kicp_device_synchronize(0)
 t0 = time.perf_counter()
-for i in range(args.calls):
+if args.batch > 0:
+    B = args.batch
+    batch = reg.prepare_batch([frames[i % 4] for i in range(B)], [scans[i % 4]["last_pose"] for i in range(B)], [rels[i % 4] for i in range(B)])
+    done = 0
+    while done < args.calls:
+        reg.ComputeRobotMotionBatch(batch, gmap, tau)
+        iters += list(batch.iterations)
+        done += B
+    args.calls = done
+for i in range(0 if args.batch > 0 else args.calls):
     reg.ComputeRobotMotion(frames[i % 4], gmap, scans[i % 4]["last_pose"], rels[i % 4], tau)
     k = reg.last_stats.iterations
     iters.append(k)
