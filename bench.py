@@ -624,9 +624,9 @@ def main():
     #      (stamped with the commit it was taken at) where rocprofv3 cannot run.
     kernel_sub = {0: "k_pass_gather32", 1: "k_pass_small", 2: "k_pass_wave"}[small_kind]
     traffic, traffic_src = (None, "not measured (--no-pmc)") if (args.no_pmc or world != 1) else _pmc_traffic(args.workload, kernel_sub)
-    # informational, never `value`: INDEPENDENT scans with four in flight (kicp_register_device_concurrent: one handle, HSA queue
+    # informational: INDEPENDENT scans with four in flight, a host thread each (kicp_register_device_concurrent: one handle, HSA queue
     # and host thread per lane) - what the device does when a workload has several scans to offer at a time (robots sharing a
-    # map, replayed logs).  The reference's sequential pipeline cannot use it, hence not the headline.
+    # map, replayed logs).  The batch call of the timed region keeps as many in flight with ONE host thread.
     conc_lanes = 4
     conc_rate = _concurrent_rate(args.workload, conc_lanes, min(len(scans), 8)) if (world == 1 and not use_comm) else None
     prof = _profile_counters(args.workload, world)
@@ -767,7 +767,8 @@ def main():
         {"scans_per_s": round(conc_rate, 1), "lanes": conc_lanes,
          "what": "kicp_register_device_concurrent: the same scans as INDEPENDENT registrations, %d in flight (one handle + HSA queue + host thread each), "
                  "512 per call, median of 5 calls, measured by tools/bench_concurrent.py in a process of its own after everything timed here; "
-                 "a throughput mode the reference's sequential pipeline cannot use - never the headline" % conc_lanes},
+                 "the batch call of the timed region keeps as many scans in flight from ONE host thread; what neither can serve is a caller whose next "
+                 "scan depends on the previous result (the reference's own pipeline): value_one_scan_in_flight and bench_pipeline are that caller's rates" % conc_lanes},
         **top_exchange,
         **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
         **({"sharded_cfg5": sharded_cfg5} if sharded_cfg5 is not None else {}),
@@ -908,9 +909,9 @@ def _pmc_traffic(workload, kernel_sub, calls=200):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     kib = 2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]
-    return kib * 1024.0, ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `tools/prof_target.py --workload %s --calls %d` "
+    return kib * 1024.0, ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `tools/prof_target.py --workload %s --calls %d%s` "
                           "after the timed region; means over %d / %d dispatches of %s: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB; bytes = (2 x FETCH_SIZE + "
-                          "WRITE_SIZE) x 1024" % (workload, calls, means["FETCH_SIZE"][1], means["WRITE_SIZE"][1], kernel_sub, means["FETCH_SIZE"][0],
+                          "WRITE_SIZE) x 1024" % (workload, calls, " --batch 64" if kernel_sub == "k_pass_gather32" else "", means["FETCH_SIZE"][1], means["WRITE_SIZE"][1], kernel_sub, means["FETCH_SIZE"][0],
                                                    means["WRITE_SIZE"][0]))
 
 

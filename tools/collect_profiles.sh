@@ -11,14 +11,15 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python benc
 python tools/prof_summary.py $(find $O/kt_bench -name "*.db" | head -1) > $O/kernel_trace_stats.txt 2>&1; head -6 $O/kernel_trace_stats.txt
 for w in cfg2 cfg5; do
   kern=k_pass_gather32
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$w -o kt -- python tools/prof_target.py --workload $w --calls 300 > $O/kt_$w.json 2> $O/kt_$w.err
+  bt=""; [ $w = cfg2 ] && bt="--batch 64"   # cfg2: through batch calls, as bench.py times it (four scans in flight, the four-waves-per-SIMD build)
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$w -o kt -- python tools/prof_target.py --workload $w --calls 300 $bt > $O/kt_$w.json 2> $O/kt_$w.err
   python tools/prof_summary.py $(find $O/kt_$w -name "*.db" | head -1) > $O/kernel_trace_$w.txt 2>&1; grep k_pass $O/kernel_trace_$w.txt
   i=0
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" "VALUBusy" "MeanOccupancyPerCU"; do
     i=$((i+1))
-    timeout 120 rocprofv3 --pmc $c -d $O/pmc_${w}_$i -o pmc -- python tools/prof_target.py --workload $w --calls 200 > /dev/null 2> $O/pmc_${w}_$i.err || echo "pmc pass $i ($c) failed for $w"
+    timeout 120 rocprofv3 --pmc $c -d $O/pmc_${w}_$i -o pmc -- python tools/prof_target.py --workload $w --calls 200 $bt > /dev/null 2> $O/pmc_${w}_$i.err || echo "pmc pass $i ($c) failed for $w"
   done
   avg=$(grep $kern $O/kernel_trace_$w.txt | head -1 | awk '{print $(NF-3)}')
   python tools/prof_counters_json.py $O/r04_counters_$w.json $kern ${avg:-0} $(find $O/pmc_${w}_* -name "*.db") > $O/counters_$w.txt 2>&1; cat $O/counters_$w.txt | cut -c1-300
@@ -27,7 +28,8 @@ for w in cfg1 cfg4 cfg5; do timeout 400 python bench.py --workload $w --cpu-seco
 for w in cfg2 cfg5; do timeout 200 python tools/gpu_dbg.py $w; done > $O/ablation.txt 2>&1; tail -16 $O/ablation.txt
 timeout 300 python tools/trace_resident.py cfg2 > $O/trace_resident_cfg2.txt 2>&1; timeout 300 python tools/trace_resident.py cfg1 > $O/trace_resident_cfg1.txt 2>&1; tail -9 $O/trace_resident_cfg2.txt
 timeout 200 python tools/trace_small.py cfg4 > $O/trace_small_cfg4.txt 2>&1
-(for w in cfg2 cfg1 cfg4; do timeout 200 python tools/ab_option.py --workload $w --batch --calls 256 --blocks 30 --option batch_resident --values 0 1; timeout 200 python tools/ab_option.py --workload $w --batch --multi --calls 128 --blocks 30 --option batch_resident --values 0 1; done) 2>&1 | grep "^{" > $O/ab_batch_resident.txt; cut -c1-300 $O/ab_batch_resident.txt
+(for w in cfg2 cfg1 cfg4; do for m in "" "--multi"; do timeout 300 python tools/ab_option.py --workload $w --batch $m --calls 256 --blocks 24 --sets batch_queues=0,batch_resident=0 batch_queues=0,batch_depth=1 batch_queues=0,batch_depth=2,batch_rotate=0 batch_queues=0,batch_depth=2 batch_queues=0 base; done; done) 2>&1 | grep "^{" > $O/ab_batch_modes.txt; cut -c1-600 $O/ab_batch_modes.txt
+timeout 300 python tools/trace_batch.py cfg2 --depths 1 2 3 > $O/trace_batch_cfg2.txt 2>&1; timeout 200 python tools/trace_batch.py cfg4 --depths 1 3 > $O/trace_batch_cfg4.txt 2>&1; grep "per workgroup\|batch_depth" $O/trace_batch_cfg2.txt
 (timeout 200 python tools/bench_concurrent.py --workload cfg2 --lanes 1 2 4; timeout 200 python tools/bench_concurrent.py --workload cfg4 --lanes 2 4) 2>&1 | grep "^{" > $O/bench_concurrent.txt; cut -c1-300 $O/bench_concurrent.txt
 python - > $O/latency_probe.txt 2>&1 <<'PY'
 import kinematic_icp_amd as K

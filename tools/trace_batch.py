@@ -33,6 +33,7 @@ n = len(scans[0]["frame"])
 B = args.scans
 for depth in args.depths:
     reg = K.KinematicRegistration()
+    reg.set_option("batch_queues", 0)  # (the resident kernel is what is traced: large scans would otherwise go out on several queues)
     reg.set_option("batch_depth", depth)
     for o in args.fixed:
         reg.set_option(o.split("=")[0], float(o.split("=")[1]))
