@@ -922,7 +922,7 @@ def _profile_counters(workload, world):
     not been profiled: nothing is borrowed from another configuration."""
     if world != 1:
         return None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r04b", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (rnd, workload))) as f:
                 d = json.load(f)
