@@ -162,8 +162,8 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
  *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
  *                  the last call that a resident launch of the generic kernel served
- *   "batch_queues" (default 4, 0 .. 8): kicp_register_device_batch keeps this many LARGE scans (those of the generic pass kernel) in
- *                  flight at a time, each on a handle and HSA queue of its own; < 2: off.  "batch_queue_passes" (read only): passes
+ *   "batch_queues" (default 4, 0 .. 8): kicp_register_device_batch keeps this many scans in flight at a time, each on a handle and HSA
+ *                  queue of its own, when the batch holds scans for the generic pass kernel; < 2: off.  "batch_queue_passes" (read only): passes
  *                  served that way so far
  *   "batch_resident" 1 (default): kicp_register_device_batch - for batches of eight scans and more that "batch_queues" does not
  *                  take - keeps ONE resident kernel on the device ACROSS the scans of a batch (what starts a pass is a polled
@@ -221,11 +221,11 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  * binding's per-call cost in between.  Every pose is bit-equal to what kicp_register_device returns for that scan alone; the
  * scans share nothing but the read-only map, which must not be updated during the call.  Because the scans do not depend on each
  * other, the call keeps SEVERAL OF THEM IN FLIGHT (one host thread - the caller's - drives them all):
- *   - scans that take the generic pass kernel (more than 4 096 points by default), batches of at least two scans per queue:
- *     option "batch_queues" (default 4) scans at a time, each on a handle + HSA queue of its own (clones of `reg`, created on
- *     first use and kept until kicp_reg_destroy(reg); they follow reg's configuration and kernel-shape options at every call),
- *     every pass an ordinary launch of the four-waves-per-SIMD build; the thread goes round the scans in flight: rows complete ->
- *     solve -> next pass or next scan;
+ *   - batches of at least two scans per queue that hold at least one scan for the generic pass kernel (more than 4 096 points by
+ *     default): option "batch_queues" (default 4) scans at a time, each on a handle + HSA queue of its own (clones of `reg`,
+ *     created on first use and kept until kicp_reg_destroy(reg); they follow reg's configuration and kernel-shape options at every
+ *     call), every pass an ordinary launch (large scans: the four-waves-per-SIMD build; small scans in such a batch: their own
+ *     kernels, one launch per pass); the thread goes round the scans in flight: rows complete -> solve -> next pass or next scan;
  *   - otherwise, batches of eight scans and more of one kind (all small, or all up to 131 072 points): ONE kernel resident across
  *     the batch's scans ("batch_resident"), option "batch_depth" (default 3, at most 4) scans in flight - the command that starts a
  *     pass names the scan it belongs to, and the command of pass k + depth goes out when the rows of pass k are in;

@@ -1322,54 +1322,103 @@ constexpr int kMaxBatchQueues = 8;
 struct BatchFlight {
     kicp_reg *h = nullptr;
     HostLoop loop;
-    PassParams pp{};
-    size_t k = 0, groups = 0;
+    PassParams pp{};     // large scans: the pass kernel's arguments
+    SmallParams sp{};    // small scans (kicp_small.hpp): a launch that serves ONE pass and leaves
+    SmallPlan pl;
+    bool small = false;
+    size_t k = 0, rows = 0, row_next = 0;  // rows of the pass in flight: the groups' (large) / the workgroups' (small); how many are in
+    uint32_t tag = 0;
     bool active = false;
     unsigned polls = 0;
+    long long words[kReduceWords] = {};            // sums of the rows that are in (large scans: the reduce payload's layout)
+    __int128 total[kNumSums] = {};                 // (small scans: two 48-bit halves per sum and row)
+    unsigned long long flags = 0;
     Deadline since;
 };
-// one sweep over the rows of a flight's pass: 1 complete (sums in out_words), 0 not yet, < 0 error
+// the rows of a flight's pass that have arrived since the last look: 1 all in (sums in out_words), 0 not yet, < 0 error
 int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
     kicp_reg *h = f.h;
-    const uint32_t tag = f.pp.sol.tag;
-    for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
-    for (size_t g = 0; g < f.groups; ++g) {
-        const unsigned long long *row = h->rows + g * kReduceWords;
-        for (int i = 0; i < kReduceWords; ++i) {
-            const unsigned long long w = __atomic_load_n(row + i, __ATOMIC_RELAXED);
-            if ((static_cast<uint32_t>(w) & 0xFFFFu) != tag) {
-                if (++f.polls % 256u == 0u) {
-                    if (h->last_via_aql) {
-                        if (h->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(h->aql.queue_error));
-                    } else {  // (the query makes the runtime flush commands it may still hold back, and reports device faults)
-                        const hipError_t q = hipStreamQuery(h->stream);
-                        if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
-                    }
-                    if (f.since.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
+    const uint32_t tag = f.tag;
+    const int row_words = f.small ? kSmallRowWords : kReduceWords;
+    for (; f.row_next < f.rows; ++f.row_next) {
+        const unsigned long long *row = h->rows + f.row_next * row_words;
+        unsigned long long w[kReduceWords];
+        bool ok = true;
+        for (int i = 0; i < row_words; ++i) {
+            w[i] = __atomic_load_n(row + i, __ATOMIC_RELAXED);
+            ok = ok && (static_cast<uint32_t>(w[i]) & 0xFFFFu) == tag;
+        }
+        if (!ok) {
+            if (++f.polls % 256u == 0u) {
+                if (h->last_via_aql) {
+                    if (h->aql.queue_error) return fail(KICP_ERR_HIP, "the AQL queue reported error " + std::to_string(h->aql.queue_error));
+                } else {  // (the query makes the runtime flush commands it may still hold back, and reports device faults)
+                    const hipError_t q = hipStreamQuery(h->stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
                 }
-                return 0;
+                if (f.since.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
             }
-            out_words[i] += static_cast<long long>(w) >> 16;
+            return 0;
+        }
+        if (f.small) {
+            for (int i = 0; i < kNumSums; ++i)
+                f.total[i] += static_cast<__int128>(w[2 * i] >> 16) + (static_cast<__int128>(static_cast<long long>(w[2 * i + 1]) >> 16) << 48);
+            f.flags |= w[2 * kNumSums] >> 16;
+        } else {
+            for (int i = 0; i < kReduceWords; ++i) f.words[i] += static_cast<long long>(w[i]) >> 16;
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (f.small) {  // (the layout of the all-reduce payload: three 40-bit limbs per sum, then the range flag - wait_rows_small)
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
+        const unsigned __int128 m40 = (static_cast<unsigned __int128>(1) << 40) - 1;
+        for (int i = 0; i < kNumSums; ++i) {
+            const unsigned __int128 u = static_cast<unsigned __int128>(f.total[i]);
+            out_words[3 * i] = static_cast<long long>(u & m40), out_words[3 * i + 1] = static_cast<long long>((u >> 40) & m40);
+            out_words[3 * i + 2] = static_cast<long long>(f.total[i] >> 80);
+        }
+        out_words[kNumLimbs] = (f.flags & 1ull) ? 1 : 0;
+    } else {
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] = f.words[i];
+    }
     return 1;
 }
 int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, size_t n, double tau) {
     kicp_reg *h = f.h;
-    const uint32_t grid = pass_grid(h, n);
-    f.groups = (grid + kGroup - 1) / kGroup;
-    if (int rc = ensure_partials(h, grid)) return rc;
-    if (int rc = ensure_rows(h, f.groups)) return rc;
-    PassParams &pp = f.pp;
+    f.pl = h->use_small ? small_plan(h, n) : SmallPlan();
+    f.small = f.pl.grid != 0 && !f.pl.generic;
+    f.row_next = 0, f.flags = 0, f.polls = 0;
+    for (auto &w : f.words) w = 0;
+    for (auto &t : f.total) t = 0;
+    PassParams &pp = f.small ? f.sp.p : f.pp;
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = h->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
-    pp.partials = h->d_partials, pp.tickets = h->d_tickets, pp.group_acc = h->d_group_acc, pp.dbg = 0;
-    SolveParams &sp = pp.sol;
-    sp.pose0 = f.loop.T, sp.pass = f.loop.iter, sp.mode = 4, sp.max_iterations = h->cfg.max_num_iterations;
-    sp.convergence_criterion = h->cfg.convergence_criterion, sp.call_id = ++h->call_id, sp.rec = h->d_rec, sp.pub_rows = h->d_rows;
-    if (int rc = next_tag(h, &sp.tag)) return rc;
-    f.polls = 0, f.since = Deadline();
+    pp.dbg = 0;
+    SolveParams &sol = pp.sol;
+    sol.pose0 = f.loop.T, sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
+    sol.convergence_criterion = h->cfg.convergence_criterion;
+    if (f.small) {  // one wave per query / sub-lanes per query: every workgroup's row goes straight to the host; the launch serves this pass only
+        f.rows = f.pl.grid;
+        if (int rc = ensure_rows(h, (f.rows * kSmallRowWords + kReduceWords - 1) / kReduceWords)) return rc;
+        if (int rc = ensure_cmd(h)) return rc;
+        if (int rc = next_tag(h, &f.tag)) return rc;
+        SmallParams &sp = f.sp;
+        sp.cmd = h->d_cmd, sp.rows = h->d_rows, sp.cmd_dev = h->d_cmd_copies, sp.relay = (h->small_cmd == 1 && h->cmd_bar) ? 0 : 1;
+        sp.timeout_ticks = 5000, sp.trace = nullptr, sp.scans = nullptr, sp.rotate = 0;
+        sp.tag0 = f.tag, sp.max_passes = 1, sp.seq_base = h->cmd_seq;
+        h->cmd_seq += 1;
+        f.since = Deadline();
+        return launch_small(h, sp, f.pl);
+    }
+    const uint32_t grid = pass_grid(h, n);
+    f.rows = (grid + kGroup - 1) / kGroup;
+    if (int rc = ensure_partials(h, grid)) return rc;
+    if (int rc = ensure_rows(h, f.rows)) return rc;
+    pp.partials = h->d_partials, pp.tickets = h->d_tickets, pp.group_acc = h->d_group_acc;
+    sol.call_id = ++h->call_id, sol.rec = h->d_rec, sol.pub_rows = h->d_rows;
+    if (int rc = next_tag(h, &sol.tag)) return rc;
+    f.tag = sol.tag;
+    f.since = Deadline();
     return launch_pass(h, pp, true);
 }
 int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
@@ -1381,13 +1430,18 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
           r->wait_mode == 0 && r->dbg == 0))
         return 1;
-    for (size_t k = 0; k < count; ++k) {  // large scans only: the small-scan kernels (kicp_small.hpp) keep their own way through a batch
+    // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
+    // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
+    // the 4.5 us such a pass takes (measured, cfg4: 5.0 us per scan on four queues, 4.5 resident).  Mixed batches come here.
+    bool any_large = false;
+    for (size_t k = 0; k < count; ++k) {
         if (n[k] == 0) return 1;
-        if (r->use_small) {
-            const SmallPlan pl = small_plan(r, n[k]);
-            if (pl.grid && !pl.generic) return 1;
+        if (!any_large) {
+            const SmallPlan pl = r->use_small ? small_plan(r, n[k]) : SmallPlan();
+            any_large = pl.grid == 0 || pl.generic;
         }
     }
+    if (!any_large) return 1;
     if (int rc = set_device(r->device)) return rc;
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
@@ -1402,9 +1456,14 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
         kicp_reg *h = r->batch_lanes[j];
         h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
         h->query_every = r->query_every, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
+        h->use_small = r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
         flights[j].h = h;
     }
     r->last_small = 0, r->last_resident_passes = 0;
+    {
+        const SmallPlan first = r->use_small ? small_plan(flights[0].h, n[0]) : SmallPlan();
+        if (first.grid && !first.generic) r->last_small = first.wave ? 2 : 1;  // ("small_active": the path of the batch's first scan)
+    }
     std::vector<unsigned char> complete(count, 0);
     size_t next_scan = 0, front = 0, finished_scans = 0;
     auto leave = [&](int rc) {  // nothing of this call may still be running when it returns: the caller owns the frames

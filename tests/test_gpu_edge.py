@@ -278,13 +278,12 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     plain = _reg({"batch_resident": 0, "batch_queues": 0}, **CFG)
     b0 = plain.prepare_batch(dev, lasts, rels)
     want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
-    reg = _reg({}, **CFG)  # (small scans never take the several-queues mode)
+    reg = _reg({"batch_queues": 0}, **CFG)
     b1 = reg.prepare_batch(dev, lasts, rels)
     for _ in range(3):
         got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
         assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
     assert reg.get_option("batch_resident_passes") >= 3 * (sum(b0.iterations) - 10) and reg.get_option("small_active") == 2.0
-    assert reg.get_option("batch_queue_passes") == 0.0
     for k in (0, 1, 2, 4, 8):
         o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
         np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
@@ -301,18 +300,23 @@ def test_batch_of_small_scans_with_the_wave_kernel_resident_across_scans():
     assert reg.get_option("batch_resident_passes") == served
 
 
-@pytest.mark.parametrize("queues", [2, 4, 8])
-def test_batch_with_several_scans_in_flight_on_queues_of_their_own_equals_the_plain_loop(queues):
-    """kicp_register_device_batch, large scans, default: "batch_queues" scans in flight at a time, each on a handle and HSA queue
-    of its own, one host thread going round them - scans of different sizes and iteration counts, a zero-correspondence scan, a
-    change of max_num_iterations between calls (the lanes follow the caller's configuration): bit-equal to one call per scan."""
+@pytest.mark.parametrize("queues,kind", [(2, "large"), (4, "large"), (8, "large"), (4, "mostly small"), (3, "mixed")])
+def test_batch_with_several_scans_in_flight_on_queues_of_their_own_equals_the_plain_loop(queues, kind):
+    """kicp_register_device_batch, default: "batch_queues" scans in flight at a time, each on a handle and HSA queue of its own,
+    one host thread going round them - scans of different sizes and iteration counts (large: the generic pass kernel; small:
+    one wave per query, a launch per pass; both kinds in one batch), a zero-correspondence scan, a change of
+    max_num_iterations between calls (the lanes follow the caller's configuration): bit-equal to one call per scan."""
     maps, src = _big_world(n_map=60000, n_src=20000, seed=29)
     g = maps[0]
     count = 19
     sizes = [20000, 12000, 9000, 20000, 15000, 10000, 16000, 9500, 20000, 17000] * 2
+    if kind == "mostly small":  # (a batch of small scans ONLY keeps the resident kernel: the other tests)
+        sizes = [3000, 1080, 4000, 700, 2048, 512, 3500, 1900, 9000, 64] * 2
+    elif kind == "mixed":
+        sizes = [20000, 1080, 9000, 700, 15000, 512, 16000, 1900, 4096, 17000] * 2
     shifts = [0.0, 0.02, -0.05, 0.08, 0.0, 0.03, 0.01, -0.02, 0.04, 0.06] * 2
     frames = [src[:k] - np.array([d, 0.0, 0.0]) for k, d in zip(sizes[:count], shifts[:count])]
-    frames[6] = np.full((9000, 3), 400.0)  # no correspondence at all
+    frames[6] = np.full((sizes[6], 3), 400.0)  # no correspondence at all
     lasts = [syn.planar_pose(0.01 * i, 0.0, 0.001 * i) for i in range(count)]
     rels = [syn.planar_pose(-0.004 * i, 0.0, 0.0005) for i in range(count)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
@@ -326,7 +330,7 @@ def test_batch_with_several_scans_in_flight_on_queues_of_their_own_equals_the_pl
         assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
         assert reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
     assert reg.get_option("batch_queue_passes") >= 3 * count and reg.get_option("batch_resident_passes") == 0.0
-    assert max(b0.iterations[:4]) >= 2
+    assert max(b0.iterations[:6]) >= 2
     for k in (0, 1, 3):  # ... and to the oracle
         o = okicp.KinematicRegistration(**CFG).ComputeRobotMotion(frames[k], maps[1], lasts[k], rels[k], 0.5)
         np.testing.assert_allclose(got[k], o, rtol=0, atol=1e-9)
