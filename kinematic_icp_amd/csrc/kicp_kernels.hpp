@@ -191,6 +191,8 @@ __device__ __forceinline__ double limbs_to_double(const long long l[3]) {
 // - the same integer the single conversion gives wherever that one fits (ties included: ip * 2^40 is even).
 constexpr int kTermLimbs = 4;
 constexpr int kWaveLimbs = kTermLimbs * kNumSums;
+constexpr int kLendJobs = 32;                     // voxels a wave's loaded queries can give away per round (gather32_pass)
+constexpr int kLendWords = kLendJobs * (1 + 7 + 7);  // per wave: the jobs, the lent lanes' own records, the records they hand back
 struct Acc {
     int limb[kWaveLimbs];
     int range_error;
@@ -1182,7 +1184,7 @@ __device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float 
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, const Best3 &t,
                                                        const KeptQuery *kept = nullptr) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9)) return;
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
@@ -1236,7 +1238,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // the search and the exact phase of one pass for lane `tid` of workgroup blockIdx.x; `acc` receives the lane's terms
 // (`src`, `n`: the scan - p.src / p.n for a kernel that serves one call, the current scan of a resident kernel that serves a batch)
 template <int BLOCK, int G, bool SPLIT, bool LAT>
-__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n, uint32_t block) {
+__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n, uint32_t block, int *lend = nullptr) {
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     const uint32_t gt = block * BLOCK + tid;  // (`block`: which BLOCK points of the scan this workgroup takes - blockIdx.x, or a resident kernel's turn)
@@ -1270,6 +1272,75 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
                 L.todo &= L.todo - 1u;  // (0 stays 0; a second voxel that the first one's result rules out is dropped here - cull_todo would)
                 visit_two(L.q, L.t, m, s1, s2, has2, has2 ? voxel_lower_bound(L.q, s2, margin) : 0.f, margin);
             }
+        } else if (G == 1 && lend != nullptr && p.dbg != 11) {  // (dbg 11: the in-process A/B switch of this, tools/ab_option.py)
+            // One lane per query, one neighbour voxel per round - and every round costs the WAVE its ~430 instructions however few
+            // lanes still have a voxel to see (cfg2: 100 % of the lanes in round 1, 42 % in round 2, 7 % in round 3, 5 % in round 4;
+            // 3.0 rounds per wave).  So from the second round on, lanes with nothing to do take over voxels of the queries that
+            // have more than one left: such a query gives away up to two voxels beyond the one it visits itself, job j goes to the
+            // j-th idle lane (dealt through a few words of LDS), which fetches the query's probe by ds_bpermute, parks its own
+            // record in LDS, visits the voxel with a fresh record and hands that record back through LDS to be merged.  The visiting
+            // order travels with every candidate (Best3::o1 / o2), so the reference's first-minimum rule holds whoever did the
+            // visiting; a voxel that a sharper minimum would have culled is visited needlessly but cannot change the outcome.
+            const bool busy = L.todo != 0u;
+            int s = 0;
+            if (busy) s = __ffs(L.todo) - 1, L.todo &= L.todo - 1u;
+            bool helps = false;
+            int jobs = 0, job0 = 0, slot = 0;
+            if (rounds > 1u) {
+                const int spare = min(2, __popc(L.todo));
+                const unsigned long long give1 = __ballot(spare >= 1), give2 = __ballot(spare >= 2), idle = __ballot(!busy);
+                if (give1 != 0ull && idle != 0ull) {  // (wave-uniform)
+                    const int lane = static_cast<int>(tid & 63u);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    job0 = __popcll(give1 & below) + __popcll(give2 & below);
+                    const int pairs = min(min(__popcll(give1) + __popcll(give2), __popcll(idle)), kLendJobs);
+                    slot = __popcll(idle & below);
+                    helps = !busy && slot < pairs;
+                    jobs = max(0, min(spare, pairs - job0));
+                    for (int j = 0; j < jobs; ++j) {
+                        const int sj = __ffs(L.todo) - 1;
+                        L.todo &= L.todo - 1u;
+                        lend[job0 + j] = lane | (sj << 8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    int from = lane;
+                    if (helps) {
+                        const int e = lend[slot];
+                        from = e & 63, s = e >> 8;
+                    }
+                    const float glx = __shfl(L.q.lx, from, 64), gly = __shfl(L.q.ly, from, 64), glz = __shfl(L.q.lz, from, 64);
+                    const uint32_t gslot = __shfl(L.q.slot0, from, 64);
+                    if (helps) {  // (a lane with nothing to do never needs its own probe again; its record waits in LDS)
+                        int *keep = lend + kLendJobs + 7 * slot;
+                        keep[0] = __float_as_int(L.t.b1), keep[1] = __float_as_int(L.t.b2), keep[2] = __float_as_int(L.t.b3);
+                        keep[3] = static_cast<int>(L.t.i1), keep[4] = static_cast<int>(L.t.i2), keep[5] = static_cast<int>(L.t.o1), keep[6] = static_cast<int>(L.t.o2);
+                        L.q = Probe{glx, gly, glz, gslot};
+                        L.t = Best3{p.search.bound_u, p.search.bound_u, p.search.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
+                    }
+                }
+            }
+            if (busy || helps) visit_bucket<1>(L.q, L.t, m, s, margin, 0);
+            if (__any(helps)) {  // (wave-uniform) the lent lanes' records go home
+                if (helps) {
+                    int *back = lend + kLendJobs + 7 * kLendJobs + 7 * slot;
+                    back[0] = __float_as_int(L.t.b1), back[1] = __float_as_int(L.t.b2), back[2] = __float_as_int(L.t.b3);
+                    back[3] = static_cast<int>(L.t.i1), back[4] = static_cast<int>(L.t.i2), back[5] = static_cast<int>(L.t.o1), back[6] = static_cast<int>(L.t.o2);
+                    const int *keep = lend + kLendJobs + 7 * slot;
+                    L.t = Best3{__int_as_float(keep[0]), __int_as_float(keep[1]), __int_as_float(keep[2]), static_cast<uint32_t>(keep[3]), static_cast<uint32_t>(keep[4]),
+                                static_cast<uint32_t>(keep[5]), static_cast<uint32_t>(keep[6])};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int j = 0; j < jobs; ++j) {
+                    const int *back = lend + kLendJobs + 7 * kLendJobs + 7 * (job0 + j);
+                    const Best3 o{__int_as_float(back[0]), __int_as_float(back[1]), __int_as_float(back[2]), static_cast<uint32_t>(back[3]), static_cast<uint32_t>(back[4]),
+                                  static_cast<uint32_t>(back[5]), static_cast<uint32_t>(back[6])};
+                    if (o.i1 != kNoIndex32) best3_merge(L.t, o);
+                }
+            }
         } else if (L.todo) {
             const int s = __ffs(L.todo) - 1;
             L.todo &= L.todo - 1u;
@@ -1298,10 +1369,12 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
     static_assert(!LAT || G == 1, "the latency-oriented build serves one lane per query");
     KICP_PASS_SHARED(BLOCK)
+    constexpr bool kLends = G == 1 && !SPLIT && !LAT;  // idle lanes take over voxels of loaded queries (gather32_pass)
+    __shared__ int s_lend[kLends ? BLOCK / 64 : 1][kLendWords];
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     Acc acc{};
-    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n, blockIdx.x);
+    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n, blockIdx.x, kLends ? &s_lend[kLends ? threadIdx.x / 64 : 0][0] : nullptr);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }

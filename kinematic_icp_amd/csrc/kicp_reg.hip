@@ -1393,7 +1393,7 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     PassParams &pp = f.small ? f.sp.p : f.pp;
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = h->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
-    pp.dbg = 0;
+    pp.dbg = h->dbg;
     SolveParams &sol = pp.sol;
     sol.pose0 = f.loop.T, sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
     sol.convergence_criterion = h->cfg.convergence_criterion;
@@ -1428,7 +1428,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     const int max_it = r->cfg.max_num_iterations;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
-          r->wait_mode == 0 && r->dbg == 0))
+          r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11)))
         return 1;
     // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
     // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
@@ -1455,7 +1455,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     for (int j = 0; j < queues; ++j) {
         kicp_reg *h = r->batch_lanes[j];
         h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
-        h->query_every = r->query_every, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
+        h->query_every = r->query_every, h->dbg = r->dbg, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
         h->use_small = r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
         flights[j].h = h;
     }
