@@ -652,8 +652,23 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     // of 21 bits each, and a wave's 64 values of a limb add up in int32.
     int range_error = a.range_error;
     int limb[kWaveLimbs];
+    if (p.dbg == 10 || p.dbg == 12) {  // (10, the census: the count's limbs carry something else; 12: the in-process A/B switch of what follows)
 #pragma unroll
-    for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
+        for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
+    } else {
+        // Two of the seven sums need no reduction.  The count: every correspondence adds 2^40 = limb 1 at 2^19, so the wave's sum is
+        // the number of lanes that hold one.  |J.col(0)|^2 = |R UnitX|^2 depends on the pose alone: every correspondence adds the SAME
+        // four limbs, so the wave's sum is that number times the limbs of any lane that holds one.  (Sums of identical integers:
+        // exactly what the additions would give.)
+        const unsigned long long holders = __ballot(a.limb[6 * kTermLimbs + 1] != 0);
+        const int n_holders = __popcll(holders);
+        const int some = holders ? static_cast<int>(__ffsll(static_cast<long long>(holders))) - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < kTermLimbs; ++k) limb[k] = n_holders * __builtin_amdgcn_readlane(a.limb[k], some);
+#pragma unroll
+        for (int k = kTermLimbs; k < 6 * kTermLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
+        limb[6 * kTermLimbs] = 0, limb[6 * kTermLimbs + 1] = n_holders << 19, limb[6 * kTermLimbs + 2] = 0, limb[6 * kTermLimbs + 3] = 0;
+    }
     range_error = __any(range_error) ? 1 : 0;
     if (lane == 63) {
 #pragma unroll
@@ -1184,7 +1199,7 @@ __device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float 
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, const Best3 &t,
                                                        const KeptQuery *kept = nullptr) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11)) return;
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;

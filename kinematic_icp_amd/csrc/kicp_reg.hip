@@ -1428,7 +1428,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     const int max_it = r->cfg.max_num_iterations;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
-          r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11)))
+          r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12)))
         return 1;
     // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
     // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
