@@ -1,6 +1,10 @@
 """Experiment: where the pass kernel's time goes (ablation switches of kicp_kernels.hpp, option "dbg"):
 0 full; 1 search without the exact phase / accumulation; 5 own + face voxels only; 3 own voxel only; 4 probe, no bucket visit;
-2 no probe either; 7 no query work at all (launch + reduction + hand-off); 8 no reduction either (launch + hand-off)."""
+2 no probe either; 7 no query work at all (launch + reduction + hand-off); 8 no reduction either (launch + hand-off).
+Switches that leave the RESULT alone (for in-process A/Bs, tools/ab_option.py --option dbg): 9 no exact fp64 fallback search for three
+near-equal candidates (changes poses in rare ties: diagnosis only); 10 the rounds census of bench.py's latency model (the count sum
+carries every wave's visiting rounds); 11 idle lanes do NOT take over voxels of loaded queries (four-waves build); 12 all seven wave
+sums through the DPP reduction (none derived from a ballot)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
