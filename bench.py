@@ -559,6 +559,47 @@ def main():
                 del w5
             except (K.KicpError, MemoryError) as e:
                 sharded_cfg5 = {"note": str(e)[:300]}
+    # ---- N > 1, informational: the SAME GPUs as independent replicas - every rank registers whole scans on its own (no exchange),
+    #      the way a fleet localising in one map or a replayed log would use a node.  Sharding one 131 072-point scan splits a pass of
+    #      a few microseconds and adds an exchange per ICP iteration; replicas multiply the single-GPU rate.  Both are printed: the
+    #      headline stays the sharded (north-star) figure.
+    value_replicas = None
+    if exchange and world > 1:
+        err, el = None, float("nan")
+        rep_steps, rep_B, nrep = 8, 256, min(len(scans), 16)
+        full = batch_rep = reg_rep = None
+        try:
+            full = [K.DeviceFrame(s["frame"], device=device) for s in scans[:nrep]]
+            reg_rep = K.KinematicRegistration(device=device)
+            batch_rep = reg_rep.prepare_batch([full[i % nrep] for i in range(rep_B)], [scans[i % nrep]["last_pose"] for i in range(rep_B)],
+                                              [rel_single[i % nrep] for i in range(rep_B)])
+            for _ in range(2):
+                reg_rep.ComputeRobotMotionBatch(batch_rep, gmap, tau)
+        except (K.KicpError, MemoryError) as e:
+            err = e
+        flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) == 0.0:
+            barrier()
+            t0 = time.perf_counter()
+            try:
+                for _ in range(rep_steps):
+                    reg_rep.ComputeRobotMotionBatch(batch_rep, gmap, tau)
+            except K.KicpError as e:
+                err = e
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0, 0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t[1].item()) == 0.0:
+                el = float(t[0].item())
+                value_replicas = {"scans_per_s": round(world * rep_steps * rep_B / el, 1), "scaling": "weak",
+                                  "what": "every rank registers WHOLE scans on its own GPU, no exchange (%d batch calls of %d scans per rank between "
+                                          "barriers, max over ranks; the batch call's default: scans in flight on queues of their own): what a node "
+                                          "does with independent scans; `value` above is the north star's sharded registration of ONE scan at a "
+                                          "time across the ranks" % (rep_steps, rep_B)}
+        if value_replicas is None:
+            value_replicas = {"note": "not measured: %s" % (str(err)[:200] if err is not None else "a peer rank failed")}
+        del full, batch_rep, reg_rep
     if use_comm:  # all GPU work is done: tear the process group down before rank 0's CPU-only epilogue
         dist.barrier()
         dist.destroy_process_group()
@@ -770,6 +811,7 @@ def main():
                  "the batch call of the timed region keeps as many scans in flight from ONE host thread; what neither can serve is a caller whose next "
                  "scan depends on the previous result (the reference's own pipeline): value_one_scan_in_flight and bench_pipeline are that caller's rates" % conc_lanes},
         **top_exchange,
+        **({} if value_replicas is None else {"value_replicas": value_replicas}),
         **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
         **({"sharded_cfg5": sharded_cfg5} if sharded_cfg5 is not None else {}),
         "roofline": roof,
