@@ -665,15 +665,49 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         const int some = holders ? static_cast<int>(__ffsll(static_cast<long long>(holders))) - 1 : 0;
 #pragma unroll
         for (int k = 0; k < kTermLimbs; ++k) limb[k] = n_holders * __builtin_amdgcn_readlane(a.limb[k], some);
-#pragma unroll
-        for (int k = kTermLimbs; k < 6 * kTermLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
         limb[6 * kTermLimbs] = 0, limb[6 * kTermLimbs + 1] = n_holders << 19, limb[6 * kTermLimbs + 2] = 0, limb[6 * kTermLimbs + 3] = 0;
-    }
-    range_error = __any(range_error) ? 1 : 0;
-    if (lane == 63) {
+        // The other twenty limbs: a reduction that HALVES the number of values a lane carries with every step it can - the lanes of a
+        // pair keep one half each and take the partner's share of it (quad_perm), twice; then the quads of a row (row_shr 4, 8) and the
+        // four rows (ds_bpermute) are added for the five values a lane is left with.  ~65 instead of 120 DPP additions; lane 60 + q
+        // ends up with the wave's sums of limbs 4 j + q (j = 0 .. 4).
+        int w10[10], x5[5];
+        const bool p0 = (lane & 1) != 0, p1 = (lane & 2) != 0;
 #pragma unroll
-        for (int k = 0; k < kWaveLimbs; ++k) s_red[wave][k] = limb[k];
-        if (range_error) atomicOr(s_flag, 2);
+        for (int j = 0; j < 10; ++j) {
+            const int lo = a.limb[kTermLimbs + 2 * j], hi = a.limb[kTermLimbs + 2 * j + 1];
+            w10[j] = (p0 ? hi : lo) + __builtin_amdgcn_update_dpp(0, p0 ? lo : hi, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int lo = w10[2 * j], hi = w10[2 * j + 1];
+            x5[j] = (p1 ? hi : lo) + __builtin_amdgcn_update_dpp(0, p1 ? lo : hi, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) x5[j] += __builtin_amdgcn_update_dpp(0, x5[j], 0x114, 0xF, 0xF, true);  // row_shr 4
+#pragma unroll
+        for (int j = 0; j < 5; ++j) x5[j] += __builtin_amdgcn_update_dpp(0, x5[j], 0x118, 0xF, 0xF, true);  // row_shr 8: lanes 12 .. 15 of a row hold its sums
+#pragma unroll
+        for (int j = 0; j < 5; ++j) x5[j] += __shfl_up(x5[j], 16, 64);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) x5[j] += __shfl_up(x5[j], 32, 64);
+        range_error = __any(range_error) ? 1 : 0;
+        if (lane >= 60) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) s_red[wave][kTermLimbs + 4 * j + (lane & 3)] = x5[j];
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < kTermLimbs; ++k) s_red[wave][k] = limb[k], s_red[wave][6 * kTermLimbs + k] = limb[6 * kTermLimbs + k];
+            if (range_error) atomicOr(s_flag, 2);
+        }
+    }
+    if (p.dbg == 10 || p.dbg == 12) {
+        range_error = __any(range_error) ? 1 : 0;
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < kWaveLimbs; ++k) s_red[wave][k] = limb[k];
+            if (range_error) atomicOr(s_flag, 2);
+        }
     }
     __syncthreads();
     if (wave != 0) return;
