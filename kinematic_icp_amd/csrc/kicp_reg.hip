@@ -1106,14 +1106,15 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
     return rc;
 }
 
-// kicp_register_device_batch with the generic pass kernel RESIDENT ACROSS THE SCANS of the batch.  The scans are still registered
-// strictly one after the other - scan k + 1's first pass is only started when scan k's last solve is done, as a loop of
-// ComputeRobotMotion calls would -, but what starts a pass is a command polled by a kernel that is already on the device
+// kicp_register_device_batch with ONE pass kernel RESIDENT ACROSS THE SCANS of the batch (batches that run_batch_queues does not
+// take: small scans only, "batch_queues" < 2).  What starts a pass is a command polled by a kernel that is already on the device
 // (~1.5 us) instead of a dispatch of 2 048 waves (~4.5 us), for pass 0 of a scan as for its later passes (run_small).  The launch
-// carries the table of the batch's scans (pointer, size); kCmdNewScan moves the kernel on to the next entry.
-// Returns 1 when the batch (from scan `first` on) is not one for this path - the caller then runs the plain loop -, else a
-// kicp status; *done = scans completed.  On a give-up of the kernel (a workgroup that saw no command in time) the scan in
-// hand and the rest are left to the plain loop, too.
+// carries the table of the batch's scans (pointer, size); every command names the scan its pass belongs to, and "batch_depth"
+// scans are in flight at a time (below).  With depth 1 scan k + 1's first pass is only started when scan k's last solve is done, as
+// a loop of ComputeRobotMotion calls would.
+// Returns 1 when the batch is not one for this path - the caller then runs the plain loop -, else a kicp status; *done = scans
+// completed from the front.  On a give-up of the kernel (a workgroup that saw no command in time) the scans in hand and the rest
+// are left to the plain loop, too.
 constexpr uint32_t kBatchMaxPasses = 1024;  // passes (= tags) one launch may serve
 int depth_of(const kicp_reg *r) { return std::min<int>(std::max(r->batch_depth, 1), static_cast<int>(kPipeSlots)); }
 int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
