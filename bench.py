@@ -272,9 +272,10 @@ def main():
         B = B or state["B"]
         nsc = len(w.scans)
         # step k registers scans k*B .. (k+1)*B-1 of the cycle: with B not a multiple of the cycle every step starts elsewhere in it
-        batches = []
+        batches, batch_scans = [], []
         for k in range(max(1, min(steps, nsc)) if not per_call else 0):
             idx = [(k * B + i) % nsc for i in range(B)]
+            batch_scans.append(idx)
             batches.append(reg.prepare_batch([w.frames[i] for i in idx], [w.scans[i]["last_pose"] for i in idx], [rels[i] for i in idx]))
 
         def step(k):
@@ -309,6 +310,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         timed.last_iterations = float(np.mean(np.concatenate([b.iterations for b in batches]))) if not per_call else float("nan")  # ICP iterations per scan of this run
+        # what the timed steps themselves returned (after the closing barrier: not timed): every batch's poses as its last step left
+        # them, with the scans they belong to - compared bit for bit with one call per scan further down (check_timed_region)
+        timed.last_results = [] if per_call else [(idx_k, b.out.copy(), np.array(b.iterations).copy()) for idx_k, b in zip(batch_scans, batches)]
         timed.last_step_s = np.diff(np.array(marks))  # this rank's clock
         return elapsed
 
@@ -352,6 +356,7 @@ def main():
     while True:
         elapsed = timed(reg, rel_single, args.steps, args.warmup)             # ---- the headline number
         step_s = timed.last_step_s.copy()
+        results_timed = timed.last_results
         if args.scans_per_step > 0 or elapsed >= args.min_timed_s or state["B"] >= 8192 or resized >= 3:
             break
         # the timed region came in short of --min-timed-s AS MEASURED (a fresh box speeds up after the calibration batch):
@@ -388,6 +393,7 @@ def main():
     small_kind = int(reg.get_option("small_active"))  # 0 generic pass kernel; small-scan path (kicp_small.hpp): 1 sub-lanes per query, 2 one wave per query
     small_active = small_kind > 0
     elapsed_multi = timed(reg, rel_multi, args.steps, min(args.warmup, 2))    # ---- same scans, several ICP iterations each
+    results_timed_multi = timed.last_results
     elapsed_py = timed(reg, rel_single, args.steps, 1, per_call=True)         # ---- informational: one Python call per scan
 
     # ---- second pass over the same steps with HIP events around every pass-kernel launch (roofline) -------------
@@ -433,6 +439,22 @@ def main():
     poses = [run_scan(reg, i, rel_single) for i in range(len(scans))]
     poses_multi = [run_scan(reg, i, rel_multi) for i in range(len(scans))]
     barrier()
+
+    # ---- the timed region's OWN poses, checked: every pose a timed batch call returned must equal, bit for bit,
+    #      the pose of the same scan registered alone by one call (which the epilogue compares with the oracle) - several scans in
+    #      flight, another build of the pass kernel, another hand-over: exact integer sums make them the same doubles, or the line is void
+    def check_timed_region(results, singles):
+        checked = bad = 0
+        for idx_k, out, _ in results:
+            for j, i in enumerate(idx_k):
+                checked += 1
+                bad += 0 if np.array_equal(out[j], singles[i], equal_nan=True) else 1
+        return checked, bad
+    timed_checked, timed_bad = check_timed_region(results_timed, poses)
+    timed_checked_multi, timed_bad_multi = check_timed_region(results_timed_multi, poses_multi)
+    if timed_bad or timed_bad_multi:
+        raise SystemExit("bench.py: %d of %d poses returned inside the timed region (%d of %d on the multi-iteration workload) differ from the pose of the "
+                         "same scan registered alone: the measurement is void" % (timed_bad, timed_checked, timed_bad_multi, timed_checked_multi))
     # informational, never `value`: the same calls with the scan handed over as a HOST array (upload inside), as fp64 - the
     # reference's std::vector<Eigen::Vector3d> - and as float32, the wire format of the message the points came in
     host_rate = host_rate_f32 = None
@@ -782,6 +804,10 @@ def main():
                                   (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
                    "pass_kernel": pass_kernel, "launch_path": launch_path, "max_pose_abs_diff_vs_oracle": max_pose_err,
                    "poses_checked_against_the_oracle": len(iters_ref_multi) + len(iters_ref),
+                   "poses_of_the_timed_region_checked": timed_checked + timed_checked_multi,
+                   "poses_of_the_timed_region_check": "every pose the timed batch calls returned (headline %d, multi-iteration %d; the batches as their last step left "
+                                                      "them) is bit-identical to the pose of the same scan registered alone by one call; those single-call poses are "
+                                                      "the ones compared with the oracle (max_abs_pose_diff_vs_oracle)" % (timed_checked, timed_checked_multi),
                    "multi_iteration": {
                        "workload": "same scans, odometry error +%.2f m / +%.1f deg: %.2f ICP iterations per scan (reference %.2f)"
                                    % (MULTI_ITER_ERROR[0], MULTI_ITER_ERROR[1], iters_gpu_multi, float(np.mean(iters_ref_multi))),
