@@ -65,8 +65,18 @@ struct IcpState {
     unsigned int pad2_[31];
 };
 
+// What the per-correspondence terms need of the pose (Registration.cpp:86-93,108-113), the same for every
+// correspondence of a pass: J.col(0) = R UnitX = c0 and J.col(1) = R (-s.y, s.x, 0) = -s.y c0 + s.x c1 with c1 = R UnitY, and the
+// fixed-point term of JTJ(0,0) = |c0|^2, which every correspondence adds unchanged.  Computed ONCE per pass - by the host, next to
+// the pose it sends (set_pose), or by the kernel where the pose comes from the device (device-side solve, resident kernels) - by
+// this one function, so that every kernel and the host see the same doubles.
+struct PassBasis {
+    double c0x, c0y, c0z, c1x, c1y, c1z;
+    int jtj00[4];  // to_fixed(|c0|^2): four signed 21-bit limbs (= 2^40 exactly for any unit quaternion)
+};
 struct SolveParams {
     Pose pose0;
+    PassBasis basis;  // of pose0 (set_pose)
     int32_t pass;
     int32_t max_iterations;
     double convergence_criterion;
@@ -121,12 +131,14 @@ struct SearchParams {
     double inv_vs;   // 1 / voxel_size (voxel_coord's fast path)
     float bound_u;   // the bound in units^2, widened by the margin
     float margin_u;  // error margin of one decision between two mirror distances, units^2
+    double tau2_lo, tau2_hi;  // tau^2 (1 -+ 2^-49): below / above, `sqrt(d2) < tau` is decided without taking the root (accepted_by_norm)
 };
 KICP_HD SearchParams search_params(double tau, double vs) {
     SearchParams sp;
     sp.bound = tau * tau * (1.0 + 9.1e-13);
     sp.upm = mirror_units_per_metre(vs);
     sp.inv_vs = 1.0 / vs;
+    sp.tau2_lo = tau * tau * (1.0 - 1.7763568394002505e-15), sp.tau2_hi = tau * tau * (1.0 + 1.7763568394002505e-15);
     // error model in metres (k_pass_gather32): |delta| <= sqrt(3) * 1.05 units = 2.78e-5 vs; D off by <= 2 sqrt(D) |delta| +
     // |delta|^2 + 4.2e-6 D; both candidates of a decision, 10 % spare; D <= min(bound, 12 vs^2)
     const double bcap = fmin(sp.bound, 12.0 * vs * vs);
@@ -197,22 +209,36 @@ struct Acc {
     int limb[kWaveLimbs];
     int range_error;
 };
-__device__ __forceinline__ void to_fixed(double x, int *limb, int &range_error) {
-    if (!(fabs(x) < kFixLimit)) {
-        range_error = 1;
-        limb[0] = limb[1] = limb[2] = limb[3] = 0;
-        return;
-    }
-    const long long ip = __double2ll_rn(x);
-    const long long fp = __double2ll_rn((x - static_cast<double>(ip)) * kFixScale);
-    I128 t{static_cast<unsigned long long>(ip) << 40, ip >> 24};
-    i128_add(t, I128{static_cast<unsigned long long>(fp), fp >> 63});
-    limb[0] = static_cast<int>(t.lo & 0x1FFFFF), limb[1] = static_cast<int>((t.lo >> 21) & 0x1FFFFF), limb[2] = static_cast<int>((t.lo >> 42) & 0x1FFFFF);
-    limb[3] = static_cast<int>(static_cast<long long>((t.lo >> 63) | (static_cast<unsigned long long>(t.hi) << 1)));
+// The term as an integer, T = rint(x 2^40) (|T| < 2^83; x 2^40 is exact, rint of a double beyond 2^52 is the double itself), split
+// into four SIGNED limbs of 21 bits by truncating divisions carried out in fp64 - every step exact: q = trunc(t 2^-k) and
+// t - q 2^k = fma(q, -2^k, t) are representable (the remainder keeps t's granularity and is shorter than t).
+//   T = l0 + l1 2^21 + l2 2^42 + l3 2^63,  |lk| < 2^21, every limb with T's sign
+// (round 4 built the same integer from two 64-bit conversions and split it with 128-bit integer arithmetic: ~30 instructions
+// against ~18; the limbs were non-negative below the top one - any split of the same integer adds up to the same sums).
+KICP_HD void to_fixed(double x, int *limb, int &range_error) {
+    const bool ok = fabs(x) < kFixLimit;
+    if (!ok) range_error = 1;
+    const double t = rint((ok ? x : 0.0) * kFixScale);
+    const double q3 = trunc(t * 0x1p-63);
+    const double r3 = fma(q3, -0x1p63, t);
+    const double q2 = trunc(r3 * 0x1p-42);
+    const double r2 = fma(q2, -0x1p42, r3);
+    const double q1 = trunc(r2 * 0x1p-21);
+    const double r1 = fma(q1, -0x1p21, r2);
+    limb[0] = static_cast<int>(r1), limb[1] = static_cast<int>(q1), limb[2] = static_cast<int>(q2), limb[3] = static_cast<int>(q3);
 }
+KICP_HD PassBasis basis_of(const Pose &T) {
+    PassBasis b;
+    quat_rotate(T, 1.0, 0.0, 0.0, b.c0x, b.c0y, b.c0z);  // J.col(0) = R * UnitX (Registration.cpp:90)
+    quat_rotate(T, 0.0, 1.0, 0.0, b.c1x, b.c1y, b.c1z);
+    int range_error = 0;  // (|c0|^2 is 1 to rounding for a unit quaternion; a NaN pose leaves zeros - its passes add nothing)
+    to_fixed(b.c0x * b.c0x + b.c0y * b.c0y + b.c0z * b.c0z, b.jtj00, range_error);
+    return b;
+}
+KICP_HD void set_pose(SolveParams &f, const Pose &T) { f.pose0 = T, f.basis = basis_of(T); }
 // the 128-bit sum of one term's limb sums s[0..3] (each a sum of at most 2^10 limbs)
 __device__ __forceinline__ void i128_add_limb_sums(I128 &t, long long s0, long long s1, long long s2, long long s3) {
-    const long long low = s0 + (s1 << 21);  // < 2^53
+    const long long low = s0 + s1 * 2097152ll;  // |.| < 2^53 (limb sums are signed)
     i128_add(t, I128{static_cast<unsigned long long>(low), low >> 63});
     i128_add(t, I128{static_cast<unsigned long long>(s2) << 42, s2 >> 22});
     i128_add(t, I128{static_cast<unsigned long long>(s3) << 63, s3 >> 1});
@@ -294,6 +320,14 @@ __device__ __forceinline__ bool closer_by_norm(double a, double best) {
     if (a < best * (1.0 - 8.8817841970012523e-16)) return true;  // 1 - 2^-50
     return sqrt(a) < sqrt(best);
 }
+// `distance < max_correspondance_distance` (Registration.cpp:75) as the reference evaluates it - on the ROUNDED square root - without
+// paying for the root where the squared distance is not within 2^-49 of tau^2: d2 < tau^2 (1 - 2^-49) makes the rounded root smaller
+// than tau whatever the roundings of tau * tau and of the root (each 2^-53), d2 >= tau^2 (1 + 2^-49) makes it larger.
+__device__ __forceinline__ bool accepted_by_norm(double d2, double tau, const SearchParams &sp) {
+    if (d2 < sp.tau2_lo) return true;
+    if (!(d2 < sp.tau2_hi)) return false;
+    return sqrt(d2) < tau;
+}
 // scan one bucket in insertion order; strict '<' on the norms keeps the first minimum (std::min_element + `distance < closest`)
 __device__ __forceinline__ void scan_points(const double *__restrict__ p, uint32_t count, uint32_t base_index, const Query &q,
                                             double &best, uint32_t &best_idx) {
@@ -370,18 +404,32 @@ __device__ __forceinline__ double exact_d2(const MapView &m, uint32_t gidx, cons
 // ------------------------------------------------------------------------------------------------------------
 // per-correspondence terms (Registration.cpp:86-93,108-113)
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void accumulate(Acc &a, const Pose &T, double sx, double sy, double qx, double qy, double qz, double tx,
-                                           double ty, double tz) {
-    const double rx = qx - tx, ry = qy - ty, rz = qz - tz;  // residual = T*source - target
-    double j0x, j0y, j0z, j1x, j1y, j1z;
-    quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);  // J.col(0) = R * UnitX
-    quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);   // J.col(1) = R * (-s.y, s.x, 0)
-    to_fixed(j0x * j0x + j0y * j0y + j0z * j0z, a.limb + 0 * kTermLimbs, a.range_error);
-    to_fixed(j0x * j1x + j0y * j1y + j0z * j1z, a.limb + 1 * kTermLimbs, a.range_error);
-    to_fixed(j1x * j1x + j1y * j1y + j1z * j1z, a.limb + 2 * kTermLimbs, a.range_error);
-    to_fixed(j0x * rx + j0y * ry + j0z * rz, a.limb + 3 * kTermLimbs, a.range_error);
-    to_fixed(j1x * rx + j1y * ry + j1z * rz, a.limb + 4 * kTermLimbs, a.range_error);
-    to_fixed(rx * rx + ry * ry + rz * rz, a.limb + 5 * kTermLimbs, a.range_error);
+// The reference forms J = [R UnitX | R (-s.y, s.x, 0)] and r = T s - t per correspondence and adds J^T J and J^T r.  With R
+// orthogonal those products have a closed form, which is what is evaluated here:
+//   JTJ(0,0) = |c0|^2 (the pose's alone: PassBasis::jtj00)     JTJ(0,1) = -s.y     JTJ(1,1) = s.x^2 + s.y^2
+//   JTr(0)   = c0 . r                                           JTr(1)   = s.x (c1 . r) - s.y (c0 . r)
+// It differs from the literal products by their own rounding (a few 1e-16 relative: tests/test_closed_form.py holds the two to
+// 1e-12 on random data, the parity suite holds the sums and poses to the oracle's, which keeps the literal form); nothing here
+// takes part in a decision - every term is rounded to 2^-40 right afterwards - so the multiply-adds are fused.
+// One function for every pass kernel: their terms are the same doubles.
+__device__ __forceinline__ void correspondence_terms(const PassBasis &B, double sx, double sy, double qx, double qy, double qz, double tx, double ty, double tz,
+                                                     double (&term)[5]) {
+    const double rx = qx - tx, ry = qy - ty, rz = qz - tz;  // residual = T*source - target (Registration.cpp:88)
+    const double a = fma(B.c0x, rx, fma(B.c0y, ry, B.c0z * rz));
+    const double b = fma(B.c1x, rx, fma(B.c1y, ry, B.c1z * rz));
+    term[0] = -sy;
+    term[1] = fma(sx, sx, sy * sy);
+    term[2] = a;
+    term[3] = fma(sx, b, -(sy * a));
+    term[4] = fma(rx, rx, fma(ry, ry, rz * rz));
+}
+__device__ __forceinline__ void accumulate(Acc &a, const PassBasis &B, double sx, double sy, double qx, double qy, double qz, double tx, double ty, double tz) {
+    double term[5];
+    correspondence_terms(B, sx, sy, qx, qy, qz, tx, ty, tz, term);
+#pragma unroll
+    for (int k = 0; k < kTermLimbs; ++k) a.limb[k] = B.jtj00[k];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) to_fixed(term[i], a.limb + (i + 1) * kTermLimbs, a.range_error);
     a.limb[6 * kTermLimbs + 1] = 1 << 19;  // the count: 1.0 = 2^40 = 2^19 * 2^21 (the other limbs stay 0)
 }
 
@@ -886,6 +934,11 @@ __device__ __forceinline__ Pose load_pose(const PassParams &p) {
     const Pose T = p.st->T;
     return Pose{uniform_d(T.qx), uniform_d(T.qy), uniform_d(T.qz), uniform_d(T.qw), uniform_d(T.tx), uniform_d(T.ty), uniform_d(T.tz)};
 }
+// the basis of the pose load_pose returned: the host's (kernel arguments: scalar registers) where the pose is the host's
+__device__ __forceinline__ PassBasis load_basis(const PassParams &p, const Pose &T) {
+    if (p.sol.pass == 0 || p.sol.mode >= 2) return p.sol.basis;
+    return basis_of(T);
+}
 
 #define KICP_PASS_SHARED(BLOCK)                       \
     __shared__ int s_red[(BLOCK) / 64][kWaveLimbs];   \
@@ -900,6 +953,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
     KICP_PASS_SHARED(BLOCK)
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
+    const PassBasis B = load_basis(p, T);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     Acc acc{};
     if (i < p.n) {
@@ -913,7 +967,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
         if (p.dbg != 2) search_global(p.map, q, best, best_idx);
         if (p.dbg == 0 && best_idx != 0xFFFFFFFFu && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
             const double *t = p.map.pool + static_cast<size_t>(best_idx) * 3;
-            accumulate(acc, T, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
+            accumulate(acc, B, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
         }
     }
     if (BLOCK > 64) __syncthreads();
@@ -1010,26 +1064,6 @@ __device__ __forceinline__ void best3_merge(Best3 &t, const Best3 &o) {
     t.b3 = fminf(t.b3, o.b3);  // o.b3 can never undercut the runner-up of a set that already holds o.b1 <= o.b2
 }
 
-// which of the 27 neighbour voxels (bit s = shift s of the reference's order) may hold a point within `lim` (units^2) of
-// the query: lower bound = sum of the squared distances to the faces crossed.  lo[a] / hi[a] = conservative squared
-// distance to the -/+ face of the own voxel on axis a.  Own voxel: always; 6 face neighbours: one term; 12 edge
-// neighbours: two; 8 corner neighbours: three (an edge sum plus one term).
-__device__ __forceinline__ uint32_t alive_mask(const float (&lo)[3], const float (&hi)[3], float lim) {
-    // reference order (kShiftTable): 0 own | 1 +x 2 -x 3 +y 4 -y 5 +z 6 -z | 7 ++0 8 +-0 9 -+0 10 --0 | 11 +0+ 12 +0- 13 -0+ 14 -0-
-    // | 15 0++ 16 0+- 17 0-+ 18 0-- | 19 +++ 20 ++- 21 +-+ 22 +-- 23 -++ 24 -+- 25 --+ 26 ---
-    const float px = hi[0], mx = lo[0], py = hi[1], my = lo[1], pz = hi[2], mz = lo[2];
-    uint32_t a = 1u;
-    a |= (px <= lim ? 1u << 1 : 0u) | (mx <= lim ? 1u << 2 : 0u) | (py <= lim ? 1u << 3 : 0u) | (my <= lim ? 1u << 4 : 0u) |
-         (pz <= lim ? 1u << 5 : 0u) | (mz <= lim ? 1u << 6 : 0u);
-    const float pp = px + py, pm = px + my, mp = mx + py, mm = mx + my;  // xy edges
-    a |= (pp <= lim ? 1u << 7 : 0u) | (pm <= lim ? 1u << 8 : 0u) | (mp <= lim ? 1u << 9 : 0u) | (mm <= lim ? 1u << 10 : 0u);
-    a |= (px + pz <= lim ? 1u << 11 : 0u) | (px + mz <= lim ? 1u << 12 : 0u) | (mx + pz <= lim ? 1u << 13 : 0u) | (mx + mz <= lim ? 1u << 14 : 0u);
-    a |= (py + pz <= lim ? 1u << 15 : 0u) | (py + mz <= lim ? 1u << 16 : 0u) | (my + pz <= lim ? 1u << 17 : 0u) | (my + mz <= lim ? 1u << 18 : 0u);
-    a |= (pp + pz <= lim ? 1u << 19 : 0u) | (pp + mz <= lim ? 1u << 20 : 0u) | (pm + pz <= lim ? 1u << 21 : 0u) | (pm + mz <= lim ? 1u << 22 : 0u);
-    a |= (mp + pz <= lim ? 1u << 23 : 0u) | (mp + mz <= lim ? 1u << 24 : 0u) | (mm + pz <= lim ? 1u << 25 : 0u) | (mm + mz <= lim ? 1u << 26 : 0u);
-    return a;
-}
-
 // PointToVoxel component: static_cast<int>(floor(c / vs)) as the reference evaluates it (kiss-icp v1.2.0 core/VoxelUtils.hpp),
 // without paying an fp64 division for every coordinate: t = c * (1 / vs) agrees with fl(c / vs) to a few ulps, so the two
 // floors can only differ when t lies within that distance of an integer - and only then is the division carried out.
@@ -1062,6 +1096,7 @@ constexpr float kCell = 65536.f;  // one voxel in mirror units
 struct KeptQuery {
     Query q;
     double sx, sy;
+    bool voxel;  // q.vx .. q.vz are valid (a query parked in LDS comes back without them: only the rare exact search needs them)
 };
 // (`src`: the scan's points - p.src, or the scan a resident kernel was told to take up next, kicp_small.hpp)
 __device__ __forceinline__ void make_query_of(Query &q, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, KeptQuery *kept = nullptr) {
@@ -1086,7 +1121,7 @@ __device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const d
     L.t = Best3{sp.bound_u, sp.bound_u, sp.bound_u, kNoIndex32, kNoIndex32, 0u, 0u};
     Query q;
     make_query_of(q, p, src, T, valid ? i : 0u, kept);
-    if (kept) kept->q = q;
+    if (kept) kept->q = q, kept->voxel = true;
     const double vs = p.map.voxel_size;
     L.q.lx = static_cast<float>((q.x - q.vx * vs) * sp.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sp.upm),
     L.q.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
@@ -1097,14 +1132,38 @@ __device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const d
     if (p.dbg == 5) L.todo &= 0x7Fu;  // own + faces
     if (p.dbg == 4) L.todo = 0u;      // probe only, no bucket visit
 }
-// drop the neighbour voxels that cannot hold anything within the margin of `best` (units^2)
+// drop the neighbour voxels that cannot hold anything within the margin of `best` (units^2).  A voxel's lower bound is the sum of
+// the squared distances to the faces crossed on the way to it (one term for the six face neighbours, two for the twelve edge
+// neighbours, three for the eight corners); it is alive while  sum <= (best + 4 margin) 1.00001  - the slack covers the fp32
+// roundings of the sum and, per face crossed, the margin by which a mirror distance may undercut the truth (round 4 subtracted the
+// margin per face: this bound is the same for corners and a hair more generous for faces and edges).
+// Branch-free, and without a compare-and-select per voxel: the 26 differences `limit - sum` are formed two per instruction (packed
+// fp32), and their SIGN BITS are shifted into the mask one v_alignbit_b32 each, last shift first.  ~50 instructions per round
+// where the compare / select / or form took 125.
+__device__ __forceinline__ uint32_t push_sign(uint32_t mask, float d) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31u); }  // (mask << 1) | (d < 0)
 __device__ __forceinline__ uint32_t cull_todo(const Lane &L, float best, float margin) {
-    // conservative (rounded-down) squared distances to the faces of the own voxel
     const Probe &P = L.q;
-    const float lo[3] = {P.lx * P.lx * 0.99999f - margin, P.ly * P.ly * 0.99999f - margin, P.lz * P.lz * 0.99999f - margin};
-    const float hi[3] = {(kCell - P.lx) * (kCell - P.lx) * 0.99999f - margin, (kCell - P.ly) * (kCell - P.ly) * 0.99999f - margin,
-                         (kCell - P.lz) * (kCell - P.lz) * 0.99999f - margin};
-    return L.todo & alive_mask(lo, hi, best + margin);
+    const v2f x = {kCell - P.lx, P.lx}, y = {kCell - P.ly, P.ly}, z = {kCell - P.lz, P.lz};  // distances to the {+, -} faces of the own voxel
+    const v2f fx = x * x, fy = y * y, fz = z * z;
+    const float lim = (best + 4.0f * margin) * 1.00001f;
+    const v2f A = {lim, lim};
+    // reference order (kShiftTable): 0 own | 1 +x 2 -x 3 +y 4 -y 5 +z 6 -z | 7 ++0 8 +-0 9 -+0 10 --0 | 11 +0+ 12 +0- 13 -0+ 14 -0-
+    // | 15 0++ 16 0+- 17 0-+ 18 0-- | 19 +++ 20 ++- 21 +-+ 22 +-- 23 -++ 24 -+- 25 --+ 26 ---
+    const v2f dx = A - fx, dy = A - fy, dz = A - fz;                    // faces {1, 2} {3, 4} {5, 6}
+    const v2f dxp = {dx.x, dx.x}, dxm = {dx.y, dx.y}, dyp = {dy.x, dy.x}, dym = {dy.y, dy.y};
+    const v2f exy_p = dxp - fy, exy_m = dxm - fy;                        // xy edges {7, 8} {9, 10}
+    const v2f exz_p = dxp - fz, exz_m = dxm - fz;                        // xz edges {11, 12} {13, 14}
+    const v2f eyz_p = dyp - fz, eyz_m = dym - fz;                        // yz edges {15, 16} {17, 18}
+    const v2f c_pp = v2f{exy_p.x, exy_p.x} - fz, c_pm = v2f{exy_p.y, exy_p.y} - fz;  // corners {19, 20} {21, 22}
+    const v2f c_mp = v2f{exy_m.x, exy_m.x} - fz, c_mm = v2f{exy_m.y, exy_m.y} - fz;  //         {23, 24} {25, 26}
+    uint32_t dead = 0u;
+    dead = push_sign(push_sign(dead, c_mm.y), c_mm.x), dead = push_sign(push_sign(dead, c_mp.y), c_mp.x);
+    dead = push_sign(push_sign(dead, c_pm.y), c_pm.x), dead = push_sign(push_sign(dead, c_pp.y), c_pp.x);
+    dead = push_sign(push_sign(dead, eyz_m.y), eyz_m.x), dead = push_sign(push_sign(dead, eyz_p.y), eyz_p.x);
+    dead = push_sign(push_sign(dead, exz_m.y), exz_m.x), dead = push_sign(push_sign(dead, exz_p.y), exz_p.x);
+    dead = push_sign(push_sign(dead, exy_m.y), exy_m.x), dead = push_sign(push_sign(dead, exy_p.y), exy_p.x);
+    dead = push_sign(push_sign(dead, dz.y), dz.x), dead = push_sign(push_sign(dead, dy.y), dy.x), dead = push_sign(push_sign(dead, dx.y), dx.x);
+    return L.todo & ~(dead << 1);  // (bit 0, the own voxel, is always alive)
 }
 // One trip over N consecutive points of a mirror bucket, in two halves so that a caller can keep several trips in flight:
 // load_trip issues the N / 2 16-byte loads at immediate offsets; process_trip turns the loaded words into distances in mirror
@@ -1229,11 +1288,22 @@ __device__ __forceinline__ float voxel_lower_bound(const Probe &P, int s, float 
     return lb;
 }
 
+// The kernel arguments as they lie in the kernarg segment, through an opaque copy of its address: what is read through this view is
+// fetched (scalar loads, scalar cache) WHERE it is used instead of being loaded at the kernel's start and kept in scalar registers
+// through the search - the pass kernels' sixteen words of basis pushed as many other values out into vector registers, and the
+// four-waves build spilled.  Every pass kernel's first (or only) argument is its PassParams, at offset 0.
+typedef const PassParams __attribute__((address_space(4))) *PassKernarg;
+__device__ __forceinline__ const PassParams &args_at_point_of_use() {
+    PassKernarg q = (PassKernarg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; kernel arguments, re-read at the point of use" : "+s"(q));
+    return *(const PassParams *)q;
+}
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
-__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, const double *__restrict__ src, const Pose &T, uint32_t i, const Best3 &t,
-                                                       const KeptQuery *kept = nullptr) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12)) return;
+// `host_pose`: T is the host's pose (the kernel arguments carry its basis); otherwise the basis is formed here, from T
+__device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, bool host_pose, const double *__restrict__ src, const Pose &T, uint32_t i,
+                                                       const Best3 &t, const KeptQuery *kept = nullptr) {
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
@@ -1246,6 +1316,10 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
     bool have_winner = false;
     if (t.b3 - t.b1 <= margin && p.dbg != 9) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
         // (which needs to look no farther than the pre-selected winner's exact distance)
+        if (kept && !kept->voxel) {
+            const double vs = m.voxel_size;
+            q.vx = voxel_coord(q.x, vs, p.search.inv_vs), q.vy = voxel_coord(q.y, vs, p.search.inv_vs), q.vz = voxel_coord(q.z, vs, p.search.inv_vs);
+        }
         const double *c1 = m.pool + static_cast<size_t>(t.i1) * 3;
         search_global(m, q, best, best_idx, exact_d2_of(c1[0], c1[1], c1[2], q));
     } else {
@@ -1265,13 +1339,22 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
             }
         }
     }
-    if (best_idx != kNoIndex32 && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+    if (best_idx != kNoIndex32 && accepted_by_norm(best, p.tau, p.search)) {  // `distance < max_correspondance_distance`, Registration.cpp:75
         if (!have_winner) {  // (found by the exact search)
             const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
             wx = tp[0], wy = tp[1], wz = tp[2];
         }
+        // The basis is taken up HERE - behind an opaque copy of the flag, so that the compiler cannot merge its two sources ahead of
+        // the exact phase and carry sixteen registers through it (the four-waves build spilled them) - and, where it is the host's,
+        // read from the kernarg segment here rather than at the kernel's start (args_at_point_of_use).
+        if (p.dbg == 13) return;  // (attribution, tools/valu_attribution.sh: the exact phase without the terms)
+        int from_args = __builtin_amdgcn_readfirstlane(host_pose ? 1 : 0);
+        asm volatile("; the basis is taken up here" : "+s"(from_args));
+        PassBasis B;
+        if (from_args) B = args_at_point_of_use().sol.basis;
+        else B = basis_of(T);
         // the untransformed source point again (L1 / L2 hit) unless the build kept it: cheaper than registers kept live through the search
-        accumulate(acc, T, kept ? kept->sx : src[3 * i], kept ? kept->sy : src[3 * i + 1], q.x, q.y, q.z, wx, wy, wz);
+        accumulate(acc, B, kept ? kept->sx : src[3 * i], kept ? kept->sy : src[3 * i + 1], q.x, q.y, q.z, wx, wy, wz);
     }
 }
 
@@ -1286,8 +1369,15 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 // (<= 131 072 points on 256 CUs) - two neighbour voxels per round (visit_two).
 // the search and the exact phase of one pass for lane `tid` of workgroup blockIdx.x; `acc` receives the lane's terms
 // (`src`, `n`: the scan - p.src / p.n for a kernel that serves one call, the current scan of a resident kernel that serves a batch)
-template <int BLOCK, int G, bool SPLIT, bool LAT>
-__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n, uint32_t block, int *lend = nullptr) {
+// `park` (the four-waves build): BLOCK x kParkWords doubles of LDS in which a lane parks its transformed point and the two source
+// coordinates the terms need while it searches - that build has no registers to keep them (128 VGPRs) and used to transform the
+// source point a second time for the exact phase (~70 fp64 instructions and three loads per lane).
+constexpr int kParkWords = 5;
+// `host_pose`: T is the host's pose (kernel arguments) and p.sol.basis its basis; where the kernel got T from the device the basis
+// is formed right before the exact phase, not kept through the search.
+template <int BLOCK, int G, bool SPLIT, bool LAT, bool PARK = false>
+__device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, bool host_pose, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n,
+                                              uint32_t block, int *lend = nullptr, double *park = nullptr) {
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     const uint32_t gt = block * BLOCK + tid;  // (`block`: which BLOCK points of the scan this workgroup takes - blockIdx.x, or a resident kernel's turn)
@@ -1296,7 +1386,12 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
     const bool valid = i < n && p.dbg != 7 && p.dbg != 8;
     Lane L;
     KeptQuery kept;
-    start_lane(L, p, src, T, i, valid, LAT ? &kept : nullptr);
+    static_assert(!(LAT && PARK), "the latency-oriented build keeps the query in registers");
+    start_lane(L, p, src, T, i, valid, (LAT || PARK) ? &kept : nullptr);
+    if (PARK) {
+        park[0 * BLOCK + tid] = kept.q.x, park[1 * BLOCK + tid] = kept.q.y, park[2 * BLOCK + tid] = kept.q.z;
+        park[3 * BLOCK + tid] = kept.sx, park[4 * BLOCK + tid] = kept.sy;
+    }
     if (G > 1 && !SPLIT) {  // deal the set bits round-robin: the r-th occupied voxel goes to sub-lane r % G
         uint32_t rest = L.todo, mine = 0u;
         for (int r = 0; rest; ++r) {
@@ -1408,7 +1503,13 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
         best3_merge(L.t, o);
     }
     // ---- exact resolution (one sub-lane per query) ----------------------------------------------------------------------
-    if (sub == 0) resolve_and_accumulate(acc, p, src, T, L.i, L.t, LAT ? &kept : nullptr);
+    if (PARK) {  // (a lane reads back what it wrote itself: no barrier)
+        kept.q.x = park[0 * BLOCK + tid], kept.q.y = park[1 * BLOCK + tid], kept.q.z = park[2 * BLOCK + tid];
+        kept.sx = park[3 * BLOCK + tid], kept.sy = park[4 * BLOCK + tid], kept.voxel = false;
+    }
+    if (sub == 0) {
+        resolve_and_accumulate(acc, p, host_pose, src, T, L.i, L.t, (LAT || PARK) ? &kept : nullptr);
+    }
     // dbg 10 (bench.py's latency model): no correspondences are formed; the "count" sum carries the number of visiting rounds
     // this WAVE ran - its chain of dependent bucket visits - from lane 0 (as rounds x 2^40: limb 1 holds bits 21..41, limb 2 the rest)
     if (p.dbg == 10 && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
@@ -1420,10 +1521,13 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     KICP_PASS_SHARED(BLOCK)
     constexpr bool kLends = G == 1 && !SPLIT && !LAT;  // idle lanes take over voxels of loaded queries (gather32_pass)
     __shared__ int s_lend[kLends ? BLOCK / 64 : 1][kLendWords];
+    __shared__ double s_park[kLends ? BLOCK * kParkWords : 1];
     if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
+    const bool host_pose = p.sol.pass == 0 || p.sol.mode >= 2;  // (load_pose)
     Acc acc{};
-    gather32_pass<BLOCK, G, SPLIT, LAT>(p, T, threadIdx.x, acc, p.src, p.n, blockIdx.x, kLends ? &s_lend[kLends ? threadIdx.x / 64 : 0][0] : nullptr);
+    gather32_pass<BLOCK, G, SPLIT, LAT, kLends>(p, T, host_pose, threadIdx.x, acc, p.src, p.n, blockIdx.x, kLends ? &s_lend[kLends ? threadIdx.x / 64 : 0][0] : nullptr,
+                                                s_park);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
 }

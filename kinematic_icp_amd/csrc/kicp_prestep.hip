@@ -36,6 +36,7 @@ struct kicp_pre {
     hipEvent_t copy_done = nullptr;
     unsigned char *copy_host = nullptr;
     size_t copy_cap = 0, copy_n = 0;
+    size_t copy_points = 0;  // points the helper thread moves (set before the job is posted, never written while it runs; copy_n is what _finish REPORTS)
     int copy_buffer = -1;
     // kicp_pre_download_begin_into: a helper thread of the handle moves the landed bytes into the caller's memory while the
     // calling thread goes on with the pipeline (waits for the DMA's event, then one memcpy); _finish only joins it
@@ -388,7 +389,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     }
     p->table_clean = true;
     for (int b = 0; b < 3; ++b) counts[b] = p->buf_n[b] = misc[4 + b];
-    if (out_frame_xyz) p->copy_n = counts[0];  // (what _finish reports; the copy itself moved the upper bound)
+    if (out_frame_xyz) p->copy_n = counts[0];  // (what _finish reports; the helper thread moves the upper bound, copy_points, and never reads this)
     if (p->last_max_probe > p->probe_limit) {
         last_error() = "VoxelDownsample: a robin-hood probe of " + std::to_string(p->last_max_probe) + " buckets exceeds the limit of " +
                        std::to_string(p->probe_limit) + " at which tsl::robin_map grows its table: the output ORDER may differ from the reference's";
@@ -488,7 +489,7 @@ static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t aft
     if (after) HIP_TRY(hipStreamWaitEvent(p->copy_stream, after, 0));
     if (bytes) HIP_TRY(hipMemcpyAsync(p->copy_host, p->buf[buffer], bytes, hipMemcpyDeviceToHost, p->copy_stream));
     HIP_TRY(hipEventRecord(p->copy_done, p->copy_stream));
-    p->copy_buffer = buffer, p->copy_n = n;
+    p->copy_buffer = buffer, p->copy_n = n, p->copy_points = n;
     return KICP_OK;
 }
 static void copy_worker(kicp_pre *p) {
@@ -499,7 +500,7 @@ static void copy_worker(kicp_pre *p) {
         if (p->copy_state == -1) return;
         lock.unlock();
         const hipError_t e = hipEventSynchronize(p->copy_done);
-        const size_t k = std::min(p->copy_n, p->copy_dst_points);
+        const size_t k = std::min(p->copy_points, p->copy_dst_points);  // (copy_points, copy_dst*: written before the job was posted, under the mutex)
         if (e == hipSuccess && k && p->copy_dst) std::memcpy(p->copy_dst, p->copy_host, k * 24);
         lock.lock();
         p->copy_error = e, p->copy_state = 2;

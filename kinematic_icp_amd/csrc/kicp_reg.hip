@@ -424,7 +424,15 @@ template <typename T>
 int fetch_upload(kicp_reg *r, const T *src, size_t n) {
     const size_t bytes = n * 3 * sizeof(T);
     if (int rc = stage_begin(r->stage, bytes, r->stream)) return rc;
-    if (!r->stage.dev) return fail(KICP_ERR_HIP, "the staging buffer is not mapped into the device's address space");
+    if (!r->stage.dev) {  // the platform does not map pinned host memory into the device's address space: the DMA engine moves the frame
+        if (int rc = stage_end(r->stage, r->stream)) return rc;
+        if (sizeof(T) == sizeof(double)) return staged_upload(r->stage, 0, r->d_frame, src, bytes, r->stream);
+        std::vector<double> wide(n * 3);  // (float32: widened on the host first - static_cast<double>(float) is exact)
+        for (size_t i = 0; i < wide.size(); ++i) wide[i] = static_cast<double>(src[i]);
+        if (int rc = staged_upload(r->stage, 0, r->d_frame, wide.data(), wide.size() * sizeof(double), r->stream)) return rc;
+        HIP_TRY(hipStreamSynchronize(r->stream));  // (`wide` goes out of scope; staged_upload has copied it into the pinned buffer, the DMAs may lag)
+        return KICP_OK;
+    }
     const unsigned char *from = reinterpret_cast<const unsigned char *>(src);
     for (size_t off = 0; off < bytes; off += kFetchPiece) {
         const size_t len = std::min(kFetchPiece, bytes - off);
@@ -491,6 +499,15 @@ int wait_record(kicp_reg *r, unsigned long long call_id, unsigned min_iter, bool
     }
 }
 
+// The flag word of a GROUP's row (finish_pass): the sum over its <= kGroup workgroups of range_error (0 / 1 each) + kLostRowUnit once if
+// the group's reader gave a row up + kGaveUpUnit per workgroup that left without a command.  The fields cannot run into each other
+// inside one group's row (<= 32 in each), but their SUMS over the groups of a launch can (a cfg5 launch has 62 groups: 256 range
+// errors would read as a lost row - ADVICE r4), so the host never adds flag words: every row's word is reduced to its three facts
+// first and those are OR-ed.
+long long row_flags(long long w) {
+    const unsigned long long u = static_cast<unsigned long long>(w);
+    return static_cast<long long>(((u & 0xFFull) ? 1ull : 0ull) | (((u >> 8) & 0xFFull) ? kLostRowUnit : 0ull) | ((u >> 16) ? kGaveUpUnit : 0ull));
+}
 // mode 4: add the tagged rows of the `groups` first-level groups as they arrive (word = value << 16 | tag)
 int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kReduceWords], size_t first_row = 0) {
     for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
@@ -524,7 +541,9 @@ int wait_rows(kicp_reg *r, size_t groups, uint32_t tag, long long out_words[kRed
                 if (deadline.passed()) return fail(KICP_ERR_HIP, "timed out waiting for the pass kernel's rows (KICP_WAIT_TIMEOUT_S)");
             }
         }
-        for (int i = 0; i < kReduceWords; ++i) out_words[i] += v[i];
+        for (int i = 0; i < kReduceWords; ++i)
+            if (i != kNumLimbs) out_words[i] += v[i];
+        out_words[kNumLimbs] |= row_flags(v[kNumLimbs]);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return KICP_OK;
@@ -778,6 +797,7 @@ int clear_stale_tickets(kicp_reg *r) {
     return KICP_OK;
 }
 
+constexpr int kMaxGiveUps = 16;  // launches in a row that may end without a completed pass before the call fails
 int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const SmallPlan &pl, const Pose &T0, double tau, double out_pose_qt[7],
               kicp_stats *stats) {
     const int max_it = r->cfg.max_num_iterations;
@@ -805,7 +825,16 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     HostLoop loop;
     loop.T = T0;
     bool finished = false;
+    int give_ups = 0;  // consecutive launches that ended in a give-up without a pass completed
     while (!finished) {
+        if (give_ups > kMaxGiveUps)
+            return fail(KICP_ERR_HIP, "the resident pass kernel gave up waiting for its command in " + std::to_string(give_ups) + " launches in a row (small_timeout_us too short for this host?)");
+        if (give_ups > 0 && pl.generic) {
+            // workgroups of the launch that gave up may have added (partial, marked) contributions to the accumulators / tickets of the
+            // slot the fresh launch's pass will use: wait for that kernel to be gone and clear them
+            r->acc_dirty = true;
+            if (int rc = clear_stale_tickets(r)) return rc;
+        }
         const uint32_t left = static_cast<uint32_t>(max_it - loop.iter);
         // Residency pays from the second pass on and costs ~1 us when there is none (the kernel lingers until it sees STOP, and
         // the next dispatch waits for it).  Consecutive scans of a drive need about the same number of iterations, so the first
@@ -814,7 +843,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
         const bool stay = r->small_resident == 1 ? (loop.iter > 0 || r->small_prev_iters > 1) : r->small_resident != 0;
         const uint32_t cnt = stay ? std::min(left, kSmallMaxPasses) : 1u;
         if (int rc = next_tag_range(r, cnt, &sp.tag0)) return rc;
-        pp.sol.pose0 = loop.T, pp.sol.pass = loop.iter;
+        set_pose(pp.sol, loop.T), pp.sol.pass = loop.iter;
         sp.max_passes = cnt, sp.seq_base = r->cmd_seq;
         r->cmd_seq += cnt;  // every sequence number this launch may wait for is now spent
         sp.trace = r->d_trace, sp.trace_pass = r->trace_pass;
@@ -853,10 +882,11 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
                 return rc;
             }
             if (gave_up) {  // (part of) the kernel left while this thread was away: run this pass and the rest in a fresh launch
-                ++r->small_relaunches;
+                ++r->small_relaunches, ++give_ups;
                 if (k + 1 < cnt) send_command(r, sp.seq_base + k + 1, kCmdStop, loop.T);  // workgroups that did see the command
                 break;
             }
+            give_ups = 0;
             finished = loop.step(r, words, stats);
             if (k + 1 == cnt) break;
             if (r->debug_stall_us > 0.0) {  // tests: be late once
@@ -930,7 +960,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc;
     pp.dbg = r->dbg;
     SolveParams &sp = pp.sol;
-    sp.pose0 = T0, sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
+    set_pose(sp, T0), sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
     sp.adaptive = r->cfg.use_adaptive_odometry_regularization, sp.fixed_regularization = r->cfg.fixed_regularization;
     sp.mode = multi ? 1 : 0, sp.call_id = call_id, sp.rec = r->d_rec;
 
@@ -965,7 +995,8 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
             // peer mailboxes: the groups' rows travel themselves when the launch has few enough of them (one reduction level less)
             // (every rank must use the same wire format - option "p2p_rows" - but may be on either side of the group limit)
             const bool p2p_rows = p2p && r->p2p_rows == 1 && groups <= static_cast<size_t>(kP2pMaxGroups);  // (2: always the single row - tests)
-            sp.pass = it, sp.pose0 = loop.T, sp.mode = multi ? 3 : (p2p ? (p2p_rows ? 6 : (r->p2p_rows ? 7 : 5)) : (rows_mode ? 4 : 2));
+            set_pose(sp, loop.T);
+            sp.pass = it, sp.mode = multi ? 3 : (p2p ? (p2p_rows ? 6 : (r->p2p_rows ? 7 : 5)) : (rows_mode ? 4 : 2));
             if (p2p) {  // every rank issues the same sequence of exchanges: the step number doubles as tag and buffer parity
                 const unsigned long long step = r->p2p_step++;
                 sp.p2p_peers = r->d_p2p_table, sp.p2p_nranks = r->nranks, sp.p2p_rank = r->rank;
@@ -1008,6 +1039,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
                 if (int rc = wait_rows(r, groups, sp.tag, words)) return rc;
                 if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
                     return fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)");
+                words[kNumLimbs] &= 0xFFll;
                 if (shm) {  // this rank's totals go into its slot from the host side; then every rank adds all slots
                     for (int i = 0; i < kReduceWords; ++i) mine_host->words[i] = words[i];
                     __atomic_store_n(&mine_host->seq, shm_value, __ATOMIC_RELEASE);
@@ -1222,6 +1254,10 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     auto leave = [&](int rc) {  // hand back what is complete from the front; the caller's plain loop takes the rest
         if (out > 0 || rc != KICP_OK) r->acc_dirty = true;  // (passes still out will not be collected)
         stop_kernel();
+        if (rc < 0) {  // nothing of this call may still be reading the caller's frames when it returns with an error (as run_batch_queues)
+            (void)aql_quiesce(r);
+            (void)hipStreamSynchronize(r->stream);
+        }
         while (front < count && complete[front]) ++front;
         *done = front;
         return rc;
@@ -1258,7 +1294,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
                     if (slots[j].active) rest += static_cast<unsigned long long>(std::max(1, max_it - slots[j].loop.iter));
                 const uint32_t cnt = static_cast<uint32_t>(std::min<unsigned long long>(kBatchMaxPasses, rest));
                 if (int rc = next_tag_range(r, cnt, &sp.tag0)) return leave(rc);
-                pp.sol.pose0 = f.loop.T, pp.sol.pass = f.loop.iter;
+                set_pose(pp.sol, f.loop.T), pp.sol.pass = f.loop.iter;
                 sp.max_passes = cnt, sp.seq_base = r->cmd_seq, sp.scan0 = static_cast<uint32_t>(f.k);
                 r->cmd_seq += cnt;
                 sp.trace = r->d_trace, sp.trace_pass = r->trace_pass;
@@ -1366,7 +1402,9 @@ int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
                 f.total[i] += static_cast<__int128>(w[2 * i] >> 16) + (static_cast<__int128>(static_cast<long long>(w[2 * i + 1]) >> 16) << 48);
             f.flags |= w[2 * kNumSums] >> 16;
         } else {
-            for (int i = 0; i < kReduceWords; ++i) f.words[i] += static_cast<long long>(w[i]) >> 16;
+            for (int i = 0; i < kReduceWords; ++i)
+                if (i != kNumLimbs) f.words[i] += static_cast<long long>(w[i]) >> 16;
+            f.words[kNumLimbs] |= row_flags(static_cast<long long>(w[kNumLimbs]) >> 16);
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1396,7 +1434,8 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.dbg = h->dbg;
     SolveParams &sol = pp.sol;
-    sol.pose0 = f.loop.T, sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
+    set_pose(sol, f.loop.T);
+    sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
     sol.convergence_criterion = h->cfg.convergence_criterion;
     if (f.small) {  // one wave per query / sub-lanes per query: every workgroup's row goes straight to the host; the launch serves this pass only
         f.rows = f.pl.grid;
@@ -1958,7 +1997,8 @@ static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size
     pp.partials = reg->d_partials, pp.tickets = reg->d_tickets;
     pp.src = reg->d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = max_correspondence_distance;
     pp.st = reg->d_state, pp.search = search_params(max_correspondence_distance, map->mirror.view.voxel_size);
-    pp.sol.pose0 = pose_from(pose_qt), pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
+    set_pose(pp.sol, pose_from(pose_qt));
+    pp.sol.pass = 0, pp.sol.mode = 1, pp.sol.call_id = call_id, pp.sol.rec = reg->d_rec;
     if (int rc = launch_pass(reg, pp)) return rc;
     hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, reg->stream, reg->d_state, reg->d_rec, call_id);
     HIP_TRY(hipGetLastError());

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
                 o.i1 = __shfl_xor(L.t.i1, off, 64), o.i2 = __shfl_xor(L.t.i2, off, 64), o.o1 = __shfl_xor(L.t.o1, off, 64), o.o2 = __shfl_xor(L.t.o2, off, 64);
                 best3_merge(L.t, o);
             }
-            if (sub == 0) resolve_and_accumulate(acc, p, p.src, T, L.i, L.t);
+            if (sub == 0) resolve_and_accumulate(acc, p, false, p.src, T, L.i, L.t);
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         tid = fresh_tid();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
             const double *src = sp.p.src;
             uint32_t n = sp.p.n;
             if (sp.scans) src = sp.scans[scan].src, n = static_cast<uint32_t>(sp.scans[scan].n);  // (uniform: scalar loads)
-            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, tid, acc, src, n, share);
+            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, false, tid, acc, src, n, share);
             share += sp.rotate;
             if (share >= gridDim.x) share -= gridDim.x;
         }
@@ -452,11 +452,9 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
                 if (found || absent) break;
                 h = (h + 2u) & m.mask;
             }
-            // J.col(0) = R * UnitX, J.col(1) = R * (-s.y, s.x, 0)  (Registration.cpp:86-93): wave-uniform, issued here so that they run
+            // the pose's part of the terms (J.col(0) = R UnitX, R UnitY; Registration.cpp:86-93): wave-uniform, issued here so that it runs
             // in the shadow of the bucket loads
-            double j0x, j0y, j0z, j1x, j1y, j1z;
-            quat_rotate(T, 1.0, 0.0, 0.0, j0x, j0y, j0z);
-            quat_rotate(T, -sy, sx, 0.0, j1x, j1y, j1z);
+            const PassBasis B = basis_of(T);
             Lane L;  // (the culling helpers' view: offsets inside the own voxel in mirror units)
             L.q.lx = static_cast<float>((q.x - q.vx * vs) * sq.upm), L.q.ly = static_cast<float>((q.y - q.vy * vs) * sq.upm),
             L.q.lz = static_cast<float>((q.z - q.vz * vs) * sq.upm);
@@ -549,14 +547,12 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
             }
             if (best.idx != kNoIndex32 && sqrt(best.d2) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
                 accepted = true;
-                const double rx = q.x - best.x, ry = q.y - best.y, rz = q.z - best.z;  // residual = T*source - target
-                // the six products of Registration.cpp:108-113 side by side: lane k forms term k = a . b with
-                //   a = j0 j0 j1 j0 j1 r,  b = j0 j1 j1 r r r   (the same three multiplications and two additions, in the same order)
-                const bool a_is_j1 = lane == 2 || lane == 4, a_is_r = lane == 5;
-                const bool b_is_j0 = lane == 0, b_is_j1 = lane == 1 || lane == 2;
-                const double ax = a_is_r ? rx : (a_is_j1 ? j1x : j0x), ay = a_is_r ? ry : (a_is_j1 ? j1y : j0y), az = a_is_r ? rz : (a_is_j1 ? j1z : j0z);
-                const double bx = b_is_j0 ? j0x : (b_is_j1 ? j1x : rx), by = b_is_j0 ? j0y : (b_is_j1 ? j1y : ry), bz = b_is_j0 ? j0z : (b_is_j1 ? j1z : rz);
-                term_value = ax * bx + ay * by + az * bz;
+                // the terms of kicp_kernels.hpp::correspondence_terms (one function for every pass kernel: the same doubles), lane k < 6
+                // taking term k to convert and park; JTJ(0,0) is the expression basis_of converts
+                double term[5];
+                correspondence_terms(B, sx, sy, q.x, q.y, q.z, best.x, best.y, best.z, term);
+                term_value = lane == 0 ? B.c0x * B.c0x + B.c0y * B.c0y + B.c0z * B.c0z
+                                       : (lane == 1 ? term[0] : (lane == 2 ? term[1] : (lane == 3 ? term[2] : (lane == 4 ? term[3] : term[4]))));
                 if (lane == 6) term_value = 1.0;  // the count
             }
         }
