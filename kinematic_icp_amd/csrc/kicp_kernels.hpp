@@ -768,9 +768,13 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             i128_add_limb_sums(t, s_red[w][kTermLimbs * lane], s_red[w][kTermLimbs * lane + 1], s_red[w][kTermLimbs * lane + 2], s_red[w][kTermLimbs * lane + 3]);
     }
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
-    if (ROWS_ONLY) {
-        // Resident kernels (several passes in flight, the pace set by the workgroup that is behind): ONE round trip to the L2 and no
-        // reader.  Lane w < kReduceWords adds word w of the workgroup's row - biased to be non-negative, with a 1 in the count field
+    // (an ordinary launch in mode 4 - round 5: the accumulators alternate with the pass tag's parity, the host's row of group g stays
+    //  where it was; dbg 14: round 4's rows -> ticket -> reload, for the in-process A/B)
+    const bool counting = ROWS_ONLY || (p.sol.mode == 4 && p.dbg != 14);
+    if (!ROWS_ONLY && counting) parity = row_tag & 1u;
+    if (counting) {
+        // ONE round trip to the L2 and no reader (round 4: the resident kernels, where several passes are in flight and the pace is
+        // set by the workgroup that is behind; round 5: every launch whose group rows go to the host).  Lane w < kReduceWords adds word w of the workgroup's row - biased to be non-negative, with a 1 in the count field
         // above it - to word w of the group's accumulator.  The addition that finds the count at group size - 1 is the last one for
         // that word: old value + own = the group's sum, which that lane hands to the host (and clears the word for the slot's next
         // turn).  Every word is completed by whichever workgroup happened to add to it last - not necessarily the same one for all
@@ -789,7 +793,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             if ((old >> kAccCountShift) == group_size - 1u) {
                 const long long total = static_cast<long long>((old & ((1ull << kAccCountShift) - 1ull)) + mine) - static_cast<long long>(group_size) * kAccBias;
                 __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(parity) * ngroups + g) * kReduceWords + lane,
+                __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(ROWS_ONLY ? parity * ngroups : 0u) + g) * kReduceWords + lane,
                                    (static_cast<unsigned long long>(total) << 16) | static_cast<unsigned long long>(row_tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -1303,7 +1307,7 @@ __device__ __forceinline__ const PassParams &args_at_point_of_use() {
 // `host_pose`: T is the host's pose (the kernel arguments carry its basis); otherwise the basis is formed here, from T
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, bool host_pose, const double *__restrict__ src, const Pose &T, uint32_t i,
                                                        const Best3 &t, const KeptQuery *kept = nullptr) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13)) return;
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13 && p.dbg != 14)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;

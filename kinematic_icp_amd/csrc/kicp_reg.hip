@@ -347,10 +347,10 @@ int ensure_partials(kicp_reg *r, size_t blocks) {
     const size_t want = blocks + blocks / 2 + 64, groups = want / kGroup + 2;
     HIP_TRY(hipMalloc(&r->d_partials, (want + groups) * kReduceWords * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&r->d_tickets, groups * kTicketStride * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(&r->d_group_acc, groups * kAccStride * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&r->d_group_acc, 2 * groups * kAccStride * sizeof(unsigned long long)));  // (two sets: an ordinary launch takes the set of its tag's parity)
     r->stream_dirty = true;
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, groups * kTicketStride * sizeof(unsigned int), r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, groups * kAccStride * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, 2 * groups * kAccStride * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_partials, 0, (want + groups) * kReduceWords * sizeof(unsigned long long), r->stream));  // tag 0 = never valid
     r->partial_blocks = want;
     return KICP_OK;
@@ -791,7 +791,7 @@ int clear_stale_tickets(kicp_reg *r) {
     if (int rc = aql_quiesce(r)) return rc;
     r->stream_dirty = true;
     HIP_TRY(hipMemsetAsync(r->d_tickets, 0, (r->partial_blocks / kGroup + 2) * kTicketStride * sizeof(unsigned int), r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, (r->partial_blocks / kGroup + 2) * kAccStride * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_group_acc, 0, 2 * (r->partial_blocks / kGroup + 2) * kAccStride * sizeof(unsigned long long), r->stream));
     __atomic_store_n(&r->rec->reserved[0], 0u, __ATOMIC_RELAXED);
     r->acc_dirty = false;
     return KICP_OK;
@@ -817,6 +817,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
+    pp.dbg = r->dbg;  // (0, or 14: the in-process A/B switch of the plain launch's hand-over)
     if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     if (pl.generic)
         if (int rc = clear_stale_tickets(r)) return rc;
@@ -942,7 +943,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     if (max_it > 0x7FFF && (!r->host_solve || r->group_rows == 0 || multi || p2p))
         return fail(KICP_ERR_ARG, "max_num_iterations > 32767 with a single-record hand-off (host_solve = 0, group_rows = 0, RCCL / callback / peer-mailbox exchange)");
     r->last_small = 0, r->last_resident_passes = 0;
-    if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0) {
+    if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 14)) {
         const SmallPlan pl = small_plan(r, n);
         if (pl.grid) return run_small(r, map, d_frame, n, pl, T0, tau, out_pose_qt, stats);
     }
@@ -1036,7 +1037,10 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
                 hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, r->stream, r->d_state, r->d_rec, call_id, it);
             }
             if (rows_mode) {
-                if (int rc = wait_rows(r, groups, sp.tag, words)) return rc;
+                if (int rc = wait_rows(r, groups, sp.tag, words)) {
+                    r->acc_dirty = true;  // (the groups' counting accumulators may hold part of this pass: cleared before the next call's)
+                    return rc;
+                }
                 if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
                     return fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)");
                 words[kNumLimbs] &= 0xFFll;
@@ -1158,7 +1162,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     constexpr size_t kBatchResidentMinScans = 8;
     if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || count > kCmdMaxScans || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
-          r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || (r->dbg >= 2 && r->dbg <= 5) || r->dbg == 9) && r->small_resident != 0))
+          r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || (r->dbg >= 2 && r->dbg <= 5) || r->dbg == 9 || r->dbg == 14) && r->small_resident != 0))
         return 1;
     // one kind of kernel serves the whole batch: the generic one (scans beyond the small-scan kernels, up to what the device holds at
     // once) or one wave per query (scans of up to kWaveMaxPoints points); anything else - or a mix - takes the plain loop
@@ -1454,6 +1458,7 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     f.rows = (grid + kGroup - 1) / kGroup;
     if (int rc = ensure_partials(h, grid)) return rc;
     if (int rc = ensure_rows(h, f.rows)) return rc;
+    if (int rc = clear_stale_tickets(h)) return rc;  // (nothing to do unless an earlier call left a pass uncollected)
     pp.partials = h->d_partials, pp.tickets = h->d_tickets, pp.group_acc = h->d_group_acc;
     sol.call_id = ++h->call_id, sol.rec = h->d_rec, sol.pub_rows = h->d_rows;
     if (int rc = next_tag(h, &sol.tag)) return rc;
@@ -1468,7 +1473,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     const int max_it = r->cfg.max_num_iterations;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
-          r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12)))
+          r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12 || r->dbg == 14)))
         return 1;
     // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
     // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
@@ -1510,6 +1515,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
         for (int j = 0; j < queues; ++j) {
             (void)aql_quiesce(flights[j].h);
             (void)hipStreamSynchronize(flights[j].h->stream);
+            if (rc < 0 && flights[j].active) flights[j].h->acc_dirty = true;  // (a pass that was not collected: its accumulators may be part full)
         }
         while (front < count && complete[front]) ++front;
         *done = front;

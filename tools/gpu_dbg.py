@@ -4,7 +4,8 @@
 Switches that leave the RESULT alone (for in-process A/Bs, tools/ab_option.py --option dbg): 9 no exact fp64 fallback search for three
 near-equal candidates (changes poses in rare ties: diagnosis only); 10 the rounds census of bench.py's latency model (the count sum
 carries every wave's visiting rounds); 11 idle lanes do NOT take over voxels of loaded queries (four-waves build); 12 all seven wave
-sums through the DPP reduction (none derived from a ballot)."""
+sums through the DPP reduction (none derived from a ballot); 13 the exact phase without the terms (tools/valu_attribution.sh); 14 the plain
+launch hands its group rows over as round 4 did (rows -> ticket -> reload) instead of through the counting accumulators."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

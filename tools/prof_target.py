@@ -72,4 +72,5 @@ K.lib().kicp_device_synchronize(0)
 dt = time.perf_counter() - t0
 print(json.dumps({"workload": args.workload, "multi": args.multi, "build": args.build, "map_points": gmap.num_points(), "map_voxels": gmap.num_voxels(),
                   "build_s": round(t_build, 2), "calls": args.calls, "scans_per_s": round(args.calls / dt, 1), "iterations_mean": float(np.mean(iters)),
-                  "pass_us_events": round(float(np.mean(pass_ms)) * 1e3, 2) if pass_ms else None}))
+                  "pass_us_events": round(float(np.mean(pass_ms)) * 1e3, 2) if pass_ms else None,
+                  "batch_queue_passes": reg.get_option("batch_queue_passes"), "batch_resident_passes": reg.get_option("batch_resident_passes")}))
