@@ -134,6 +134,12 @@ struct kicp_reg {
     ShmSlot *d_shm = nullptr;  // device view of the same memory
     size_t shm_bytes = 0;
     unsigned long long shm_step = 0;  // hand-offs issued so far (same on every rank)
+    // Sharded batches with several scans in flight (run_batch_queues): lane j of the batch call owns the slots [2 buffers][nranks]
+    // behind the single-call area, area 1 + j, and counts its own hand-offs - lane j registers scans j, j + lanes, j + 2 lanes ... on
+    // EVERY rank, so its sequence of exchanges is the same everywhere whatever order the lanes' passes complete in.
+    static constexpr int kShmLanes = 8;  // (= kMaxBatchQueues)
+    unsigned long long shm_lane_step[kShmLanes] = {};
+    bool shm_poisoned = false;  // a sharded batch failed half-way: the ranks' lane counters may disagree until the segment is set up again
     std::string shm_name;
     // one-shot exchange over peer mappings (kicp_reg_p2p_*): this rank's mailbox in its own HBM (fine-grained), the peers'
     // mailboxes as IPC mappings, and the table of all of them the pass kernel reads
@@ -1360,6 +1366,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
 // Returns 1 when the batch is not one for this path (the caller goes on to run_batch_resident / the plain loop), else a kicp
 // status; *done = scans completed from the front.
 constexpr int kMaxBatchQueues = 8;
+static_assert(kMaxBatchQueues == kicp_reg::kShmLanes, "a lane of a sharded batch call owns one area of the shared segment");
 struct BatchFlight {
     kicp_reg *h = nullptr;
     HostLoop loop;
@@ -1375,6 +1382,10 @@ struct BatchFlight {
     __int128 total[kNumSums] = {};                 // (small scans: two 48-bit halves per sum and row)
     unsigned long long flags = 0;
     Deadline since;
+    // sharded batches: this lane's next scan (static deal), and - once this rank's rows are in - the hand-off it waits for
+    size_t next = 0;
+    bool at_peers = false;
+    unsigned long long shm_value = 0;
 };
 // the rows of a flight's pass that have arrived since the last look: 1 all in (sums in out_words), 0 not yet, < 0 error
 int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
@@ -1434,6 +1445,7 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     for (auto &w : f.words) w = 0;
     for (auto &t : f.total) t = 0;
     PassParams &pp = f.small ? f.sp.p : f.pp;
+    if (n == 0) d_frame = reinterpret_cast<const double *>(h->d_state);  // (an empty shard: the one workgroup's lanes are all idle, but an idle lane still reads point 0)
     pp.src = d_frame, pp.n = static_cast<uint32_t>(n), pp.map = map->mirror.view, pp.tau = tau, pp.st = h->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.dbg = h->dbg;
@@ -1471,15 +1483,21 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     *done = 0;
     const int queues = std::min(r->batch_queues, kMaxBatchQueues);
     const int max_it = r->cfg.max_num_iterations;
+    // SHARDED batches (the shared segment attached, kicp_reg_shm_init): every rank calls with ITS shard of every scan, the lanes'
+    // exchanges go through the segment (below).  Every decision up to here and in the loop must then be the same on every rank - so
+    // none of them looks at the shard sizes, which differ.
+    const bool sharded = r->shm != nullptr;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
+    if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
           r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12 || r->dbg == 14)))
         return 1;
+    if (sharded && r->shm_poisoned)
+        return fail(KICP_ERR_COMM, "the shared-segment exchange is out of step after a sharded batch that failed: kicp_reg_shm_destroy and _init again on every rank");
     // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
     // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
     // the 4.5 us such a pass takes (measured, cfg4: 5.0 us per scan on four queues, 4.5 resident).  Mixed batches come here.
-    bool any_large = false;
-    for (size_t k = 0; k < count; ++k) {
+    bool any_large = sharded;  // (a shard goes through the generic kernel whatever its size: its group rows feed the exchange)
+    for (size_t k = 0; k < count && !sharded; ++k) {
         if (n[k] == 0) return 1;
         if (!any_large) {
             const SmallPlan pl = r->use_small ? small_plan(r, n[k]) : SmallPlan();
@@ -1501,8 +1519,9 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
         kicp_reg *h = r->batch_lanes[j];
         h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
         h->query_every = r->query_every, h->dbg = r->dbg, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
-        h->use_small = r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
+        h->use_small = sharded ? 0 : r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
         flights[j].h = h;
+        flights[j].next = static_cast<size_t>(j);  // (sharded: lane j's first scan)
     }
     r->last_small = 0, r->last_resident_passes = 0;
     {
@@ -1517,27 +1536,59 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
             (void)hipStreamSynchronize(flights[j].h->stream);
             if (rc < 0 && flights[j].active) flights[j].h->acc_dirty = true;  // (a pass that was not collected: its accumulators may be part full)
         }
+        if (rc < 0 && sharded) r->shm_poisoned = true;  // (the ranks' lane counters can no longer be assumed equal)
         while (front < count && complete[front]) ++front;
         *done = front;
         return rc;
     };
+    // the slots of lane j's hand-off `step` in the shared segment: [nranks], double-buffered by the hand-off's parity
+    auto lane_slots = [&](int j, unsigned long long step) { return r->shm + 2 * static_cast<size_t>(r->nranks) * (1 + j) + (step & 1) * r->nranks; };
     while (finished_scans < count) {
         for (int j = 0; j < queues; ++j) {
             BatchFlight &f = flights[j];
             if (!f.active) {
-                if (next_scan >= count) continue;
-                f.k = next_scan++, f.active = true;
+                if (sharded) {  // the deal is static - lane j registers scans j, j + queues, ... - so that every rank's lane j issues the same exchanges
+                    if (f.next >= count) continue;
+                    f.k = f.next, f.next += static_cast<size_t>(queues), f.active = true;
+                } else {
+                    if (next_scan >= count) continue;
+                    f.k = next_scan++, f.active = true;
+                }
+                f.at_peers = false;
                 f.loop = HostLoop();
                 f.loop.T = pose_mul(pose_from(last_poses_qt + 7 * f.k), pose_from(rel_odoms_qt + 7 * f.k));  // Registration.cpp:156
                 if (int rc = flight_launch(f, map, d_frames[f.k], n[f.k], tau)) return leave(rc);
                 continue;
             }
             long long words[kReduceWords];
-            const int ready = flight_rows(f, words);
-            if (ready < 0) return leave(ready);
-            if (ready == 0) continue;
-            if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
-                return leave(fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)"));
+            if (!f.at_peers) {
+                const int ready = flight_rows(f, words);
+                if (ready < 0) return leave(ready);
+                if (ready == 0) continue;
+                if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
+                    return leave(fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)"));
+                if (sharded) {  // this rank's totals of the pass go into its slot of the lane's area; then the lane waits for every rank's
+                    const unsigned long long step = r->shm_lane_step[j]++;
+                    kicp_reg::ShmSlot *mine = lane_slots(j, step) + r->rank;
+                    for (int i = 0; i < kReduceWords; ++i) mine->words[i] = words[i];
+                    __atomic_store_n(&mine->seq, step + 1, __ATOMIC_RELEASE);
+                    f.at_peers = true, f.shm_value = step + 1, f.since = Deadline(), f.polls = 0;
+                }
+            }
+            if (sharded) {  // (a non-blocking look: the other lanes' rows and hand-offs are served meanwhile)
+                const kicp_reg::ShmSlot *slots = lane_slots(j, f.shm_value - 1);
+                bool all_in = true;
+                for (int k = 0; k < r->nranks && all_in; ++k) all_in = __atomic_load_n(&slots[k].seq, __ATOMIC_ACQUIRE) == f.shm_value;
+                if (!all_in) {
+                    if (++f.polls % 4096u == 0u && f.since.passed()) return leave(fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off (KICP_WAIT_TIMEOUT_S)"));
+                    continue;
+                }
+                for (int i = 0; i < kReduceWords; ++i) words[i] = 0;
+                for (int k = 0; k < r->nranks; ++k)
+                    for (int i = 0; i < kReduceWords; ++i) words[i] += slots[k].words[i];  // (exact integers: the order does not matter)
+                words[kNumLimbs] = words[kNumLimbs] != 0 ? 1 : 0;
+                f.at_peers = false;
+            }
             ++r->batch_queue_passes;
             if (!f.loop.step(f.h, words, nullptr)) {
                 if (int rc = flight_launch(f, map, d_frames[f.k], n[f.k], tau)) return leave(rc);
@@ -2056,7 +2107,7 @@ int kicp_reg_comm_destroy(kicp_reg *reg) {
     return KICP_OK;
 }
 // Shared segment layout: one header slot (magic word written LAST by rank 0, then the rank count) followed by the
-// [2 buffers][nranks] hand-off slots.
+// [2 buffers][nranks] hand-off slots of single calls and, behind them, one such area per lane of a sharded batch call.
 constexpr unsigned long long kShmMagic = 0x4B49435053484D31ull;  // "KICPSHM1"
 int kicp_reg_shm_destroy(kicp_reg *reg) {
     if (!reg) return fail(KICP_ERR_ARG, "null argument");
@@ -2076,7 +2127,7 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     if (reg->comm) return fail(KICP_ERR_ARG, "an RCCL communicator is already attached");
     kicp_reg_shm_destroy(reg);
     if (int rc = set_device(reg->device)) return rc;
-    const size_t bytes = (1 + 2 * static_cast<size_t>(nranks)) * sizeof(kicp_reg::ShmSlot);
+    const size_t bytes = (1 + 2 * static_cast<size_t>(nranks) * (1 + kicp_reg::kShmLanes)) * sizeof(kicp_reg::ShmSlot);  // header, single-call area, the lanes' areas
     const std::string nm = std::string(name[0] == '/' ? "" : "/") + name;
     void *ptr = MAP_FAILED;
     if (rank == 0) {
@@ -2140,6 +2191,8 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     reg->shm = static_cast<kicp_reg::ShmSlot *>(ptr) + 1;
     reg->d_shm = dptr ? static_cast<kicp_reg::ShmSlot *>(dptr) + 1 : nullptr;
     reg->shm_bytes = bytes, reg->shm_step = 0, reg->shm_name = nm, reg->nranks = nranks, reg->rank = rank;
+    for (auto &st : reg->shm_lane_step) st = 0;
+    reg->shm_poisoned = false;
     return KICP_OK;
 }
 // ---- one-shot exchange over peer mappings -----------------------------------------------------

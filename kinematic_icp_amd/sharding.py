@@ -104,3 +104,46 @@ def add_small_rows(rows, tag):
             totals[i] += lo + (hi << HALF_BITS)
         flags |= int(row[2 * NUM_SUMS]) >> TAG_BITS
     return pack(totals), flags, ok
+
+
+# ---- several SHARDED scans in flight: the lanes of the shared segment (kicp_reg.hip run_batch_queues, `sharded`) ---------------
+# A sharded batch call keeps `lanes` scans in flight on every rank.  Lane j registers scans j, j + lanes, j + 2 lanes, ... - the
+# same deal on every rank, so lane j issues the same sequence of exchanges everywhere, whatever order the lanes' passes complete
+# in on each rank.  Each lane owns an area [2 buffers][nranks] of slots (sequence word + 24 limb words) and counts its own
+# hand-offs: hand-off s of a lane goes into buffer s & 1 with sequence s + 1; a rank may overwrite its slot of buffer s & 1 with
+# hand-off s + 2 only after it has seen every rank's hand-off s + 1, which every rank publishes after reading hand-off s.
+# This class is the reference of that protocol (tests/test_sharding.py runs it with eight processes); the library's loop is the
+# same state machine around the GPU's rows.
+SLOT_WORDS = 32  # 256-byte slots: sequence word, 24 limb words, padding
+
+
+class SegmentLanes:
+    def __init__(self, buffer, nranks, rank, lanes):
+        self.slots = np.ndarray((lanes, 2, nranks, SLOT_WORDS), dtype=np.int64, buffer=buffer)
+        self.nranks, self.rank, self.lanes = nranks, rank, lanes
+        self.step = [0] * lanes
+
+    @staticmethod
+    def nbytes(nranks, lanes):
+        return lanes * 2 * nranks * SLOT_WORDS * 8
+
+    def publish(self, lane, words):
+        """this rank's totals of the lane's next hand-off; returns the sequence value to collect"""
+        step = self.step[lane]
+        self.step[lane] += 1
+        slot = self.slots[lane, step & 1, self.rank]
+        slot[1:1 + REDUCE_WORDS] = words
+        slot[0] = step + 1  # (last: a reader that sees the sequence word sees the words)
+        return step + 1
+
+    def collect(self, lane, value):
+        """the sum over all ranks of hand-off `value` of the lane, or None while a rank's slot is missing (non-blocking)"""
+        area = self.slots[lane, (value - 1) & 1]
+        if not np.all(area[:, 0] == value):
+            return None
+        return area[:, 1:1 + REDUCE_WORDS].sum(axis=0)
+
+
+def lane_scans(lane, lanes, count):
+    """the scans lane `lane` of a sharded batch registers, in order (the static deal)"""
+    return list(range(lane, count, lanes))

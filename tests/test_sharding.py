@@ -153,6 +153,110 @@ def test_gloo_world_size_8(tmp_path):
     np.testing.assert_allclose(poses[0][:7], expect, atol=1e-9)
 
 
+def _lane_worker(rank, world, lanes, shm_name, out_dir, seed):
+    """one rank of a sharded BATCH with `lanes` scans in flight: the library's loop (run_batch_queues, sharded) with the oracle
+    standing in for the GPU's pass, non-blocking looks at the lanes in turn, random pauses so that the lanes' passes complete in a
+    different order on every rank"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    from multiprocessing import shared_memory
+    seg = shared_memory.SharedMemory(name=shm_name)
+    cfg, omap, frame, last, rel = _world()
+    tau = cfg.first_frame_tau()
+    scans = _batch_of_scans(frame, last, rel)
+    ex = sh.SegmentLanes(seg.buf, world, rank, lanes)
+    rng = np.random.default_rng(seed + rank)
+    state = [dict(todo=sh.lane_scans(j, lanes, len(scans)), k=None, waiting=None) for j in range(lanes)]
+    poses = [None] * len(scans)
+    deadline = time.time() + 120
+    while any(st["todo"] or st["k"] is not None for st in state):
+        assert time.time() < deadline, "a lane never got its peers' hand-off"
+        for j, st in enumerate(state):
+            if st["k"] is None:
+                if not st["todo"]:
+                    continue
+                st["k"] = st["todo"].pop(0)
+                fr, la, re = scans[st["k"]]
+                lo, hi = sh.shard_bounds(len(fr), world, rank)
+                st.update(shard=fr[lo:hi], T=okicp.se3_mul(la, re), it=0, beta=None)
+            if st["waiting"] is None:
+                if rng.random() < 0.3:
+                    time.sleep(rng.random() * 2e-3)  # this rank's GPU is late with this lane's rows
+                    continue
+                st["waiting"] = ex.publish(j, sh.pack(shard_pass_fixed(omap, st["shard"], st["T"], tau)))
+            words = ex.collect(j, st["waiting"])
+            if words is None:
+                continue
+            st["waiting"] = None
+            sums = sh.unpack(words)
+            if st["it"] == 0:
+                st["beta"] = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+            dx = okicp.solve(sums[:5], sums[6], st["beta"])
+            st["T"] = okicp.se3_mul(st["T"], okicp.motion_model(dx))
+            st["it"] += 1
+            if np.hypot(dx[0], dx[1]) < 1e-3 or st["it"] >= 10:
+                poses[st["k"]] = np.concatenate([st["T"], [st["it"]]])
+                st["k"] = None
+    np.save(os.path.join(out_dir, "lanes_%d.npy" % rank), np.array(poses))
+    del ex
+    seg.close()
+
+
+def _batch_of_scans(frame, last, rel):
+    """eleven registrations that differ in size, start and iteration count (one of two points: some ranks' shards are empty)"""
+    out = []
+    for i in range(11):
+        rel_i = syn.pose_mul(rel, syn.planar_pose(0.02 * i, 0.0, np.deg2rad(0.3 * i)))
+        out.append((frame[: len(frame) - 97 * i] if i != 5 else frame[100:102], last, rel_i))
+    return out
+
+
+@pytest.mark.parametrize("world,lanes", [(8, 4), (3, 2)])
+def test_sharded_batch_with_scans_in_flight_over_the_segment_lanes(tmp_path, world, lanes):
+    """The interleaved protocol of sharded batches (kinematic_icp_amd/sharding.py::SegmentLanes = kicp_reg.hip run_batch_queues,
+    `sharded`): eight ranks (the node size the north star names), four scans in flight on each, the lanes' hand-offs completing in a
+    different order on every rank - every rank ends with the same bits for every scan, equal to registering the scan sharded in
+    lock step (one scan at a time), and to the unsharded oracle to 1e-9."""
+    import multiprocessing as mp
+    from multiprocessing import shared_memory
+    seg = shared_memory.SharedMemory(create=True, size=sh.SegmentLanes.nbytes(world, lanes))
+    try:
+        np.ndarray((seg.size // 8,), dtype=np.int64, buffer=seg.buf)[:] = 0
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_lane_worker, args=(r, world, lanes, seg.name, str(tmp_path), 1234)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+    finally:
+        seg.close()
+        seg.unlink()
+    got = [np.load(tmp_path / ("lanes_%d.npy" % r)) for r in range(world)]
+    assert all(np.array_equal(g, got[0]) for g in got[1:])
+    cfg, omap, frame, last, rel = _world()
+    tau = cfg.first_frame_tau()
+    for k, (fr, la, re) in enumerate(_batch_of_scans(frame, last, rel)):
+        # lock step, one scan at a time (the emulated collective of test_emulated_world_sizes_give_identical_bits)
+        T, beta, its = okicp.se3_mul(la, re), None, 0
+        for it in range(10):
+            words = np.sum([sh.pack(shard_pass_fixed(omap, fr[slice(*sh.shard_bounds(len(fr), world, r))], T, tau)) for r in range(world)], 0)
+            sums = sh.unpack(words)
+            if it == 0:
+                beta = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+            dx = okicp.solve(sums[:5], sums[6], beta)
+            T, its = okicp.se3_mul(T, okicp.motion_model(dx)), it + 1
+            if np.hypot(dx[0], dx[1]) < 1e-3:
+                break
+        assert np.array_equal(got[0][k][:7], T, equal_nan=True) and int(got[0][k][7]) == its, k
+        if len(fr) > 100:
+            ref = okicp.KinematicRegistration()
+            np.testing.assert_allclose(T, ref.ComputeRobotMotion(fr, omap, la, re, tau), atol=1e-9)
+            assert its == ref.last_stats.iterations
+    assert sh.lane_scans(1, 4, 11) == [1, 5, 9] and sorted(sum((sh.lane_scans(j, lanes, 11) for j in range(lanes)), [])) == list(range(11))
+
+
 def test_small_scan_rows_add_up_exactly():
     """The small-scan kernels' row format (two 48-bit halves per 128-bit sum, kicp_small.hpp) against the limb payload: totals of
     either sign up to the accumulation range (|term| < 2^43, 1024 terms per workgroup), 272 rows, stale and marked rows."""
