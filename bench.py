@@ -108,10 +108,11 @@ def main():
                                                           "of scans + the map exceed what the caches hold)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "p2p", "torch"],
-                    help="N>1 exchange of the per-iteration sums: built-in RCCL all-reduce (default), host shared segment (no device "
-                         "collective), one-shot peer-mailbox exchange over xGMI mappings (no collective library), or torch.distributed "
-                         "all-reduce callback")
+    ap.add_argument("--comm", default="shm", choices=["rccl", "shm", "p2p", "torch"],
+                    help="N>1 exchange of the per-iteration sums behind `value`: host shared segment (default since round 5: no device collective, "
+                         "and the only exchange whose steps a batch call can interleave - several sharded scans in flight per rank, option "
+                         "batch_queues), built-in RCCL all-reduce (the north star's form; measured beside it in the same run: value_rccl, "
+                         "rccl_ranks), one-shot peer-mailbox exchange over xGMI mappings (value_p2p), or a torch.distributed all-reduce callback")
     ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for barriers/timing")
     ap.add_argument("--mode", default="shard", choices=["shard", "replicas"],
                     help="N>1: 'shard' (default, the north star) splits every scan's points across the ranks and exchanges the sums each "
@@ -552,6 +553,14 @@ def main():
                 exch[alt] = r
                 release(held.pop("f"), alt)
                 held.clear()
+                if alt == "shm":  # the same exchange with ONE sharded scan in flight (round 4's rate: a scan at a time, a hand-off per pass)
+                    held["s"], held["ks"] = make_reg(alt)
+                    held["s"].set_option("batch_queues", 0)
+                    es = timed(held["s"], w.rel_single, steps, 1, w=w, B=B_w)
+                    r["scans_per_s_one_scan_in_flight"] = round(steps * B_w / es, 1)
+                    r["scans_in_flight"] = int(reg2.get_option("batch_queues")) if reg2.get_option("batch_queue_passes") > 0 else 1
+                    release(held.pop("s"), alt)
+                    held.clear()
             except K.KicpError as e:
                 exch[alt] = {"note": str(e)[:200]}
                 held.clear()
@@ -801,7 +810,8 @@ def main():
                    "points_per_gpu": hi - lo,
                    "scans_per_s_one_python_call_per_scan": round((world if replicas else 1) * n_scans_timed / elapsed_py, 2),
                    "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
-                                  (("points sharded x%d, map replicated, %s all-reduce" % (world, args.comm)) if use_comm else "single GPU"),
+                                  (("points sharded x%d, map replicated, %s exchange of the 24 limb words per ICP pass, %d sharded scan(s) in flight per rank"
+                                    % (world, args.comm, in_flight)) if use_comm else "single GPU"),
                    "pass_kernel": pass_kernel, "launch_path": launch_path, "max_pose_abs_diff_vs_oracle": max_pose_err,
                    "poses_checked_against_the_oracle": len(iters_ref_multi) + len(iters_ref),
                    "poses_of_the_timed_region_checked": timed_checked + timed_checked_multi,
