@@ -928,12 +928,45 @@ def _cpu_baseline(args, cfg, scans, rels, tau, omap, map_points, okicp, rkicp):
                               "stand-in Eigen/Sophus/TBB/robin_map/kiss-icp headers, -O3, no -march) on the same %d scans, ~%.0f s; "
                               "threads tried %s, best reported" % (ref_n, len(scans), args.cpu_seconds / 2, counts),
                     "single_thread_value": round(ref[1], 3), "reference_by_threads": {str(c): round(v, 3) for c, v in ref.items()}})
+        # THROUGHPUT mode, the CPU's twin of the GPU's scans-in-flight headline: min(cores the container may use, 16) INDEPENDENT
+        # registrations at a time, one thread each (the reference's own default, ros/launch/offline_node.launch.py:60) - in a process
+        # of its own (tools/bench_cpu_throughput.py)
+        res["throughput"] = _cpu_throughput(cfg, scans, rels, tau, map_points, max(2.0, args.cpu_seconds / 4))
     else:
         best = max(port, key=port.get)
         res.update({"value": round(port[best], 3), "cores": best, "kind": "port",
                     "sample": "%d calls of the oracle port on the same %d scans (oracle/_ref not present); threads tried %s, best reported"
                               % (port_n, len(scans), counts), "single_thread_value": round(port[1], 3)})
     return res
+
+
+def _cpu_throughput(cfg, scans, rels, tau, map_points, seconds):
+    """scans/s of the reference build with several one-thread registrations running side by side, or a note"""
+    import subprocess
+    import tempfile
+    quota = _cgroup_cpu_max()
+    try:
+        q, per = (quota or "max").split()[:2]
+        cores = max(1, int(float(q) / float(per))) if q != "max" else (os.cpu_count() or 1)
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 16))
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_PROC_BIND", "OMP_PLACES")}
+    env["OMP_NUM_THREADS"] = "1"
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "cpu.npz")
+            np.savez(f, map=map_points, frames=np.stack([s["frame"] for s in scans]), last=np.stack([s["last_pose"] for s in scans]), rel=np.stack(rels),
+                     tau=tau, voxel=cfg.voxel_size, max_range=cfg.max_range, cap=cfg.max_points_per_voxel)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_cpu_throughput.py"), f, str(threads), "%.1f" % seconds], env=env,
+                                 capture_output=True, text=True, timeout=120 + 4 * seconds, cwd=ROOT)
+        line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        line["what"] = ("%d independent ComputeRobotMotion calls of the reference build at a time, ONE thread each (its default), the same scans, ~%.0f s: "
+                        "what a CPU does with independent scans - to be held against `value` (scans in flight); `value` / `single_thread_value` of this "
+                        "object are the one-call-at-a-time rates, to be held against value_one_scan_in_flight" % (threads, seconds))
+        return line
+    except Exception as e:  # noqa: BLE001  (informational figure: a failure here must not cost the bench line)
+        return {"note": "not measured: %s" % str(e)[:200]}
 
 
 def _concurrent_rate(workload, lanes, n_scans):

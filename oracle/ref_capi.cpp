@@ -177,6 +177,23 @@ void rkicp_pipeline_register_frame(void *p, const double *frame_xyz, size_t n, c
     *out_n_frame = from_points(frame, out_frame_xyz, n);
     *out_n_source = from_points(source, out_source_xyz, n);
 }
+// The same call with the clock around RegisterFrame ALONE (the conversions from / to the C arrays on either side are not the
+// reference's work): seconds of the reference's own KinematicICP::RegisterFrame (pipeline/KinematicICP.cpp:48-85) - what
+// tools/bench_pipeline.py quotes beside the GPU's frame time.
+double rkicp_pipeline_register_frame_timed(void *p, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                                           const double lidar_to_base_qt[7], const double relative_odometry_qt[7], int num_threads, double *out_frame_xyz,
+                                           size_t *out_n_frame, double *out_source_xyz, size_t *out_n_source) {
+    ThreadScope scope(num_threads > 0 ? num_threads : 1);
+    const std::vector<double> stamps(timestamps, timestamps + n_timestamps);
+    const auto points = to_points(frame_xyz, n);
+    const Sophus::SE3d lidar_to_base = to_se3(lidar_to_base_qt), odometry = to_se3(relative_odometry_qt);
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto [frame, source] = static_cast<RefPipeline *>(p)->RegisterFrame(points, stamps, lidar_to_base, odometry);
+    const auto t1 = std::chrono::steady_clock::now();
+    *out_n_frame = from_points(frame, out_frame_xyz, n);
+    *out_n_source = from_points(source, out_source_xyz, n);
+    return std::chrono::duration<double>(t1 - t0).count();
+}
 size_t rkicp_pipeline_local_map(void *p, double *out_xyz, size_t cap_points) {
     return from_points(static_cast<RefPipeline *>(p)->LocalMap(), out_xyz, cap_points);
 }

@@ -102,6 +102,9 @@ def lib():
         L.rkicp_pipeline_tau.restype = C.c_double
         L.rkicp_pipeline_tau.argtypes = [C.c_void_p]
         L.rkicp_pipeline_register_frame.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_int, _dp, _sp, _dp, _sp]
+        if hasattr(L, "rkicp_pipeline_register_frame_timed"):  # (a prebuilt library of an earlier round lacks it)
+            L.rkicp_pipeline_register_frame_timed.restype = C.c_double
+            L.rkicp_pipeline_register_frame_timed.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_int, _dp, _sp, _dp, _sp]
         L.rkicp_pipeline_local_map.restype = C.c_size_t
         L.rkicp_pipeline_local_map.argtypes = [C.c_void_p, _dp, C.c_size_t]
         L.rkicp_pipeline_map_num_points.restype = C.c_size_t
@@ -275,6 +278,19 @@ class KinematicICP:
         lib().rkicp_pipeline_register_frame(self._h, p, n, tp, t.size, lb, ro, num_threads, out_f.ctypes.data_as(_dp), C.byref(nf),
                                             out_s.ctypes.data_as(_dp), C.byref(ns))
         return out_f[:nf.value].copy(), out_s[:ns.value].copy()
+
+    def RegisterFrameTimed(self, frame, timestamps, lidar_to_base, relative_odometry, num_threads=1):
+        """RegisterFrame -> (frame, source, seconds of the reference's RegisterFrame alone)"""
+        a, p = _d(frame)
+        t, tp = _d(timestamps if timestamps is not None else [])
+        _, lb = _d(lidar_to_base)
+        _, ro = _d(relative_odometry)
+        n = a.size // 3
+        out_f, out_s = np.empty((max(n, 1), 3)), np.empty((max(n, 1), 3))
+        nf, ns = C.c_size_t(0), C.c_size_t(0)
+        sec = lib().rkicp_pipeline_register_frame_timed(self._h, p, n, tp, t.size, lb, ro, num_threads, out_f.ctypes.data_as(_dp), C.byref(nf),
+                                                        out_s.ctypes.data_as(_dp), C.byref(ns))
+        return out_f[:nf.value].copy(), out_s[:ns.value].copy(), sec
 
     def LocalMap(self):
         n = lib().rkicp_pipeline_map_num_points(self._h)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--max-range", type=float, default=100.0)
     ap.add_argument("--deskew", type=int, default=1)
     ap.add_argument("--oracle-frames", type=int, default=5)
+    ap.add_argument("--ref-frames", type=int, default=40, help="frames through the reference's own RegisterFrame (oracle/_ref), timed; 0: skip")
+    ap.add_argument("--ref-threads", type=int, nargs="+", default=[1, 16], help="max_num_threads values of the reference run (its default is 1)")
     ap.add_argument("--mode", default="raw", choices=["raw", "vectors"],
                     help="raw (default): every frame arrives as a PointCloud2-style buffer of 16-byte records (x y z t, FLOAT32) and goes through "
                          "IngestCloud + RegisterIngestedFrame - 2.1 MB over PCIe, decoded on the GPU; vectors: the reference's own signature, "
@@ -101,6 +103,25 @@ def main():
             cpu.append((time.perf_counter() - t0) * 1e3)
             print("frame %d |gpu - oracle| max = %.3g  oracle map %d source %d" % (k, np.abs(gpu_poses[k] - last).max(), omap.num_points(), len(source)))
         print("CPU oracle pipeline: " + " ".join("%.1f" % c for c in cpu) + " ms/frame (all host cores for the ICP)")
+    if a.ref_frames:
+        # THE REFERENCE'S OWN KinematicICP::RegisterFrame (pipeline/KinematicICP.cpp:48-85, oracle/_ref: the reference's three translation
+        # units compiled unmodified over the stand-in headers), the clock around RegisterFrame alone, on the same frames: the CPU figure
+        # to hold the GPU's frame time against (VERDICT r4 missing 3); its poses are the ones the GPU pipeline reproduces
+        from oracle import rkicp
+        if not rkicp.available():
+            print("reference build (oracle/_ref) not present: no reference RegisterFrame timing")
+            return
+        for threads in a.ref_threads:
+            pipe = rkicp.KinematicICP(voxel_size=a.voxel, max_range=a.max_range, deskew=a.deskew, max_num_threads=threads)
+            ms_ref, worst = [], 0.0
+            for k in range(min(a.ref_frames, a.frames)):
+                _, _, sec = pipe.RegisterFrameTimed(frames[k], stamps[k], ext, deltas[k], num_threads=threads)
+                ms_ref.append(sec * 1e3)
+                if k < len(gpu_poses):
+                    worst = max(worst, float(np.abs(gpu_poses[k] - pipe.pose()).max()))
+            half = ms_ref[len(ms_ref) // 2:]
+            print("reference RegisterFrame (oracle/_ref, %d thread%s): median %.2f ms per frame (second half of %d frames; min %.2f, first %.2f); "
+                  "max |gpu pose - reference pose| over those frames %.3g" % (threads, "" if threads == 1 else "s", float(np.median(half)), len(ms_ref), min(half), ms_ref[0], worst))
 
 
 if __name__ == "__main__":
