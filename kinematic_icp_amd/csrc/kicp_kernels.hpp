@@ -674,6 +674,39 @@ constexpr unsigned long long kGaveUpUnit = 1ull << 16;
 // the host repeats the pass (resident kernel) or fails the call - instead of a wave spinning on the device for ever.
 constexpr unsigned long long kLostRowUnit = 1ull << 8;
 constexpr long long kRowWaitTicks = 200000000ll;
+// The hand-over of a workgroup's exact sums through its group's COUNTING ACCUMULATORS (wave 0; lanes 0..6 hold the seven 128-bit
+// totals `t`): ONE round trip to the L2 and no reader.  Lane w < kReduceWords adds word w of the workgroup's row - biased to be
+// non-negative, with a 1 in the count field above it - to word w of the group's accumulator.  The addition that finds the count at
+// group size - 1 is the last one for that word: old value + own = the group's sum, which that lane hands to the host (and clears
+// the word for the set's next turn).  Every word is completed by whichever workgroup happened to add to it last - not necessarily
+// the same one for all 24 - and carries the pass tag, which is how the host tells a complete row anyway (wait_rows).
+// `acc_set` / `row_set`: which of the launch's sets of accumulators / of host rows the pass uses (resident kernels: the pass's slot
+// for both; an ordinary launch: the tag's parity for the accumulators, row set 0).  Round 4: the resident generic kernel; round 5:
+// every launch whose group rows go to the host, and the small-scan kernels (kicp_small.hpp), whose every workgroup used to send a
+// row of its own across PCIe.
+__device__ __forceinline__ void counting_hand_over(const I128 &t, int range_error, int gave_up, const PassParams &p, uint32_t row_tag, uint32_t acc_set,
+                                                   uint32_t row_set, int lane) {
+    const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
+    long long l[3] = {0ll, 0ll, 0ll};
+    if (lane < kNumSums) i128_to_limbs(t, l);
+    const int from = min(lane, kNumLimbs - 1) / 3;
+    const long long a0 = __shfl(l[0], from, 64), a1 = __shfl(l[1], from, 64), a2 = __shfl(l[2], from, 64);
+    long long word = lane % 3 == 0 ? a0 : (lane % 3 == 1 ? a1 : a2);
+    if (lane >= kNumLimbs) word = lane == kNumLimbs ? static_cast<long long>(range_error) + (gave_up ? static_cast<long long>(kGaveUpUnit) : 0ll) : 0ll;
+    if (lane < kReduceWords) {
+        const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
+        unsigned long long *acc = p.group_acc + (static_cast<size_t>(acc_set) * ngroups + g) * kAccStride + lane;
+        const unsigned long long mine = static_cast<unsigned long long>(word + kAccBias);  // |word| < 2^40: (0, 2^42)
+        const unsigned long long old = __hip_atomic_fetch_add(acc, (1ull << kAccCountShift) + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old >> kAccCountShift) == group_size - 1u) {
+            const long long total = static_cast<long long>((old & ((1ull << kAccCountShift) - 1ull)) + mine) - static_cast<long long>(group_size) * kAccBias;
+            __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(row_set) * ngroups + g) * kReduceWords + lane,
+                               (static_cast<unsigned long long>(total) << 16) | static_cast<unsigned long long>(row_tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ROWS_ONLY: the caller only ever runs mode 4 (the resident kernel): none of the other hand-offs is compiled in.
 // `parity` (resident kernel: pass & 1): workgroup rows, tickets and the groups' host rows are double-buffered by pass parity, so
 // that what a workgroup writes for pass k + 1 - in particular the marked empty row of a workgroup that gave up waiting for the
@@ -773,30 +806,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     const bool counting = ROWS_ONLY || (p.sol.mode == 4 && p.dbg != 14);
     if (!ROWS_ONLY && counting) parity = row_tag & 1u;
     if (counting) {
-        // ONE round trip to the L2 and no reader (round 4: the resident kernels, where several passes are in flight and the pace is
-        // set by the workgroup that is behind; round 5: every launch whose group rows go to the host).  Lane w < kReduceWords adds word w of the workgroup's row - biased to be non-negative, with a 1 in the count field
-        // above it - to word w of the group's accumulator.  The addition that finds the count at group size - 1 is the last one for
-        // that word: old value + own = the group's sum, which that lane hands to the host (and clears the word for the slot's next
-        // turn).  Every word is completed by whichever workgroup happened to add to it last - not necessarily the same one for all
-        // 24 - and carries the pass tag, which is how the host tells a complete row anyway (wait_rows).
-        long long l[3] = {0ll, 0ll, 0ll};
-        if (lane < kNumSums) i128_to_limbs(t, l);
-        const int from = min(lane, kNumLimbs - 1) / 3;
-        const long long a0 = __shfl(l[0], from, 64), a1 = __shfl(l[1], from, 64), a2 = __shfl(l[2], from, 64);
-        long long word = lane % 3 == 0 ? a0 : (lane % 3 == 1 ? a1 : a2);
-        if (lane >= kNumLimbs) word = lane == kNumLimbs ? static_cast<long long>(range_error) + (gave_up ? static_cast<long long>(kGaveUpUnit) : 0ll) : 0ll;
-        if (lane < kReduceWords) {
-            const uint32_t group_size = min(static_cast<uint32_t>(kGroup), nblocks - g * kGroup);
-            unsigned long long *acc = p.group_acc + (static_cast<size_t>(parity) * ngroups + g) * kAccStride + lane;
-            const unsigned long long mine = static_cast<unsigned long long>(word + kAccBias);  // |word| < 2^40: (0, 2^42)
-            const unsigned long long old = __hip_atomic_fetch_add(acc, (1ull << kAccCountShift) + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((old >> kAccCountShift) == group_size - 1u) {
-                const long long total = static_cast<long long>((old & ((1ull << kAccCountShift) - 1ull)) + mine) - static_cast<long long>(group_size) * kAccBias;
-                __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.sol.pub_rows + (static_cast<size_t>(ROWS_ONLY ? parity * ngroups : 0u) + g) * kReduceWords + lane,
-                                   (static_cast<unsigned long long>(total) << 16) | static_cast<unsigned long long>(row_tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        counting_hand_over(t, range_error, gave_up, p, row_tag, parity, ROWS_ONLY ? parity : 0u, lane);
         return;
     }
     unsigned long long *const rows0 = p.partials + (ROWS_ONLY ? static_cast<size_t>(parity) * nblocks * kReduceWords : 0u);

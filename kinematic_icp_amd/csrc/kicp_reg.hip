@@ -169,6 +169,8 @@ struct kicp_reg {
     int small_wave = 1;           // option "small_wave": scans of up to kWaveMaxPoints points take k_pass_wave (one wave per query)
     int wave_block = 0;           // option "wave_block": its workgroup size (256 | 512 | 1024; 0 = by scan size)
     int small_resident = 1;       // option "small_resident": the kernel stays for the call's later iterations
+    int small_group_rows = 1;     // option "small_group_rows": the small-scan kernels' workgroups hand their sums over through their groups' counting
+                                  // accumulators - one row per 32 workgroups crosses PCIe (1, round 5) | every workgroup sends a row of its own (0, round 3)
     double small_timeout_us = 20000.0;  // option "small_timeout_us": how long a resident workgroup waits for a command
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
@@ -811,9 +813,11 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     // generic plan: a launch that will not stay goes out as the plain pass kernel (launch_pass, its own grid)
     const size_t groups_resident = (grid + kGroup - 1) / kGroup, groups_plain = (pass_grid(r, n) + kGroup - 1) / kGroup;
     // (rows, tickets and host rows of a resident launch are double-buffered by pass parity: finish_pass, small_publish)
-    if (pl.generic) {
-        if (int rc = ensure_partials(r, std::max<uint32_t>(kPipeSlots * grid, pass_grid(r, n)))) return rc;
-        if (int rc = ensure_rows(r, std::max(kPipeSlots * groups_resident, groups_plain))) return rc;
+    // grouped: the launch's rows are GROUP rows (the generic kernel's; the small-scan kernels' with "small_group_rows")
+    const bool grouped = pl.generic || r->small_group_rows != 0;
+    if (grouped) {
+        if (int rc = ensure_partials(r, std::max<uint32_t>(kPipeSlots * grid, pl.generic ? pass_grid(r, n) : 0u))) return rc;
+        if (int rc = ensure_rows(r, std::max(kPipeSlots * groups_resident, pl.generic ? groups_plain : size_t(0)))) return rc;
     } else if (int rc = ensure_rows(r, kPipeSlots * static_cast<size_t>(grid))) {
         return rc;
     }
@@ -824,10 +828,11 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
     pp.dbg = r->dbg;  // (0, or 14: the in-process A/B switch of the plain launch's hand-over)
-    if (pl.generic) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
-    if (pl.generic)
+    if (grouped) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
+    if (grouped)
         if (int rc = clear_stale_tickets(r)) return rc;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
+    sp.group_rows = grouped ? 1 : 0;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);  // 100 MHz wall clock
     HostLoop loop;
     loop.T = T0;
@@ -836,7 +841,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     while (!finished) {
         if (give_ups > kMaxGiveUps)
             return fail(KICP_ERR_HIP, "the resident pass kernel gave up waiting for its command in " + std::to_string(give_ups) + " launches in a row (small_timeout_us too short for this host?)");
-        if (give_ups > 0 && pl.generic) {
+        if (give_ups > 0 && grouped) {
             // workgroups of the launch that gave up may have added (partial, marked) contributions to the accumulators / tickets of the
             // slot the fresh launch's pass will use: wait for that kernel to be gone and clear them
             r->acc_dirty = true;
@@ -868,7 +873,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
             long long words[kReduceWords];
             bool gave_up = false;
             int rc_rows;
-            if (pl.generic) {
+            if (grouped) {
                 rc_rows = wait_rows(r, plain ? groups_plain : groups_resident, sp.tag0 + k, words, plain ? 0 : (k % kPipeSlots) * groups_resident);
                 // workgroups that left without a command (kGaveUpUnit each), or a row that never reached its group's reader
                 // (kLostRowUnit): either way this pass is run again, in a fresh launch
@@ -1185,14 +1190,15 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     const bool wave = pl.wave;
     const uint32_t grid = wave ? pl.grid : static_cast<uint32_t>((n_max + 255) / 256);
     const size_t groups = (grid + kGroup - 1) / kGroup;
-    if (wave) {
+    const bool grouped = !wave || r->small_group_rows != 0;  // the rows the host adds are group rows (the wave kernel's: "small_group_rows")
+    if (!grouped) {
         if (int rc = ensure_rows(r, kPipeSlots * static_cast<size_t>(grid))) return rc;
     } else {
         if (int rc = ensure_partials(r, kPipeSlots * grid)) return rc;
         if (int rc = ensure_rows(r, kPipeSlots * groups)) return rc;
     }
     if (int rc = ensure_cmd(r)) return rc;
-    if (!wave)
+    if (grouped)
         if (int rc = clear_stale_tickets(r)) return rc;
     // The batch's scan table.  Where the CPU can write HBM through the PCIe BAR (the kernarg ring and the command copies live there
     // already) the table is written in place - a microsecond, no copy, no synchronisation; the launch's acquire makes it visible like
@@ -1232,6 +1238,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
     sp.scans = r->d_scans;
+    sp.group_rows = grouped ? 1 : 0;
     // (the workgroups' shares of a scan move on by about 0.38 of the grid per pass - far from where they were, and back only after many passes)
     if (!wave && r->batch_rotate && depth_of(r) > 1) sp.rotate = (static_cast<uint32_t>(grid * 0.381966) | 1u) % grid;
     // Several scans of the batch are in flight at a time (option "batch_depth", 1 .. kPipeSlots; 1: one).  The scans of a batch do not
@@ -1331,9 +1338,9 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         f.waiting = false;
         long long words[kReduceWords];
         bool gave_up = false;
-        if (int rc = wave ? wait_rows_small(r, grid, sp.tag0 + at, at % kPipeSlots, words, &gave_up) : wait_rows(r, groups, sp.tag0 + at, words, (at % kPipeSlots) * groups))
+        if (int rc = !grouped ? wait_rows_small(r, grid, sp.tag0 + at, at % kPipeSlots, words, &gave_up) : wait_rows(r, groups, sp.tag0 + at, words, (at % kPipeSlots) * groups))
             return leave(rc);
-        if (!wave) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
+        if (grouped) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
         if (gave_up) {  // (part of) the kernel has left: the scans in hand and the rest go through the plain loop
             ++r->small_relaunches;
             return leave(KICP_OK);
@@ -1373,7 +1380,8 @@ struct BatchFlight {
     PassParams pp{};     // large scans: the pass kernel's arguments
     SmallParams sp{};    // small scans (kicp_small.hpp): a launch that serves ONE pass and leaves
     SmallPlan pl;
-    bool small = false;
+    bool small = false;    // a small-scan kernel's launch ...
+    bool own_rows = false; // ... whose workgroups send rows of their own ("small_group_rows" 0)
     size_t k = 0, rows = 0, row_next = 0;  // rows of the pass in flight: the groups' (large) / the workgroups' (small); how many are in
     uint32_t tag = 0;
     bool active = false;
@@ -1391,7 +1399,7 @@ struct BatchFlight {
 int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
     kicp_reg *h = f.h;
     const uint32_t tag = f.tag;
-    const int row_words = f.small ? kSmallRowWords : kReduceWords;
+    const int row_words = f.own_rows ? kSmallRowWords : kReduceWords;
     for (; f.row_next < f.rows; ++f.row_next) {
         const unsigned long long *row = h->rows + f.row_next * row_words;
         unsigned long long w[kReduceWords];
@@ -1412,7 +1420,7 @@ int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
             }
             return 0;
         }
-        if (f.small) {
+        if (f.own_rows) {
             for (int i = 0; i < kNumSums; ++i)
                 f.total[i] += static_cast<__int128>(w[2 * i] >> 16) + (static_cast<__int128>(static_cast<long long>(w[2 * i + 1]) >> 16) << 48);
             f.flags |= w[2 * kNumSums] >> 16;
@@ -1423,7 +1431,7 @@ int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (f.small) {  // (the layout of the all-reduce payload: three 40-bit limbs per sum, then the range flag - wait_rows_small)
+    if (f.own_rows) {  // (the layout of the all-reduce payload: three 40-bit limbs per sum, then the range flag - wait_rows_small)
         for (int i = 0; i < kReduceWords; ++i) out_words[i] = 0;
         const unsigned __int128 m40 = (static_cast<unsigned __int128>(1) << 40) - 1;
         for (int i = 0; i < kNumSums; ++i) {
@@ -1453,12 +1461,22 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     set_pose(sol, f.loop.T);
     sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
     sol.convergence_criterion = h->cfg.convergence_criterion;
-    if (f.small) {  // one wave per query / sub-lanes per query: every workgroup's row goes straight to the host; the launch serves this pass only
-        f.rows = f.pl.grid;
-        if (int rc = ensure_rows(h, (f.rows * kSmallRowWords + kReduceWords - 1) / kReduceWords)) return rc;
+    f.own_rows = f.small && h->small_group_rows == 0;
+    if (f.small) {  // one wave per query / sub-lanes per query; the launch serves this pass only
+        if (f.own_rows) {  // every workgroup's row goes straight to the host
+            f.rows = f.pl.grid;
+            if (int rc = ensure_rows(h, (f.rows * kSmallRowWords + kReduceWords - 1) / kReduceWords)) return rc;
+        } else {  // one row per group of 32 workgroups (counting accumulators)
+            f.rows = (f.pl.grid + kGroup - 1) / kGroup;
+            if (int rc = ensure_partials(h, kPipeSlots * f.pl.grid)) return rc;
+            if (int rc = ensure_rows(h, kPipeSlots * f.rows)) return rc;
+            if (int rc = clear_stale_tickets(h)) return rc;
+            pp.group_acc = h->d_group_acc, sol.pub_rows = h->d_rows, sol.rec = h->d_rec;
+        }
         if (int rc = ensure_cmd(h)) return rc;
         if (int rc = next_tag(h, &f.tag)) return rc;
         SmallParams &sp = f.sp;
+        sp.group_rows = f.own_rows ? 0 : 1;
         sp.cmd = h->d_cmd, sp.rows = h->d_rows, sp.cmd_dev = h->d_cmd_copies, sp.relay = (h->small_cmd == 1 && h->cmd_bar) ? 0 : 1;
         sp.timeout_ticks = 5000, sp.trace = nullptr, sp.scans = nullptr, sp.rotate = 0;
         sp.tag0 = f.tag, sp.max_passes = 1, sp.seq_base = h->cmd_seq;
@@ -1519,6 +1537,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
         kicp_reg *h = r->batch_lanes[j];
         h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
         h->query_every = r->query_every, h->dbg = r->dbg, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
+        h->small_group_rows = r->small_group_rows;
         h->use_small = sharded ? 0 : r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
         flights[j].h = h;
         flights[j].next = static_cast<size_t>(j);  // (sharded: lane j's first scan)
@@ -1773,6 +1792,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "fetch_upload") reg->fetch_frames = value != 0.0 ? 1 : 0;
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
     else if (k == "small_resident") reg->small_resident = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);  // 1 adaptive (default), 2 always, 0 never
+    else if (k == "small_group_rows") reg->small_group_rows = value != 0.0 ? 1 : 0;
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
     else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
     else if (k == "small_trace") {  // debugging aid: per-pass wall-clock stamps of workgroup 0 + host-side phase times
@@ -1830,6 +1850,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "fetch_upload") return reg->fetch_frames;
     if (k == "small") return reg->use_small;
     if (k == "small_resident") return reg->small_resident;
+    if (k == "small_group_rows") return reg->small_group_rows;
     if (k == "small_block") return reg->small_block;
     if (k == "small_wave") return reg->small_wave;
     if (k == "trace_host_us") return reg->trace_n ? reg->trace_host_us / static_cast<double>(reg->trace_n) : 0.0;
@@ -2019,7 +2040,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->query_every = reg->query_every, c->lanes_per_query = reg->lanes_per_query, c->occupancy = reg->occupancy, c->latency_kernel = reg->latency_kernel;
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
-    c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us;
+    c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us, c->small_group_rows = reg->small_group_rows;
     c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues;
     *out = c;
     return KICP_OK;

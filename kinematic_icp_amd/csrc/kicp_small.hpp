@@ -56,7 +56,9 @@ struct SmallParams {
     PassParams p;                   // (p.sol.mode is not used: the host always solves; p.partials / p.tickets unused)
     const unsigned long long *cmd;  // device view of the host-mapped command lines (kPipeSlots x kCmdWords words, 64-byte aligned)
     unsigned long long *cmd_dev;    // kCmdReplicas copies of the command lines in device memory (await_command)
-    int32_t relay, pad_;            // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
+    int32_t relay;                  // 1: workgroup 0 relays the host line into the copies; 0: the host writes the copies (BAR)
+    int32_t group_rows;             // small-scan kernels: 1 the workgroups' sums go through their groups' counting accumulators and ONE row per group of
+                                    // 32 reaches the host (p.group_acc, p.sol.pub_rows; round 5, default) | 0 every workgroup sends its own row (`rows`)
     long long *trace;               // debugging aid (option "small_trace"): workgroup 0 stamps its passes here, 4 wall-clock words each
     unsigned long long *rows;       // device view of the host-mapped rows [kPipeSlots][gridDim.x][kSmallRowWords]: pass k writes buffer k % kPipeSlots, so the
                                     // give-up marker of pass k + 1 never lands on a row of pass k the host has not read yet
@@ -121,7 +123,7 @@ __device__ __forceinline__ uint32_t await_command(const SmallParams &sp, uint32_
             if ((ctrl >> 32) == (want & 0xFFFFFFFFull) && (ctrl & 0xFFull) >= kCmdContinue && (ctrl & 0xFFull) <= kCmdNewScan) break;
             if (wall_clock64() - t0 > sp.timeout_ticks) {
                 ctrl = 0ull;  // give up: mark the rows of the pass that will not run, then leave
-                if (MARK_ROWS && lane < kSmallRowWords)
+                if (MARK_ROWS && !sp.group_rows && lane < kSmallRowWords)
                     __hip_atomic_store(sp.rows + (static_cast<size_t>((pass + 1u) % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + lane,
                                        ((lane == 2 * kNumSums ? kSmallGaveUp : 0ull) << 16) | (sp.tag0 + pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
@@ -149,7 +151,7 @@ __device__ __forceinline__ double uniform_lane_d(double v, int l) {
 
 // workgroup sum of the lanes' terms -> one row of self-validating words in host memory
 template <int BLOCK>
-__device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &sp, uint32_t tid, uint32_t pass, int (*s_red)[kWaveLimbs], int *s_flag) {
+__device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &sp, uint32_t tid, uint32_t pass, int (*s_red)[kWaveLimbs], int *s_flag, int gave_up = 0) {
     const uint32_t tag = sp.tag0 + pass;
     const int lane = tid & 63, wave = tid >> 6;
     int limb[kWaveLimbs];
@@ -167,6 +169,10 @@ __device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &s
     if (lane < kNumSums)
         for (int w = 0; w < BLOCK / 64; ++w)
             i128_add_limb_sums(t, s_red[w][kTermLimbs * lane], s_red[w][kTermLimbs * lane + 1], s_red[w][kTermLimbs * lane + 2], s_red[w][kTermLimbs * lane + 3]);
+    if (sp.group_rows) {  // one row per group of 32 workgroups reaches the host (kicp_kernels.hpp::counting_hand_over)
+        counting_hand_over(t, (*s_flag & 2) ? 1 : 0, gave_up, sp.p, tag, pass % kPipeSlots, pass % kPipeSlots, lane);
+        return;
+    }
     // |workgroup sum| < 2^83 * BLOCK: bits 0..47 and 48..95 (the upper half carries the sign)
     const unsigned long long m48 = (1ull << 48) - 1;
     const unsigned long long h0 = t.lo & m48, h1 = ((t.lo >> 48) | (static_cast<unsigned long long>(t.hi) << 16)) & m48;
@@ -188,13 +194,14 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
     __shared__ int s_flag;
     __shared__ unsigned long long s_cmd[kCmdWords];
     Pose T = fresh_args().p.sol.pose0;
+    int gave_up = 0;  // (wave-uniform; group_rows) no command arrived in time: this round only hands over the marked empty sums
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         const PassParams &p = sp.p;
         uint32_t tid = fresh_tid();
         if (tid == 0) s_flag = 0;
         Acc acc{};
-        {
+        if (!gave_up) {
             const uint32_t gt = blockIdx.x * BLOCK + tid;
             const uint32_t i = gt / G;
             const int sub = static_cast<int>(gt % G);
@@ -233,9 +240,15 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         tid = fresh_tid();
-        small_publish<BLOCK>(acc, sp, tid, pass, s_red, &s_flag);
-        if (pass + 1 >= sp.max_passes) return;
-        if (await_command(sp, tid, pass, s_cmd) != kCmdContinue) return;
+        small_publish<BLOCK>(acc, sp, tid, pass, s_red, &s_flag, gave_up);
+        if (gave_up || pass + 1 >= sp.max_passes) return;
+        const uint32_t op = await_command(sp, tid, pass, s_cmd);
+        if (op != kCmdContinue) {
+            if (op != 0u || !sp.group_rows) return;  // STOP - or, with a row per workgroup, the marked row is out (await_command)
+            gave_up = 1;  // (group rows: the mark travels through the group's accumulators, like k_pass_resident's)
+            if (fresh_tid() == 0 && sp.p.sol.rec) __hip_atomic_store(&sp.p.sol.rec->reserved[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            continue;
+        }
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[2]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[3]))),
                  uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[4]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[5]))),
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
     double sx = 0.0, sy = 0.0, sz = 0.0;
     uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0))), n_scan = 0u;
     bool new_scan = true;
+    int gave_up = 0;  // (wave-uniform; group_rows) no command arrived in time: this round only hands over the marked empty sums
     for (uint32_t pass = 0;; ++pass) {
         const SmallParams &sp = fresh_args();
         const PassParams &p = sp.p;
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
         if (stamp) sp.trace[4 * blockIdx.x] = wall_clock64();
         bool accepted = false;
         double term_value = 0.0;  // lane k < 6: the k-th term of this wave's correspondence (lane 6: the count)
-        if (qi < n_scan) {
+        if (qi < n_scan && !gave_up) {
             const SearchParams &sq = p.search;
             const float margin = sq.margin_u;
             const double vs = m.voxel_size;
@@ -572,20 +586,29 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
             I128 t{0ull, 0ll};
             if (ln < kNumSums)
                 for (int w = 0; w < kWaves; ++w) i128_add(t, I128{s_term[w][2 * ln], static_cast<long long>(s_term[w][2 * ln + 1])});
-            const unsigned long long m48 = (1ull << 48) - 1;
-            const unsigned long long h0 = t.lo & m48, h1 = ((t.lo >> 48) | (static_cast<unsigned long long>(t.hi) << 16)) & m48;
-            const unsigned long long v0 = __shfl(h0, ln >> 1, 64), v1 = __shfl(h1, ln >> 1, 64);
-            unsigned long long word = (ln & 1) ? v1 : v0;
-            if (ln == 2 * kNumSums) word = (s_flag & 2) ? 1ull : 0ull;
-            if (ln > 2 * kNumSums) word = 0ull;
-            if (ln < kSmallRowWords)
-                __hip_atomic_store(sp.rows + (static_cast<size_t>(pass % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (sp.group_rows) {  // one row per group of 32 workgroups reaches the host (kicp_kernels.hpp::counting_hand_over)
+                counting_hand_over(t, (s_flag & 2) ? 1 : 0, gave_up, sp.p, sp.tag0 + pass, pass % kPipeSlots, pass % kPipeSlots, ln);
+            } else {
+                const unsigned long long m48 = (1ull << 48) - 1;
+                const unsigned long long h0 = t.lo & m48, h1 = ((t.lo >> 48) | (static_cast<unsigned long long>(t.hi) << 16)) & m48;
+                const unsigned long long v0 = __shfl(h0, ln >> 1, 64), v1 = __shfl(h1, ln >> 1, 64);
+                unsigned long long word = (ln & 1) ? v1 : v0;
+                if (ln == 2 * kNumSums) word = (s_flag & 2) ? 1ull : 0ull;
+                if (ln > 2 * kNumSums) word = 0ull;
+                if (ln < kSmallRowWords)
+                    __hip_atomic_store(sp.rows + (static_cast<size_t>(pass % kPipeSlots) * gridDim.x + blockIdx.x) * kSmallRowWords + ln, (word << 16) | (sp.tag0 + pass),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 2] = wall_clock64();
-        if (pass + 1 >= sp.max_passes) return;
+        if (gave_up || pass + 1 >= sp.max_passes) return;
         const uint32_t op = await_command<true, 1>(sp, tid, pass, s_cmd);
-        if (op != kCmdContinue && op != kCmdNewScan) return;
+        if (op != kCmdContinue && op != kCmdNewScan) {
+            if (op != 0u || !sp.group_rows) return;  // STOP - or, with a row per workgroup, the marked row is out (await_command)
+            gave_up = 1;  // (group rows: the mark travels through the group's accumulators, like k_pass_resident's)
+            if (fresh_tid() == 0 && sp.p.sol.rec) __hip_atomic_store(&sp.p.sol.rec->reserved[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            continue;
+        }
         if (sp.scans && command_scan(s_cmd) != scan) scan = command_scan(s_cmd), new_scan = true;
         if (sp.trace != nullptr && tid == 0 && pass == sp.trace_pass) sp.trace[4 * blockIdx.x + 3] = wall_clock64();
         T = Pose{uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[0]))), uniform_d(__longlong_as_double(static_cast<long long>(s_cmd[1]))),
