@@ -174,6 +174,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
  *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
  *                  256 b .. 256 b + 255
+ *   "small_group_rows" the workgroups of the small-scan kernels hand their exact sums over through their groups' counting accumulators in
+ *                  HBM - ONE row per 32 workgroups crosses PCIe (5 rows instead of 135 for a 1 080-point scan): 2 always; 0 never (every
+ *                  workgroup sends a row of its own straight to the host, round 3); 1 (default) where it measured faster - the
+ *                  wave-per-query kernel while one pass is out at a time
  *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
  *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
  *                  wave_block 0 = by scan size, default)
@@ -232,6 +236,14 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  *   - anything else, and "batch_queues" 0 with "batch_depth" 1 or "batch_resident" 0: the scans strictly one after the other
  *     (every scan runs launch -> hand-off -> solve to completion before the next one starts) - what a caller needs whose next
  *     scan depends on the previous result, and what kicp_register_device gives one call at a time.
+ * SHARDED batches (round 5): with the shared segment attached (kicp_reg_shm_init) EVERY rank calls with the same count and the same
+ * poses and hands over ITS shard of every scan (frame k of rank r = points [n_k r / R, n_k (r + 1) / R) of scan k; an empty shard
+ * is legal: n[k] == 0).  "batch_queues" >= 2 then keeps that many SHARDED scans in flight per rank: lane j of the call registers scans
+ * j, j + lanes, j + 2 lanes, ... on every rank and exchanges its per-pass totals through an area of its own in the segment, so the
+ * lanes' exchanges interleave freely while every lane's sequence of exchanges is the same on every rank.  Poses and iteration counts
+ * are bit-equal to the single-GPU batch on the whole scans, on every rank.  A sharded batch that fails half-way leaves the ranks'
+ * lane counters in doubt: later sharded batches return KICP_ERR_COMM until kicp_reg_shm_destroy / _init have been redone on every
+ * rank.  (RCCL / callback / peer-mailbox exchanges: a batch call registers the scans one after the other, an exchange per pass.)
  * Poses: count x 7 doubles.  `out_iterations` (nullable): ICP iterations each scan ran.  Returns the first error (< 0) - scans
  * after the first one that failed are then unspecified (some of them may have completed), nothing of the call is still running
  * on the device - otherwise the largest warning code seen (KICP_OK if none). */

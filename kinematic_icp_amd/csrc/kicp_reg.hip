@@ -170,7 +170,10 @@ struct kicp_reg {
     int wave_block = 0;           // option "wave_block": its workgroup size (256 | 512 | 1024; 0 = by scan size)
     int small_resident = 1;       // option "small_resident": the kernel stays for the call's later iterations
     int small_group_rows = 1;     // option "small_group_rows": the small-scan kernels' workgroups hand their sums over through their groups' counting
-                                  // accumulators - one row per 32 workgroups crosses PCIe (1, round 5) | every workgroup sends a row of its own (0, round 3)
+                                  // accumulators - one row per 32 workgroups crosses PCIe - 2 always | 0 never (round 3: every workgroup sends a row of
+                                  // its own) | 1 (default) where it measured faster: the wave-per-query kernel with ONE pass out at a time (-1 us per
+                                  // pass on cfg4: the host adds 5 rows instead of 135); with several passes in flight the rows' crossing is hidden
+                                  // anyway and the accumulators' extra round trip to the L2 is not (+0.2 us), and k_pass_small's few rows gain nothing
     double small_timeout_us = 20000.0;  // option "small_timeout_us": how long a resident workgroup waits for a command
     double debug_stall_us = 0.0;  // tests: stall the host once before its next CONTINUE command (exercises the give-up path)
     unsigned long long small_relaunches = 0;  // launches repeated because a resident kernel gave up waiting
@@ -585,6 +588,11 @@ struct SmallPlan {
     bool wave = false;
     bool generic = false, lat = false;  // generic: the generic pass kernel, resident (k_pass_resident); rows = group rows
 };
+// do the rows of a launch of plan `pl` reach the host per GROUP of workgroups (`pipelined`: several passes of the launch are out at a time)
+bool grouped_rows(const kicp_reg *r, const SmallPlan &pl, bool pipelined) {
+    if (pl.generic || r->small_group_rows == 2) return true;
+    return r->small_group_rows == 1 && pl.wave && !pipelined;
+}
 SmallPlan small_plan(const kicp_reg *r, size_t n) {
     SmallPlan pl;
     if (n == 0) return pl;
@@ -814,7 +822,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     const size_t groups_resident = (grid + kGroup - 1) / kGroup, groups_plain = (pass_grid(r, n) + kGroup - 1) / kGroup;
     // (rows, tickets and host rows of a resident launch are double-buffered by pass parity: finish_pass, small_publish)
     // grouped: the launch's rows are GROUP rows (the generic kernel's; the small-scan kernels' with "small_group_rows")
-    const bool grouped = pl.generic || r->small_group_rows != 0;
+    const bool grouped = grouped_rows(r, pl, false);
     if (grouped) {
         if (int rc = ensure_partials(r, std::max<uint32_t>(kPipeSlots * grid, pl.generic ? pass_grid(r, n) : 0u))) return rc;
         if (int rc = ensure_rows(r, std::max(kPipeSlots * groups_resident, pl.generic ? groups_plain : size_t(0)))) return rc;
@@ -1190,7 +1198,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     const bool wave = pl.wave;
     const uint32_t grid = wave ? pl.grid : static_cast<uint32_t>((n_max + 255) / 256);
     const size_t groups = (grid + kGroup - 1) / kGroup;
-    const bool grouped = !wave || r->small_group_rows != 0;  // the rows the host adds are group rows (the wave kernel's: "small_group_rows")
+    const bool grouped = grouped_rows(r, pl, depth_of(r) > 1);  // the rows the host adds are group rows (the wave kernel's: "small_group_rows")
     if (!grouped) {
         if (int rc = ensure_rows(r, kPipeSlots * static_cast<size_t>(grid))) return rc;
     } else {
@@ -1461,7 +1469,7 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     set_pose(sol, f.loop.T);
     sol.pass = f.loop.iter, sol.mode = 4, sol.max_iterations = h->cfg.max_num_iterations;
     sol.convergence_criterion = h->cfg.convergence_criterion;
-    f.own_rows = f.small && h->small_group_rows == 0;
+    f.own_rows = f.small && !grouped_rows(h, f.pl, false);
     if (f.small) {  // one wave per query / sub-lanes per query; the launch serves this pass only
         if (f.own_rows) {  // every workgroup's row goes straight to the host
             f.rows = f.pl.grid;
@@ -1792,7 +1800,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "fetch_upload") reg->fetch_frames = value != 0.0 ? 1 : 0;
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
     else if (k == "small_resident") reg->small_resident = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);  // 1 adaptive (default), 2 always, 0 never
-    else if (k == "small_group_rows") reg->small_group_rows = value != 0.0 ? 1 : 0;
+    else if (k == "small_group_rows") reg->small_group_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
     else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
     else if (k == "small_trace") {  // debugging aid: per-pass wall-clock stamps of workgroup 0 + host-side phase times

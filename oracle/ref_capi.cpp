@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "kinematic_icp/correspondence_threshold/CorrespondenceThreshold.hpp"
@@ -125,6 +126,38 @@ double rkicp_register_timed(void *m, const double *frame_xyz, size_t n, const do
     const auto t1 = std::chrono::steady_clock::now();
     from_se3(pose, out_pose_qt);
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// THROUGHPUT of independent registrations: `threads` host threads, each registering scans (dealt round-robin, frames converted
+// once up front) with its OWN KinematicRegistration at ONE thread (the reference's default, ros/launch/offline_node.launch.py:60)
+// against the shared read-only map, for about `seconds`.  Returns the wall time; *out_scans = registrations completed.  What a CPU
+// does with independent scans - the twin of the GPU path's scans-in-flight mode (bench.py cpu_baseline.throughput).
+double rkicp_register_throughput(void *m, const double *frames_xyz, const size_t *n, size_t count, const double *last_poses_qt, const double *rel_odoms_qt,
+                                 double tau, int max_num_iterations, double convergence_criterion, int use_adaptive_odometry_regularization,
+                                 double fixed_regularization, int threads, double seconds, size_t *out_scans) {
+    std::vector<std::vector<Vec3>> frames(count);
+    size_t at = 0;
+    for (size_t k = 0; k < count; ++k) frames[k] = to_points(frames_xyz + 3 * at, n[k]), at += n[k];
+    ThreadScope scope(1);
+    std::vector<size_t> done(static_cast<size_t>(threads), 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            kinematic_icp::KinematicRegistration registration(max_num_iterations, convergence_criterion, 1, use_adaptive_odometry_regularization != 0, fixed_regularization);
+            for (size_t i = static_cast<size_t>(t); std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds; i += static_cast<size_t>(threads)) {
+                const size_t k = i % count;
+                volatile double sink = registration.ComputeRobotMotion(frames[k], *as_map(m), to_se3(last_poses_qt + 7 * k), to_se3(rel_odoms_qt + 7 * k), tau).translation().x();
+                (void)sink;
+                ++done[static_cast<size_t>(t)];
+            }
+        });
+    for (auto &th : pool) th.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    size_t total = 0;
+    for (size_t d : done) total += d;
+    if (out_scans) *out_scans = total;
+    return wall;
 }
 
 // ---- kinematic_icp::CorrespondenceThreshold (the reference's own translation unit) -----------------------------------

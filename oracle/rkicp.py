@@ -102,6 +102,10 @@ def lib():
         L.rkicp_pipeline_tau.restype = C.c_double
         L.rkicp_pipeline_tau.argtypes = [C.c_void_p]
         L.rkicp_pipeline_register_frame.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_int, _dp, _sp, _dp, _sp]
+        if hasattr(L, "rkicp_register_throughput"):
+            L.rkicp_register_throughput.restype = C.c_double
+            L.rkicp_register_throughput.argtypes = [C.c_void_p, _dp, _sp, C.c_size_t, _dp, _dp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
+                                                    C.c_double, _sp]
         if hasattr(L, "rkicp_pipeline_register_frame_timed"):  # (a prebuilt library of an earlier round lacks it)
             L.rkicp_pipeline_register_frame_timed.restype = C.c_double
             L.rkicp_pipeline_register_frame_timed.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_int, _dp, _sp, _dp, _sp]
@@ -219,6 +223,19 @@ class KinematicRegistration:
             self.max_num_threads_, int(self.use_adaptive_odometry_regularization_), self.fixed_regularization_, int(repeats),
             out.ctypes.data_as(_dp))
         return out, sec
+
+
+def register_throughput(voxel_map, frames, last_poses, rel_odoms, tau, threads, seconds, max_num_iteration=10, convergence_criterion=1e-3,
+                        use_adaptive_odometry_regularization=True, fixed_regularization=0.0):
+    """`threads` independent one-thread registrations at a time for ~`seconds` (rkicp_register_throughput) -> (scans, wall seconds)"""
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1, 3) for f in frames]))
+    n = (C.c_size_t * len(frames))(*[len(f) for f in frames])
+    _, lp = _d(np.stack(last_poses))
+    _, ro = _d(np.stack(rel_odoms))
+    scans = C.c_size_t(0)
+    wall = lib().rkicp_register_throughput(voxel_map._h, flat.ctypes.data_as(_dp), n, len(frames), lp, ro, tau, max_num_iteration, convergence_criterion,
+                                           int(use_adaptive_odometry_regularization), fixed_regularization, threads, seconds, C.byref(scans))
+    return scans.value, wall
 
 
 class CorrespondenceThreshold:

@@ -28,7 +28,8 @@ KERNELS = [
     ("default", {}),                                                        # <= 4 096 points: one wave per query, resident
     ("sub_lanes", {"small_wave": 0}),                                       # k_pass_small
     ("small_one_launch_per_pass", {"small_resident": 0}),
-    ("small_row_per_workgroup", {"small_group_rows": 0}),                   # round 3's hand-over (default since round 5: a row per group of 32 workgroups)
+    ("small_row_per_workgroup", {"small_group_rows": 0}),                   # round 3's hand-over everywhere
+    ("small_row_per_group", {"small_group_rows": 2, "small_wave": 0}),      # round 5's (counting accumulators), also where the default does not take it
     ("generic_auto_lanes", {"small": 0}),                                   # k_pass_gather32, 4 / 2 / 1 sub-lanes by scan size
     ("generic_latency_build", {"small": 0, "lanes_per_query": 1}),          # <.., LAT>
     ("generic_four_waves", {"small": 0, "lanes_per_query": 1, "latency_kernel": 0}),

@@ -72,7 +72,7 @@ def test_small_path_bits_equal_generic_path(case4):
     variants += [dict(small_wave=1, small_resident=r, aql=a, wave_block=b) for r in (1, 0) for a in (1, 0) for b in (0, 256, 512, 1024)]
     variants += [dict(small_wave=w, small_cmd=1, aql=a) for w in (1, 0) for a in (1, 0)]  # the host writes the command copies through the BAR
     # a row per workgroup straight to the host (round 3's hand-over; the default since round 5 is a row per GROUP of 32 workgroups)
-    variants += [dict(small_wave=w, small_group_rows=0, small_resident=r, aql=a) for w in (1, 0) for r in (1, 0) for a in (1, 0)]
+    variants += [dict(small_wave=w, small_group_rows=g, small_resident=r, aql=a) for w in (1, 0) for g in (0, 2) for r in (1, 0) for a in (1, 0)]
     for opts in variants:
         reg = K.KinematicRegistration()
         for k, v in opts.items():
@@ -109,7 +109,7 @@ def test_small_path_sizes_and_limits(case4):
         assert reg.last_stats.iterations == oreg.last_stats.iterations
 
 
-@pytest.mark.parametrize("group_rows", [1, 0])
+@pytest.mark.parametrize("group_rows", [2, 0])
 @pytest.mark.parametrize("cmd", [0, 1])
 @pytest.mark.parametrize("wave", [1, 0])
 def test_resident_kernel_gives_up_and_the_host_relaunches(case4, wave, cmd, group_rows):
