@@ -734,6 +734,10 @@ def main():
     us_per_pass = 1e6 * elapsed / n_scans_timed / max(iters_gpu, 1e-9)
     valu_issue = None
     insts = ((prof or {}).get("raw", {}).get("SQ_INSTS_VALU", {}) or {}).get("mean_per_dispatch") if prof else None
+    insts_src = (prof or {}).get("source", "profiles/")
+    in_run = getattr(_pmc_traffic, "insts_valu", None)
+    if in_run:  # measured in THIS run, at this commit, on this box (a third --pmc pass next to FETCH_SIZE and WRITE_SIZE)
+        insts, insts_src = in_run[0], "this run: rocprofv3 --pmc SQ_INSTS_VALU over the same bare loop as the traffic passes, mean over %d dispatches" % in_run[1]
     if insts and world == 1:
         simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
         bound = insts * 4.0 / (simds * SCLK_GHZ * 1e3)
@@ -741,7 +745,7 @@ def main():
                       "bound_us_per_pass": round(bound, 2), "frac": round(bound / us_per_pass, 4),
                       "what": "wave-level VALU instructions of one pass (SQ_INSTS_VALU per dispatch of the pass kernel, %s) x 4 cycles / (%d SIMDs x "
                               "%.1f GHz): the time the machine's VALU issue slots need for one pass if they never idle; frac = that / the wall clock "
-                              "per pass of the timed region" % (prof.get("source", "profiles/"), simds, SCLK_GHZ)}
+                              "per pass of the timed region" % (insts_src, simds, SCLK_GHZ)}
     roof = {"bound": "hbm", "achieved": None if traffic_gbs is None else round(traffic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 4),
             "frac_latency": None if latency is None else round(latency["latency_bound_us"] / kernel_us, 4),
@@ -995,7 +999,7 @@ def _pmc_traffic(workload, kernel_sub, calls=200):
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found on this box"
     means = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):  # (the third: the VALU issue bound of the timed region is priced with THIS run's count)
         d = tempfile.mkdtemp(prefix="kicp_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "prof_target.py"), "--workload", workload,
                "--calls", str(calls)] + (["--batch", "64"] if kernel_sub == "k_pass_gather32" else [])
@@ -1012,14 +1016,19 @@ def _pmc_traffic(workload, kernel_sub, calls=200):
                     vals += [float(v) for (v,) in c.execute("select value from counters_collection where counter_name = ? and %s like ?" % name_col,
                                                              (ctr, "%" + kernel_sub + "%"))]
                     c.close()
+            if not vals and ctr == "SQ_INSTS_VALU":
+                continue  # (informational: the traffic figure does not depend on it)
             if not vals:
                 return None, "rocprofv3 --pmc %s gave no rows for %s (rc %d: %s)" % (ctr, kernel_sub, r.returncode, r.stderr.decode(errors="replace")[-200:])
             means[ctr] = (float(np.mean(vals)), len(vals))
         except (OSError, subprocess.SubprocessError, sqlite3.Error) as e:
+            if ctr == "SQ_INSTS_VALU":
+                continue
             return None, "rocprofv3 --pmc %s failed: %s" % (ctr, str(e)[:200])
         finally:
             shutil.rmtree(d, ignore_errors=True)
     kib = 2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]
+    _pmc_traffic.insts_valu = means.get("SQ_INSTS_VALU")  # (mean per dispatch, dispatches) | None
     return kib * 1024.0, ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `tools/prof_target.py --workload %s --calls %d%s` "
                           "after the timed region; means over %d / %d dispatches of %s: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB; bytes = (2 x FETCH_SIZE + "
                           "WRITE_SIZE) x 1024" % (workload, calls, " --batch 64" if kernel_sub == "k_pass_gather32" else "", means["FETCH_SIZE"][1], means["WRITE_SIZE"][1], kernel_sub, means["FETCH_SIZE"][0],
@@ -1033,7 +1042,7 @@ def _profile_counters(workload, world):
     not been profiled: nothing is borrowed from another configuration."""
     if world != 1:
         return None
-    for rnd in ("r04b", "r04", "r03", "r02"):
+    for rnd in ("r05", "r04b", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (rnd, workload))) as f:
                 d = json.load(f)
