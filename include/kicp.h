@@ -310,6 +310,14 @@ typedef struct kicp_cloud_layout {
 } kicp_cloud_layout;
 int kicp_pre_ingest(kicp_pre *pre, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
                     double *out_min_stamp, double *out_max_stamp);
+/* LOOK-AHEAD (round 5; a node that knows its next message - a bag replay, a queue of depth 2): announce the NEXT cloud.  Nothing is
+ * copied yet; the next kicp_pre_frame[_ingested] call - the pre-steps of the CURRENT cloud - uploads and decodes the announced one into
+ * a second slot on a stream of its own once its own kernels are queued, so the 2 MB of message k + 1 cross PCIe while the GPU works on
+ * message k and the calling thread would only wait.  The kicp_pre_ingest call for the same message (same pointer, count, layout and
+ * sensor pose) then finds it decoded and returns at once; any other message voids the announcement.  `data` must stay valid and
+ * unchanged until that kicp_pre_ingest call.  Results are those of the plain kicp_pre_ingest, bit for bit. */
+int kicp_pre_ingest_ahead(kicp_pre *pre, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7]);
+unsigned long long kicp_pre_ahead_hits(const kicp_pre *pre); /* kicp_pre_ingest calls so far that found their message decoded ahead */
 /* kicp_pre_preprocess on the ingested cloud (no host input; deskews only if the cloud carried stamps) */
 int kicp_pre_preprocess_ingested(kicp_pre *pre, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
                                  double min_range, int deskew, int dst_buffer, size_t *out_n);

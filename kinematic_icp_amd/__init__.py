@@ -98,6 +98,8 @@ _SIGNATURES = {
     "kicp_pre_preprocess": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
                                       C.POINTER(C.c_size_t)]),
     "kicp_pre_ingest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp, _dp, _dp]),
+    "kicp_pre_ingest_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp]),
+    "kicp_pre_ahead_hits": (C.c_ulonglong, [C.c_void_p]),
     "kicp_pre_preprocess_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_pre_frame": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp, C.c_size_t,
@@ -545,6 +547,18 @@ class PreSteps:
         lo, hi = C.c_double(), C.c_double()
         _check(lib().kicp_pre_ingest(self._h, buf.ctypes.data if buf.size else None, n_points, C.byref(layout), q, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def IngestAhead(self, raw, n_points, point_step, offset_x, offset_y, offset_z, stamp_datatype=0, offset_stamp=0, sensor_pose=None):
+        """kicp_pre_ingest_ahead: announce the NEXT message (`raw` must be a buffer whose memory the later Ingest call passes again - a
+        numpy uint8 array); it is uploaded and decoded by the next Frame() call on the current one."""
+        buf = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8))
+        layout = CloudLayout(point_step, offset_x, offset_y, offset_z, stamp_datatype, offset_stamp)
+        q = None if sensor_pose is None else _d(sensor_pose)[1]
+        self._ahead_keep = (buf, raw)  # (borrowed by the backend until the Ingest call for the same bytes)
+        _check(lib().kicp_pre_ingest_ahead(self._h, buf.ctypes.data if buf.size else None, n_points, C.byref(layout), q))
+
+    def ahead_hits(self):
+        return int(lib().kicp_pre_ahead_hits(self._h))
 
     def PreprocessIngested(self, relative_motion, lidar_to_base, max_range, min_range, deskew, dst=0):
         _, r = _d(relative_motion)

@@ -141,6 +141,12 @@ public:
         kicp_bridge::check(kicp_pre_ingest(pre_, data, n_points, &layout, nullptr, &lo, &hi), "IngestCloud");
         return {layout.stamp_datatype != 0 && n_points != 0, lo, hi};
     }
+    // Look-ahead for callers that already hold the NEXT message (a bag replay; ros/src/kinematic_icp_ros/nodes/offline_node.cpp reads
+    // its messages in a loop): announce it before RegisterIngestedFrame of the current one - it is then uploaded and decoded while the
+    // current frame's pre-steps run, and its IngestCloud call returns at once.  The bytes must stay valid until that IngestCloud call.
+    void AnnounceNextCloud(const void *data, size_t n_points, const kicp_cloud_layout &layout) {
+        kicp_bridge::check(kicp_pre_ingest_ahead(pre_, data, n_points, &layout, nullptr), "AnnounceNextCloud");
+    }
     Vector3dVectorTuple RegisterIngestedFrame(const Sophus::SE3d &lidar_to_base, const Sophus::SE3d &relative_odometry) {
         const Sophus::SE3d relative_odometry_in_lidar = lidar_to_base.inverse() * relative_odometry * lidar_to_base;
         double rel_lidar[7], ext[7];

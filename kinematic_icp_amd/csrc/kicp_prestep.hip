@@ -50,16 +50,36 @@ struct kicp_pre {
     unsigned long long *d_minmax = nullptr, *d_block_minmax = nullptr;
     size_t ingested_n = 0;
     bool ingested = false, ingested_stamps = false;
+    // LOOK-AHEAD ingest (kicp_pre_ingest_ahead, round 5): the NEXT message is uploaded and decoded into a second slot (d_in2 / d_ts2) on
+    // a stream of its own by the kicp_pre_frame_ingested call of the CURRENT one - while that call's kernels run and its thread would
+    // only wait -, and the kicp_pre_ingest call for the same message then just swaps the slots.
+    double *d_in2 = nullptr, *d_ts2 = nullptr;
+    hipStream_t ahead_stream = nullptr;
+    unsigned long long *h_minmax = nullptr;  // pinned landing area of the stamps' extrema
+    struct Ahead {
+        const void *data = nullptr;
+        size_t n = 0;
+        kicp_cloud_layout layout{};
+        bool has_pose = false;
+        Pose pose{};
+        int state = 0;  // 0 none | 1 announced | 2 in the second slot
+        double lo = 0.0, hi = 0.0;
+    } ahead;
+    unsigned long long ahead_hits = 0;  // kicp_pre_ingest calls that found their message decoded ahead (kicp_pre_ahead_hits)
 };
 namespace {
 int pre_ensure(kicp_pre *p, size_t n) {
     if (n <= p->cap_n) return KICP_OK;
     const size_t cap = n + n / 4 + 1024;
-    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
-    p->d_in = p->d_ts = p->d_staged = nullptr, p->d_flags = p->d_block_counts = nullptr, p->d_table = nullptr, p->cap_n = 0;
+    if (p->ahead_stream) HIP_TRY(hipStreamSynchronize(p->ahead_stream));
+    p->ahead.state = 0;  // (a cloud waiting in the second slot goes with it: its kicp_pre_ingest call uploads it again)
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
+    p->d_in = p->d_ts = p->d_in2 = p->d_ts2 = p->d_staged = nullptr, p->d_flags = p->d_block_counts = nullptr, p->d_table = nullptr, p->cap_n = 0;
     const size_t slots = reference_bucket_count(cap);  // >= the reference's bucket count for every frame of <= cap points
     HIP_TRY(hipMalloc(&p->d_in, cap * 24));
     HIP_TRY(hipMalloc(&p->d_ts, cap * 8));
+    HIP_TRY(hipMalloc(&p->d_in2, cap * 24));
+    HIP_TRY(hipMalloc(&p->d_ts2, cap * 8));
     HIP_TRY(hipMalloc(&p->d_staged, cap * 24));
     HIP_TRY(hipMalloc(&p->d_flags, cap * 4));
     HIP_TRY(hipMalloc(&p->d_block_counts, (std::max(cap, slots) / 256 + 2) * 4));
@@ -145,7 +165,9 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
-    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
+    if (p->ahead_stream) hipStreamSynchronize(p->ahead_stream), hipStreamDestroy(p->ahead_stream);
+    if (p->h_minmax) hipHostFree(p->h_minmax);
+    hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
     hipFree(p->d_misc), hipFree(p->d_raw), hipFree(p->d_minmax), hipFree(p->d_block_minmax);
     p->stage.release();
     if (p->copy_thread.joinable()) {  // the helper thread finishes the job it has, then leaves
@@ -184,9 +206,8 @@ int kicp_pre_preprocess(kicp_pre *p, const double *frame_xyz, size_t n, const do
     }
     return pre_run_preprocess(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, dst_buffer, out_n);
 }
-int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
-                    double *out_min_stamp, double *out_max_stamp) {
-    KICP_TRACE_CALL();
+namespace {
+int ingest_validate(const kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout) {
     if (!p || !layout || (!data && n_points)) return fail(KICP_ERR_ARG, "bad argument");
     const kicp_cloud_layout &L = *layout;
     const int st = L.stamp_datatype;
@@ -197,54 +218,115 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
         (st != 0 && L.offset_stamp + static_cast<unsigned long long>(stamp_bytes) > L.point_step))
         return fail(KICP_ERR_ARG, "field offsets do not fit inside point_step");
     if (n_points > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "cloud too large");
-    if (int rc = set_device(p->device)) return rc;
-    p->ingested = true, p->ingested_n = n_points, p->ingested_stamps = st != 0 && n_points != 0;
-    if (out_min_stamp) *out_min_stamp = 0.0;
-    if (out_max_stamp) *out_max_stamp = 0.0;
-    if (n_points == 0) return KICP_OK;
-    if (int rc = pre_ensure(p, n_points)) return rc;
+    return KICP_OK;
+}
+// Upload + decode of one message (n_points > 0, <= p->cap_n) on `stream` into (out_xyz, out_ts); the stamps' extrema land in the
+// pinned p->h_minmax behind it.  Nothing is waited for: the caller synchronises `stream` (`data` is borrowed until then).
+int ingest_queue(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout &L, const Pose *sensor_pose, hipStream_t stream, double *out_xyz,
+                 double *out_ts) {
+    const int st = L.stamp_datatype;
+    const uint32_t stamp_bytes = st == KICP_FIELD_FLOAT64 ? 8u : 4u;
     const size_t bytes = n_points * static_cast<size_t>(L.point_step);
     if (bytes > p->raw_cap) {
+        HIP_TRY(hipDeviceSynchronize());  // (rare: the buffer grows; nothing may still be reading the old one)
         hipFree(p->d_raw);
         p->d_raw = nullptr, p->raw_cap = 0;
         HIP_TRY(hipMalloc(&p->d_raw, bytes + bytes / 4 + 4096));
         p->raw_cap = bytes + bytes / 4 + 4096;
     }
     if (!p->d_minmax) HIP_TRY(hipMalloc(&p->d_minmax, 16));
-    const uint32_t grid_in = static_cast<uint32_t>((n_points + 255) / 256);
-    if (!(st != 0 && grid_in <= kFusedScanBlocks)) {  // (the atomics of larger grids start from the identity; frame-sized ones fold per-workgroup extrema)
-        const unsigned long long init[2] = {~0ull, 0ull};
-        HIP_TRY(hipMemcpyAsync(p->d_minmax, init, 16, hipMemcpyHostToDevice, p->stream));
+    if (!p->h_minmax) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_minmax), 32, hipHostMallocDefault));
+    const uint32_t grid = static_cast<uint32_t>((n_points + 255) / 256);
+    if (!(st != 0 && grid <= kFusedScanBlocks)) {  // (the atomics of larger grids start from the identity; frame-sized ones fold per-workgroup extrema)
+        p->h_minmax[2] = ~0ull, p->h_minmax[3] = 0ull;
+        HIP_TRY(hipMemcpyAsync(p->d_minmax, p->h_minmax + 2, 16, hipMemcpyHostToDevice, stream));
     }
-    if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, p->stream)) return rc;
+    if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, stream)) return rc;
     IngestParams ip{};
     ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
     ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
-    ip.transform = sensor_pose_qt ? 1 : 0;
+    ip.transform = sensor_pose ? 1 : 0;
     ip.aligned = (L.point_step % 4 == 0 && L.offset_x % 4 == 0 && L.offset_y % 4 == 0 && L.offset_z % 4 == 0 &&
                   (st == 0 || (L.offset_stamp % stamp_bytes == 0 && L.point_step % stamp_bytes == 0))) ? 1 : 0;  // (d_raw itself is 256-byte aligned)
-    if (sensor_pose_qt) ip.T = pose_from(sensor_pose_qt);
-    ip.out_xyz = p->d_in, ip.out_stamps = p->d_ts, ip.minmax = p->d_minmax;
-    const uint32_t grid = static_cast<uint32_t>((n_points + 255) / 256);
-    // the stamps' extrema per workgroup, folded by the normalisation kernel (frame-sized grids; d_block_counts has room for them:
-    // >= cap / 256 + 2 words of 4 bytes... so they get a buffer of their own)
+    if (sensor_pose) ip.T = *sensor_pose;
+    ip.out_xyz = out_xyz, ip.out_stamps = out_ts, ip.minmax = p->d_minmax;
+    // the stamps' extrema per workgroup, folded by the normalisation kernel (frame-sized grids)
     ip.block_minmax = nullptr;
     if (st != 0 && grid <= kFusedScanBlocks) {
         if (!p->d_block_minmax) HIP_TRY(hipMalloc(&p->d_block_minmax, static_cast<size_t>(kFusedScanBlocks) * 16));
         ip.block_minmax = p->d_block_minmax;
     }
-    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, p->stream, ip);
+    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, stream, ip);
     if (st != 0) {
-        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, p->stream, p->d_ts, ip.n, p->d_minmax, static_cast<const unsigned long long *>(ip.block_minmax), grid);
-        unsigned long long mm[2];
-        HIP_TRY(hipMemcpyAsync(mm, p->d_minmax, 16, hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
-        if (out_min_stamp) *out_min_stamp = ordered_value(mm[0]);
-        if (out_max_stamp) *out_max_stamp = ordered_value(mm[1]);
-    } else {
-        HIP_TRY(hipStreamSynchronize(p->stream));  // `data` is borrowed for the call only
+        hipLaunchKernelGGL(k_normalize_stamps, dim3(grid), dim3(256), 0, stream, out_ts, ip.n, p->d_minmax, static_cast<const unsigned long long *>(ip.block_minmax), grid);
+        HIP_TRY(hipMemcpyAsync(p->h_minmax, p->d_minmax, 16, hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipGetLastError());
+    return KICP_OK;
+}
+bool same_layout(const kicp_cloud_layout &a, const kicp_cloud_layout &b) {
+    return a.point_step == b.point_step && a.offset_x == b.offset_x && a.offset_y == b.offset_y && a.offset_z == b.offset_z && a.stamp_datatype == b.stamp_datatype &&
+           (a.stamp_datatype == 0 || a.offset_stamp == b.offset_stamp);
+}
+// the announced next message goes into the second slot now (called by the chained pre-steps once their own kernels are queued);
+// *queued: something was put on p->ahead_stream that ahead_collect must wait for
+int ahead_queue(kicp_pre *p, bool *queued) {
+    *queued = false;
+    kicp_pre::Ahead &a = p->ahead;
+    if (a.state != 1 || a.n == 0 || a.n > p->cap_n) return KICP_OK;  // (a cloud that does not fit the buffers is left to its kicp_pre_ingest call)
+    if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
+    if (int rc = ingest_queue(p, a.data, a.n, a.layout, a.has_pose ? &a.pose : nullptr, p->ahead_stream, p->d_in2, p->d_ts2)) return rc;
+    *queued = true;
+    return KICP_OK;
+}
+int ahead_collect(kicp_pre *p) {
+    HIP_TRY(hipStreamSynchronize(p->ahead_stream));
+    kicp_pre::Ahead &a = p->ahead;
+    a.lo = a.hi = 0.0;
+    if (a.layout.stamp_datatype != 0) a.lo = ordered_value(p->h_minmax[0]), a.hi = ordered_value(p->h_minmax[1]);
+    a.state = 2;
+    return KICP_OK;
+}
+}  // namespace
+int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
+                    double *out_min_stamp, double *out_max_stamp) {
+    KICP_TRACE_CALL();
+    if (int rc = ingest_validate(p, data, n_points, layout)) return rc;
+    const kicp_cloud_layout &L = *layout;
+    const int st = L.stamp_datatype;
+    if (int rc = set_device(p->device)) return rc;
+    if (out_min_stamp) *out_min_stamp = 0.0;
+    if (out_max_stamp) *out_max_stamp = 0.0;
+    kicp_pre::Ahead &a = p->ahead;
+    const bool pose_matches = sensor_pose_qt ? (a.has_pose && std::memcmp(&a.pose, sensor_pose_qt, 7 * sizeof(double)) == 0) : !a.has_pose;
+    if (a.state == 2 && a.data == data && a.n == n_points && same_layout(a.layout, L) && pose_matches) {
+        // the message was uploaded and decoded ahead (kicp_pre_ingest_ahead + the previous frame's chained pre-steps): take the slot
+        std::swap(p->d_in, p->d_in2), std::swap(p->d_ts, p->d_ts2);
+        a.state = 0, ++p->ahead_hits;
+        p->ingested = true, p->ingested_n = n_points, p->ingested_stamps = st != 0 && n_points != 0;
+        if (out_min_stamp) *out_min_stamp = a.lo;
+        if (out_max_stamp) *out_max_stamp = a.hi;
+        return KICP_OK;
+    }
+    a.state = 0;  // (another message than the one announced: the announcement is void)
+    p->ingested = true, p->ingested_n = n_points, p->ingested_stamps = st != 0 && n_points != 0;
+    if (n_points == 0) return KICP_OK;
+    if (int rc = pre_ensure(p, n_points)) return rc;
+    Pose T{};
+    if (sensor_pose_qt) T = pose_from(sensor_pose_qt);
+    if (int rc = ingest_queue(p, data, n_points, L, sensor_pose_qt ? &T : nullptr, p->stream, p->d_in, p->d_ts)) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));  // (`data` is borrowed for the call only)
+    if (st != 0) {
+        if (out_min_stamp) *out_min_stamp = ordered_value(p->h_minmax[0]);
+        if (out_max_stamp) *out_max_stamp = ordered_value(p->h_minmax[1]);
+    }
+    return KICP_OK;
+}
+int kicp_pre_ingest_ahead(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7]) {
+    if (int rc = ingest_validate(p, data, n_points, layout)) return rc;
+    kicp_pre::Ahead &a = p->ahead;
+    a.data = data, a.n = n_points, a.layout = *layout, a.has_pose = sensor_pose_qt != nullptr, a.state = n_points ? 1 : 0;
+    if (sensor_pose_qt) a.pose = pose_from(sensor_pose_qt);
     return KICP_OK;
 }
 int kicp_pre_preprocess_ingested(kicp_pre *p, const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range,
@@ -381,7 +463,13 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     HIP_TRY(hipGetLastError());
     uint32_t misc[8] = {};
     HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
+    // everything of this frame is queued: the next message, if one was announced, goes up now - this thread copies it into the staging
+    // buffer and the GPU pulls and decodes it on a stream of its own while the kernels above run
+    bool ahead_out = false;
+    if (int rc = ahead_queue(p, &ahead_out)) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (ahead_out)
+        if (int rc = ahead_collect(p)) return rc;
     p->last_max_probe = misc[2];
     if (misc[1]) {
         HIP_TRY(hipMemsetAsync(p->d_misc + 1, 0, 4, p->stream));
@@ -427,6 +515,7 @@ int kicp_pre_frame(kicp_pre *p, const double *frame_xyz, size_t n, const double 
     }
     return pre_frame_chain(p, n, do_deskew, relative_motion_qt, lidar_to_base_qt, max_range, min_range, voxel_a, voxel_b, out_frame_xyz, cap_points, out_counts);
 }
+unsigned long long kicp_pre_ahead_hits(const kicp_pre *p) { return p ? p->ahead_hits : 0ull; }
 size_t kicp_pre_ingested_count(const kicp_pre *p) { return (p && p->ingested) ? p->ingested_n : 0; }
 unsigned int kicp_pre_last_max_probe(const kicp_pre *p) { return p ? p->last_max_probe : 0u; }
 int kicp_pre_set_probe_limit(kicp_pre *p, unsigned int limit) {

@@ -204,27 +204,40 @@ int main(int argc, char **argv) {
                 print_pose("pose", icp.pose());
             }
             printf("map %zu\n", icp.LocalMap().size());
-        } else if (mode == "pipeline_timed_raw") {  // the same frames as 16-byte PointCloud2 records (x y z t, FLOAT32): IngestCloud + RegisterIngestedFrame in the clock
+        } else if (mode == "pipeline_timed_raw" || mode == "pipeline_timed_raw_ahead") {  // the same frames as 16-byte PointCloud2 records (x y z t, FLOAT32): IngestCloud + RegisterIngestedFrame in the clock
+            // (_ahead: a bag replay that holds message k + 1 while it registers message k - AnnounceNextCloud: the next message's upload hides
+            //  behind the current frame's pre-steps)
+            const bool ahead = mode == "pipeline_timed_raw_ahead";
             const auto h = read_doubles(f, 4);
             kinematic_icp::pipeline::Config cfg;
             cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
             kinematic_icp::pipeline::KinematicICP icp(cfg);
             const auto ext = read_doubles(f, 7);
             const kicp_cloud_layout layout{16, 0, 4, 8, KICP_FIELD_FLOAT32, 12};
-            for (int k = 0; k < static_cast<int>(h[0]); ++k) {
+            const int n_frames = static_cast<int>(h[0]);
+            std::vector<std::vector<float>> msgs(static_cast<size_t>(n_frames));  // (the messages as they arrive from the driver / the bag: outside the clock)
+            std::vector<std::vector<double>> deltas(static_cast<size_t>(n_frames));
+            for (int k = 0; k < n_frames; ++k) {
                 const auto n = read_doubles(f, 1);
                 const size_t np = static_cast<size_t>(n[0]);
                 const auto xyz = read_doubles(f, np * 3), stamps = read_doubles(f, np);
-                const auto delta = read_doubles(f, 7);
-                std::vector<float> msg(np * 4);  // (the message as it arrives from the driver: outside the clock)
+                deltas[k] = read_doubles(f, 7);
+                auto &msg = msgs[k];
+                msg.resize(np * 4);
                 for (size_t i = 0; i < np; ++i)
                     msg[4 * i] = static_cast<float>(xyz[3 * i]), msg[4 * i + 1] = static_cast<float>(xyz[3 * i + 1]), msg[4 * i + 2] = static_cast<float>(xyz[3 * i + 2]),
                               msg[4 * i + 3] = static_cast<float>(stamps[i]);
+            }
+            for (int k = 0; k < n_frames; ++k) {
+                const auto &msg = msgs[k];
+                const auto &delta = deltas[k];
+                const size_t np = msg.size() / 4;
                 const auto t0 = std::chrono::steady_clock::now();
                 double ms = 0.0;
                 size_t n_deskewed = 0, n_source = 0;
                 {
                     (void)icp.IngestCloud(msg.data(), np, layout);
+                    if (ahead && k + 1 < n_frames) icp.AnnounceNextCloud(msgs[k + 1].data(), msgs[k + 1].size() / 4, layout);
                     const auto [deskewed, source] = icp.RegisterIngestedFrame(kicp_bridge::from_params(ext.data()), kicp_bridge::from_params(delta.data()));
                     ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                     n_deskewed = deskewed.size(), n_source = source.size();

@@ -153,3 +153,10 @@ def test_facade_pipeline_from_pointcloud2_bytes(tmp_path):
     assert raw[2] == "stamps 1 0 1"
     raw = raw[:2] + raw[3:]
     assert raw == host[:len(raw)] and len(raw) == 10
+    # AnnounceNextCloud (round 5): message k + 1 uploaded and decoded while frame k's pre-steps run - the same poses, sizes and map
+    keep = lambda lines: [l for l in lines if l.startswith("pose") or l.startswith("map")]  # noqa: E731  (the timing lines differ)
+    plain = subprocess.check_output([build_facade(), "pipeline_timed_raw", str(f)], text=True).splitlines()
+    ahead = subprocess.check_output([build_facade(), "pipeline_timed_raw_ahead", str(f)], text=True).splitlines()
+    assert keep(ahead) == keep(plain) and len(keep(plain)) == 6
+    sizes = lambda lines: [l.split()[l.split().index("in"):l.split().index("map_on_device")] for l in lines if l.startswith("frame")]  # noqa: E731
+    assert sizes(ahead) == sizes(plain)

@@ -151,6 +151,60 @@ def test_gpu_pipeline_from_raw_bytes_equals_pipeline_from_host_arrays(deskew):
         np.testing.assert_allclose(a.download(0), okicp.se3_act(ext, theirs), rtol=0, atol=1e-11)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("stamp,layout", [(U32, "ouster"), (F32, "packed"), (None, "packed"), (F64, "odd")])
+def test_gpu_look_ahead_ingest_equals_the_plain_ingest(stamp, layout):
+    """kicp_pre_ingest_ahead (round 5): message k + 1 is uploaded and decoded by the chained pre-steps of message k; its Ingest call
+    then takes the slot.  Decoded clouds, stamp extrema and every output of the chained pre-steps equal the plain sequence's, bit for
+    bit - over four messages of different sizes; an announcement that is not followed by its message is void."""
+    import kinematic_icp_amd as kicp
+    from kinematic_icp_amd import synthetic as syn
+    rng = np.random.Generator(np.random.PCG64(21))
+    scale = 1e9 if stamp == U32 else 1.0
+    msgs = []
+    for n in (30_000, 41_000, 12_345, 41_000):
+        rec, step, off = make_cloud(rng, n, stamp, layout, scale=scale)
+        msgs.append((np.frombuffer(rec.tobytes(), dtype=np.uint8).copy(), n, step, off))
+    rel = syn.planar_pose(0.4, 0.01, np.deg2rad(3.0))
+    ext = syn.planar_pose(0.2, 0.0, 0.05, 0.7)
+
+    def args(m):
+        raw, n, step, off = m
+        return (raw, n, step, off["x"], off["y"], off["z"], stamp or 0, off.get("t", 0))
+
+    def chain(pre):
+        counts, frame = pre.Frame(None, None, rel, ext, 60.0, 1.0, True, 0.5, 1.5)
+        return counts, frame, pre.download(1), pre.download(2)
+
+    plain, ahead = kicp.PreSteps(), kicp.PreSteps()
+    want = []
+    for m in msgs:
+        lohi = plain.Ingest(*args(m))
+        want.append((lohi, plain.ingested(), chain(plain)))
+    for k, m in enumerate(msgs):
+        lohi = ahead.Ingest(*args(m))
+        got_cloud = ahead.ingested()
+        if k + 1 < len(msgs):
+            ahead.IngestAhead(*args(msgs[k + 1]))
+        got = chain(ahead)  # (uploads message k + 1 behind its own kernels)
+        assert lohi == want[k][0]
+        np.testing.assert_array_equal(got_cloud[0], want[k][1][0])
+        if want[k][1][1] is None:
+            assert got_cloud[1] is None
+        else:
+            np.testing.assert_array_equal(got_cloud[1], want[k][1][1])
+        assert got[0] == want[k][2][0]
+        for a, b in zip(got[1:], want[k][2][1:]):
+            np.testing.assert_array_equal(a, b)
+    assert ahead.ahead_hits() == len(msgs) - 1 and plain.ahead_hits() == 0  # (messages 1 .. 3 were found decoded)
+    # an announcement followed by ANOTHER message: void - the other message is ingested as usual
+    ahead.IngestAhead(*args(msgs[0]))
+    chain(ahead)
+    assert ahead.Ingest(*args(msgs[2])) == want[2][0]
+    np.testing.assert_array_equal(ahead.ingested()[0], want[2][1][0])
+    assert chain(ahead)[0] == want[2][2][0] and ahead.ahead_hits() == len(msgs) - 1
+
+
 def test_ordered_integer_keys_of_doubles_are_monotone():
     """k_ingest merges the stamps' extrema with integer atomics on an order-preserving map double -> uint64
     (kicp_pre.hpp ordered_key / ordered_value); re-enacted here: monotone over negatives, zeros, subnormals and infinities,

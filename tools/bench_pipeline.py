@@ -22,6 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from kinematic_icp_amd import synthetic as syn  # noqa: E402
 
 
+FACADE_MODE = {"raw": "pipeline_timed_raw", "raw_ahead": "pipeline_timed_raw_ahead", "vectors": "pipeline_timed"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=40)
@@ -33,10 +36,11 @@ def main():
     ap.add_argument("--oracle-frames", type=int, default=5)
     ap.add_argument("--ref-frames", type=int, default=40, help="frames through the reference's own RegisterFrame (oracle/_ref), timed; 0: skip")
     ap.add_argument("--ref-threads", type=int, nargs="+", default=[1, 16], help="max_num_threads values of the reference run (its default is 1)")
-    ap.add_argument("--mode", default="raw", choices=["raw", "vectors"],
+    ap.add_argument("--mode", default="raw", choices=["raw", "raw_ahead", "vectors"],
                     help="raw (default): every frame arrives as a PointCloud2-style buffer of 16-byte records (x y z t, FLOAT32) and goes through "
                          "IngestCloud + RegisterIngestedFrame - 2.1 MB over PCIe, decoded on the GPU; vectors: the reference's own signature, "
-                         "std::vector<Eigen::Vector3d> + std::vector<double> (4.2 MB)")
+                         "std::vector<Eigen::Vector3d> + std::vector<double> (4.2 MB); raw_ahead: raw, with the NEXT message announced before the "
+                         "current one is registered (AnnounceNextCloud: a bag replay holds it) - its upload hides behind the current frame's pre-steps")
     ap.add_argument("--dump", default="", help="only write the input file for tests/cpp/facade_test (e.g. to run it under rocprofv3)")
     ap.add_argument("--check", default="", help="output of `facade_test pipeline_timed <dump>` to analyse instead of running it here")
     a = ap.parse_args()
@@ -65,12 +69,12 @@ def main():
                 np.array([float(len(fr))]).tofile(fh)
                 np.ascontiguousarray(fr).tofile(fh), st.tofile(fh), dl.tofile(fh)
         if a.dump:
-            print(test_facade.build_facade(), "pipeline_timed_raw" if a.mode == "raw" else "pipeline_timed", f)
+            print(test_facade.build_facade(), FACADE_MODE[a.mode], f)
             return
         if a.check:
             out = open(a.check).read().splitlines()
         else:
-            out = subprocess.check_output([test_facade.build_facade(), "pipeline_timed_raw" if a.mode == "raw" else "pipeline_timed", f], text=True).splitlines()
+            out = subprocess.check_output([test_facade.build_facade(), FACADE_MODE[a.mode], f], text=True).splitlines()
     ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
     ondev = np.array([int(l.split()[-1]) for l in out if l.startswith("frame")])
     ms_free = np.array([float(l.split()[4].strip("(")) for l in out if l.startswith("frame")])
@@ -78,7 +82,8 @@ def main():
         if not l.startswith("pose"):
             print(l)
     steady = ms[len(ms) // 2:]
-    print("mode %s: %s" % (a.mode, "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 records" if a.mode == "raw" else "RegisterFrame on fp64 vectors"))
+    print("mode %s: %s" % (a.mode, {"raw": "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 records", "vectors": "RegisterFrame on fp64 vectors",
+                               "raw_ahead": "IngestCloud + AnnounceNextCloud(next message) + RegisterIngestedFrame on 16-byte FLOAT32 records"}[a.mode]))
     print("GPU RegisterFrame: median %.3f ms (second half; %.3f ms incl. freeing the returned clouds; p10 %.3f, min %.3f), first %.1f ms, map updates on device %d/%d" %
           (np.median(steady), np.median(ms_free[len(ms) // 2:]), np.percentile(steady, 10), steady.min(), ms[0], ondev.sum(), len(ondev)))
     gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
