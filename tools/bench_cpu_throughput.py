@@ -15,6 +15,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rkicp  # noqa: E402
 
+try:  # (a caller whose main thread is bound to one core - OMP_PROC_BIND binds the initial thread of many a process - hands that mask down)
+    os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+except (AttributeError, OSError):
+    pass
 d = np.load(sys.argv[1])
 threads, budget = int(sys.argv[2]), float(sys.argv[3])
 if not rkicp.available():

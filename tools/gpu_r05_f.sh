@@ -1,0 +1,20 @@
+# round 5: look-ahead ingest (tests, the pipeline with and without it), the CPU throughput baseline with its threads unpinned
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05f; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_ingest.py tests/test_facade.py tests/test_gpu_presteps.py tests/test_golden_pipeline.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest.log | grep -v "version\|Hostname\|Librccl"
+timeout 300 python tools/bench_pipeline.py --frames 40 --mode raw --dump /tmp/pipe.bin > /dev/null 2>&1
+for m in raw raw_ahead; do
+  mode=pipeline_timed_raw; [ $m = raw_ahead ] && mode=pipeline_timed_raw_ahead
+  for rep in 1 2 3; do
+    timeout 300 tests/cpp/facade_test $mode /tmp/pipe.bin > /tmp/pipe_$m.txt
+    timeout 900 python tools/bench_pipeline.py --frames 40 --mode $m --check /tmp/pipe_$m.txt --oracle-frames 0 --ref-frames $([ $rep = 1 ] && echo 40 || echo 0) 2>&1 | grep -v "^frame [0-9]* ms" > $O/pipeline_${m}_$rep.txt; grep "GPU RegisterFrame\|reference RegisterFrame" $O/pipeline_${m}_$rep.txt | cut -c1-220
+  done
+  KICP_TRACE=1 tests/cpp/facade_test $mode /tmp/pipe.bin 2>&1 >/dev/null | tail -14 > $O/pipeline_calls_$m.txt
+done
+cat $O/pipeline_calls_raw_ahead.txt
+timeout 600 python bench.py --no-pmc --scans 16 > $O/bench_n1_quick.json 2> $O/bench_n1_quick.err; echo "bench rc=$?"; python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05f/bench_n1_quick.json"))
+print({k: d.get(k) for k in ("value", "value_one_scan_in_flight")}, {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "single_thread_value", "throughput")})
+PY
+du -sh $O
