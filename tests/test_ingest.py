@@ -162,7 +162,7 @@ def test_gpu_look_ahead_ingest_equals_the_plain_ingest(stamp, layout):
     rng = np.random.Generator(np.random.PCG64(21))
     scale = 1e9 if stamp == U32 else 1.0
     msgs = []
-    for n in (30_000, 41_000, 12_345, 41_000):
+    for n in (41_000, 30_000, 12_345, 41_000, 70_000):  # (the last one outgrows the buffers: it is left to its own Ingest call)
         rec, step, off = make_cloud(rng, n, stamp, layout, scale=scale)
         msgs.append((np.frombuffer(rec.tobytes(), dtype=np.uint8).copy(), n, step, off))
     rel = syn.planar_pose(0.4, 0.01, np.deg2rad(3.0))
@@ -196,13 +196,13 @@ def test_gpu_look_ahead_ingest_equals_the_plain_ingest(stamp, layout):
         assert got[0] == want[k][2][0]
         for a, b in zip(got[1:], want[k][2][1:]):
             np.testing.assert_array_equal(a, b)
-    assert ahead.ahead_hits() == len(msgs) - 1 and plain.ahead_hits() == 0  # (messages 1 .. 3 were found decoded)
+    assert ahead.ahead_hits() == 3 and plain.ahead_hits() == 0  # (messages 1 .. 3 were found decoded; message 4 did not fit the buffers of its predecessors)
     # an announcement followed by ANOTHER message: void - the other message is ingested as usual
     ahead.IngestAhead(*args(msgs[0]))
     chain(ahead)
     assert ahead.Ingest(*args(msgs[2])) == want[2][0]
     np.testing.assert_array_equal(ahead.ingested()[0], want[2][1][0])
-    assert chain(ahead)[0] == want[2][2][0] and ahead.ahead_hits() == len(msgs) - 1
+    assert chain(ahead)[0] == want[2][2][0] and ahead.ahead_hits() == 3
 
 
 def test_ordered_integer_keys_of_doubles_are_monotone():
