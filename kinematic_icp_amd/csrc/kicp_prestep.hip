@@ -600,6 +600,17 @@ static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t aft
     p->copy_buffer = buffer, p->copy_n = n, p->copy_points = n;
     return KICP_OK;
 }
+// wait for an event of the download WITHOUT going to sleep on it: a blocking wait wakes the thread by interrupt, tens of microseconds
+// after the transfer has landed - more than the copy it is waiting to start takes; the wait is bounded (a frame's transfer takes
+// ~100 us), after 5 ms the thread does block
+static hipError_t spin_on_event(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 5.0) return hipEventSynchronize(ev);
+    }
+}
 static void copy_worker(kicp_pre *p) {
     hipSetDevice(p->device);
     std::unique_lock<std::mutex> lock(p->copy_mutex);
@@ -611,12 +622,12 @@ static void copy_worker(kicp_pre *p) {
         const size_t want = std::min(p->copy_points, p->copy_dst_points) * 24;  // (copy_points, copy_dst*, copy_piece_bytes: written before the job was posted)
         if (p->copy_piece_bytes && p->copy_dst) {
             for (int i = 0; i < kicp_pre::kCopyPieces && e == hipSuccess; ++i) {
-                e = hipEventSynchronize(p->copy_piece_done[i]);
+                e = spin_on_event(p->copy_piece_done[i]);
                 const size_t off = std::min(want, p->copy_piece_bytes * i), len = std::min(p->copy_piece_bytes, want - off);
                 if (e == hipSuccess && len) std::memcpy(reinterpret_cast<unsigned char *>(p->copy_dst) + off, p->copy_host + off, len);
             }
         } else {
-            e = hipEventSynchronize(p->copy_done);
+            e = spin_on_event(p->copy_done);
             if (e == hipSuccess && want && p->copy_dst) std::memcpy(p->copy_dst, p->copy_host, want);
         }
         lock.lock();
