@@ -1,6 +1,7 @@
 // kicp_prestep.hip -- the pipeline's pre-steps behind include/kicp.h (kicp_pre_*): wire-format ingest, deskew + crop +
 // transform, voxel downsample (kernels: kicp_pre.hpp).
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -10,6 +11,57 @@
 using namespace kicp;
 using namespace kicp::host;
 
+namespace {
+// One job at a time on a thread of its own: the look-ahead upload's host work (a 2 MB copy into the staging buffer and a dozen API
+// calls, ~85 us) runs beside the calling thread's own queueing of the frame's kernels (~100 us of API calls) instead of after it.
+struct JobThread {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    int state = 0;  // 0 idle | 1 posted | 2 done | -1 leaving
+    int result = 0;
+    int device = 0;
+    void run() {
+        hipSetDevice(device);
+        std::unique_lock<std::mutex> lock(m);
+        for (;;) {
+            cv.wait(lock, [this] { return state == 1 || state == -1; });
+            if (state == -1) return;
+            lock.unlock();
+            const int rc = job();
+            lock.lock();
+            result = rc, state = 2;
+            cv.notify_all();
+        }
+    }
+    void post(int dev, std::function<int()> fn) {
+        device = dev;
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = std::move(fn), state = 1;
+        }
+        cv.notify_all();
+    }
+    int wait() {  // (only after post)
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [this] { return state == 2; });
+        state = 0;
+        return result;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        {
+            std::unique_lock<std::mutex> lock(m);
+            cv.wait(lock, [this] { return state != 1; });
+            state = -1;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
+}  // namespace
 struct kicp_pre {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -71,6 +123,10 @@ struct kicp_pre {
         double lo = 0.0, hi = 0.0;
     } ahead;
     unsigned long long ahead_hits = 0;  // kicp_pre_ingest calls that found their message decoded ahead (kicp_pre_ahead_hits)
+    JobThread ahead_thread;             // queues the look-ahead upload beside the calling thread's own kernels
+    // the chained pre-steps hand the WHOLE download of buffer 0 to the helper thread (its dozen API calls cost the calling thread ~40 us):
+    bool copy_job_begins = false;       // the posted job starts with download_queue(0, copy_job_n, after chain_ready)
+    size_t copy_job_n = 0;
 };
 namespace {
 int pre_ensure(kicp_pre *p, size_t n) {
@@ -170,6 +226,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
+    p->ahead_thread.stop();
     if (p->ahead_stream) hipStreamSynchronize(p->ahead_stream), hipStreamDestroy(p->ahead_stream);
     if (p->h_minmax) hipHostFree(p->h_minmax);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
@@ -407,6 +464,8 @@ int kicp_pre_voxel_downsample(kicp_pre *p, int src, double voxel_size, int dst, 
     return rc;
 }
 static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after);
+static int download_settle(kicp_pre *p);
+static int download_queue(kicp_pre *p, int buffer, size_t n, hipEvent_t after);
 static void copy_worker(kicp_pre *p);
 // ---- the whole pre-step chain of one frame behind ONE host synchronisation (KinematicICP.cpp:54-62) ------------------------
 // What d_in / d_ts hold (n_in points: an uploaded frame or an ingested cloud) is preprocessed into buffer 0, buffer 0 is
@@ -434,6 +493,18 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     pp.motion_inverse = pose_inverse(rel), pp.lidar_to_base = pose_from(lidar_to_base_qt);
     pp.max_range = max_range, pp.min_range = min_range;
     pp.flags = p->d_flags, pp.staged = p->d_staged, pp.block_counts = p->d_block_counts;
+    // the next message, if one was announced, goes up NOW, from a thread of its own: its 2 MB copy into the staging buffer and its
+    // launches run beside this thread's queueing of the frame's kernels, the GPU pulls and decodes it on a stream of its own
+    bool ahead_out = false;
+    if (p->ahead.state == 1 && p->ahead.n != 0 && p->ahead.n <= p->cap_n) {
+        if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
+        p->ahead_thread.post(p->device, [p] {
+            bool queued = false;
+            if (int rc = ahead_queue(p, &queued)) return rc;
+            return queued ? ahead_collect(p) : static_cast<int>(KICP_OK);
+        });
+        ahead_out = true;
+    }
     hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, p->stream, pp);
     const int raw_c = grid <= kFusedScanBlocks ? 1 : 0, raw_g = sgrid <= kFusedScanBlocks ? 1 : 0;
     if (!raw_c) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, cnt + 0);
@@ -441,12 +512,12 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
                        static_cast<const uint32_t *>(p->d_block_counts), raw_c, cnt + 0, static_cast<uint32_t>(n_in), p->buf[0]);
     if (out_frame_xyz) {  // buffer 0 is complete behind this point: its download overlaps the downsamples (n_in points: an upper bound)
         HIP_TRY(hipEventRecord(p->chain_ready, p->stream));
-        if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
-        if (int rc = download_begin_impl(p, 0, n_in, p->chain_ready)) return rc;
+        if (int rc = download_settle(p)) return rc;  // (an earlier download nobody collected)
         if (!p->copy_thread.joinable()) p->copy_thread = std::thread(copy_worker, p);
-        {
+        {   // the helper thread queues the transfer (behind chain_ready, in pieces) AND moves the pieces into the caller's memory
             std::lock_guard<std::mutex> lock(p->copy_mutex);
-            p->copy_dst = out_frame_xyz, p->copy_dst_points = cap_points, p->copy_state = 1;
+            p->copy_dst = out_frame_xyz, p->copy_dst_points = cap_points, p->copy_job_begins = true, p->copy_job_n = n_in;
+            p->copy_buffer = 0, p->copy_n = n_in, p->copy_points = n_in, p->copy_state = 1;
         }
         p->copy_cv.notify_all();
     }
@@ -470,13 +541,17 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     HIP_TRY(hipGetLastError());
     uint32_t misc[8] = {};
     HIP_TRY(hipMemcpyAsync(misc, p->d_misc, sizeof misc, hipMemcpyDeviceToHost, p->stream));
-    // everything of this frame is queued: the next message, if one was announced, goes up now - this thread copies it into the staging
-    // buffer and the GPU pulls and decodes it on a stream of its own while the kernels above run
-    bool ahead_out = false;
-    if (int rc = ahead_queue(p, &ahead_out)) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (ahead_out)
-        if (int rc = ahead_collect(p)) return rc;
+    const auto t_queued = std::chrono::steady_clock::now();
+    const hipError_t chain_rc = hipStreamSynchronize(p->stream);
+    const auto t_chain = std::chrono::steady_clock::now();
+    if (ahead_out)  // (always collected, whatever this frame's outcome: the thread holds a borrowed pointer)
+        if (int rc = p->ahead_thread.wait()) return rc;
+    HIP_TRY(chain_rc);
+    if (g_trace) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[kicp]   chained pre-steps: own kernels done %.3f ms after the last one was queued, look-ahead upload (%s) collected %.3f ms later\n",
+                     ms(t_queued, t_chain), ahead_out ? "its own thread" : "none", ms(t_chain, std::chrono::steady_clock::now()));
+    }
     p->last_max_probe = misc[2];
     if (misc[1]) {
         HIP_TRY(hipMemsetAsync(p->d_misc + 1, 0, 4, p->stream));
@@ -561,7 +636,7 @@ int kicp_pre_download_begin(kicp_pre *p, int buffer) {
     if (int rc = set_device(p->device)) return rc;
     return download_begin_impl(p, buffer, p->buf_n[buffer], nullptr);
 }
-static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after) {
+static int download_settle(kicp_pre *p) {
     if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
     if (!p->copy_done) HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
     if (p->copy_buffer >= 0) {  // an earlier download nobody collected: let it (and the helper thread's copy) finish first
@@ -573,6 +648,17 @@ static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t aft
         lock.unlock();
         HIP_TRY(hipStreamSynchronize(p->copy_stream));
     }
+    return KICP_OK;
+}
+static int download_queue(kicp_pre *p, int buffer, size_t n, hipEvent_t after);
+static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t after) {
+    if (int rc = download_settle(p)) return rc;
+    if (int rc = download_queue(p, buffer, n, after)) return rc;
+    p->copy_buffer = buffer, p->copy_n = n, p->copy_points = n;
+    return KICP_OK;
+}
+// the transfer itself (calling thread, or the helper thread for the chained pre-steps)
+static int download_queue(kicp_pre *p, int buffer, size_t n, hipEvent_t after) {
     const size_t bytes = n * 24;
     if (bytes > p->copy_cap) {
         if (p->copy_host) HIP_TRY(hipHostFree(p->copy_host));
@@ -597,7 +683,6 @@ static int download_begin_impl(kicp_pre *p, int buffer, size_t n, hipEvent_t aft
         HIP_TRY(hipMemcpyAsync(p->copy_host, p->buf[buffer], bytes, hipMemcpyDeviceToHost, p->copy_stream));
     }
     HIP_TRY(hipEventRecord(p->copy_done, p->copy_stream));
-    p->copy_buffer = buffer, p->copy_n = n, p->copy_points = n;
     return KICP_OK;
 }
 // wait for an event of the download WITHOUT going to sleep on it: a blocking wait wakes the thread by interrupt, tens of microseconds
@@ -619,8 +704,13 @@ static void copy_worker(kicp_pre *p) {
         if (p->copy_state == -1) return;
         lock.unlock();
         hipError_t e = hipSuccess;
+        if (p->copy_job_begins) {  // (chained pre-steps: the transfer is queued here, behind the event that says buffer 0 is complete)
+            p->copy_job_begins = false;
+            if (download_queue(p, 0, p->copy_job_n, p->chain_ready) != KICP_OK) e = hipErrorUnknown;
+        }
         const size_t want = std::min(p->copy_points, p->copy_dst_points) * 24;  // (copy_points, copy_dst*, copy_piece_bytes: written before the job was posted)
-        if (p->copy_piece_bytes && p->copy_dst) {
+        if (e != hipSuccess) {
+        } else if (p->copy_piece_bytes && p->copy_dst) {
             for (int i = 0; i < kicp_pre::kCopyPieces && e == hipSuccess; ++i) {
                 e = spin_on_event(p->copy_piece_done[i]);
                 const size_t off = std::min(want, p->copy_piece_bytes * i), len = std::min(p->copy_piece_bytes, want - off);
