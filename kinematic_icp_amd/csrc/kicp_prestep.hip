@@ -124,14 +124,18 @@ struct kicp_pre {
     } ahead;
     unsigned long long ahead_hits = 0;  // kicp_pre_ingest calls that found their message decoded ahead (kicp_pre_ahead_hits)
     JobThread ahead_thread;             // queues the look-ahead upload beside the calling thread's own kernels
+    bool ahead_job_out = false;         // ... and is only waited for where its result (or a buffer it uses) is needed: ahead_join
+    HostStage stage_ahead;              // its own pinned staging buffer (the calling thread goes on using `stage` meanwhile)
     // the chained pre-steps hand the WHOLE download of buffer 0 to the helper thread (its dozen API calls cost the calling thread ~40 us):
     bool copy_job_begins = false;       // the posted job starts with download_queue(0, copy_job_n, after chain_ready)
     size_t copy_job_n = 0;
 };
 namespace {
+int ahead_join(kicp_pre *p);
 int pre_ensure(kicp_pre *p, size_t n) {
     if (n <= p->cap_n) return KICP_OK;
     const size_t cap = n + n / 4 + 1024;
+    if (int rc = ahead_join(p)) return rc;
     if (p->ahead_stream) HIP_TRY(hipStreamSynchronize(p->ahead_stream));
     p->ahead.state = 0;  // (a cloud waiting in the second slot goes with it: its kicp_pre_ingest call uploads it again)
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
@@ -226,7 +230,9 @@ void kicp_pre_destroy(kicp_pre *p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (double *b : p->buf) hipFree(b);
+    (void)ahead_join(p);
     p->ahead_thread.stop();
+    p->stage_ahead.release();
     if (p->ahead_stream) hipStreamSynchronize(p->ahead_stream), hipStreamDestroy(p->ahead_stream);
     if (p->h_minmax) hipHostFree(p->h_minmax);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
@@ -287,7 +293,7 @@ int ingest_validate(const kicp_pre *p, const void *data, size_t n_points, const 
 // Upload + decode of one message (n_points > 0, <= p->cap_n) on `stream` into (out_xyz, out_ts); the stamps' extrema land in the
 // pinned p->h_minmax behind it.  Nothing is waited for: the caller synchronises `stream` (`data` is borrowed until then).
 int ingest_queue(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout &L, const Pose *sensor_pose, hipStream_t stream, double *out_xyz,
-                 double *out_ts) {
+                 double *out_ts, HostStage &stage) {
     const int st = L.stamp_datatype;
     const uint32_t stamp_bytes = st == KICP_FIELD_FLOAT64 ? 8u : 4u;
     const size_t bytes = n_points * static_cast<size_t>(L.point_step);
@@ -305,7 +311,7 @@ int ingest_queue(kicp_pre *p, const void *data, size_t n_points, const kicp_clou
         p->h_minmax[2] = ~0ull, p->h_minmax[3] = 0ull;
         HIP_TRY(hipMemcpyAsync(p->d_minmax, p->h_minmax + 2, 16, hipMemcpyHostToDevice, stream));
     }
-    if (int rc = staged_upload(p->stage, 0, p->d_raw, data, bytes, stream)) return rc;
+    if (int rc = staged_upload(stage, 0, p->d_raw, data, bytes, stream)) return rc;
     IngestParams ip{};
     ip.raw = p->d_raw, ip.n = static_cast<uint32_t>(n_points), ip.point_step = L.point_step;
     ip.off_x = L.offset_x, ip.off_y = L.offset_y, ip.off_z = L.offset_z, ip.off_t = L.offset_stamp, ip.stamp_type = st;
@@ -339,7 +345,7 @@ int ahead_queue(kicp_pre *p, bool *queued) {
     kicp_pre::Ahead &a = p->ahead;
     if (a.state != 1 || a.n == 0 || a.n > p->cap_n) return KICP_OK;  // (a cloud that does not fit the buffers is left to its kicp_pre_ingest call)
     if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
-    if (int rc = ingest_queue(p, a.data, a.n, a.layout, a.has_pose ? &a.pose : nullptr, p->ahead_stream, p->d_in2, p->d_ts2)) return rc;
+    if (int rc = ingest_queue(p, a.data, a.n, a.layout, a.has_pose ? &a.pose : nullptr, p->ahead_stream, p->d_in2, p->d_ts2, p->stage_ahead)) return rc;
     *queued = true;
     return KICP_OK;
 }
@@ -351,6 +357,12 @@ int ahead_collect(kicp_pre *p) {
     a.state = 2;
     return KICP_OK;
 }
+// the look-ahead upload, if one is out, must be over before its result is looked at or anything it uses changes hands
+int ahead_join(kicp_pre *p) {
+    if (!p->ahead_job_out) return KICP_OK;
+    p->ahead_job_out = false;
+    return p->ahead_thread.wait();
+}
 }  // namespace
 int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7],
                     double *out_min_stamp, double *out_max_stamp) {
@@ -361,6 +373,7 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
     if (int rc = set_device(p->device)) return rc;
     if (out_min_stamp) *out_min_stamp = 0.0;
     if (out_max_stamp) *out_max_stamp = 0.0;
+    if (int rc = ahead_join(p)) return rc;  // (the announced message's upload has had the registration and the map update to finish behind)
     kicp_pre::Ahead &a = p->ahead;
     const bool pose_matches = sensor_pose_qt ? (a.has_pose && std::memcmp(&a.pose, sensor_pose_qt, 7 * sizeof(double)) == 0) : !a.has_pose;
     if (a.state == 2 && a.data == data && a.n == n_points && same_layout(a.layout, L) && pose_matches) {
@@ -378,7 +391,7 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
     if (int rc = pre_ensure(p, n_points)) return rc;
     Pose T{};
     if (sensor_pose_qt) T = pose_from(sensor_pose_qt);
-    if (int rc = ingest_queue(p, data, n_points, L, sensor_pose_qt ? &T : nullptr, p->stream, p->d_in, p->d_ts)) return rc;
+    if (int rc = ingest_queue(p, data, n_points, L, sensor_pose_qt ? &T : nullptr, p->stream, p->d_in, p->d_ts, p->stage)) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));  // (`data` is borrowed for the call only)
     if (st != 0) {
         if (out_min_stamp) *out_min_stamp = ordered_value(p->h_minmax[0]);
@@ -388,6 +401,7 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
 }
 int kicp_pre_ingest_ahead(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_layout *layout, const double sensor_pose_qt[7]) {
     if (int rc = ingest_validate(p, data, n_points, layout)) return rc;
+    if (int rc = ahead_join(p)) return rc;
     kicp_pre::Ahead &a = p->ahead;
     a.data = data, a.n = n_points, a.layout = *layout, a.has_pose = sensor_pose_qt != nullptr, a.state = n_points ? 1 : 0;
     if (sensor_pose_qt) a.pose = pose_from(sensor_pose_qt);
@@ -496,6 +510,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     // the next message, if one was announced, goes up NOW, from a thread of its own: its 2 MB copy into the staging buffer and its
     // launches run beside this thread's queueing of the frame's kernels, the GPU pulls and decodes it on a stream of its own
     bool ahead_out = false;
+    if (int rc = ahead_join(p)) return rc;
     if (p->ahead.state == 1 && p->ahead.n != 0 && p->ahead.n <= p->cap_n) {
         if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
         p->ahead_thread.post(p->device, [p] {
@@ -544,13 +559,12 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     const auto t_queued = std::chrono::steady_clock::now();
     const hipError_t chain_rc = hipStreamSynchronize(p->stream);
     const auto t_chain = std::chrono::steady_clock::now();
-    if (ahead_out)  // (always collected, whatever this frame's outcome: the thread holds a borrowed pointer)
-        if (int rc = p->ahead_thread.wait()) return rc;
+    if (ahead_out) p->ahead_job_out = true;  // (collected by the kicp_pre_ingest call of that message - or whoever needs its buffers first: ahead_join)
     HIP_TRY(chain_rc);
     if (g_trace) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[kicp]   chained pre-steps: own kernels done %.3f ms after the last one was queued, look-ahead upload (%s) collected %.3f ms later\n",
-                     ms(t_queued, t_chain), ahead_out ? "its own thread" : "none", ms(t_chain, std::chrono::steady_clock::now()));
+        std::fprintf(stderr, "[kicp]   chained pre-steps: own kernels done %.3f ms after the last one was queued; look-ahead upload: %s\n", ms(t_queued, t_chain),
+                     ahead_out ? "on its own thread, collected by the message's kicp_pre_ingest" : "none");
     }
     p->last_max_probe = misc[2];
     if (misc[1]) {
