@@ -6,8 +6,10 @@
 // microseconds of search sitting on a launch + reduction-tree + hand-off floor three times as long.  k_pass_small removes the
 // floor's parts one by one:
 //   * at most kSmallMaxGroups workgroups of 1024 lanes (G sub-lanes per query, the same search code as k_pass_gather32), so
-//     there is NO inter-workgroup reduction: every workgroup folds its lanes in LDS and stores its row - two 64-byte lines of
-//     self-validating words - straight into host-mapped memory, where the host adds the (<= 16) rows;
+//     there is NO inter-workgroup reduction tree: every workgroup folds its lanes in LDS and stores its row - two 64-byte lines of
+//     self-validating words - straight into host-mapped memory, where the host adds the (<= 16) rows; or (round 5, group_rows:
+//     the wave-per-query kernel's hundreds of workgroups) adds it into its group's counting accumulators, whose completing
+//     additions send ONE row per 32 workgroups to the host (kicp_kernels.hpp::counting_hand_over);
 //   * the kernel stays RESIDENT for the iterations of one ComputeRobotMotion call: after publishing the rows of pass k it
 //     polls one 64-byte command line in host-mapped memory for the pose of pass k + 1 (or STOP).  A host -> GPU -> host round
 //     trip through a polled line costs ~3.5 us against ~7.5 us through a launch (profiles/r02a_micro_handoff.txt); the kernel
@@ -328,9 +330,9 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
 // each): the fp64 point AND its 16-bit mirror word (which only says whether the slot holds a point) are loaded together, the
 // distance is the reference's own fp64 expression - no pre-selection, no margin, no exact fall-back - and the minimum is a DPP
 // reduction followed by the reference's rule among the lanes whose norm could tie (closer_by_norm, ties to the earlier one in
-// visiting order): the generic kernel's decision, so the two paths give the same bits.  The six products of the normal
-// equations are formed side by side by lanes 0-5, which also convert and park them (no wave reduction: a wave has ONE
-// correspondence).  A query costs its wave a few hundred instructions and three dependent memory accesses (probe, buckets,
+// visiting order): the generic kernel's decision, so the two paths give the same bits.  The terms of the normal equations
+// come from the same function as the generic kernel's (correspondence_terms: the closed form over the pose's basis, wave-uniform
+// here); lanes 0-5 take one each to convert and park (no wave reduction: a wave has ONE correspondence).  A query costs its wave a few hundred instructions and three dependent memory accesses (probe, buckets,
 // nothing else: the source point stays in registers across the passes of a call); a 1 080-point scan occupies 1 080 SIMDs.
 // Wave 0 adds the workgroup's (<= 16) correspondences and stores the row as small_publish does.  Resident loop and command
 // protocol: as k_pass_small.
