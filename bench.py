@@ -381,13 +381,16 @@ def main():
         launch_path += ("; inside a batch the pass kernel stays RESIDENT across the batch's scans (one launch per batch call, every pass - a scan's first "
                         "one included - started by a command the kernel polls: option batch_resident), with up to %d scans of the batch in flight "
                         "(option batch_depth)" % depth)
-    in_flight = queues if queued_batch else (depth if resident_batch else 1)
+        if batch_threads > 1:
+            launch_path += ("; %d such kernels side by side, each serving a contiguous part of the batch from a host thread of its own (option batch_threads)" % batch_threads)
+    batch_threads = int(max(0, reg.get_option("batch_threads_active")))  # (batches of small scans: resident kernels side by side, a host thread each)
+    in_flight = queues if queued_batch else ((depth * max(1, batch_threads)) if resident_batch else 1)
     # the same batch calls with ONE scan in flight at a time (the batch's scans strictly one after the other: what a caller gets whose
     # next scan depends on the previous result) - informational, next to the headline
     elapsed_serial = None
     if in_flight > 1 and not exchange:
         reg_serial = reg.copy()
-        reg_serial.set_option("batch_queues", 0), reg_serial.set_option("batch_depth", 1)
+        reg_serial.set_option("batch_queues", 0), reg_serial.set_option("batch_depth", 1), reg_serial.set_option("batch_threads", 0)
         elapsed_serial = timed(reg_serial, rel_single, max(2, args.steps // 4), 1)
         serial_steps = max(2, args.steps // 4)
         del reg_serial

@@ -171,6 +171,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  of such a batch is a call of its own.  "batch_resident_passes" (read only): passes served that way so far
  *   "batch_depth"  (default 3, 1 .. 4): scans of the batch that kernel has in flight - the host answers the rows of pass k while the
  *                  workgroups search passes k + 1 .. k + depth - 1, which belong to other scans; 1: one scan at a time
+ *   "batch_threads" (default 2, 0 .. 9): batches of SMALL scans only (every scan at most 4 096 points, at least 16 scans per thread): this many
+ *                  resident kernels side by side, each serving a contiguous part of the batch from a host thread of the library's lane pool
+ *                  (a 1 080-point scan occupies half of the device; as many as fit the device at once are used); < 2: one kernel,
+ *                  the caller's thread.  "batch_threads_active" (read only): how many the last batch call used (0: another path)
  *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
  *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
  *                  256 b .. 256 b + 255
@@ -233,7 +237,9 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  *   - otherwise, batches of eight scans and more of one kind (all small, or all up to 131 072 points): ONE kernel resident across
  *     the batch's scans ("batch_resident"), option "batch_depth" (default 3, at most 4) scans in flight - the command that starts a
  *     pass names the scan it belongs to, and the command of pass k + depth goes out when the rows of pass k are in;
- *   - anything else, and "batch_queues" 0 with "batch_depth" 1 or "batch_resident" 0: the scans strictly one after the other
+ *     (batches of small scans with at least 16 scans per thread: "batch_threads" (default 2) such kernels, each with a part of the batch
+ *     and a host thread of the library's pool);
+ *   - anything else, and "batch_queues" 0 with "batch_threads" 0 and "batch_depth" 1, or "batch_resident" 0: the scans strictly one after the other
  *     (every scan runs launch -> hand-off -> solve to completion before the next one starts) - what a caller needs whose next
  *     scan depends on the previous result, and what kicp_register_device gives one call at a time.
  * SHARDED batches (round 5): with the shared segment attached (kicp_reg_shm_init) EVERY rank calls with the same count and the same

@@ -184,6 +184,9 @@ struct kicp_reg {
     unsigned long long batch_queue_passes = 0;  // passes served that way so far (get-only "batch_queue_passes")
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
+    int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
+    int batch_threads = 2;        // option "batch_threads": batches of small scans only: this many resident kernels at a time, each serving a contiguous
+                                  // part of the batch from a host thread of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
     ScanRef *scans_bar = nullptr; // the same memory as the CPU writes it through the PCIe BAR (nullptr: d_scans is plain device memory)
@@ -1688,6 +1691,81 @@ LanePool &lane_pool() {
 }
 }  // namespace
 
+namespace {
+// Batches of SMALL scans only (one wave per query: <= 4 096 points each), round 5.  One resident kernel with three scans in flight
+// serves such a batch at ~4.3 us per scan however many scans there are: a 1 080-point scan occupies 135 of the device's 256 CUs, and
+// a workgroup needs its ~4 us per pass (search, hand-over, next command).  The other half of the device takes a SECOND resident kernel:
+// the batch is cut into `batch_threads` contiguous parts, part t is served by run_batch_resident on handle t (the caller's, then clones
+// of it: the lanes of run_batch_queues) from a host thread of the lane pool - the scans are independent, every pose stays bit-equal to
+// registering that scan alone.  All kernels must be co-resident (a resident kernel waits for its host, which waits for the rows of ALL
+// its workgroups): T x workgroups x waves per workgroup must fit the device at 16 waves per CU, else fewer threads.
+// Returns 1 when the batch is not one for this path.
+int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
+                               const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, int *worst) {
+    constexpr size_t kMinScansPerThread = 16;
+    int threads = std::min(r->batch_threads, kMaxBatchQueues + 1);
+    if (threads < 2 || count < 2 * kMinScansPerThread || r->cfg.max_num_iterations <= 0 || kicp_map_empty(map)) return 1;
+    if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm &&
+          !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0 && r->debug_stall_us == 0.0))
+        return 1;
+    size_t n_max = 0, n_min = ~size_t(0);
+    for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
+    if (n_min == 0) return 1;
+    const SmallPlan pl = small_plan(r, n_max), pl_min = small_plan(r, n_min);
+    if (!(pl.wave && pl_min.wave && pl.grid)) return 1;
+    const size_t waves_per_kernel = static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64);
+    threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, waves_per_kernel)}));
+    if (threads < 2) return 1;
+    if (int rc = set_device(r->device)) return rc;
+    if (int rc = map_sync(map, r->device, r->stream)) return rc;  // (once, here: the lanes then only read the copy)
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    while (static_cast<int>(r->batch_lanes.size()) < threads - 1) {
+        kicp_reg *c = nullptr;
+        if (int rc = kicp_reg_clone(r, &c)) return rc;
+        r->batch_lanes.push_back(c);
+    }
+    std::vector<kicp_reg *> handles{r};
+    std::vector<unsigned long long> passes_before, relaunches_before;
+    for (int t = 1; t < threads; ++t) {
+        kicp_reg *h = r->batch_lanes[t - 1];
+        h->cfg = r->cfg, h->query_every = r->query_every, h->dbg = 0, h->latency_kernel = r->latency_kernel, h->batch_queues = 0, h->batch_threads = 0;
+        h->use_small = r->use_small, h->small_wave = r->small_wave, h->wave_block = r->wave_block, h->small_block = r->small_block, h->small_resident = r->small_resident;
+        h->small_group_rows = r->small_group_rows, h->small_timeout_us = r->small_timeout_us, h->batch_depth = r->batch_depth, h->batch_rotate = r->batch_rotate;
+        h->batch_resident = 1, h->resident_generic = 1, h->small_cmd = r->cmd_bar ? 1 : r->small_cmd;
+        handles.push_back(h);
+    }
+    for (kicp_reg *h : handles) passes_before.push_back(h->batch_resident_passes), relaunches_before.push_back(h->small_relaunches);
+    std::vector<int> rcs(static_cast<size_t>(threads), KICP_OK), worsts(static_cast<size_t>(threads), KICP_OK);
+    std::vector<std::string> messages(static_cast<size_t>(threads));
+    const std::function<void(size_t)> lane = [&](size_t t) {
+        kicp_reg *h = handles[t];
+        const size_t lo = count * t / static_cast<size_t>(threads), hi = count * (t + 1) / static_cast<size_t>(threads);
+        size_t done = 0;
+        int rc = run_batch_resident(h, map, hi - lo, d_frames + lo, n + lo, last_poses_qt + 7 * lo, rel_odoms_qt + 7 * lo, tau, out_poses_qt + 7 * lo,
+                                    out_iterations ? out_iterations + lo : nullptr, &done, &worsts[t]);
+        kicp_stats st;
+        for (size_t k = lo + done; rc >= 0 && k < hi; ++k) {  // (not a batch for the resident kernel after all, or its kernel gave up: one call per scan)
+            rc = run_registration(h, map, d_frames[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, tau, out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
+            if (rc >= 0) worsts[t] = std::max(worsts[t], rc);
+            if (rc >= 0 && out_iterations) out_iterations[k] = st.iterations;
+        }
+        rcs[t] = rc < 0 ? rc : KICP_OK;
+        if (rc < 0) messages[t] = kicp_last_error();  // (the message is per thread: carry it over)
+    };
+    lane_pool().run(static_cast<size_t>(threads), lane);
+    r->last_batch_threads = threads;
+    for (int t = 1; t < threads; ++t) {  // (the caller reads the counters on its own handle)
+        r->batch_resident_passes += handles[t]->batch_resident_passes - passes_before[t];
+        r->small_relaunches += handles[t]->small_relaunches - relaunches_before[t];
+    }
+    for (int t = 0; t < threads; ++t) {
+        if (rcs[t] < 0) return fail(rcs[t], messages[t]);
+        *worst = std::max(*worst, worsts[t]);
+    }
+    return KICP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 // ---- registration ---------------------------------------------------------------------------------------------------
@@ -1790,6 +1868,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
     else if (k == "batch_queues") reg->batch_queues = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues);
     else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
+    else if (k == "batch_threads") reg->batch_threads = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues + 1);
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
@@ -1838,6 +1917,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "resident_generic") return reg->resident_generic;
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
+    if (k == "batch_threads") return reg->batch_threads;
+    if (k == "batch_threads_active") return reg->last_batch_threads;
     if (k == "batch_depth") return reg->batch_depth;
     if (k == "batch_rotate") return reg->batch_rotate;
     if (k == "batch_queues") return reg->batch_queues;
@@ -1897,11 +1978,18 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
     for (size_t k = 0; k < count; ++k)
         if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
     size_t first = 0;
+    if (reg) reg->last_batch_threads = 0;
     if (reg && map) {  // large scans: several in flight, a queue each
         const int rc = run_batch_queues(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt, out_iterations,
                                         &first, &worst);
         if (rc < 0) return rc;
         if (rc != 1 && first == count) return worst;
+    }
+    if (reg && map && first == 0) {  // small scans only: two resident kernels, each with a part of the batch and a host thread
+        const int rc = run_batch_resident_threads(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
+                                                  out_iterations, &worst);
+        if (rc < 0) return rc;
+        if (rc != 1) return worst;
     }
     if (reg && map && first == 0) {  // a pass kernel resident across the batch's scans, where the batch is one for it
         const int rc = run_batch_resident(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
@@ -2049,7 +2137,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us, c->small_group_rows = reg->small_group_rows;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads;
     *out = c;
     return KICP_OK;
 }

@@ -367,3 +367,40 @@ def test_a_batch_longer_than_one_resident_launch_serves(n_src):
     assert sum(b0.iterations) == 1280  # more passes than one launch's budget of 1 024
     assert np.array_equal(got, want) and list(b1.iterations) == list(b0.iterations)
     assert reg.get_option("batch_resident_passes") == sum(b0.iterations)
+
+
+@pytest.mark.parametrize("threads", [2, 3])
+def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(threads):
+    """kicp_register_device_batch on small scans only (round 5, option "batch_threads"): the batch is cut into contiguous parts, each
+    served by a resident kernel of its own from a host thread of the library's pool - sizes that differ, iteration counts 1 .. 10, a scan
+    without correspondences in every part: bit-equal to one call per scan, counters added up on the caller's handle."""
+    maps, src = _big_world(n_map=60000, n_src=20000, seed=31)
+    g = maps[0]
+    count = 16 * threads + 7
+    rng = np.random.default_rng(3)
+    sizes = [int(rng.integers(64, 4096)) for _ in range(count)]
+    shifts = [float(rng.uniform(-0.06, 0.08)) for _ in range(count)]
+    frames = [src[(17 * i) % 4000:(17 * i) % 4000 + k] - np.array([d, 0.0, 0.0]) for i, (k, d) in enumerate(zip(sizes, shifts))]
+    for t in range(threads):
+        frames[5 + 16 * t] = np.full((700, 3), 400.0 + t)  # no correspondence at all
+    lasts = [syn.planar_pose(0.002 * i, 0.0, 0.0005 * i) for i in range(count)]
+    rels = [syn.planar_pose(-0.001 * i, 0.0, 0.0005) for i in range(count)]
+    dev = [K.DeviceFrame(f, device=0) for f in frames]
+    plain = _reg({"batch_resident": 0, "batch_queues": 0, "batch_threads": 0}, **CFG)
+    b0 = plain.prepare_batch(dev, lasts, rels)
+    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
+    assert plain.get_option("batch_threads_active") == 0.0 and max(b0.iterations) >= 3
+    reg = _reg({"batch_threads": threads}, **CFG)
+    b1 = reg.prepare_batch(dev, lasts, rels)
+    for _ in range(3):
+        before = reg.get_option("batch_resident_passes")
+        got = reg.ComputeRobotMotionBatch(b1, g, 0.5).copy()
+        assert np.array_equal(got, want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
+        assert reg.get_option("batch_threads_active") == float(threads) and reg.last_status == K.KICP_WARN_NO_CORRESPONDENCES
+        assert reg.get_option("batch_resident_passes") - before == sum(b0.iterations) - 10 * threads + threads  # (a NaN scan's later passes are accounted, not run)
+    one = _reg({"batch_threads": 0}, **CFG)
+    b2 = one.prepare_batch(dev, lasts, rels)
+    assert np.array_equal(one.ComputeRobotMotionBatch(b2, g, 0.5), want, equal_nan=True) and one.get_option("batch_threads_active") == 0.0
+    # too few scans per thread: one kernel, the caller's thread
+    short = reg.prepare_batch(dev[:20], lasts[:20], rels[:20])
+    assert np.array_equal(reg.ComputeRobotMotionBatch(short, g, 0.5), want[:20], equal_nan=True) and reg.get_option("batch_threads_active") == 0.0
