@@ -370,6 +370,7 @@ def main():
                    % {0.0: "host memory", 1.0: "device memory", 2.0: "device memory + HDP flush"}.get(reg.get_option("aql_kernarg"), "?")
                    if reg.get_option("aql_active") == 1.0 else "hipLaunchKernelGGL on the handle's stream")
     resident_batch = reg.get_option("batch_resident_passes") > 0
+    batch_threads = int(max(0, reg.get_option("batch_threads_active")))  # (batches of small scans: resident kernels side by side, a host thread each)
     queued_batch = reg.get_option("batch_queue_passes") > 0
     queues = int(reg.get_option("batch_queues")) if queued_batch else 0
     depth = int(reg.get_option("batch_depth"))
@@ -383,7 +384,6 @@ def main():
                         "(option batch_depth)" % depth)
         if batch_threads > 1:
             launch_path += ("; %d such kernels side by side, each serving a contiguous part of the batch from a host thread of its own (option batch_threads)" % batch_threads)
-    batch_threads = int(max(0, reg.get_option("batch_threads_active")))  # (batches of small scans: resident kernels side by side, a host thread each)
     in_flight = queues if queued_batch else ((depth * max(1, batch_threads)) if resident_batch else 1)
     # the same batch calls with ONE scan in flight at a time (the batch's scans strictly one after the other: what a caller gets whose
     # next scan depends on the previous result) - informational, next to the headline

@@ -171,7 +171,7 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  of such a batch is a call of its own.  "batch_resident_passes" (read only): passes served that way so far
  *   "batch_depth"  (default 3, 1 .. 4): scans of the batch that kernel has in flight - the host answers the rows of pass k while the
  *                  workgroups search passes k + 1 .. k + depth - 1, which belong to other scans; 1: one scan at a time
- *   "batch_threads" (default 2, 0 .. 9): batches of SMALL scans only (every scan at most 4 096 points, at least 16 scans per thread): this many
+ *   "batch_threads" (default 3, 0 .. 9): batches of SMALL scans only (every scan at most 4 096 points, at least 16 scans per thread): this many
  *                  resident kernels side by side, each serving a contiguous part of the batch from a host thread of the library's lane pool
  *                  (a 1 080-point scan occupies half of the device; as many as fit the device at once are used); < 2: one kernel,
  *                  the caller's thread.  "batch_threads_active" (read only): how many the last batch call used (0: another path)
@@ -237,7 +237,7 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  *   - otherwise, batches of eight scans and more of one kind (all small, or all up to 131 072 points): ONE kernel resident across
  *     the batch's scans ("batch_resident"), option "batch_depth" (default 3, at most 4) scans in flight - the command that starts a
  *     pass names the scan it belongs to, and the command of pass k + depth goes out when the rows of pass k are in;
- *     (batches of small scans with at least 16 scans per thread: "batch_threads" (default 2) such kernels, each with a part of the batch
+ *     (batches of small scans with at least 16 scans per thread: "batch_threads" (default 3) such kernels, each with a part of the batch
  *     and a host thread of the library's pool);
  *   - anything else, and "batch_queues" 0 with "batch_threads" 0 and "batch_depth" 1, or "batch_resident" 0: the scans strictly one after the other
  *     (every scan runs launch -> hand-off -> solve to completion before the next one starts) - what a caller needs whose next

@@ -185,7 +185,7 @@ struct kicp_reg {
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
     int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
-    int batch_threads = 2;        // option "batch_threads": batches of small scans only: this many resident kernels at a time, each serving a contiguous
+    int batch_threads = 3;        // option "batch_threads": batches of small scans only: this many resident kernels at a time, each serving a contiguous
                                   // part of the batch from a host thread of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)

@@ -378,11 +378,12 @@ def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(threads):
     g = maps[0]
     count = 16 * threads + 7
     rng = np.random.default_rng(3)
-    sizes = [int(rng.integers(64, 4096)) for _ in range(count)]
+    sizes = [int(rng.integers(64, 1300)) for _ in range(count)]  # (three kernels of <= 1 365 waves fit the device side by side; a 4 096-point scan's kernel fills it alone)
     shifts = [float(rng.uniform(-0.06, 0.08)) for _ in range(count)]
     frames = [src[(17 * i) % 4000:(17 * i) % 4000 + k] - np.array([d, 0.0, 0.0]) for i, (k, d) in enumerate(zip(sizes, shifts))]
     for t in range(threads):
         frames[5 + 16 * t] = np.full((700, 3), 400.0 + t)  # no correspondence at all
+    big = [K.DeviceFrame(src[:4000], device=0)] * count  # ... and a batch of scans whose kernel fills the device alone stays on one kernel
     lasts = [syn.planar_pose(0.002 * i, 0.0, 0.0005 * i) for i in range(count)]
     rels = [syn.planar_pose(-0.001 * i, 0.0, 0.0005) for i in range(count)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
@@ -401,6 +402,9 @@ def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(threads):
     one = _reg({"batch_threads": 0}, **CFG)
     b2 = one.prepare_batch(dev, lasts, rels)
     assert np.array_equal(one.ComputeRobotMotionBatch(b2, g, 0.5), want, equal_nan=True) and one.get_option("batch_threads_active") == 0.0
+    bb = reg.prepare_batch(big, lasts, rels)
+    reg.ComputeRobotMotionBatch(bb, g, 0.5)
+    assert reg.get_option("batch_threads_active") == 0.0
     # too few scans per thread: one kernel, the caller's thread
     short = reg.prepare_batch(dev[:20], lasts[:20], rels[:20])
     assert np.array_equal(reg.ComputeRobotMotionBatch(short, g, 0.5), want[:20], equal_nan=True) and reg.get_option("batch_threads_active") == 0.0
