@@ -6,7 +6,8 @@
 // The public `map_` member (a tsl::robin_map<Voxel, std::vector<Eigen::Vector3d>> in the reference, reachable through
 // KinematicICP::VoxelMap(), pipeline/KinematicICP.hpp:94-95) is a READ-ONLY view here: size / empty / iteration / find / at /
 // count over (voxel, points) pairs, materialised from the backend on first use after a change (the container itself lives
-// behind the C-ABI as a flat table + bucket pools).  Writing through it is not supported: the map is
+// behind the C-ABI as a flat table + bucket pools).  Writing through it is not supported and does not
+// compile - clear / erase / insert / emplace / operator[] ... end in a static_assert that names the way out: the map is
 // changed through AddPoints / Update / RemovePointsFarFromLocation / Clear, as every caller in the reference does.
 #pragma once
 #include <Eigen/Core>
@@ -16,6 +17,7 @@
 #include <sophus/se3.hpp>
 #include <stdexcept>
 #include <tuple>
+#include <type_traits>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -51,6 +53,29 @@ struct VoxelHashMap {
             if (it == end()) throw std::out_of_range("VoxelHashMap::map_.at: no such voxel");
             return it->second;
         }
+        // Every mutator of the reference's container is a COMPILE-TIME error with the way out in its text (the reference itself
+        // never writes `map_` from outside the struct: its writers are AddPoints / Update / RemovePointsFarFromLocation / Clear).
+        template <class...>
+        struct mutation : std::false_type {};
+#define KICP_MAP_VIEW_READ_ONLY(name)                                                                                              \
+    template <class... A>                                                                                                          \
+    void name(A &&...) {                                                                                                           \
+        static_assert(mutation<A...>::value,                                                                                       \
+                      "kiss_icp::VoxelHashMap::map_ is a read-only view in this backend (the container lives behind the C-ABI): "  \
+                      "change the map through AddPoints / Update / RemovePointsFarFromLocation / Clear");                          \
+    }
+        KICP_MAP_VIEW_READ_ONLY(clear)
+        KICP_MAP_VIEW_READ_ONLY(erase)
+        KICP_MAP_VIEW_READ_ONLY(insert)
+        KICP_MAP_VIEW_READ_ONLY(insert_or_assign)
+        KICP_MAP_VIEW_READ_ONLY(emplace)
+        KICP_MAP_VIEW_READ_ONLY(emplace_hint)
+        KICP_MAP_VIEW_READ_ONLY(try_emplace)
+        KICP_MAP_VIEW_READ_ONLY(reserve)
+        KICP_MAP_VIEW_READ_ONLY(rehash)
+        KICP_MAP_VIEW_READ_ONLY(swap)
+        KICP_MAP_VIEW_READ_ONLY(operator[])
+#undef KICP_MAP_VIEW_READ_ONLY
 
     private:
         friend struct VoxelHashMap;
