@@ -171,10 +171,12 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  of such a batch is a call of its own.  "batch_resident_passes" (read only): passes served that way so far
  *   "batch_depth"  (default 3, 1 .. 4): scans of the batch that kernel has in flight - the host answers the rows of pass k while the
  *                  workgroups search passes k + 1 .. k + depth - 1, which belong to other scans; 1: one scan at a time
- *   "batch_threads" (default 3, 0 .. 9): batches of SMALL scans only (every scan at most 4 096 points, at least 16 scans per thread): this many
+ *   "batch_threads" (default 8, 0 .. 9): batches of scans that leave most of the device empty - every scan at most 4 096 points, or every
+ *                  scan one for the generic kernel with at most 24 576 points; at least 16 scans per thread -: up to this many
  *                  resident kernels side by side, each serving a contiguous part of the batch from a host thread of the library's lane pool
- *                  (a 1 080-point scan occupies half of the device; as many as fit the device at once are used); < 2: one kernel,
- *                  the caller's thread.  "batch_threads_active" (read only): how many the last batch call used (0: another path)
+ *                  (as many as fit the device at once: three for 1 080-point scans, eight for 16 384-point scans; generic scans only
+ *                  if three fit - two would not beat the queues); < 2: one kernel, the caller's thread, or the queues.
+ *                  "batch_threads_active" (read only): how many the last batch call used (0: another path)
  *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
  *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
  *                  256 b .. 256 b + 255
@@ -228,8 +230,11 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
 /* A queue of INDEPENDENT registrations against one map (several robots on one map, replayed scans), without a language
  * binding's per-call cost in between.  Every pose is bit-equal to what kicp_register_device returns for that scan alone; the
  * scans share nothing but the read-only map, which must not be updated during the call.  Because the scans do not depend on each
- * other, the call keeps SEVERAL OF THEM IN FLIGHT (one host thread - the caller's - drives them all):
- *   - batches of at least two scans per queue that hold at least one scan for the generic pass kernel (more than 4 096 points by
+ * other, the call keeps SEVERAL OF THEM IN FLIGHT (one host thread - the caller's - drives them all, except in the first case):
+ *   - batches of at least 32 scans that leave most of the device empty (all of at most 4 096 points, or all generic of at most 24 576):
+ *     "batch_threads" (default 8) resident kernels side by side - as many as fit the device at once -, each with a contiguous part of
+ *     the batch, "batch_depth" scans of it in flight, and a host thread of the library's pool;
+ *   - otherwise, batches of at least two scans per queue that hold at least one scan for the generic pass kernel (more than 4 096 points by
  *     default): option "batch_queues" (default 4) scans at a time, each on a handle + HSA queue of its own (clones of `reg`,
  *     created on first use and kept until kicp_reg_destroy(reg); they follow reg's configuration and kernel-shape options at every
  *     call), every pass an ordinary launch (large scans: the four-waves-per-SIMD build; small scans in such a batch: their own
@@ -237,8 +242,6 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  *   - otherwise, batches of eight scans and more of one kind (all small, or all up to 131 072 points): ONE kernel resident across
  *     the batch's scans ("batch_resident"), option "batch_depth" (default 3, at most 4) scans in flight - the command that starts a
  *     pass names the scan it belongs to, and the command of pass k + depth goes out when the rows of pass k are in;
- *     (batches of small scans with at least 16 scans per thread: "batch_threads" (default 3) such kernels, each with a part of the batch
- *     and a host thread of the library's pool);
  *   - anything else, and "batch_queues" 0 with "batch_threads" 0 and "batch_depth" 1, or "batch_resident" 0: the scans strictly one after the other
  *     (every scan runs launch -> hand-off -> solve to completion before the next one starts) - what a caller needs whose next
  *     scan depends on the previous result, and what kicp_register_device gives one call at a time.

@@ -21,6 +21,7 @@ struct JobThread {
     std::function<int()> job;
     int state = 0;  // 0 idle | 1 posted | 2 done | -1 leaving
     int result = 0;
+    std::string message;  // the job's error text (kicp_last_error is per thread: the waiting thread takes it over)
     int device = 0;
     void run() {
         hipSetDevice(device);
@@ -32,6 +33,7 @@ struct JobThread {
             const int rc = job();
             lock.lock();
             result = rc, state = 2;
+            if (rc < 0) message = last_error();
             cv.notify_all();
         }
     }
@@ -48,6 +50,7 @@ struct JobThread {
         std::unique_lock<std::mutex> lock(m);
         cv.wait(lock, [this] { return state == 2; });
         state = 0;
+        if (result < 0) last_error() = message;
         return result;
     }
     void stop() {
@@ -518,7 +521,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
             if (int rc = ahead_queue(p, &queued)) return rc;
             return queued ? ahead_collect(p) : static_cast<int>(KICP_OK);
         });
-        ahead_out = true;
+        ahead_out = p->ahead_job_out = true;  // (collected by the kicp_pre_ingest call of that message - or whoever needs its buffers first: ahead_join)
     }
     hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, p->stream, pp);
     const int raw_c = grid <= kFusedScanBlocks ? 1 : 0, raw_g = sgrid <= kFusedScanBlocks ? 1 : 0;
@@ -559,7 +562,6 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
     const auto t_queued = std::chrono::steady_clock::now();
     const hipError_t chain_rc = hipStreamSynchronize(p->stream);
     const auto t_chain = std::chrono::steady_clock::now();
-    if (ahead_out) p->ahead_job_out = true;  // (collected by the kicp_pre_ingest call of that message - or whoever needs its buffers first: ahead_join)
     HIP_TRY(chain_rc);
     if (g_trace) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

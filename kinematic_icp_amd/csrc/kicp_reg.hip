@@ -185,8 +185,9 @@ struct kicp_reg {
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
     int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
-    int batch_threads = 3;        // option "batch_threads": batches of small scans only: this many resident kernels at a time, each serving a contiguous
-                                  // part of the batch from a host thread of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
+    int batch_threads = 8;        // option "batch_threads": batches of scans that leave most of the device empty: up to this many resident kernels at a
+                                  // time - as many as fit the device side by side -, each serving a contiguous part of the batch from a host thread
+                                  // of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
     int batch_resident = 1;       // option "batch_resident": kicp_register_device_batch keeps that kernel resident ACROSS the scans of the batch
     ScanRef *d_scans = nullptr;   // the batch's scan table (device memory)
     ScanRef *scans_bar = nullptr; // the same memory as the CPU writes it through the PCIe BAR (nullptr: d_scans is plain device memory)
@@ -1692,14 +1693,20 @@ LanePool &lane_pool() {
 }  // namespace
 
 namespace {
-// Batches of SMALL scans only (one wave per query: <= 4 096 points each), round 5.  One resident kernel with three scans in flight
-// serves such a batch at ~4.3 us per scan however many scans there are: a 1 080-point scan occupies 135 of the device's 256 CUs, and
-// a workgroup needs its ~4 us per pass (search, hand-over, next command).  The other half of the device takes a SECOND resident kernel:
+// Batches of scans that leave most of the device empty, round 5: small scans only (one wave per query: <= 4 096 points each), or
+// scans of the generic kernel of <= kThreadsMaxGenericPoints points each.  One resident kernel with three scans in flight
+// serves a batch of 1 080-point scans at ~4.3 us per scan however many scans there are: such a scan occupies 135 of the device's 256
+// CUs, and a workgroup needs its ~4 us per pass (search, hand-over, next command); a 16 384-point scan's resident kernel (64
+// workgroups, 32 CUs) takes 8.1 us per scan where four queues of ordinary launches take 4.6 - the command processor starts a kernel
+// every ~4.5 us whatever the number of queues (6 and 8 queues measured SLOWER than 4), a resident kernel needs no dispatch at all.
+// The rest of the device takes MORE resident kernels:
 // the batch is cut into `batch_threads` contiguous parts, part t is served by run_batch_resident on handle t (the caller's, then clones
 // of it: the lanes of run_batch_queues) from a host thread of the lane pool - the scans are independent, every pose stays bit-equal to
 // registering that scan alone.  All kernels must be co-resident (a resident kernel waits for its host, which waits for the rows of ALL
-// its workgroups): T x workgroups x waves per workgroup must fit the device at 16 waves per CU, else fewer threads.
+// its workgroups): T x workgroups x waves per workgroup must fit the device at 16 waves per CU - the generic kernel's latency build:
+// 8 waves = two workgroups per CU -, else fewer threads; generic scans come here only if three kernels fit (two would not beat the queues).
 // Returns 1 when the batch is not one for this path.
+constexpr size_t kThreadsMaxGenericPoints = 24576;  // (five and more such kernels fit the device)
 int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
                                const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, int *worst) {
     constexpr size_t kMinScansPerThread = 16;
@@ -1712,10 +1719,13 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
     if (n_min == 0) return 1;
     const SmallPlan pl = small_plan(r, n_max), pl_min = small_plan(r, n_min);
-    if (!(pl.wave && pl_min.wave && pl.grid)) return 1;
-    const size_t waves_per_kernel = static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64);
-    threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, waves_per_kernel)}));
-    if (threads < 2) return 1;
+    const bool wave = pl.wave && pl_min.wave && pl.grid, generic = pl.generic && pl_min.generic && n_max <= kThreadsMaxGenericPoints;
+    if (!wave && !generic) return 1;
+    // kernels that fit the device side by side
+    const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64))
+                            : static_cast<size_t>(r->num_cus) * 2 / std::max<size_t>(1, (n_max + 255) / 256);
+    threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, fit}));
+    if (threads < (wave ? 2 : 3)) return 1;
     if (int rc = set_device(r->device)) return rc;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;  // (once, here: the lanes then only read the copy)
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1979,17 +1989,17 @@ int kicp_register_device_batch(kicp_reg *reg, kicp_map *map, size_t count, const
         if (!d_frames_xyz[k] && n[k]) return fail(KICP_ERR_ARG, "null frame");
     size_t first = 0;
     if (reg) reg->last_batch_threads = 0;
+    if (reg && map) {  // scans that leave most of the device empty: several resident kernels, each with a part of the batch and a host thread
+        const int rc = run_batch_resident_threads(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
+                                                  out_iterations, &worst);
+        if (rc < 0) return rc;
+        if (rc != 1) return worst;
+    }
     if (reg && map) {  // large scans: several in flight, a queue each
         const int rc = run_batch_queues(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt, out_iterations,
                                         &first, &worst);
         if (rc < 0) return rc;
         if (rc != 1 && first == count) return worst;
-    }
-    if (reg && map && first == 0) {  // small scans only: two resident kernels, each with a part of the batch and a host thread
-        const int rc = run_batch_resident_threads(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,
-                                                  out_iterations, &worst);
-        if (rc < 0) return rc;
-        if (rc != 1) return worst;
     }
     if (reg && map && first == 0) {  // a pass kernel resident across the batch's scans, where the batch is one for it
         const int rc = run_batch_resident(reg, map, count, d_frames_xyz, n, last_poses_qt, rel_odoms_qt, max_correspondence_distance, out_poses_qt,

@@ -369,21 +369,26 @@ def test_a_batch_longer_than_one_resident_launch_serves(n_src):
     assert reg.get_option("batch_resident_passes") == sum(b0.iterations)
 
 
-@pytest.mark.parametrize("threads", [2, 3])
-def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(threads):
-    """kicp_register_device_batch on small scans only (round 5, option "batch_threads"): the batch is cut into contiguous parts, each
-    served by a resident kernel of its own from a host thread of the library's pool - sizes that differ, iteration counts 1 .. 10, a scan
-    without correspondences in every part: bit-equal to one call per scan, counters added up on the caller's handle."""
+@pytest.mark.parametrize("kind,threads", [("wave", 2), ("wave", 3), ("generic", 3), ("generic", 4)])
+def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(kind, threads):
+    """kicp_register_device_batch on scans that leave most of the device empty (round 5, option "batch_threads"): the batch is cut into
+    contiguous parts, each served by a resident kernel of its own from a host thread of the library's pool - sizes that differ, iteration
+    counts 1 .. 10, a scan without correspondences in every part: bit-equal to one call per scan, counters added up on the caller's
+    handle.  `wave`: one wave per query (<= 4 096 points); `generic`: the generic kernel's resident build on 16 500 .. 20 000-point scans
+    (65 .. 79 workgroups each: up to six such kernels fit the device; fewer than three would not beat the four queues, which then stay)."""
     maps, src = _big_world(n_map=60000, n_src=20000, seed=31)
     g = maps[0]
     count = 16 * threads + 7
     rng = np.random.default_rng(3)
-    sizes = [int(rng.integers(64, 1300)) for _ in range(count)]  # (three kernels of <= 1 365 waves fit the device side by side; a 4 096-point scan's kernel fills it alone)
+    if kind == "wave":
+        sizes = [int(rng.integers(64, 1300)) for _ in range(count)]  # (three kernels of <= 1 365 waves fit the device side by side; a 4 096-point scan's kernel fills it alone)
+    else:
+        sizes = [int(rng.integers(16500, 20001)) for _ in range(count)]
     shifts = [float(rng.uniform(-0.06, 0.08)) for _ in range(count)]
-    frames = [src[(17 * i) % 4000:(17 * i) % 4000 + k] - np.array([d, 0.0, 0.0]) for i, (k, d) in enumerate(zip(sizes, shifts))]
+    starts = [(17 * i) % (4000 if kind == "wave" else len(src) - k + 1) for i, k in enumerate(sizes)]
+    frames = [src[a:a + k] - np.array([d, 0.0, 0.0]) for a, k, d in zip(starts, sizes, shifts)]
     for t in range(threads):
-        frames[5 + 16 * t] = np.full((700, 3), 400.0 + t)  # no correspondence at all
-    big = [K.DeviceFrame(src[:4000], device=0)] * count  # ... and a batch of scans whose kernel fills the device alone stays on one kernel
+        frames[5 + 16 * t] = np.full((700 if kind == "wave" else 17000, 3), 400.0 + t)  # no correspondence at all
     lasts = [syn.planar_pose(0.002 * i, 0.0, 0.0005 * i) for i in range(count)]
     rels = [syn.planar_pose(-0.001 * i, 0.0, 0.0005) for i in range(count)]
     dev = [K.DeviceFrame(f, device=0) for f in frames]
@@ -402,9 +407,17 @@ def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(threads):
     one = _reg({"batch_threads": 0}, **CFG)
     b2 = one.prepare_batch(dev, lasts, rels)
     assert np.array_equal(one.ComputeRobotMotionBatch(b2, g, 0.5), want, equal_nan=True) and one.get_option("batch_threads_active") == 0.0
-    bb = reg.prepare_batch(big, lasts, rels)
-    reg.ComputeRobotMotionBatch(bb, g, 0.5)
-    assert reg.get_option("batch_threads_active") == 0.0
+    if kind == "wave":  # ... and a batch of scans whose kernel fills the device alone stays on one kernel
+        big = [K.DeviceFrame(src[:4000], device=0)] * count
+        bb = reg.prepare_batch(big, lasts, rels)
+        reg.ComputeRobotMotionBatch(bb, g, 0.5)
+        assert reg.get_option("batch_threads_active") == 0.0
+    else:  # ... and two kernels of the generic build would not beat the four queues: those stay
+        two = _reg({"batch_threads": 2}, **CFG)
+        b3 = two.prepare_batch(dev, lasts, rels)
+        before = two.get_option("batch_queue_passes")
+        assert np.array_equal(two.ComputeRobotMotionBatch(b3, g, 0.5), want, equal_nan=True)
+        assert two.get_option("batch_threads_active") == 0.0 and two.get_option("batch_queue_passes") > before
     # too few scans per thread: one kernel, the caller's thread
     short = reg.prepare_batch(dev[:20], lasts[:20], rels[:20])
     assert np.array_equal(reg.ComputeRobotMotionBatch(short, g, 0.5), want[:20], equal_nan=True) and reg.get_option("batch_threads_active") == 0.0
