@@ -177,6 +177,10 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  (as many as fit the device at once: three for 1 080-point scans, eight for 16 384-point scans; generic scans only
  *                  if three fit - two would not beat the queues); < 2: one kernel, the caller's thread, or the queues.
  *                  "batch_threads_active" (read only): how many the last batch call used (0: another path)
+ *   "batch_threads_large" 0 (default) | 1: generic scans too large for three resident kernels of the latency build (up to 131 072 points)
+ *                  take resident kernels of the FOUR-WAVES build side by side (four workgroups per CU: two kernels of 512 workgroups
+ *                  fill the device) instead of the queues - measured 5 % slower than the queues on 131 072-point scans, kept for
+ *                  experiments; "resident_four_waves" 1: that build for the ONE resident kernel of a batch ("batch_queues" 0)
  *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
  *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
  *                  256 b .. 256 b + 255

@@ -184,7 +184,11 @@ struct kicp_reg {
     unsigned long long batch_queue_passes = 0;  // passes served that way so far (get-only "batch_queue_passes")
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
+    int resident_four = 0;        // run_batch_resident on generic scans: the four-waves-per-SIMD build of the resident kernel (set per call by
+                                  // run_batch_resident_threads: two such kernels of <= 512 workgroups fill the device; the latency build holds one)
     int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
+    int batch_threads_large = 0;  // option "batch_threads_large": 1 = scans too large for three kernels of the latency build take resident kernels
+                                  // of the four-waves build side by side instead of the queues (experiment until measured)
     int batch_threads = 8;        // option "batch_threads": batches of scans that leave most of the device empty: up to this many resident kernels at a
                                   // time - as many as fit the device side by side -, each serving a contiguous part of the batch from a host thread
                                   // of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
@@ -267,7 +271,9 @@ const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split, 
     std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s, %s>(", b, g, occ, split ? "true" : "false", lat ? "true" : "false");
     return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0) + (lat ? 2 : 0), name);
 }
-const AqlKernel *aql_resident_kernel_for(kicp_reg *r) { return aql_lookup(r, -7, "void kicp::k_pass_resident<256, 2, true>("); }
+const AqlKernel *aql_resident_kernel_for(kicp_reg *r, bool lat) {
+    return lat ? aql_lookup(r, -7, "void kicp::k_pass_resident<256, 2, true>(") : aql_lookup(r, -8, "void kicp::k_pass_resident<256, 4, false>(");
+}
 const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
     if (wave) std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(", block);
@@ -684,7 +690,7 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
     const int b = pl.block, g = pl.g;
     const uint32_t grid = pl.grid;
     if (r->use_aql && !r->stream_dirty) {
-        if (const AqlKernel *k = pl.generic ? aql_resident_kernel_for(r) : aql_small_kernel_for(r, b, g, pl.wave)) {
+        if (const AqlKernel *k = pl.generic ? aql_resident_kernel_for(r, pl.lat) : aql_small_kernel_for(r, b, g, pl.wave)) {
             if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &sp, sizeof sp, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
                 r->last_via_aql = true;
                 return KICP_OK;
@@ -701,7 +707,8 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
         else if (g == 2) hipLaunchKernelGGL((k_pass_small<B, 2>), dim3(grid), dim3(B), 0, r->stream, sp); \
         else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
     } while (0)
-    if (pl.generic) hipLaunchKernelGGL((k_pass_resident<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+    if (pl.generic && pl.lat) hipLaunchKernelGGL((k_pass_resident<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else if (pl.generic) hipLaunchKernelGGL((k_pass_resident<256, 4, false>), dim3(grid), dim3(256), 0, r->stream, sp);
     else if (b == 1024) KICP_SMALL(1024);
     else if (b == 512) KICP_SMALL(512);
     else KICP_SMALL(256);
@@ -1239,7 +1246,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
         r->stream_dirty = false;
     }
-    if (!wave) pl.generic = true, pl.lat = true, pl.g = 1, pl.block = 256, pl.grid = grid;
+    if (!wave) pl.generic = true, pl.lat = !r->resident_four, pl.g = 1, pl.block = 256, pl.grid = grid;
     SmallParams sp{};
     PassParams &pp = sp.p;
     pp.src = d_frames[0], pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
@@ -1719,13 +1726,17 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
     if (n_min == 0) return 1;
     const SmallPlan pl = small_plan(r, n_max), pl_min = small_plan(r, n_min);
-    const bool wave = pl.wave && pl_min.wave && pl.grid, generic = pl.generic && pl_min.generic && n_max <= kThreadsMaxGenericPoints;
+    const bool wave = pl.wave && pl_min.wave && pl.grid, generic = pl.generic && pl_min.generic;
     if (!wave && !generic) return 1;
-    // kernels that fit the device side by side
-    const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64))
-                            : static_cast<size_t>(r->num_cus) * 2 / std::max<size_t>(1, (n_max + 255) / 256);
+    // kernels that fit the device side by side; generic scans: the latency build (two workgroups per CU) where three and more of its
+    // kernels fit, else the four-waves build (four per CU) where two and more do - 131 072-point scans: two kernels of 512 workgroups
+    const size_t grid_g = std::max<size_t>(1, (n_max + 255) / 256);
+    const size_t fit_lat = n_max <= kThreadsMaxGenericPoints ? static_cast<size_t>(r->num_cus) * 2 / grid_g : 0, fit_four = static_cast<size_t>(r->num_cus) * 4 / grid_g;
+    const bool four = generic && fit_lat < 3 && r->batch_threads_large != 0;
+    if (generic && fit_lat < 3 && !four) return 1;
+    const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64)) : (four ? fit_four : fit_lat);
     threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, fit}));
-    if (threads < (wave ? 2 : 3)) return 1;
+    if (threads < ((wave || four) ? 2 : 3)) return 1;
     if (int rc = set_device(r->device)) return rc;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;  // (once, here: the lanes then only read the copy)
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1744,6 +1755,8 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         h->batch_resident = 1, h->resident_generic = 1, h->small_cmd = r->cmd_bar ? 1 : r->small_cmd;
         handles.push_back(h);
     }
+    const int four_before = r->resident_four;
+    for (kicp_reg *h : handles) h->resident_four = four ? 1 : 0;
     for (kicp_reg *h : handles) passes_before.push_back(h->batch_resident_passes), relaunches_before.push_back(h->small_relaunches);
     std::vector<int> rcs(static_cast<size_t>(threads), KICP_OK), worsts(static_cast<size_t>(threads), KICP_OK);
     std::vector<std::string> messages(static_cast<size_t>(threads));
@@ -1763,6 +1776,7 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         if (rc < 0) messages[t] = kicp_last_error();  // (the message is per thread: carry it over)
     };
     lane_pool().run(static_cast<size_t>(threads), lane);
+    r->resident_four = four_before;
     r->last_batch_threads = threads;
     for (int t = 1; t < threads; ++t) {  // (the caller reads the counters on its own handle)
         r->batch_resident_passes += handles[t]->batch_resident_passes - passes_before[t];
@@ -1878,6 +1892,8 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
     else if (k == "batch_queues") reg->batch_queues = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues);
     else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
+    else if (k == "batch_threads_large") reg->batch_threads_large = value != 0.0 ? 1 : 0;
+    else if (k == "resident_four_waves") reg->resident_four = value != 0.0 ? 1 : 0;
     else if (k == "batch_threads") reg->batch_threads = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues + 1);
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
     else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
@@ -1927,6 +1943,8 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "resident_generic") return reg->resident_generic;
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
+    if (k == "batch_threads_large") return reg->batch_threads_large;
+    if (k == "resident_four_waves") return reg->resident_four;
     if (k == "batch_threads") return reg->batch_threads;
     if (k == "batch_threads_active") return reg->last_batch_threads;
     if (k == "batch_depth") return reg->batch_depth;
@@ -2147,7 +2165,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us, c->small_group_rows = reg->small_group_rows;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads, c->batch_threads_large = reg->batch_threads_large;
     *out = c;
     return KICP_OK;
 }
@@ -2421,6 +2439,7 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
         all += name;
     }
     all += "void kicp::k_pass_resident<256, 2, true>(\n";
+    all += "void kicp::k_pass_resident<256, 4, false>(\n";
     if (out && cap) {
         const size_t n = std::min(cap - 1, all.size());
         std::memcpy(out, all.data(), n);

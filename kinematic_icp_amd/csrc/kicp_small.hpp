@@ -272,6 +272,11 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
     __shared__ int s_red[BLOCK / 64][kWaveLimbs];
     __shared__ int s_flag;
     __shared__ unsigned long long s_cmd[kCmdWords];
+    // the four-waves-per-SIMD build (LAT false; round 5: it fits its 128 registers now that the query is parked in LDS and the basis is
+    // read where it is used): idle lanes take over voxels of loaded queries, as in k_pass_gather32's build of that shape
+    constexpr bool kLends = !LAT;
+    __shared__ int s_lend[kLends ? BLOCK / 64 : 1][kLendWords];
+    __shared__ double s_park[kLends ? BLOCK * kParkWords : 1];
     Pose T = fresh_args().p.sol.pose0;
     int gave_up = 0;  // (wave-uniform) no command arrived in time: this round only hands over the marked empty row
     uint32_t scan = static_cast<uint32_t>(uniform_i(static_cast<int>(fresh_args().scan0)));  // (a batch: index into sp.scans of the scan this pass belongs to)
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_resident(const SmallParams 
             const double *src = sp.p.src;
             uint32_t n = sp.p.n;
             if (sp.scans) src = sp.scans[scan].src, n = static_cast<uint32_t>(sp.scans[scan].n);  // (uniform: scalar loads)
-            gather32_pass<BLOCK, 1, false, LAT>(sp.p, T, false, tid, acc, src, n, share);
+            gather32_pass<BLOCK, 1, false, LAT, kLends>(sp.p, T, false, tid, acc, src, n, share, kLends ? &s_lend[kLends ? tid / 64 : 0][0] : nullptr, s_park);
             share += sp.rotate;
             if (share >= gridDim.x) share -= gridDim.x;
         }
