@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--min-timed-s", type=float, default=0.3, help="shortest acceptable timed region (auto batch size)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic")
     ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="registration option set on every handle bench.py makes (experiments: kicp.h lists them)")
     ap.add_argument("--scans", type=int, default=64, help="distinct synthetic scans cycled through (SURVEY.md section 8d asks for >= 50; 64 x 3.1 MB "
                                                           "of scans + the map exceed what the caches hold)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
@@ -184,6 +185,8 @@ def main():
     def make_reg(comm, **kw):
         """a registration handle with the requested exchange attached (None: single GPU / replicas)"""
         reg = K.KinematicRegistration(device=device, **kw)  # reference defaults (KinematicICP.hpp:51-56) unless asked otherwise
+        for o in args.set:
+            reg.set_option(o.split("=")[0], float(o.split("=")[1]))
         keep = []
         if comm == "shm":
             name = "kicp_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))

@@ -177,6 +177,13 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  (as many as fit the device at once: three for 1 080-point scans, eight for 16 384-point scans; generic scans only
  *                  if three fit - two would not beat the queues); < 2: one kernel, the caller's thread, or the queues.
  *                  "batch_threads_active" (read only): how many the last batch call used (0: another path)
+ *   "shard_threads" (default 0, 0 .. 8; the same on every rank): SHARDED batches (shared segment attached) of at least 32 scans whose
+ *                  largest shard on any rank has at most 24 576 points: up to this many resident kernels side by side per rank, part t of
+ *                  the batch on kernel t, its passes completed by the peers' through lane t of the segment (the ranks agree on the
+ *                  launch shape through lane 0 first); three-quarters of the device at most, shared among the ranks that sit on one
+ *                  device.  EXPERIMENTAL and off by default: a part's kernel waits for its peers' as well as for its host, and every
+ *                  part costs its rank a spinning host thread - with two ranks on ONE GPU, 3 per rank measured 2.4 x the queues on
+ *                  8 192-point shards, 4 and more per rank stalled intermittently (a stall ends in KICP_ERR_COMM after KICP_WAIT_TIMEOUT_S)
  *   "batch_threads_large" 0 (default) | 1: generic scans too large for three resident kernels of the latency build (up to 131 072 points)
  *                  take resident kernels of the FOUR-WAVES build side by side (four workgroups per CU: two kernels of 512 workgroups
  *                  fill the device) instead of the queues - measured 5 % slower than the queues on 131 072-point scans, kept for

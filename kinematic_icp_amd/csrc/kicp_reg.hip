@@ -187,6 +187,8 @@ struct kicp_reg {
     int resident_four = 0;        // run_batch_resident on generic scans: the four-waves-per-SIMD build of the resident kernel (set per call by
                                   // run_batch_resident_threads: two such kernels of <= 512 workgroups fill the device; the latency build holds one)
     int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
+    int shard_threads = 0;        // option "shard_threads": SHARDED batches (the shared segment attached) on up to this many resident kernels side by side
+                                  // per rank (run_batch_resident_threads); 0 / 1 (default): the queues
     int batch_threads_large = 0;  // option "batch_threads_large": 1 = scans too large for three kernels of the latency build take resident kernels
                                   // of the four-waves build side by side instead of the queues (experiment until measured)
     int batch_threads = 8;        // option "batch_threads": batches of scans that leave most of the device empty: up to this many resident kernels at a
@@ -1182,26 +1184,60 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
 // completed from the front.  On a give-up of the kernel (a workgroup that saw no command in time) the scans in hand and the rest
 // are left to the plain loop, too.
 constexpr uint32_t kBatchMaxPasses = 1024;  // passes (= tags) one launch may serve
+// A SHARDED batch on resident kernels (run_batch_resident_threads with the shared segment attached): the kernel of part t registers
+// this rank's shards of the part's scans, and every pass's rows are completed by the other ranks' through lane t of the owner's
+// segment before the solve - every rank runs the same parts in the same order, so lane t's hand-offs line up.
+struct ShardCtx {
+    kicp_reg *owner;      // the handle the segment is attached to (the batch call's)
+    int lane;             // its area of the segment, and its hand-off counter
+    size_t n_max;         // the largest shard of any scan of the batch on ANY rank (agreed through the segment: the launch's shape)
+};
+// one hand-off on lane `lane` of o's segment: this rank's words go out, every rank's come back - summed into `sum`, and (per_rank != nullptr)
+// one by one; blocking, bounded by KICP_WAIT_TIMEOUT_S
+int shm_lane_exchange(kicp_reg *o, int lane, const long long *mine, long long *sum, long long *per_rank = nullptr) {  // per_rank: [nranks][kReduceWords]
+    const unsigned long long step = o->shm_lane_step[lane]++;
+    kicp_reg::ShmSlot *slots = o->shm + 2 * static_cast<size_t>(o->nranks) * (1 + lane) + (step & 1) * o->nranks;
+    for (int i = 0; i < kReduceWords; ++i) slots[o->rank].words[i] = mine[i];
+    __atomic_store_n(&slots[o->rank].seq, step + 1, __ATOMIC_RELEASE);
+    const Deadline deadline;
+    unsigned polls = 0;
+    for (int k = 0; k < o->nranks; ++k)
+        while (__atomic_load_n(&slots[k].seq, __ATOMIC_ACQUIRE) != step + 1)
+            if (++polls % 4096u == 0u && deadline.passed()) return fail(KICP_ERR_COMM, "timed out waiting for a peer rank's hand-off (KICP_WAIT_TIMEOUT_S)");
+    for (int i = 0; i < kReduceWords; ++i) sum[i] = 0;
+    for (int k = 0; k < o->nranks; ++k)
+        for (int i = 0; i < kReduceWords; ++i) {
+            sum[i] += slots[k].words[i];  // (exact integers: the order does not matter)
+            if (per_rank) per_rank[static_cast<size_t>(k) * kReduceWords + i] = slots[k].words[i];
+        }
+    return KICP_OK;
+}
 int depth_of(const kicp_reg *r) { return std::min<int>(std::max(r->batch_depth, 1), static_cast<int>(kPipeSlots)); }
 int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
-                       const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
+                       const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst, const ShardCtx *shard = nullptr) {
     *done = 0;
     const int max_it = r->cfg.max_num_iterations;
     // (a batch call in this mode costs ~8 us of its own - the table, the kernel's leaving, the queue drained before the next call -
     //  against ~2.2 us saved per scan: from eight scans on it pays; measured in-process, cfg2 and cfg4, batches of 2 / 4 / 16 / 256)
     constexpr size_t kBatchResidentMinScans = 8;
     if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || count > kCmdMaxScans || max_it <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
+    if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && (!r->shm || shard) && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
           r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || (r->dbg >= 2 && r->dbg <= 5) || r->dbg == 9 || r->dbg == 14) && r->small_resident != 0))
         return 1;
     // one kind of kernel serves the whole batch: the generic one (scans beyond the small-scan kernels, up to what the device holds at
     // once) or one wave per query (scans of up to kWaveMaxPoints points); anything else - or a mix - takes the plain loop
     size_t n_max = 0, n_min = ~size_t(0);
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
-    if (n_min == 0) return 1;
-    SmallPlan pl = small_plan(r, n_max);
-    const SmallPlan pl_min = small_plan(r, n_min);
-    if (!(pl.generic && pl_min.generic) && !(pl.wave && pl_min.wave && pl.grid)) return 1;
+    SmallPlan pl;
+    if (shard) {  // shards: the generic kernel whatever their size (empty ones included), one launch shape on every rank
+        n_max = std::max<size_t>(shard->n_max, 1);
+        pl.generic = true;
+    } else {
+        if (n_min == 0) return 1;
+        pl = small_plan(r, n_max);
+        const SmallPlan pl_min = small_plan(r, n_min);
+        if (!(pl.generic && pl_min.generic) && !(pl.wave && pl_min.wave && pl.grid)) return 1;
+    }
     if (int rc = set_device(r->device)) return rc;
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
@@ -1236,11 +1272,11 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     // (the previous batch's kernel has left: the host had its last rows and sent STOP before it returned)
     if (int rc = aql_quiesce(r)) return rc;
     if (r->scans_bar) {
-        for (size_t k = 0; k < count; ++k) r->scans_bar[k] = ScanRef{d_frames[k], n[k]};
+        for (size_t k = 0; k < count; ++k) r->scans_bar[k] = ScanRef{n[k] ? d_frames[k] : reinterpret_cast<const double *>(r->d_state), n[k]};  // (an idle lane still reads point 0)
         _mm_sfence();
     } else {
         std::vector<ScanRef> table(count);
-        for (size_t k = 0; k < count; ++k) table[k] = ScanRef{d_frames[k], n[k]};
+        for (size_t k = 0; k < count; ++k) table[k] = ScanRef{n[k] ? d_frames[k] : reinterpret_cast<const double *>(r->d_state), n[k]};
         r->stream_dirty = true;
         HIP_TRY(hipMemcpyAsync(r->d_scans, table.data(), count * sizeof(ScanRef), hipMemcpyHostToDevice, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
@@ -1249,13 +1285,15 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     if (!wave) pl.generic = true, pl.lat = !r->resident_four, pl.g = 1, pl.block = 256, pl.grid = grid;
     SmallParams sp{};
     PassParams &pp = sp.p;
-    pp.src = d_frames[0], pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
+    pp.src = n[0] ? d_frames[0] : reinterpret_cast<const double *>(r->d_state), pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.dbg = r->dbg;
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
     pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
+    // (sharded: a command may wait for the slowest PEER's rows - a workgroup that gave up would take this rank out of step with the others)
+    if (shard) sp.timeout_ticks = std::max<long long>(sp.timeout_ticks, 200000000ll);
     sp.scans = r->d_scans;
     sp.group_rows = grouped ? 1 : 0;
     // (the workgroups' shares of a scan move on by about 0.38 of the grid per pass - far from where they were, and back only after many passes)
@@ -1362,9 +1400,16 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         if (grouped) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
         if (gave_up) {  // (part of) the kernel has left: the scans in hand and the rest go through the plain loop
             ++r->small_relaunches;
+            if (shard) return leave(fail(KICP_ERR_COMM, "a resident kernel of a sharded batch gave up waiting for its command: the ranks are out of step"));
             return leave(KICP_OK);
         }
         ++r->batch_resident_passes;
+        if (shard) {  // this rank's sums of the pass + every other rank's = the scan's
+            long long total[kReduceWords];
+            if (int rc = shm_lane_exchange(shard->owner, shard->lane, words, total)) return leave(rc);
+            for (int i = 0; i < kReduceWords; ++i) words[i] = total[i];
+            words[kNumLimbs] = words[kNumLimbs] != 0 ? 1 : 0;
+        }
         if (!f.loop.step(r, words, &f.st)) continue;
         pose_to(f.loop.T, out_poses_qt + 7 * f.k);
         if (out_iterations) out_iterations[f.k] = f.loop.iter;
@@ -1719,20 +1764,65 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
     constexpr size_t kMinScansPerThread = 16;
     int threads = std::min(r->batch_threads, kMaxBatchQueues + 1);
     if (threads < 2 || count < 2 * kMinScansPerThread || r->cfg.max_num_iterations <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->shm &&
+    if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql &&
           !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0 && r->debug_stall_us == 0.0))
         return 1;
+    // SHARDED (the shared segment attached): every rank is here with ITS shards of the same `count` scans, and every decision from
+    // here on must be the same on every rank - so the ranks first agree, through lane 0 of the segment, on the largest shard any of
+    // them holds (shards of one scan differ by a point between ranks: a size threshold could fall between them)
+    const bool sharded = r->shm != nullptr;
+    size_t sharers_max = 1;  // the most ranks any one device carries
     size_t n_max = 0, n_min = ~size_t(0);
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
-    if (n_min == 0) return 1;
-    const SmallPlan pl = small_plan(r, n_max), pl_min = small_plan(r, n_min);
-    const bool wave = pl.wave && pl_min.wave && pl.grid, generic = pl.generic && pl_min.generic;
+    if (sharded) {
+        // opt-in (option "shard_threads", the same on every rank): a part's kernel waits for its peers' as well as for its host, so a kernel
+        // that is not running - no room on a device that ranks share, no hardware queue slot among too many queues - stalls every rank
+        // until the exchange times out (seen with two ranks of bench.py on ONE GPU from eight resident kernels on), and every part
+        // costs its rank a spinning host thread; the queues (one thread per rank, nothing resident) stay the default for shards
+        if (r->shard_threads < 2) return 1;
+        if (r->shm_poisoned)
+            return fail(KICP_ERR_COMM, "the shared-segment exchange is out of step after a sharded batch that failed: kicp_reg_shm_destroy and _init again on every rank");
+        threads = std::min({threads, r->shard_threads, kicp_reg::kShmLanes});
+        long long mine[kReduceWords] = {}, sum[kReduceWords];
+        std::vector<long long> every(static_cast<size_t>(r->nranks) * kReduceWords);
+        mine[0] = static_cast<long long>(n_max), mine[1] = static_cast<long long>(count);
+        {   // which physical device this rank sits on: ranks that share one (a test box with one GPU) must share its room, too
+            char bus[64] = {};
+            unsigned long long hsh = 1469598103934665603ull;
+            if (hipDeviceGetPCIBusId(bus, sizeof bus, r->device) == hipSuccess)
+                for (const char *c = bus; *c; ++c) hsh = (hsh ^ static_cast<unsigned char>(*c)) * 1099511628211ull;
+            mine[2] = static_cast<long long>(hsh >> 1);
+        }
+        if (int rc = shm_lane_exchange(r, 0, mine, sum, every.data())) {
+            r->shm_poisoned = true;
+            return rc;
+        }
+        for (int k = 0; k < r->nranks; ++k) {
+            if (every[static_cast<size_t>(k) * kReduceWords + 1] != static_cast<long long>(count)) {
+                r->shm_poisoned = true;
+                return fail(KICP_ERR_ARG, "the ranks of a sharded batch call disagree on the number of scans");
+            }
+            n_max = std::max(n_max, static_cast<size_t>(every[static_cast<size_t>(k) * kReduceWords]));
+        }
+        for (int k = 0; k < r->nranks; ++k) {  // (the ranks of the fullest device set the number of parts for everybody)
+            size_t same = 0;
+            for (int j = 0; j < r->nranks; ++j) same += every[static_cast<size_t>(j) * kReduceWords + 2] == every[static_cast<size_t>(k) * kReduceWords + 2] ? 1 : 0;
+            sharers_max = std::max(sharers_max, same);
+        }
+    } else if (n_min == 0) {
+        return 1;
+    }
+    const SmallPlan pl = sharded ? SmallPlan() : small_plan(r, n_max), pl_min = sharded ? SmallPlan() : small_plan(r, n_min);
+    const bool wave = !sharded && pl.wave && pl_min.wave && pl.grid, generic = sharded || (pl.generic && pl_min.generic);  // (shards: the generic kernel whatever their size)
     if (!wave && !generic) return 1;
     // kernels that fit the device side by side; generic scans: the latency build (two workgroups per CU) where three and more of its
     // kernels fit, else the four-waves build (four per CU) where two and more do - 131 072-point scans: two kernels of 512 workgroups
     const size_t grid_g = std::max<size_t>(1, (n_max + 255) / 256);
-    const size_t fit_lat = n_max <= kThreadsMaxGenericPoints ? static_cast<size_t>(r->num_cus) * 2 / grid_g : 0, fit_four = static_cast<size_t>(r->num_cus) * 4 / grid_g;
-    const bool four = generic && fit_lat < 3 && r->batch_threads_large != 0;
+    // (sharded: a part's kernel also waits for its PEERS' - a kernel that finds no room would stall every rank until the exchange
+    //  times out, so a quarter of the device stays free and ranks that share a device share its room)
+    const size_t fit_lat = n_max > kThreadsMaxGenericPoints ? 0 : (sharded ? static_cast<size_t>(r->num_cus) * 3 / 2 / grid_g / sharers_max : static_cast<size_t>(r->num_cus) * 2 / grid_g);
+    const size_t fit_four = static_cast<size_t>(r->num_cus) * 4 / grid_g;
+    const bool four = generic && fit_lat < 3 && r->batch_threads_large != 0 && !sharded;
     if (generic && fit_lat < 3 && !four) return 1;
     const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64)) : (four ? fit_four : fit_lat);
     threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, fit}));
@@ -1764,8 +1854,11 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         kicp_reg *h = handles[t];
         const size_t lo = count * t / static_cast<size_t>(threads), hi = count * (t + 1) / static_cast<size_t>(threads);
         size_t done = 0;
+        const ShardCtx shard{r, static_cast<int>(t), n_max};
         int rc = run_batch_resident(h, map, hi - lo, d_frames + lo, n + lo, last_poses_qt + 7 * lo, rel_odoms_qt + 7 * lo, tau, out_poses_qt + 7 * lo,
-                                    out_iterations ? out_iterations + lo : nullptr, &done, &worsts[t]);
+                                    out_iterations ? out_iterations + lo : nullptr, &done, &worsts[t], sharded ? &shard : nullptr);
+        if (sharded && rc >= 0 && done != hi - lo)  // (one call per scan would leave the peers' lane without its partner)
+            rc = fail(KICP_ERR_COMM, "a part of a sharded batch was not served by its resident kernel: the ranks are out of step");
         kicp_stats st;
         for (size_t k = lo + done; rc >= 0 && k < hi; ++k) {  // (not a batch for the resident kernel after all, or its kernel gave up: one call per scan)
             rc = run_registration(h, map, d_frames[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, tau, out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
@@ -1783,7 +1876,10 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         r->small_relaunches += handles[t]->small_relaunches - relaunches_before[t];
     }
     for (int t = 0; t < threads; ++t) {
-        if (rcs[t] < 0) return fail(rcs[t], messages[t]);
+        if (rcs[t] < 0) {
+            if (sharded) r->shm_poisoned = true;  // (the ranks' lane counters can no longer be assumed equal)
+            return fail(rcs[t], messages[t]);
+        }
         *worst = std::max(*worst, worsts[t]);
     }
     return KICP_OK;
@@ -1893,6 +1989,7 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     else if (k == "batch_queues") reg->batch_queues = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues);
     else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
     else if (k == "batch_threads_large") reg->batch_threads_large = value != 0.0 ? 1 : 0;
+    else if (k == "shard_threads") reg->shard_threads = std::min<int>(std::max(static_cast<int>(value), 0), kicp_reg::kShmLanes);
     else if (k == "resident_four_waves") reg->resident_four = value != 0.0 ? 1 : 0;
     else if (k == "batch_threads") reg->batch_threads = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues + 1);
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
@@ -1944,6 +2041,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
     if (k == "batch_threads_large") return reg->batch_threads_large;
+    if (k == "shard_threads") return reg->shard_threads;
     if (k == "resident_four_waves") return reg->resident_four;
     if (k == "batch_threads") return reg->batch_threads;
     if (k == "batch_threads_active") return reg->last_batch_threads;
@@ -2165,7 +2263,7 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us, c->small_group_rows = reg->small_group_rows;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads, c->batch_threads_large = reg->batch_threads_large;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads, c->batch_threads_large = reg->batch_threads_large, c->shard_threads = reg->shard_threads;
     *out = c;
     return KICP_OK;
 }
