@@ -1742,6 +1742,22 @@ LanePool &lane_pool() {
     static LanePool *pool = new LanePool;  // (never destroyed: its threads outlive main's statics)
     return *pool;
 }
+// CPUs this process may keep busy: its affinity mask, cut down to the cgroup's CPU quota where there is one (cpu.max: "quota period")
+int host_cpu_budget() {
+    static const int budget = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int cpus = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+            std::fclose(f);
+        }
+        return std::max(1, cpus);
+    }();
+    return budget;
+}
 }  // namespace
 
 namespace {
@@ -1762,7 +1778,11 @@ constexpr size_t kThreadsMaxGenericPoints = 24576;  // (five and more such kerne
 int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
                                const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, int *worst) {
     constexpr size_t kMinScansPerThread = 16;
+    // (every part's host thread spins on its kernel's rows: no more parts than CPUs this process may keep busy, one left for the rest;
+    //  a sharded batch applies that cap only once the ranks have exchanged theirs: until then every decision must be the same everywhere)
+    const int cpu_cap = std::max(1, host_cpu_budget() - 1);
     int threads = std::min(r->batch_threads, kMaxBatchQueues + 1);
+    if (!r->shm) threads = std::min(threads, cpu_cap);
     if (threads < 2 || count < 2 * kMinScansPerThread || r->cfg.max_num_iterations <= 0 || kicp_map_empty(map)) return 1;
     if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql &&
           !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0 && r->debug_stall_us == 0.0))
@@ -1782,10 +1802,10 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         if (r->shard_threads < 2) return 1;
         if (r->shm_poisoned)
             return fail(KICP_ERR_COMM, "the shared-segment exchange is out of step after a sharded batch that failed: kicp_reg_shm_destroy and _init again on every rank");
-        threads = std::min({threads, r->shard_threads, kicp_reg::kShmLanes});
+        threads = std::min({threads, r->shard_threads, kicp_reg::kShmLanes});  // (may differ between ranks - their CPU budgets do: the smallest counts, below)
         long long mine[kReduceWords] = {}, sum[kReduceWords];
         std::vector<long long> every(static_cast<size_t>(r->nranks) * kReduceWords);
-        mine[0] = static_cast<long long>(n_max), mine[1] = static_cast<long long>(count);
+        mine[0] = static_cast<long long>(n_max), mine[1] = static_cast<long long>(count), mine[3] = std::min(threads, cpu_cap);
         {   // which physical device this rank sits on: ranks that share one (a test box with one GPU) must share its room, too
             char bus[64] = {};
             unsigned long long hsh = 1469598103934665603ull;
@@ -1803,6 +1823,7 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
                 return fail(KICP_ERR_ARG, "the ranks of a sharded batch call disagree on the number of scans");
             }
             n_max = std::max(n_max, static_cast<size_t>(every[static_cast<size_t>(k) * kReduceWords]));
+            threads = static_cast<int>(std::min<long long>(threads, every[static_cast<size_t>(k) * kReduceWords + 3]));
         }
         for (int k = 0; k < r->nranks; ++k) {  // (the ranks of the fullest device set the number of parts for everybody)
             size_t same = 0;
