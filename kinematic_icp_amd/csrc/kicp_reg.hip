@@ -1742,19 +1742,20 @@ LanePool &lane_pool() {
     static LanePool *pool = new LanePool;  // (never destroyed: its threads outlive main's statics)
     return *pool;
 }
-// CPUs this process may keep busy: its affinity mask, cut down to the cgroup's CPU quota where there is one (cpu.max: "quota period")
+// CPUs this process may keep busy: the machine's, cut down to the cgroup's CPU quota where there is one (cpu.max: "quota period").
+// (Not the calling thread's affinity mask: many a runtime pins the thread that initialised it - under torch the bench's main thread is
+//  allowed ONE CPU - while the lane pool's threads ask for every CPU when they start.)
 int host_cpu_budget() {
     static const int budget = [] {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        int cpus = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+        long long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        if (cpus < 1) cpus = 1;
         if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long quota = 0, period = 0;
             if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
                 cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
             std::fclose(f);
         }
-        return std::max(1, cpus);
+        return static_cast<int>(std::max<long long>(1, std::min<long long>(cpus, 1 << 20)));
     }();
     return budget;
 }
