@@ -144,6 +144,19 @@ class SegmentLanes:
         return area[:, 1:1 + REDUCE_WORDS].sum(axis=0)
 
 
+    def collect_each(self, lane, value):
+        """every rank's words of hand-off `value` of the lane, [nranks][REDUCE_WORDS], or None while a rank's slot is missing"""
+        area = self.slots[lane, (value - 1) & 1]
+        if not np.all(area[:, 0] == value):
+            return None
+        return area[:, 1:1 + REDUCE_WORDS].copy()
+
+
+def part_bounds(part, parts, count):
+    """the contiguous part `part` of a batch of `count` scans cut into `parts` (run_batch_resident_threads)"""
+    return count * part // parts, count * (part + 1) // parts
+
+
 def lane_scans(lane, lanes, count):
     """the scans lane `lane` of a sharded batch registers, in order (the static deal)"""
     return list(range(lane, count, lanes))
