@@ -183,7 +183,8 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the re
  *                  launch shape through lane 0 first); three-quarters of the device at most, shared among the ranks that sit on one
  *                  device.  EXPERIMENTAL and off by default: a part's kernel waits for its peers' as well as for its host, and every
  *                  part costs its rank a spinning host thread - with two ranks on ONE GPU, 3 per rank measured 2.4 x the queues on
- *                  8 192-point shards, 4 and more per rank stalled intermittently (a stall ends in KICP_ERR_COMM after KICP_WAIT_TIMEOUT_S)
+ *                  8 192-point shards, 4 and more per rank stalled intermittently (a stall ends in KICP_ERR_COMM after KICP_WAIT_TIMEOUT_S; one process
+ *                  alone runs eight: it is several processes with many never-ending kernels each on ONE device that do not get on)
  *   "batch_threads_large" 0 (default) | 1: generic scans too large for three resident kernels of the latency build (up to 131 072 points)
  *                  take resident kernels of the FOUR-WAVES build side by side (four workgroups per CU: two kernels of 512 workgroups
  *                  fill the device) instead of the queues - measured 5 % slower than the queues on 131 072-point scans, kept for

@@ -219,9 +219,12 @@ def _threads_worker(rank, world, name, threads, count, barrier, q):
             pass
 
 
-# (three kernels per rank: what the option is documented for.  Four and more per rank stalled now and then when two ranks SHARE one GPU -
-#  a part's kernel waits for its peers' as well as for its host -, one reason the option is off by default; a rank with a GPU of its own,
-#  like the single process of tests/test_gpu_edge.py, runs eight side by side)
+# (three kernels per rank: what the option is documented for.  With four and more per rank and two ranks SHARING one GPU a kernel's rows
+#  now and then never arrive - not a late start: setting the handles up before the ranks meet and a command timeout beyond the exchange's
+#  own turned the stall into that plain time-out, every time from five kernels per rank on; three ranks x three kernels and one process
+#  with eight run clean, so it is not the number of resident kernels on the device but how many never-ending ones each of SEVERAL
+#  processes keeps on it.  One reason the option is off by default; a rank with a GPU of its own is the single process of
+#  tests/test_gpu_edge.py)
 @pytest.mark.parametrize("world,threads", [(2, 3), (3, 3)])
 def test_sharded_batch_on_resident_kernels_side_by_side(world, threads):
     """Two / three ranks sharing the box's GPU, each with ITS shards of 16 x threads + 5 scans: the ranks agree on the launch shape
