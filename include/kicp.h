@@ -105,7 +105,10 @@ int kicp_map_update_pose_device(kicp_map *map, int device, const double *d_point
  * _begin.  Any other call on the map finishes a pending update first, so forgetting _finish costs nothing but the overlap. */
 int kicp_map_update_pose_device_begin(kicp_map *map, int device, const double *d_points_xyz, size_t n, const double pose_qt[7]);
 int kicp_map_update_finish(kicp_map *map);
-int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU */
+int kicp_map_last_update_on_device(const kicp_map *map); /* 1 if the last kicp_map_update_pose_device ran on the GPU (collects a pending update first) */
+/* Updates so far that ran on the GPU and have been collected; unlike every other call on the map this one does NOT wait for a pending
+ * update (a diagnostic a timed loop can read without disturbing what it measures). */
+unsigned long long kicp_map_device_updates(const kicp_map *map);
 /* Preferred device for BULK host-side insertions (not part of the reference API): with device >= 0, kicp_map_add_points /
  * kicp_map_update_origin / kicp_map_update_pose calls of 4096 points or more stage their points into HBM and insert them
  * there (the same map as the sequential host insertion builds, an order of magnitude faster); -1 (default) = always on the
@@ -366,7 +369,10 @@ int kicp_pre_set_probe_limit(kicp_pre *pre, unsigned int limit);
  * out_frame_xyz (nullable; room for every INPUT point, cap_points >= n): buffer 0 starts travelling there in the background as
  * soon as it is complete - collect it with kicp_pre_download_finish(pre, 0, ...), whose out_n is out_counts[0]; the first
  * out_counts[0] points are the frame.  kicp_pre_frame: host input as kicp_pre_preprocess; kicp_pre_frame_ingested: the cloud
- * of the last kicp_pre_ingest (kicp_pre_ingested_count points).  May return KICP_WARN_TABLE_ORDER like the downsample. */
+ * of the last kicp_pre_ingest (kicp_pre_ingested_count points).  May return KICP_WARN_TABLE_ORDER like the downsample.
+ * Buffers 1 and 3 take turns between calls (round 6): the previous call's buffer 1 - device memory a map update begun with
+ * kicp_map_update_pose_device_begin may still be reading - is buffer 3 afterwards, unchanged until the call after this one; a pointer
+ * taken with kicp_pre_device_ptr(pre, 1, ..) stays valid that long. */
 int kicp_pre_frame(kicp_pre *pre, const double *frame_xyz, size_t n, const double *timestamps, size_t n_timestamps,
                    const double relative_motion_qt[7], const double lidar_to_base_qt[7], double max_range, double min_range, int deskew,
                    double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points, size_t out_counts[3]);
@@ -374,6 +380,16 @@ int kicp_pre_frame_ingested(kicp_pre *pre, const double relative_motion_qt[7], c
                             double min_range, int deskew, double voxel_a, double voxel_b, double *out_frame_xyz, size_t cap_points,
                             size_t out_counts[3]);
 size_t kicp_pre_ingested_count(const kicp_pre *pre);
+/* Backend knobs of the chained pre-steps (not part of the reference API):
+ *   "fused"  1 (default; KICP_PRE_FUSED=0 in the environment): kicp_pre_frame* run the frame's pre-steps as FIVE launches
+ *            (kicp_pre.hpp: k_frame_*) and hand the three counts over through host memory the call polls; 0: one launch per
+ *            step (preprocess, compact, 2 x {claim, replay, gather}) and a copy + stream synchronisation at the end.  Same results.
+ *   "guess"  the survivor count from which the fused chain sizes its first table before it knows the real one (default: the
+ *            previous frame's; the first frame: the input count).  A wrong power-of-two bracket costs the frame the unfused
+ *            downsamples, never a different result.
+ *   "fused_frames" / "guess_misses" (read only): frames the fused chain served / of those, frames whose guess was wrong. */
+int kicp_pre_set_option(kicp_pre *pre, const char *name, double value);
+double kicp_pre_get_option(const kicp_pre *pre, const char *name);
 int kicp_pre_upload(kicp_pre *pre, int buffer, const double *xyz, size_t n);
 int kicp_pre_download(const kicp_pre *pre, int buffer, double *out_xyz, size_t cap_points, size_t *out_n);
 /* The same download in the background: _begin queues the copy of the buffer's current contents on a stream of its own

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "kicp_map_update_pose_device_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _dp]),
     "kicp_map_update_finish": (C.c_int, [C.c_void_p]),
     "kicp_map_last_update_on_device": (C.c_int, [C.c_void_p]),
+    "kicp_map_device_updates": (C.c_ulonglong, [C.c_void_p]),
     "kicp_map_set_device": (C.c_int, [C.c_void_p, C.c_int]),
     "kicp_map_num_points": (C.c_size_t, [C.c_void_p]),
     "kicp_map_num_voxels": (C.c_size_t, [C.c_void_p]),
@@ -100,6 +101,8 @@ _SIGNATURES = {
     "kicp_pre_ingest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp, _dp, _dp]),
     "kicp_pre_ingest_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _dp]),
     "kicp_pre_ahead_hits": (C.c_ulonglong, [C.c_void_p]),
+    "kicp_pre_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "kicp_pre_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "kicp_pre_preprocess_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "kicp_pre_ingested": (C.c_int, [C.c_void_p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "kicp_pre_frame": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp, C.c_size_t,
@@ -556,6 +559,12 @@ class PreSteps:
         q = None if sensor_pose is None else _d(sensor_pose)[1]
         self._ahead_keep = (buf, raw)  # (borrowed by the backend until the Ingest call for the same bytes)
         _check(lib().kicp_pre_ingest_ahead(self._h, buf.ctypes.data if buf.size else None, n_points, C.byref(layout), q))
+
+    def set_option(self, name, value):
+        _check(lib().kicp_pre_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        return float(lib().kicp_pre_get_option(self._h, name.encode()))
 
     def ahead_hits(self):
         return int(lib().kicp_pre_ahead_hits(self._h))

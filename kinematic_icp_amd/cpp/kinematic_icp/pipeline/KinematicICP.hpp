@@ -9,6 +9,7 @@
 #pragma once
 #include <Eigen/Core>
 #include <cmath>
+#include <cstdlib>
 #include <kiss_icp/core/Preprocessing.hpp>
 #include <kiss_icp/core/VoxelHashMap.hpp>
 #include <kiss_icp/core/VoxelUtils.hpp>
@@ -210,8 +211,15 @@ protected:
         guard.armed = false;
         if (!frame.empty()) kicp_bridge::check(kicp_pre_download_finish(pre_, 0, frame.front().data(), frame.size(), nullptr), "download");
         frame.resize(counts[0]);  // (the landing area held every input point; shrinking costs nothing)
-        trace.lap("map update: wait");
-        local_map_.UpdateFinish();
+        // The map update's kernels are still running: whatever touches the map next - the next frame's registration, LocalMap(),
+        // VoxelMap() - collects them first (kicp.h: kicp_map_update_pose_device_begin), so they overlap the caller's own work and the
+        // next frame's pre-steps instead of this thread's idle wait (round 6; the points they read stay in the pre-step workspace's
+        // spare buffer meanwhile).  KICP_SYNC_MAP_UPDATE=1: wait here, as round 5 did.
+        static const bool sync_update = [] { const char *e = std::getenv("KICP_SYNC_MAP_UPDATE"); return e && *e && *e != '0'; }();
+        if (sync_update) {
+            trace.lap("map update: wait");
+            local_map_.UpdateFinish();
+        }
         return std::move(result);  // built in place: no copy of the clouds on the way out
     }
 #endif

@@ -132,6 +132,7 @@ struct kicp_map {
     bool device_ahead = false;
     kicp::DevMapCounters dev{};
     int last_update_on_device = 0;
+    unsigned long long device_updates = 0;  // updates that ran (and were collected) on the GPU so far (kicp_map_device_updates)
     // a voxel coordinate beyond +-2^20 was seen: the packed keys of the device-side maintenance cannot hold it, so this map's
     // updates stay on the host from now on (until Clear); registration and queries on the device are unaffected
     bool host_updates_only = false;

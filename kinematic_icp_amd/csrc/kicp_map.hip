@@ -369,7 +369,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
             return host_fallback();
         }
         if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
-        map->last_update_on_device = 1;
+        map->last_update_on_device = 1, ++map->device_updates;
         return KICP_OK;
     }
     for (int attempt = 0;; ++attempt) {
@@ -411,7 +411,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     HIP_TRY(hipStreamSynchronize(st));
     if (c.error) return fail(KICP_ERR_CAPACITY, c.error == 3 ? "device-side map update: voxel table full" : "device-side map update ran out of room");
     map->dev = c;
-    map->last_update_on_device = 1;
+    map->last_update_on_device = 1, ++map->device_updates;
     return KICP_OK;
 }
 
@@ -434,6 +434,7 @@ int map_finish_pending(kicp_map *map) {
         return map_update_device(map, mr.device, map->pending_points, map->pending_n, map->pending_pose, map->pending_has_origin ? map->pending_origin : nullptr);
     }
     if (c.error) return fail(KICP_ERR_CAPACITY, "device-side map update ran out of room");
+    ++map->device_updates;
     return KICP_OK;
 }
 }  // namespace host
@@ -575,6 +576,7 @@ int kicp_map_update_finish(kicp_map *map) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     return map_finish_pending(map);
 }
+unsigned long long kicp_map_device_updates(const kicp_map *map) { return map ? map->device_updates : 0ull; }
 int kicp_map_last_update_on_device(const kicp_map *map) {
     if (map) (void)map_finish_pending(const_cast<kicp_map *>(map));
     return map ? map->last_update_on_device : 0;

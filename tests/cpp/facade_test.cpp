@@ -24,6 +24,11 @@ static std::vector<Eigen::Vector3d> to_points(const std::vector<double> &v) {
     if (!p.empty()) std::memcpy(p.front().data(), v.data(), v.size() * sizeof(double));
     return p;
 }
+struct FrameLog {  // one frame of a timed drive, printed after the drive
+    double ms, ms_with_free;
+    size_t n_deskewed, n_source;
+    Sophus::SE3d pose;
+};
 static void print_pose(const char *tag, const Sophus::SE3d &T) {
     double p[7];
     kicp_bridge::to_params(T, p);
@@ -184,6 +189,9 @@ int main(int argc, char **argv) {
             cfg.voxel_size = h[1], cfg.max_range = h[2], cfg.deskew = h[3] != 0.0;
             kinematic_icp::pipeline::KinematicICP icp(cfg);
             const auto ext = read_doubles(f, 7);
+            std::vector<FrameLog> log;
+            const size_t n_total = static_cast<size_t>(h[0]);
+            auto drive_t0 = std::chrono::steady_clock::now();
             for (int k = 0; k < static_cast<int>(h[0]); ++k) {
                 const auto n = read_doubles(f, 1);
                 const auto frame = to_points(read_doubles(f, static_cast<size_t>(n[0]) * 3));
@@ -199,11 +207,22 @@ int main(int argc, char **argv) {
                     n_deskewed = deskewed.size(), n_source = source.size();
                 }  // the caller drops the returned clouds here
                 const double ms_with_free = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                printf("frame %d ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, ms, ms_with_free, n_deskewed,
-                       n_source, kicp_map_last_update_on_device(icp.VoxelMap().handle()));
-                print_pose("pose", icp.pose());
+                // (nothing is printed - and nothing asked of the map - between frames: the map update of frame k is still running when
+                //  RegisterFrame returns and is collected by frame k + 1's registration, inside ITS clock)
+                log.push_back({ms, ms_with_free, n_deskewed, n_source, icp.pose()});
+                if (log.size() == n_total / 2) drive_t0 = std::chrono::steady_clock::now();  // (the steady half: tables, buffers and threads are in place)
             }
-            printf("map %zu\n", icp.LocalMap().size());
+            const double drive_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - drive_t0).count();
+            const size_t map_points = icp.LocalMap().size();  // (collects the last frame's map update)
+            const unsigned long long on_device = kicp_map_device_updates(icp.VoxelMap().handle());
+            for (size_t k = 0; k < log.size(); ++k) {
+                printf("frame %zu ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, log[k].ms, log[k].ms_with_free, log[k].n_deskewed,
+                       log[k].n_source, on_device == log.size() ? 1 : 0);
+                print_pose("pose", log[k].pose);
+            }
+            printf("drive %zu frames %.4f ms (the second half of the drive, wall clock around the loop: what a deferred map update cannot hide in)\n",
+                   log.size() - n_total / 2, drive_ms);
+            printf("map %zu\n", map_points);
         } else if (mode == "pipeline_timed_raw" || mode == "pipeline_timed_raw_ahead") {  // the same frames as 16-byte PointCloud2 records (x y z t, FLOAT32): IngestCloud + RegisterIngestedFrame in the clock
             // (_ahead: a bag replay that holds message k + 1 while it registers message k - AnnounceNextCloud: the next message's upload hides
             //  behind the current frame's pre-steps)
@@ -228,6 +247,9 @@ int main(int argc, char **argv) {
                     msg[4 * i] = static_cast<float>(xyz[3 * i]), msg[4 * i + 1] = static_cast<float>(xyz[3 * i + 1]), msg[4 * i + 2] = static_cast<float>(xyz[3 * i + 2]),
                               msg[4 * i + 3] = static_cast<float>(stamps[i]);
             }
+            std::vector<FrameLog> log;
+            const size_t n_total = static_cast<size_t>(n_frames);
+            auto drive_t0 = std::chrono::steady_clock::now();
             for (int k = 0; k < n_frames; ++k) {
                 const auto &msg = msgs[k];
                 const auto &delta = deltas[k];
@@ -243,11 +265,22 @@ int main(int argc, char **argv) {
                     n_deskewed = deskewed.size(), n_source = source.size();
                 }
                 const double ms_with_free = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                printf("frame %d ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, ms, ms_with_free, n_deskewed,
-                       n_source, kicp_map_last_update_on_device(icp.VoxelMap().handle()));
-                print_pose("pose", icp.pose());
+                // (nothing is printed - and nothing asked of the map - between frames: the map update of frame k is still running when
+                //  RegisterFrame returns and is collected by frame k + 1's registration, inside ITS clock)
+                log.push_back({ms, ms_with_free, n_deskewed, n_source, icp.pose()});
+                if (log.size() == n_total / 2) drive_t0 = std::chrono::steady_clock::now();  // (the steady half: tables, buffers and threads are in place)
             }
-            printf("map %zu\n", icp.LocalMap().size());
+            const double drive_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - drive_t0).count();
+            const size_t map_points = icp.LocalMap().size();  // (collects the last frame's map update)
+            const unsigned long long on_device = kicp_map_device_updates(icp.VoxelMap().handle());
+            for (size_t k = 0; k < log.size(); ++k) {
+                printf("frame %zu ms %.4f (%.4f incl. freeing the results) in %zu source %zu map_on_device %d\n", k, log[k].ms, log[k].ms_with_free, log[k].n_deskewed,
+                       log[k].n_source, on_device == log.size() ? 1 : 0);
+                print_pose("pose", log[k].pose);
+            }
+            printf("drive %zu frames %.4f ms (the second half of the drive, wall clock around the loop: what a deferred map update cannot hide in)\n",
+                   log.size() - n_total / 2, drive_ms);
+            printf("map %zu\n", map_points);
         }
     } catch (const std::exception &e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -211,3 +211,32 @@ def test_the_chained_frame_call_equals_the_separate_calls(deskew, source):
             np.testing.assert_array_equal(frame, sep.download(0))
         for b in (0, 1, 2):
             np.testing.assert_array_equal(pre.download(b), sep.download(b))
+    # the frames above went through the five-launch chain (kicp_pre.hpp k_frame_*); the last one's crop left a count in another
+    # power-of-two bracket than the chain had guessed its first table for: found on the device, finished by the unfused downsamples
+    assert pre.get_option("fused_frames") == 4 and pre.get_option("guess_misses") >= 1
+
+
+@pytest.mark.parametrize("guess", [0, 100, 5000, 70000])
+def test_the_fused_chain_equals_the_unfused_one_whatever_it_guesses(guess):
+    """The five-launch chain sizes its first table from a GUESS of the crop's survivor count (the previous frame's): a right guess,
+    a guess in a smaller and in a larger power-of-two bracket, and no guess at all give the unfused chain's buffers bit for bit;
+    the tables are left clean for the next frame either way (two frames per handle)."""
+    rng = np.random.default_rng(77)
+    ext = np.concatenate([[0, 0, np.sin(0.05), np.cos(0.05)], [0.3, 0.0, 0.9]])
+    rel = syn.planar_pose(0.3, 0.0, 0.02)
+    fused, plain = K.PreSteps(), K.PreSteps()
+    plain.set_option("fused", 0)
+    for n, max_range in ((9000, 40.0), (9000, 60.0), (300, 60.0)):
+        pts = (rng.uniform(-50, 50, (n, 3)) * np.array([1.0, 1.0, 0.1])).astype(np.float32).astype(np.float64)
+        ts = np.linspace(0.0, 1.0, n)
+        fused.set_option("guess", guess)
+        c1, f1 = fused.Frame(pts, ts, rel, ext, max_range, 0.5, 1, 0.5, 1.5)
+        c0, f0 = plain.Frame(pts, ts, rel, ext, max_range, 0.5, 1, 0.5, 1.5)
+        assert c1 == c0 and 0 < c1[2] <= c1[1] <= c1[0] <= n
+        np.testing.assert_array_equal(f1, f0)
+        for b in (0, 1, 2):
+            np.testing.assert_array_equal(fused.download(b), plain.download(b))
+        ref = okicp.voxel_downsample(okicp.voxel_downsample(f0, 0.5), 1.5)
+        np.testing.assert_array_equal(fused.download(2), ref)
+    assert plain.get_option("fused_frames") == 0 and fused.get_option("fused_frames") == 3
+    assert fused.get_option("guess_misses") >= (1 if guess == 100 else 0)

@@ -79,8 +79,13 @@ def main():
     ondev = np.array([int(l.split()[-1]) for l in out if l.startswith("frame")])
     ms_free = np.array([float(l.split()[4].strip("(")) for l in out if l.startswith("frame")])
     for l in out:
-        if not l.startswith("pose"):
+        if not l.startswith("pose") and not l.startswith("drive"):
             print(l)
+    for l in out:
+        if l.startswith("drive"):  # the whole loop, wall clock: what the deferred map updates cannot hide in
+            w = l.split()
+            print("drive: the last %d frames in %.2f ms = %.0f frames/s (%.3f ms per frame, wall clock around the loop)" %
+                  (int(w[1]), float(w[3]), int(w[1]) / float(w[3]) * 1e3, float(w[3]) / int(w[1])))
     steady = ms[len(ms) // 2:]
     print("mode %s: %s" % (a.mode, {"raw": "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 records", "vectors": "RegisterFrame on fp64 vectors",
                                "raw_ahead": "IngestCloud + AnnounceNextCloud(next message) + RegisterIngestedFrame on 16-byte FLOAT32 records"}[a.mode]))
