@@ -109,6 +109,9 @@ def main():
                                                           "of scans + the map exceed what the caches hold)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-frames", type=int, default=24,
+                    help="frames of the `pipeline` block (the whole drop-in KinematicICP::RegisterFrame - ingest, pre-steps, registration, map update - on a "
+                         "synthetic drive of 131 072-point PointCloud2 messages, with the reference's own RegisterFrame timed beside it); 0: skip")
     ap.add_argument("--comm", default="shm", choices=["rccl", "shm", "p2p", "torch"],
                     help="N>1 exchange of the per-iteration sums behind `value`: host shared segment (default since round 5: no device collective, "
                          "and the only exchange whose steps a batch call can interleave - several sharded scans in flight per rank, option "
@@ -692,6 +695,7 @@ def main():
     pass_ms_multi = np.array([ms for _, lst in per_call_multi for ms in lst], dtype=np.float64)
 
     cpu = None if args.no_cpu_baseline else _cpu_baseline(args, cfg, scans[:8], rel_single[:8], tau, omap, map_points, okicp, rkicp)
+    pipeline = _pipeline_block(args.pipeline_frames, with_reference=not args.no_cpu_baseline) if (world == 1 and args.pipeline_frames > 0 and args.workload == "cfg2") else None
 
     n_scans_timed = args.steps * B
     value = (world if replicas else 1) * n_scans_timed / elapsed  # replicas: every rank completed its own scans
@@ -862,6 +866,7 @@ def main():
         **({"sharded_cfg5": sharded_cfg5} if sharded_cfg5 is not None else {}),
         "roofline": roof,
         "cpu_baseline": cpu,
+        **({} if pipeline is None else {"pipeline": pipeline}),
     }
     if elapsed < 0.25:
         out["config"]["warning"] = "timed region shorter than 0.25 s: raise --steps or --scans-per-step (0 = automatic)"
@@ -870,6 +875,26 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+
+
+def _pipeline_block(frames, with_reference=True):
+    """The frame, not the registration alone: the drop-in KinematicICP::RegisterFrame (pipeline/KinematicICP.cpp:48-85: pre-steps,
+    registration, threshold, map update - all on the GPU) on a synthetic drive of 131 072-point frames that arrive as PointCloud2
+    bytes, measured by tools/bench_pipeline.py in a process of its own (the C++ facade test binary is the caller, as a ROS node would
+    be), after everything timed above.  Not part of `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_pipeline.py"), "--frames", str(frames), "--json", "raw,raw_ahead",
+           "--ref-frames", str(frames if with_reference else 0), "--ref-threads", "1", "16"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        block = json.loads(line)
+        block["what"] = ("whole frames through the drop-in KinematicICP (IngestCloud + RegisterIngestedFrame): wire-format ingest, deskew + crop + two voxel "
+                         "downsamples, registration, adaptive threshold, map update, the two returned clouds back in host vectors; "
+                         "ms_per_frame = the clock around those calls, frames_per_s = wall clock around the drive loop")
+        return block
+    except Exception as e:  # noqa: BLE001 - the block is an extra: its failure must not cost the run its headline line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def _voxel_census(points, vs):

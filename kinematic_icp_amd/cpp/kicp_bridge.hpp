@@ -9,6 +9,7 @@
 #include <sophus/se3.hpp>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kicp.h"
@@ -24,6 +25,12 @@ inline void to_params(const Sophus::SE3d &T, double p[7]) {
 }
 inline Sophus::SE3d from_params(const double p[7]) {
     return Sophus::SE3d(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]));
+}
+// what tbb::this_task_arena::max_concurrency() answers in the reference's constructors (Registration.cpp:141-142): the hardware
+// threads of this machine, at least one
+inline int hardware_threads() {
+    const unsigned n = std::thread::hardware_concurrency();
+    return n > 0u ? static_cast<int>(n) : 1;
 }
 inline const double *xyz(const std::vector<Eigen::Vector3d> &v) {
     static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d must be 3 packed doubles");

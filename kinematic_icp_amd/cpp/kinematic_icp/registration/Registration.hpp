@@ -16,7 +16,10 @@ struct KinematicRegistration {
                                    const bool use_adaptive_odometry_regularization, const double fixed_regularization)
         : max_num_iterations_(max_num_iteration),
           convergence_criterion_(convergence_criterion),
-          max_num_threads_(max_num_threads),  // kept for API parity: the GPU path has no host thread pool to size
+          // Registration.cpp:141-142: "only manipulate the number of threads if the user specifies something greater than 0", else
+          // tbb::this_task_arena::max_concurrency() = the hardware threads this process may use.  The field reads like the
+          // reference's; the GPU path itself has no host thread pool to size with it.
+          max_num_threads_(max_num_threads > 0 ? max_num_threads : kicp_bridge::hardware_threads()),
           use_adaptive_odometry_regularization_(use_adaptive_odometry_regularization),
           fixed_regularization_(fixed_regularization) {
         const kicp_reg_config c = config();

@@ -1742,19 +1742,49 @@ LanePool &lane_pool() {
     static LanePool *pool = new LanePool;  // (never destroyed: its threads outlive main's statics)
     return *pool;
 }
-// CPUs this process may keep busy: the machine's, cut down to the cgroup's CPU quota where there is one (cpu.max: "quota period").
-// (Not the calling thread's affinity mask: many a runtime pins the thread that initialised it - under torch the bench's main thread is
-//  allowed ONE CPU - while the lane pool's threads ask for every CPU when they start.)
+// CPUs this process may keep busy with spinning lane threads: what a thread of the lane pool is ALLOWED to run on once it has asked for
+// every CPU (sched_getaffinity after the reset: the cpuset of a container - docker --cpuset-cpus, Slurm, a k8s static CPU policy -
+// is what remains; measured on a short-lived thread of its own, not on the caller: many a runtime pins the thread that initialised
+// it - under torch the bench's main thread is allowed ONE CPU), cut down to the cgroup's CPU quota where there is one
+// (v2: cpu.max "quota period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us).  The batch paths that spend a host thread per resident
+// kernel take min(option, budget - 1) of them and fall back to ONE kernel driven by the caller's thread below two.
 int host_cpu_budget() {
     static const int budget = [] {
         long long cpus = sysconf(_SC_NPROCESSORS_ONLN);
         if (cpus < 1) cpus = 1;
-        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long allowed = 0;
+        std::thread([&allowed] {
+            cpu_set_t all, got;
+            CPU_ZERO(&all);
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
+            (void)sched_setaffinity(0, sizeof all, &all);
+            CPU_ZERO(&got);
+            if (sched_getaffinity(0, sizeof got, &got) == 0) allowed = CPU_COUNT(&got);
+        }).join();
+        if (allowed > 0) cpus = std::min(cpus, allowed);
+        auto cap = [&cpus](long long quota, long long period) {
+            if (quota > 0 && period > 0) cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+        };
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2 ("max 100000": no quota - fscanf stops at "max")
             long long quota = 0, period = 0;
-            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
-                cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2) cap(quota, period);
             std::fclose(f);
         }
+        long long q1 = 0, p1 = 0;  // cgroup v1
+        for (const char *dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+            if (FILE *f = std::fopen((std::string(dir) + "/cpu.cfs_quota_us").c_str(), "r")) {
+                if (std::fscanf(f, "%lld", &q1) != 1) q1 = 0;
+                std::fclose(f);
+            }
+            if (FILE *f = std::fopen((std::string(dir) + "/cpu.cfs_period_us").c_str(), "r")) {
+                if (std::fscanf(f, "%lld", &p1) != 1) p1 = 0;
+                std::fclose(f);
+            }
+            if (q1 > 0 && p1 > 0) break;
+        }
+        cap(q1, p1);
+        if (const char *e = std::getenv("KICP_CPU_BUDGET"))  // (tests; a deployment that knows better)
+            if (std::atoi(e) > 0) cpus = std::atoi(e);
         return static_cast<int>(std::max<long long>(1, std::min<long long>(cpus, 1 << 20)));
     }();
     return budget;

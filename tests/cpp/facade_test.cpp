@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "kinematic_icp/pipeline/KinematicICP.hpp"
@@ -98,6 +99,11 @@ int main(int argc, char **argv) {
             icp.SetPose(Sophus::SE3d());
             kinematic_icp::pipeline::KinematicICP icp_moved(std::move(icp));
             printf("pipeline_copy %zu %zu\n", icp_copy.LocalMap().size(), icp_moved.LocalMap().size());
+            // max_num_threads <= 0 reads back as the hardware's thread count, as in the reference's constructor (Registration.cpp:141-142)
+            const int hw = static_cast<int>(std::thread::hardware_concurrency());
+            printf("threads_field %d %d %d\n", kinematic_icp::KinematicRegistration(10, 1e-3, 0, true, 0.0).max_num_threads_ == (hw > 0 ? hw : 1) ? 1 : 0,
+                   kinematic_icp::KinematicRegistration(10, 1e-3, -3, true, 0.0).max_num_threads_ == (hw > 0 ? hw : 1) ? 1 : 0,
+                   kinematic_icp::KinematicRegistration(10, 1e-3, 4, true, 0.0).max_num_threads_);
         } else if (mode == "pipeline") {
             const auto h = read_doubles(f, 4);  // n_frames, voxel, max_range, deskew
             kinematic_icp::pipeline::Config cfg;

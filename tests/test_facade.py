@@ -71,6 +71,7 @@ def test_facade_registration_matches_golden(tmp_path):
     ref = okicp.KinematicRegistration().ComputeRobotMotion(wide, m, g["a_last"], g["a_rel"], float(g["a_tau"]))
     np.testing.assert_allclose(f32_pose, ref, rtol=0, atol=1e-9)
     assert out[12] == "pipeline_copy %d 0" % m.num_points()
+    assert out[13] == "threads_field 1 1 4"  # max_num_threads <= 0 -> the hardware's thread count, as Registration.cpp:141-142 stores it
 
 
 @pytest.mark.gpu

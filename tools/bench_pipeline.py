@@ -8,6 +8,7 @@ or, keeping the timed process free of this script's memory footprint (what profi
     python tools/bench_pipeline.py --check /tmp/pipe.txt --oracle-frames 40
 """
 import argparse
+import json
 import os
 import subprocess
 import sys
@@ -23,6 +24,53 @@ from kinematic_icp_amd import synthetic as syn  # noqa: E402
 
 
 FACADE_MODE = {"raw": "pipeline_timed_raw", "raw_ahead": "pipeline_timed_raw_ahead", "vectors": "pipeline_timed"}
+MODE_WHAT = {"raw": "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 PointCloud2 records (2.1 MB over PCIe per frame, decoded on the GPU)",
+             "raw_ahead": "raw, with the NEXT message announced before the current one is registered (a bag replay holds it): its upload hides behind the frame's pre-steps",
+             "vectors": "RegisterFrame on std::vector<Eigen::Vector3d> + std::vector<double>, the reference's own signature (4.2 MB over PCIe per frame)"}
+
+
+def json_block(a, facade, f, frames, stamps, ext, deltas):
+    """every mode on the same frames: per-frame wall time of the drop-in RegisterFrame (the clock around the call), the drive's steady
+    frame rate (wall clock around the loop: deferred map updates cannot hide in it), wall time per C-ABI call (KICP_TRACE, a run of
+    its own), and the reference's own RegisterFrame (oracle/_ref) on the same frames with the largest pose difference"""
+    import re
+    from oracle import rkicp
+    res = {"frames": len(frames), "points_per_frame": int(len(frames[0])), "deskew": bool(a.deskew), "voxel_size": a.voxel, "modes": {}}
+    gpu_poses = None
+    for m in [x for x in a.json.split(",") if x]:
+        out = subprocess.check_output([facade, FACADE_MODE[m], f], text=True).splitlines()
+        ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
+        drive = [l.split() for l in out if l.startswith("drive")]
+        steady = ms[len(ms) // 2:]
+        gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
+        tr = subprocess.run([facade, FACADE_MODE[m], f], text=True, capture_output=True, env=dict(os.environ, KICP_TRACE="1")).stderr.splitlines()
+        calls = {}
+        for l in tr:
+            mt = re.match(r"\[kicp\] (kicp_\w+)\s+([0-9.]+) ms", l)
+            if mt:
+                calls.setdefault(mt.group(1), []).append(float(mt.group(2)))
+        res["modes"][m] = {"what": MODE_WHAT[m],
+                           "ms_per_frame_median": round(float(np.median(steady)), 4), "ms_per_frame_p10": round(float(np.percentile(steady, 10)), 4),
+                           "ms_per_frame_min": round(float(steady.min()), 4), "ms_first_frame": round(float(ms[0]), 2),
+                           "frames_per_s": None if not drive else round(int(drive[0][1]) / float(drive[0][3]) * 1e3, 1),
+                           "frames_per_s_what": "frames of the drive's second half / wall clock around that part of the loop",
+                           "map_updates_on_device": int(sum(int(l.split()[-1]) for l in out if l.startswith("frame"))),
+                           "ms_per_c_abi_call_median": {k: round(float(np.median(v[len(v) // 2:])), 4) for k, v in sorted(calls.items())}}
+    if rkicp.available() and a.ref_frames:
+        res["reference"] = {}
+        for threads in a.ref_threads:
+            pipe = rkicp.KinematicICP(voxel_size=a.voxel, max_range=a.max_range, deskew=a.deskew, max_num_threads=threads)
+            ms_ref, worst = [], 0.0
+            for k in range(min(a.ref_frames, len(frames))):
+                _, _, sec = pipe.RegisterFrameTimed(frames[k], stamps[k], ext, deltas[k], num_threads=threads)
+                ms_ref.append(sec * 1e3)
+                worst = max(worst, float(np.abs(gpu_poses[k] - pipe.pose()).max()))
+            half = ms_ref[len(ms_ref) // 2:]
+            res["reference"]["%d_threads" % threads] = {"ms_per_frame_median": round(float(np.median(half)), 3), "ms_per_frame_min": round(min(half), 3),
+                                                        "max_abs_pose_diff_gpu_vs_reference": worst}
+        res["reference"]["what"] = ("the reference's own KinematicICP::RegisterFrame (pipeline/KinematicICP.cpp:48-85; oracle/_ref: its translation units compiled "
+                                    "unmodified over the stand-in headers), the clock around RegisterFrame alone, same frames (fp64 vectors in host memory)")
+    return res
 
 
 def main():
@@ -41,6 +89,8 @@ def main():
                          "IngestCloud + RegisterIngestedFrame - 2.1 MB over PCIe, decoded on the GPU; vectors: the reference's own signature, "
                          "std::vector<Eigen::Vector3d> + std::vector<double> (4.2 MB); raw_ahead: raw, with the NEXT message announced before the "
                          "current one is registered (AnnounceNextCloud: a bag replay holds it) - its upload hides behind the current frame's pre-steps")
+    ap.add_argument("--json", default="", metavar="MODES", help="comma-separated modes (e.g. raw,raw_ahead): run each on the same frames, add the C-ABI calls' wall times "
+                                                                "(KICP_TRACE) and the reference runs, print ONE JSON object (bench.py's `pipeline` block)")
     ap.add_argument("--dump", default="", help="only write the input file for tests/cpp/facade_test (e.g. to run it under rocprofv3)")
     ap.add_argument("--check", default="", help="output of `facade_test pipeline_timed <dump>` to analyse instead of running it here")
     a = ap.parse_args()
@@ -70,6 +120,9 @@ def main():
                 np.ascontiguousarray(fr).tofile(fh), st.tofile(fh), dl.tofile(fh)
         if a.dump:
             print(test_facade.build_facade(), FACADE_MODE[a.mode], f)
+            return
+        if a.json:
+            print(json.dumps(json_block(a, test_facade.build_facade(), f, frames, stamps, ext, deltas)))
             return
         if a.check:
             out = open(a.check).read().splitlines()
