@@ -422,28 +422,9 @@ def main():
     for i in range(min(n_ev, 512)):
         run_scan(reg, i, rel_multi, per_call_multi)
     barrier()
-    # fixed floor of a pass, measured live: the same launch with every query switched off (launch + reduction + hand-off);
-    # and the census behind the latency model: visiting rounds per wave (dbg 10: the "count" sum carries every wave's rounds)
+    # fixed floor of a pass and the census behind the latency model (visiting rounds per wave): the pass kernel's ablation switches,
+    # which live in libkicp_amd_dbg.so only - tools/dbg_census.py measures both in a process of its own, after everything timed here
     floor_us, rounds_per_wave = None, None
-    if not use_comm and not small_active:  # (the dbg switches belong to the generic pass kernel)
-        reg.set_option("dbg", 7)
-        tmp = []
-        for i in range(64 + 256):
-            run_scan(reg, i, rel_single, tmp)
-        fl = np.array([lst[0] for _, lst in tmp[64:] if lst], dtype=np.float64)  # (pass 0: with every query off the call ends there)
-        floor_us = float(fl.mean() * 1e3) if fl.size else None
-        reg.set_option("dbg", 10)
-        lanes = int(reg.get_option("lanes_per_query")) or (4 if hi - lo <= 4096 else (2 if hi - lo <= 32768 else 1))  # (0 = by scan size, as the library picks)
-        waves = -(-(hi - lo) * lanes // 64)
-        rr = []
-        max_it = reg.max_num_iterations_
-        reg.max_num_iterations_ = 1  # (the census pass carries no correspondences: there is nothing to iterate on)
-        for i in range(min(len(scans), 16)):
-            run_scan(reg, i, rel_single)
-            rr.append(reg.last_stats.n_corr[0] / waves)
-        reg.max_num_iterations_ = max_it
-        rounds_per_wave = float(np.mean(rr))
-        reg.set_option("dbg", 0)
     reg.set_option("timing", 0)
     reg.set_option("latency_kernel", latency_kernel_option)
     poses = [run_scan(reg, i, rel_single) for i in range(len(scans))]
@@ -485,7 +466,7 @@ def main():
         for i in range(k_host):
             reg.ComputeRobotMotion(f32_frames[i % nh], gmap, scans[i % nh]["last_pose"], scans[i % nh]["rel_odom"], tau)
         host_rate_f32 = k_host / (time.perf_counter() - t1)
-    pass_kernel = int(reg.get_option("pass_kernel"))
+    pass_kernel = 3  # (the 16-bit-mirror gather: the only pass kernel since round 6)
     # ---- latency model inputs: the time of one DEPENDENT load step under the pass kernel's own launch shape, far (a working set
     #      of the map's size: probes, buckets, winners) and near (the record next to the probed key: the same line again)
     #      UNLOADED - one wave per CU, so that what is measured is latency and nothing queues: no wave of the pass can take a
@@ -711,6 +692,8 @@ def main():
     # map, replayed logs).  The batch call of the timed region keeps as many in flight with ONE host thread.
     conc_lanes = 4
     conc_rate = _concurrent_rate(args.workload, conc_lanes, min(len(scans), 8)) if (world == 1 and not use_comm) else None
+    if not use_comm and not small_active and world == 1:
+        floor_us, rounds_per_wave = _dbg_census(args.workload, 0 if queued_batch else int(latency_kernel_option))
     prof = _profile_counters(args.workload, world)
     if traffic is None and prof and prof.get("hbm_bytes_per_launch"):
         traffic = float(prof["hbm_bytes_per_launch"])
@@ -875,6 +858,21 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+
+
+def _dbg_census(workload, latency_kernel):
+    """floor of a pass (every query off) and visiting rounds per wave of the generic pass kernel, by tools/dbg_census.py on the library
+    build that carries the kernels' ablation switches (libkicp_amd_dbg.so); (None, None) where that build is absent"""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "kinematic_icp_amd", "libkicp_amd_dbg.so")):
+        return None, None
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_census.py"), "--workload", workload, "--latency-kernel", str(latency_kernel)],
+                             capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        return float(d["floor_us"]), float(d["rounds_per_wave"])
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
 def _pipeline_block(frames, with_reference=True):

@@ -6,7 +6,11 @@
     .globl kicp_hsaco_start
     .hidden kicp_hsaco_start
 kicp_hsaco_start:
+#ifdef KICP_DBG_BUILD
+    .incbin "build_dbg/kicp_reg.hsaco"
+#else
     .incbin "build/kicp_reg.hsaco"
+#endif
     .globl kicp_hsaco_end
     .hidden kicp_hsaco_end
 kicp_hsaco_end:

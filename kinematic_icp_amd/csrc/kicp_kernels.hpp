@@ -8,14 +8,13 @@
 //       k_pass_gather32 variant 3 (default): thread (or 2 / 4 sub-lanes) per query; the 16-bit mirror pre-selects (packed
 //                      fp32 arithmetic, integer-key tournament), the winner and anything within the error margin of it
 //                      are resolved in fp64.
-//       k_pass_gather   variant 0: thread-per-query, plain fp64 (baseline of the ablation).
-//                      (Variants 1/2 of round 1 - neighbourhoods staged in LDS per wave, optionally after binning the scan
-//                      by cell - were slower than variant 3 on every BASELINE config and spilled registers; removed.)
+//                      (Removed after losing every A/B: round 1's variants with the neighbourhoods staged in LDS per wave, and - in
+//                      round 6 - the plain fp64 gather that served as the ablation's baseline; k_closest still runs the plain
+//                      fp64 search, search_global, which is also the exact fallback of the mirror search.)
 //   finish_pass : wave / workgroup reduction of the exact sums, then either tagged rows for the host (default: the host
 //                 adds the rows of the first-level groups and solves, Registration.cpp:119-125,159-167,181-184) or the
 //                 full device-side tree whose last workgroup solves on one lane (host_solve = 0) / leaves the totals
 //                 for an all-reduce (RCCL and callback modes).
-//   k_solve     : the solve/update step alone (multi-GPU with device-side solve: runs after the all-reduce).
 //   k_closest   : GetClosestNeighbor for a batch of queries (API parity / tests).
 //
 // Roofline: gather + reduction, ~0.02 flop/B -> memory bound, no MFMA.
@@ -159,8 +158,19 @@ struct PassParams {
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     unsigned long long *group_acc; // resident kernels: the groups' counting accumulators (finish_pass, ROWS_ONLY), zero between passes
     SolveParams sol;
-    int32_t dbg;          // ablation switches for tools/gpu_dbg.py (0 = normal operation)
+    int32_t dbg;          // ablation switches for tools/gpu_dbg.py (0 = normal operation); read by the DBG build only (dbg_is)
 };
+// The ablation / attribution switches (`dbg`, tools/gpu_dbg.py, tools/ab_option.py, bench.py's floor and rounds census) exist in
+// libkicp_amd_dbg.so only (make dbg: -DKICP_DBG_BUILD).  In the production library every test below is a compile-time constant:
+// the pass kernels carry no branch, no scalar load and no register for them (round 6; they cost the issue-bound kernel SALU work).
+#ifdef KICP_DBG_BUILD
+constexpr bool kDbgBuild = true;
+#else
+constexpr bool kDbgBuild = false;
+#endif
+__device__ __forceinline__ bool dbg_is(const PassParams &p, int v) { return kDbgBuild && p.dbg == v; }
+__device__ __forceinline__ bool dbg_not(const PassParams &p, int v) { return !kDbgBuild || p.dbg != v; }
+
 
 // ------------------------------------------------------------------------------------------------------------
 // exact accumulation
@@ -433,57 +443,8 @@ __device__ __forceinline__ void accumulate(Acc &a, const PassBasis &B, double sx
     a.limb[6 * kTermLimbs + 1] = 1 << 19;  // the count: 1.0 = 2^40 = 2^19 * 2^21 (the other limbs stay 0)
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// solve + pose update (Registration.cpp:119-125, 159-167, 181-184), one lane
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void solve_and_update(IcpState *st, const SolveParams &f, const long long limbs[kNumLimbs], int range_error) {
-    double sums[kNumSums];
-#pragma unroll
-    for (int i = 0; i < kNumSums; ++i) sums[i] = limbs_to_double(limbs + 3 * i);
-    HostRecord *rec = f.rec;
-    const double n = sums[6];
-    Pose T = f.pass == 0 ? f.pose0 : st->T;
-    double beta;
-    if (f.pass == 0) {  // ComputeOdometryRegularization at the predicted pose (Registration.cpp:48-60,171-177)
-        beta = f.adaptive ? 1.0 / (sums[5] / n + DBL_MIN) : f.fixed_regularization;
-        st->beta = beta;
-        st->converged = 0, st->nan_flag = 0;
-    } else {
-        beta = st->beta;
-    }
-    double dx0, dx1;
-    solve_perturbation(sums, n, beta, dx0, dx1);
-    T = pose_mul(T, motion_model(dx0, dx1));  // current_estimate * delta_motion (Registration.cpp:181-182)
-    st->T = T;
-    int converged = f.pass == 0 ? 0 : st->converged, nan_flag = f.pass == 0 ? 0 : st->nan_flag;
-    int done = 0;
-    if (sqrt(dx0 * dx0 + dx1 * dx1) < f.convergence_criterion) done = 1, converged = 1;  // Registration.cpp:184
-    if (f.pass + 1 >= f.max_iterations) done = 1;
-    if (!(n > 0.0) || range_error) done = 1, nan_flag = 1 + (range_error ? 1 : 0);  // 0/0: NaN pose from here on, as in the reference
-    st->iter = f.pass + 1, st->converged = converged, st->nan_flag = nan_flag, st->done = done;
-    if (rec) {
-        // The record lives in host memory: every field goes out as a system-scope write-through store, then ONE wait,
-        // then the sequence word (no release fence: that would write back the whole L2 first).
-        auto put_d = [](double *p, double v) {
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        };
-        auto put_i = [](int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-        if (f.pass < kMaxLog) {
-            put_d(&rec->log_ncorr[f.pass], n);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) put_d(&rec->log_sums[f.pass][i], sums[i]);
-            put_d(&rec->log_dx[f.pass][0], dx0), put_d(&rec->log_dx[f.pass][1], dx1);
-        }
-        put_d(&rec->T.qx, T.qx), put_d(&rec->T.qy, T.qy), put_d(&rec->T.qz, T.qz), put_d(&rec->T.qw, T.qw);
-        put_d(&rec->T.tx, T.tx), put_d(&rec->T.ty, T.ty), put_d(&rec->T.tz, T.tz), put_d(&rec->beta, beta);
-        put_i(&rec->done, done), put_i(&rec->iter, f.pass + 1), put_i(&rec->converged, converged), put_i(&rec->nan_flag, nan_flag);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&rec->seq, (f.call_id << 16) | (done ? 0x8000ull : 0ull) | static_cast<unsigned long long>(f.pass + 1),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
+// (The solve + pose update - Registration.cpp:119-125, 159-167, 181-184 - is the host's: kicp_reg.hip HostLoop::step.  The device-side
+//  twin that round 1 to 5 carried - the launch's last workgroup solving on one lane - lost every A/B and went in round 6.)
 // Workgroup epilogue of every pass kernel: exact workgroup sum, then a last-arriver tree.  Default (mode 4): ONE level -
 // the last workgroup of every group of kGroup sends the group's row, tagged, to the host.  Other modes: two levels, the
 // last workgroup of the launch finishes the iteration.  Inter-workgroup traffic follows cdna_hip_programming.md
@@ -542,46 +503,6 @@ __device__ __forceinline__ long long sum_rows_tagged(const unsigned long long *r
         }
     }
     return v + __shfl_down(v, kReduceWords, 64);
-}
-
-// mode 5 (last workgroup of the launch, wave 0; lanes 0..23 hold this rank's totals): all-gather of the totals through the
-// ranks' mailboxes + sum in rank order.  Every word is self-validating (value << 16 | tag), so no ordering between the
-// stores of a slot - which travel over xGMI - is assumed.  Returns the node-wide totals in lanes 0..23; word kNumLimbs + 1
-// (padding in the single-GPU layout) is set to 1 when a peer's slot did not arrive in time.
-__device__ __forceinline__ long long p2p_exchange(const SolveParams &f, long long total, int lane) {
-    const uint32_t nr = static_cast<uint32_t>(f.p2p_nranks), tag = f.p2p_tag;
-    const size_t buf = static_cast<size_t>(f.p2p_parity) * nr * kP2pWords;
-    // lane l < 48 owns half (l & 1) of word (l >> 1)
-    const long long mine = __shfl(total, lane >> 1, 64);
-    const unsigned long long half = (lane & 1) ? (static_cast<unsigned long long>(mine) >> 32) : (static_cast<unsigned long long>(mine) & 0xFFFFFFFFull);
-    long long lo_hi = 0;
-    int late = 0;
-    if (lane < kP2pWords) {
-        const unsigned long long w = (half << 16) | tag;
-        for (uint32_t r = 0; r < nr; ++r)
-            __hip_atomic_store(f.p2p_peers[r] + buf + static_cast<size_t>(f.p2p_rank) * kP2pWords + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long *box = f.p2p_peers[f.p2p_rank] + buf;
-        const long long t0 = wall_clock64();
-        for (uint32_t r = 0; r < nr && !late; ++r) {
-            unsigned long long got;
-            for (;;) {
-                got = __hip_atomic_load(box + static_cast<size_t>(r) * kP2pWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((static_cast<uint32_t>(got) & 0xFFFFu) == tag) break;
-                if (wall_clock64() - t0 > f.p2p_timeout_ticks) {
-                    late = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            lo_hi += static_cast<long long>((got >> 16) & 0xFFFFFFFFull);  // sums of <= 16 32-bit halves: no overflow
-        }
-    }
-    late = __any(late) ? 1 : 0;
-    // word = lo + (hi << 32), carries included (the halves were summed separately)
-    const long long lo = __shfl(lo_hi, 2 * (lane % kReduceWords), 64), hi = __shfl(lo_hi, 2 * (lane % kReduceWords) + 1, 64);
-    long long sum = static_cast<long long>(static_cast<unsigned long long>(lo) + (static_cast<unsigned long long>(hi) << 32));
-    if (lane == kNumLimbs + 1) sum = late;
-    return sum;
 }
 
 // mode 6, the last workgroup of group 0 (wave 0): add every rank's group rows out of this rank's mailbox.  Lanes r < nranks first
@@ -718,7 +639,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
                                             uint32_t parity = 0u) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IcpState *st = p.st;
-    if (!ROWS_ONLY && p.dbg == 8) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
+    if (!ROWS_ONLY && dbg_is(p, 8)) {  // ablation (tools/gpu_dbg.py): no reduction at all, workgroup 0 hands over zeros
         if (p.sol.mode == 4 && wave == 0 && blockIdx.x % kGroup == 0 && lane < kReduceWords)
             __hip_atomic_store(p.sol.pub_rows + static_cast<size_t>(blockIdx.x / kGroup) * kReduceWords + lane, static_cast<unsigned long long>(p.sol.tag),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -733,7 +654,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     // of 21 bits each, and a wave's 64 values of a limb add up in int32.
     int range_error = a.range_error;
     int limb[kWaveLimbs];
-    if (p.dbg == 10 || p.dbg == 12) {  // (10, the census: the count's limbs carry something else; 12: the in-process A/B switch of what follows)
+    if (dbg_is(p, 10) || dbg_is(p, 12)) {  // (10, the census: the count's limbs carry something else; 12: the in-process A/B switch of what follows)
 #pragma unroll
         for (int k = 0; k < kWaveLimbs; ++k) limb[k] = wave_sum_to_lane63(a.limb[k]);
     } else {
@@ -782,7 +703,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             if (range_error) atomicOr(s_flag, 2);
         }
     }
-    if (p.dbg == 10 || p.dbg == 12) {
+    if (dbg_is(p, 10) || dbg_is(p, 12)) {
         range_error = __any(range_error) ? 1 : 0;
         if (lane == 63) {
 #pragma unroll
@@ -803,7 +724,7 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
     const uint32_t nblocks = gridDim.x, b = blockIdx.x, g = b / kGroup, ngroups = (nblocks + kGroup - 1) / kGroup;
     // (an ordinary launch in mode 4 - round 5: the accumulators alternate with the pass tag's parity, the host's row of group g stays
     //  where it was; dbg 14: round 4's rows -> ticket -> reload, for the in-process A/B)
-    const bool counting = ROWS_ONLY || (p.sol.mode == 4 && p.dbg != 14);
+    const bool counting = ROWS_ONLY || (p.sol.mode == 4 && dbg_not(p, 14));
     if (!ROWS_ONLY && counting) parity = row_tag & 1u;
     if (counting) {
         counting_hand_over(t, range_error, gave_up, p, row_tag, parity, ROWS_ONLY ? parity : 0u, lane);
@@ -897,7 +818,6 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
             total += sum_rows(p.partials + (static_cast<size_t>(nblocks) + base) * kReduceWords, min(static_cast<uint32_t>(kGroup), ngroups - base), lane);
     }
     // ---- last workgroup of the launch ------------------------------------------------------------------------
-    if (p.sol.mode == 5) total = p2p_exchange(p.sol, total, lane);
     if (p.sol.mode == 7) {
         // Group rows are what the ranks exchange (mode 6), but this launch has more groups than a rank's share of the mailbox
         // holds: its total travels as ONE row.  A row's words carry 48 bits, so the limb sums are brought back into limb range
@@ -923,17 +843,11 @@ __device__ __forceinline__ void finish_pass(Acc &a, const PassParams &p, int (*s
         total = p2p_collect_rows(f, lane);
     }
     if (lane < kReduceWords) st->reduce[lane] = total;
-    long long limbs[kNumLimbs + 1];
-#pragma unroll
-    for (int i = 0; i <= kNumLimbs; ++i) limbs[i] = __shfl(total, i, 64);
-    if (p.sol.mode == 2 || p.sol.mode == 5 || p.sol.mode == 7) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
+    if (p.sol.mode == 7) {  // hand the totals to the host: write-through stores, one wait, then the sequence word
         if (lane < kReduceWords) __hip_atomic_store(p.sol.pub_words + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(p.sol.pub_seq, p.sol.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
     }
-    if (lane != 0 || p.sol.mode != 0) return;
-    solve_and_update(st, p.sol, limbs, limbs[kNumLimbs] != 0);
 }
 
 // wave-uniform values belong in SGPRs: tell the compiler explicitly
@@ -948,45 +862,10 @@ __device__ __forceinline__ Pose load_pose(const PassParams &p) {
     const Pose T = p.st->T;
     return Pose{uniform_d(T.qx), uniform_d(T.qy), uniform_d(T.qz), uniform_d(T.qw), uniform_d(T.tx), uniform_d(T.ty), uniform_d(T.tz)};
 }
-// the basis of the pose load_pose returned: the host's (kernel arguments: scalar registers) where the pose is the host's
-__device__ __forceinline__ PassBasis load_basis(const PassParams &p, const Pose &T) {
-    if (p.sol.pass == 0 || p.sol.mode >= 2) return p.sol.basis;
-    return basis_of(T);
-}
-
 #define KICP_PASS_SHARED(BLOCK)                       \
     __shared__ int s_red[(BLOCK) / 64][kWaveLimbs];   \
     __shared__ int s_flag;                            \
     if (threadIdx.x == 0) s_flag = 0;
-
-// ------------------------------------------------------------------------------------------------------------
-// variant 0: thread-per-query gather from HBM/L2
-// ------------------------------------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pass_gather(const PassParams p) {
-    KICP_PASS_SHARED(BLOCK)
-    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
-    const Pose T = load_pose(p);
-    const PassBasis B = load_basis(p, T);
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    Acc acc{};
-    if (i < p.n) {
-        const double sx = p.src[3 * i], sy = p.src[3 * i + 1], sz = p.src[3 * i + 2];
-        double rx, ry, rz;
-        quat_rotate(T, sx, sy, sz, rx, ry, rz);
-        Query q;
-        make_query(q, rx + T.tx, ry + T.ty, rz + T.tz, p.map.voxel_size);
-        double best = p.tau * p.tau * (1.0 + 9.1e-13);
-        uint32_t best_idx = 0xFFFFFFFFu;
-        if (p.dbg != 2) search_global(p.map, q, best, best_idx);
-        if (p.dbg == 0 && best_idx != 0xFFFFFFFFu && sqrt(best) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
-            const double *t = p.map.pool + static_cast<size_t>(best_idx) * 3;
-            accumulate(acc, B, sx, sy, q.x, q.y, q.z, t[0], t[1], t[2]);
-        }
-    }
-    if (BLOCK > 64) __syncthreads();
-    finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // variant 3: thread-per-query gather over the 16-bit mirror, per-lane work lists
@@ -1141,10 +1020,10 @@ __device__ __forceinline__ void start_lane(Lane &L, const PassParams &p, const d
     L.q.lz = static_cast<float>((q.z - q.vz * vs) * sp.upm);
     // ONE probe at the own voxel: the occupancy mask of the 27 neighbours (bit s = shift s of the reference's order) and
     // the record of their buckets.  Only voxels that hold points are ever visited; empty space costs nothing.
-    if (valid && p.dbg != 2) table_lookup_entry(p.map, q.vx, q.vy, q.vz, L.q.slot0, L.todo);
-    if (p.dbg == 3) L.todo &= 1u;     // experiments: own voxel only
-    if (p.dbg == 5) L.todo &= 0x7Fu;  // own + faces
-    if (p.dbg == 4) L.todo = 0u;      // probe only, no bucket visit
+    if (valid && dbg_not(p, 2)) table_lookup_entry(p.map, q.vx, q.vy, q.vz, L.q.slot0, L.todo);
+    if (dbg_is(p, 3)) L.todo &= 1u;     // experiments: own voxel only
+    if (dbg_is(p, 5)) L.todo &= 0x7Fu;  // own + faces
+    if (dbg_is(p, 4)) L.todo = 0u;      // probe only, no bucket visit
 }
 // drop the neighbour voxels that cannot hold anything within the margin of `best` (units^2).  A voxel's lower bound is the sum of
 // the squared distances to the faces crossed on the way to it (one term for the six face neighbours, two for the twelve edge
@@ -1317,7 +1196,7 @@ __device__ __forceinline__ const PassParams &args_at_point_of_use() {
 // `host_pose`: T is the host's pose (the kernel arguments carry its basis); otherwise the basis is formed here, from T
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, bool host_pose, const double *__restrict__ src, const Pose &T, uint32_t i,
                                                        const Best3 &t, const KeptQuery *kept = nullptr) {
-    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13 && p.dbg != 14)) return;
+    if (i == kNoIndex32 || t.i1 == kNoIndex32 || (kDbgBuild && p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13 && p.dbg != 14)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
     Query q;
@@ -1328,7 +1207,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
     uint32_t best_idx = kNoIndex32;
     double wx = 0.0, wy = 0.0, wz = 0.0;  // the winner's coordinates, as far as they have passed through registers already
     bool have_winner = false;
-    if (t.b3 - t.b1 <= margin && p.dbg != 9) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
+    if (t.b3 - t.b1 <= margin && dbg_not(p, 9)) {  // three near-equal candidates: leave it to the exact fp64 search (dbg 9: experiment without it)
         // (which needs to look no farther than the pre-selected winner's exact distance)
         if (kept && !kept->voxel) {
             const double vs = m.voxel_size;
@@ -1361,7 +1240,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
         // The basis is taken up HERE - behind an opaque copy of the flag, so that the compiler cannot merge its two sources ahead of
         // the exact phase and carry sixteen registers through it (the four-waves build spilled them) - and, where it is the host's,
         // read from the kernarg segment here rather than at the kernel's start (args_at_point_of_use).
-        if (p.dbg == 13) return;  // (attribution, tools/valu_attribution.sh: the exact phase without the terms)
+        if (dbg_is(p, 13)) return;  // (attribution, tools/valu_attribution.sh: the exact phase without the terms)
         int from_args = __builtin_amdgcn_readfirstlane(host_pose ? 1 : 0);
         asm volatile("; the basis is taken up here" : "+s"(from_args));
         PassBasis B;
@@ -1397,7 +1276,7 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
     const uint32_t gt = block * BLOCK + tid;  // (`block`: which BLOCK points of the scan this workgroup takes - blockIdx.x, or a resident kernel's turn)
     const uint32_t i = gt / G;
     const int sub = static_cast<int>(gt % G);
-    const bool valid = i < n && p.dbg != 7 && p.dbg != 8;
+    const bool valid = i < n && dbg_not(p, 7) && dbg_not(p, 8);
     Lane L;
     KeptQuery kept;
     static_assert(!(LAT && PARK), "the latency-oriented build keeps the query in registers");
@@ -1430,7 +1309,7 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
                 L.todo &= L.todo - 1u;  // (0 stays 0; a second voxel that the first one's result rules out is dropped here - cull_todo would)
                 visit_two(L.q, L.t, m, s1, s2, has2, has2 ? voxel_lower_bound(L.q, s2, margin) : 0.f, margin);
             }
-        } else if (G == 1 && lend != nullptr && p.dbg != 11) {  // (dbg 11: the in-process A/B switch of this, tools/ab_option.py)
+        } else if (G == 1 && lend != nullptr && dbg_not(p, 11)) {  // (dbg 11: the in-process A/B switch of this, tools/ab_option.py)
             // One lane per query, one neighbour voxel per round - and every round costs the WAVE its ~430 instructions however few
             // lanes still have a voxel to see (cfg2: 100 % of the lanes in round 1, 42 % in round 2, 7 % in round 3, 5 % in round 4;
             // 3.0 rounds per wave).  So from the second round on, lanes with nothing to do take over voxels of the queries that
@@ -1526,7 +1405,7 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
     }
     // dbg 10 (bench.py's latency model): no correspondences are formed; the "count" sum carries the number of visiting rounds
     // this WAVE ran - its chain of dependent bucket visits - from lane 0 (as rounds x 2^40: limb 1 holds bits 21..41, limb 2 the rest)
-    if (p.dbg == 10 && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
+    if (dbg_is(p, 10) && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
 }
 template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
@@ -1536,7 +1415,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     constexpr bool kLends = G == 1 && !SPLIT && !LAT;  // idle lanes take over voxels of loaded queries (gather32_pass)
     __shared__ int s_lend[kLends ? BLOCK / 64 : 1][kLendWords];
     __shared__ double s_park[kLends ? BLOCK * kParkWords : 1];
-    if (p.sol.mode < 2 && p.sol.pass != 0 && p.st->done) return;
     const Pose T = load_pose(p);
     const bool host_pose = p.sol.pass == 0 || p.sol.mode >= 2;  // (load_pose)
     Acc acc{};
@@ -1544,18 +1422,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
                                                 s_park);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// solve step alone: multi-GPU (after the all-reduce of st->reduce)
-// ------------------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(64) void k_solve(IcpState *st, const SolveParams f) {
-    if (threadIdx.x != 0) return;
-    if (f.pass != 0 && st->done) return;
-    long long limbs[kNumLimbs];
-#pragma unroll
-    for (int i = 0; i < kNumLimbs; ++i) limbs[i] = st->reduce[i];
-    solve_and_update(st, f, limbs, st->reduce[kNumLimbs] != 0);
 }
 
 // multi-GPU with host-side solve: hand the all-reduced limb totals to the host

@@ -95,7 +95,6 @@ struct kicp_reg {
     unsigned long long *rows = nullptr, *d_rows = nullptr;  // host / device view
     size_t rows_groups = 0;
     uint32_t tag = 0;       // tag of the last pass (1..65535)
-    int group_rows = 1;     // option "group_rows": 1 = mode 4 (default), 0 = the device folds everything (mode 2)
     double *d_frame = nullptr;  // device copy of host frames
     size_t frame_cap = 0;
     HostStage stage;            // pinned staging for transfers from / to caller memory
@@ -105,19 +104,12 @@ struct kicp_reg {
     int fetch_frames = 1;         // option "fetch_upload": larger host frames are pulled by the GPU out of the staging buffer piece by piece (1) | DMA engine (0)
     bool bar_frame_tried = false;
     // options
-    int pass_kernel = 3;  // 3 fp32-mirror gather (default), 0 fp64 gather
-    int block = 256;      // workgroup size of variants 0/3 (64 | 128 | 256)
-    int loop_mode = 1;    // 0 enqueue every iteration up front; 1 stepped: keep one iteration queued ahead, poll the stop flag
     int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
     int dbg = 0;
     int query_every = 512; // polls between hipStreamQuery calls while waiting (a call costs ~1 us of host time)
-    int speculate = 0;     // stepped loop: queue iteration it+1 before the stop flag of it is known (adapts to the last scan)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
-    int occupancy = 4;        // variant 3: waves per SIMD the kernel is compiled for (4 default | 3)
     int latency_kernel = 1;   // variant 3, one lane per query: the two-voxels-per-round build (0 never | 1 scans <= kLatencyMaxPoints | 2 always)
-    int split_buckets = 1;    // variant 3 with two sub-lanes per query: the pair shares every bucket (1 default) | deals the voxels (0)
-    int host_solve = 1;    // 1: the pass kernel publishes the limb totals and the host solves (default); 0: device-side solve
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -184,13 +176,7 @@ struct kicp_reg {
     unsigned long long batch_queue_passes = 0;  // passes served that way so far (get-only "batch_queue_passes")
     int batch_rotate = 1;         // option "batch_rotate": the workgroups of that kernel take turns at the parts of a scan (k_pass_resident)
     int batch_depth = 3;          // option "batch_depth": scans of a batch in flight at a time in that mode (run_batch_resident)
-    int resident_four = 0;        // run_batch_resident on generic scans: the four-waves-per-SIMD build of the resident kernel (set per call by
-                                  // run_batch_resident_threads: two such kernels of <= 512 workgroups fill the device; the latency build holds one)
     int last_batch_threads = 0;   // resident kernels (= host threads) the last batch call ran side by side (get-only "batch_threads_active"; 0: not that path)
-    int shard_threads = 0;        // option "shard_threads": SHARDED batches (the shared segment attached) on up to this many resident kernels side by side
-                                  // per rank (run_batch_resident_threads); 0 / 1 (default): the queues
-    int batch_threads_large = 0;  // option "batch_threads_large": 1 = scans too large for three kernels of the latency build take resident kernels
-                                  // of the four-waves build side by side instead of the queues (experiment until measured)
     int batch_threads = 8;        // option "batch_threads": batches of scans that leave most of the device empty: up to this many resident kernels at a
                                   // time - as many as fit the device side by side -, each serving a contiguous part of the batch from a host thread
                                   // of its own (run_batch_resident_threads); < 2: one kernel, the caller's thread
@@ -224,11 +210,7 @@ struct Deadline {
     bool passed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_s(); }
 };
 
-template <int BLOCK>
-void launch_gather(const PassParams &p, uint32_t grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_pass_gather<BLOCK>, dim3(grid), dim3(BLOCK), 0, s, p);
-}
-int normalized_block(int b) { return (b == 64 || b == 256 || b == 512) ? b : 128; }
+constexpr int kPassBlock = 256;  // workgroup size of every build of the generic pass kernel
 // Sub-lanes per query of variant 3.  Small scans are latency bound (few waves, each lane's chain of dependent bucket
 // visits decides the kernel time): spreading a query's neighbour voxels over 2-4 lanes shortens that chain.  Large
 // scans already fill the machine and only pay for the extra waves.
@@ -237,15 +219,9 @@ int lanes_for(const kicp_reg *r, size_t n) {
     if (r->lanes_per_query > 0) return r->lanes_per_query;
     return n <= 4096 ? 4 : (n <= 32768 ? 2 : 1);
 }
-// 512-thread workgroups exist for variant 3 with one lane per query only (large scans: one workgroup per CU); elsewhere 256
-int effective_block(const kicp_reg *r, size_t n) {
-    const int b = normalized_block(r->block);
-    return (b == 512 && !(r->pass_kernel == 3 && lanes_for(r, n) == 1)) ? 256 : b;
-}
 uint32_t pass_grid(const kicp_reg *r, size_t n) {
-    const int block = effective_block(r, n);
-    const size_t threads = r->pass_kernel == 3 ? n * static_cast<size_t>(lanes_for(r, n)) : n;
-    return static_cast<uint32_t>(std::max<size_t>(1, (threads + block - 1) / block));
+    const size_t threads = n * static_cast<size_t>(lanes_for(r, n));
+    return static_cast<uint32_t>(std::max<size_t>(1, (threads + kPassBlock - 1) / kPassBlock));
 }
 // AQL kernel objects, looked up once per template instantiation by DEMANGLED name (kicp_aql.hpp), or nullptr
 bool aql_up(kicp_reg *r) {
@@ -274,7 +250,7 @@ const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split, 
     return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0) + (lat ? 2 : 0), name);
 }
 const AqlKernel *aql_resident_kernel_for(kicp_reg *r, bool lat) {
-    return lat ? aql_lookup(r, -7, "void kicp::k_pass_resident<256, 2, true>(") : aql_lookup(r, -8, "void kicp::k_pass_resident<256, 4, false>(");
+    return lat ? aql_lookup(r, -7, "void kicp::k_pass_resident<256, 2, true>(") : nullptr;  // (the resident generic kernel exists as the latency-oriented build only)
 }
 const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
@@ -295,71 +271,45 @@ int aql_quiesce(kicp_reg *r) {
     return fail(KICP_ERR_HIP, "the AQL queue did not drain (KICP_WAIT_TIMEOUT_S)");
 }
 // allow_aql: nothing on the handle's HIP stream has to be ordered behind this kernel and the host will poll for the result
+// The generic pass kernel comes in four builds, all of 256-thread workgroups (round 6: the 64 / 128 / 512-thread workgroups, the
+// three-waves register budget, the voxel-dealing pair of sub-lanes and the plain fp64 gather never won an A/B and are gone):
+//   one lane per query, two waves per SIMD, two neighbour voxels per round (LAT)   scans of up to 131 072 points, one call at a time
+//   one lane per query, four waves per SIMD                                        larger scans; several scans in flight
+//   two lanes per query sharing every bucket / four lanes per query               scans of up to 32 768 / 4 096 points
 int launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
     const uint32_t grid = pass_grid(r, p.n);
-    if (r->pass_kernel == 3) {
-        const int b = effective_block(r, p.n), g = lanes_for(r, p.n);
-        // register budget: 4 waves per SIMD (<= 128 VGPRs) by default; the roomier 3-wave build (155 VGPRs, nothing recomputed)
-        // measured no faster on any BASELINE scan (the kernel is VALU-issue bound), it stays selectable for experiments
-        // the latency-oriented build (two neighbour voxels per round, two waves per SIMD): scans of one lane per query that
-        // leave the machine at most two waves per SIMD anyway
-        const bool lat = g == 1 && b != 512 && (r->latency_kernel == 2 || (r->latency_kernel == 1 && p.n <= kLatencyMaxPoints));
-        const int occ = lat ? 2 : ((r->occupancy == 3 && b != 512) ? 3 : 4);
-        const bool split = g == 2 && r->split_buckets;
-        // While HIP work may be pending on the handle's stream (a frame upload, a mirror refresh, a clear) the kernel goes
-        // through the stream, ordered behind it; once the host has that pass's result the stream is known to be idle.
-        if (allow_aql && r->use_aql && !r->stream_dirty) {
-            if (const AqlKernel *k = aql_kernel_for(r, b, g, occ, split, lat)) {
-                // Fences of the packet.  Acquire: agent scope - the kernel start invalidates the vector / scalar L1s and the
-                // XCDs' L2 lines of device memory, so everything earlier kernels released and every DMA the host has waited
-                // for is seen; it is what makes a kernarg slot re-read from host memory, too (no acquire: stale arguments).
-                // System scope costs 3.4 us more per dispatch on this part (measured: 25.9 vs 22.6 us per cfg2 scan).
-                // (Dropping the acquire for the later passes of a call - same frame, same map - was measured too: no gain.)
-                // Release: agent scope; the results leave through system-scope stores into host-mapped memory, and
-                // AqlDispatcher::drain() puts a system-scope release behind the kernels before HIP work follows them.
-                if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &p, sizeof p, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
-                    r->last_via_aql = true;
-                    return KICP_OK;
-                }
+    const int g = lanes_for(r, p.n);
+    // the latency-oriented build (two neighbour voxels per round, two waves per SIMD): scans of one lane per query that
+    // leave the machine at most two waves per SIMD anyway
+    const bool lat = g == 1 && (r->latency_kernel == 2 || (r->latency_kernel == 1 && p.n <= kLatencyMaxPoints));
+    const int occ = lat ? 2 : 4;
+    const bool split = g == 2;
+    // While HIP work may be pending on the handle's stream (a frame upload, a mirror refresh, a clear) the kernel goes
+    // through the stream, ordered behind it; once the host has that pass's result the stream is known to be idle.
+    if (allow_aql && r->use_aql && !r->stream_dirty) {
+        if (const AqlKernel *k = aql_kernel_for(r, kPassBlock, g, occ, split, lat)) {
+            // Fences of the packet.  Acquire: agent scope - the kernel start invalidates the vector / scalar L1s and the
+            // XCDs' L2 lines of device memory, so everything earlier kernels released and every DMA the host has waited
+            // for is seen; it is what makes a kernarg slot re-read from host memory, too (no acquire: stale arguments).
+            // System scope costs 3.4 us more per dispatch on this part (measured: 25.9 vs 22.6 us per cfg2 scan).
+            // (Dropping the acquire for the later passes of a call - same frame, same map - was measured too: no gain.)
+            // Release: agent scope; the results leave through system-scope stores into host-mapped memory, and
+            // AqlDispatcher::drain() puts a system-scope release behind the kernels before HIP work follows them.
+            if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(kPassBlock), &p, sizeof p, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
+                r->last_via_aql = true;
+                return KICP_OK;
             }
         }
-        if (allow_aql) r->stream_dirty = false;  // the host waits for this pass: by then everything queued before it is done
-        if (int rc = aql_quiesce(r)) return rc;  // kernels dispatched through the AQL queue come first
-        r->last_via_aql = false;
-#define KICP_G32(B, G, SPLIT)                                                                                     \
-    do {                                                                                                          \
-        if (occ == 3) hipLaunchKernelGGL((k_pass_gather32<B, G, 3, SPLIT>), dim3(grid), dim3(B), 0, r->stream, p); \
-        else hipLaunchKernelGGL((k_pass_gather32<B, G, 4, SPLIT>), dim3(grid), dim3(B), 0, r->stream, p);          \
-    } while (0)
-#define KICP_G32_BLOCKS(G, SPLIT)                   \
-    do {                                            \
-        if (b == 64) KICP_G32(64, G, SPLIT);        \
-        else if (b == 256) KICP_G32(256, G, SPLIT); \
-        else KICP_G32(128, G, SPLIT);               \
-    } while (0)
-        if (lat) {
-            if (b == 64) hipLaunchKernelGGL((k_pass_gather32<64, 1, 2, false, true>), dim3(grid), dim3(64), 0, r->stream, p);
-            else if (b == 256) hipLaunchKernelGGL((k_pass_gather32<256, 1, 2, false, true>), dim3(grid), dim3(256), 0, r->stream, p);
-            else hipLaunchKernelGGL((k_pass_gather32<128, 1, 2, false, true>), dim3(grid), dim3(128), 0, r->stream, p);
-        } else if (g == 1 && b == 512) hipLaunchKernelGGL((k_pass_gather32<512, 1, 4, false>), dim3(grid), dim3(512), 0, r->stream, p);  // experiment: one workgroup per CU
-        else if (g == 1) KICP_G32_BLOCKS(1, false);
-        else if (split) KICP_G32_BLOCKS(2, true);
-        else if (g == 2) KICP_G32_BLOCKS(2, false);
-        else KICP_G32_BLOCKS(4, false);
-#undef KICP_G32_BLOCKS
-#undef KICP_G32
-        return KICP_OK;
     }
-    if (int rc = aql_quiesce(r)) return rc;
+    if (allow_aql) r->stream_dirty = false;  // the host waits for this pass: by then everything queued before it is done
+    if (int rc = aql_quiesce(r)) return rc;  // kernels dispatched through the AQL queue come first
     r->last_via_aql = false;
-    switch (effective_block(r, p.n)) {
-        case 64: launch_gather<64>(p, grid, r->stream); break;
-        case 256: launch_gather<256>(p, grid, r->stream); break;
-        default: launch_gather<128>(p, grid, r->stream); break;
-    }
+    if (lat) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 1, 2, false, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+    else if (g == 1) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 1, 4, false>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+    else if (g == 2) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 2, 4, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+    else hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 4, 4, false>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
     return KICP_OK;
 }
-
 int ensure_partials(kicp_reg *r, size_t blocks) {
     if (blocks <= r->partial_blocks) return KICP_OK;
     if (int rc = aql_quiesce(r)) return rc;
@@ -627,7 +577,7 @@ SmallPlan small_plan(const kicp_reg *r, size_t n) {
     // (the latency-oriented build only: with 235 VGPRs it keeps everything in registers across the pass loop, the four-waves-per-
     // SIMD build does not; two workgroups per CU)
     pl.lat = r->latency_kernel != 0;
-    if (!pl.lat || !r->resident_generic || r->lanes_per_query > 1 || normalized_block(r->block) != 256 || r->occupancy != 4 ||
+    if (!pl.lat || !r->resident_generic || r->lanes_per_query > 1 || 
         n > kLatencyMaxPoints * static_cast<size_t>(std::max(1, r->num_cus)) / 256)
         return pl;  // (explicit kernel-shape options keep the plain kernel they name)
     pl.generic = true, pl.g = 1, pl.block = 256;
@@ -710,7 +660,7 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
         else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
     } while (0)
     if (pl.generic && pl.lat) hipLaunchKernelGGL((k_pass_resident<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
-    else if (pl.generic) hipLaunchKernelGGL((k_pass_resident<256, 4, false>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else if (pl.generic) return fail(KICP_ERR_ARG, "the resident generic kernel exists as the latency-oriented build only");
     else if (b == 1024) KICP_SMALL(1024);
     else if (b == 512) KICP_SMALL(512);
     else KICP_SMALL(256);
@@ -970,19 +920,19 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
     const bool p2p = r->d_p2p_table != nullptr;
-    // (the single-record hand-offs - device-side solve, group_rows = 0, the device collectives - count iterations in 15 bits of
-    // their sequence word; the default tagged-row hand-offs and the small-scan path have no such limit)
-    if (max_it > 0x7FFF && (!r->host_solve || r->group_rows == 0 || multi || p2p))
-        return fail(KICP_ERR_ARG, "max_num_iterations > 32767 with a single-record hand-off (host_solve = 0, group_rows = 0, RCCL / callback / peer-mailbox exchange)");
+    // (the single-record hand-offs - the device collectives and the peer mailboxes - count iterations in 15 bits of their sequence
+    // word; the default tagged-row hand-offs and the small-scan path have no such limit)
+    if (max_it > 0x7FFF && (multi || p2p))
+        return fail(KICP_ERR_ARG, "max_num_iterations > 32767 with a single-record hand-off (RCCL / callback / peer-mailbox exchange)");
     r->last_small = 0, r->last_resident_passes = 0;
-    if (r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 14)) {
+    if (r->use_small && !shm && !multi && !p2p && r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 14)) {
         const SmallPlan pl = small_plan(r, n);
         if (pl.grid) return run_small(r, map, d_frame, n, pl, T0, tau, out_pose_qt, stats);
     }
     if (int rc = ensure_partials(r, pass_grid(r, n))) return rc;
     if (int rc = clear_stale_tickets(r)) return rc;
-    if (shm && !r->host_solve) return fail(KICP_ERR_ARG, "the shared-segment mode needs host_solve = 1");
-    if (p2p && (!r->host_solve || multi || shm)) return fail(KICP_ERR_ARG, "the peer-mailbox mode needs host_solve = 1 and no other exchange attached");
+    if (p2p && (multi || shm)) return fail(KICP_ERR_ARG, "the peer-mailbox mode needs no other exchange attached");
+    if (shm && multi) return fail(KICP_ERR_ARG, "the shared-segment mode needs no other exchange attached");
     if (p2p && r->p2p_poisoned)
         return fail(KICP_ERR_COMM, "the peer-mailbox exchange is out of step after an earlier failure: kicp_reg_p2p_destroy, _export and _connect again on every rank");
     const unsigned long long call_id = ++r->call_id;
@@ -1001,21 +951,11 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     const bool pass_events = r->timing == 2;
     if (pass_events && !r->evp[0])
         for (auto &e : r->evp) HIP_TRY(hipEventCreate(&e));
-    auto enqueue_iteration = [&](int it) -> int {
-        sp.pass = it;
-        const bool ev = pass_events && it < KICP_MAX_LOG_PASSES;
-        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it], r->stream));
-        if (int rc = launch_pass(r, pp)) return rc;
-        if (ev) HIP_TRY(hipEventRecord(r->evp[2 * it + 1], r->stream));
-        if (multi) {
-            if (int rc = enqueue_allreduce(r)) return rc;
-            hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, r->stream, r->d_state, sp);
-        }
-        return KICP_OK;
-    };
     unsigned long long seq = 0;
-    if (r->host_solve) {
-        // ---- host-side solve: one launch per iteration, the pose travels as a kernel argument ----------------------
+    {
+        // ---- one launch per iteration, the pose travels as a kernel argument, the host solves (Registration.cpp:119-125,159-167,
+        //      181-184).  (Round 6: the device-side solve - last workgroup of the launch, stepped or queued up front - is gone: it
+        //      lost every A/B since round 2 and no exchange needs it.)
         HostRecord *rec = r->rec;
         HostLoop loop;
         loop.T = T0;
@@ -1023,13 +963,13 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         for (int it = 0; it < max_it; ++it) {
             const RoctxScope pass_span("icp pass: launch -> rows -> solve");
             ++passes_run;
-            const bool rows_mode = !multi && !p2p && r->group_rows != 0;
+            const bool rows_mode = !multi && !p2p;
             const size_t groups = (pass_grid(r, n) + kGroup - 1) / kGroup;
             // peer mailboxes: the groups' rows travel themselves when the launch has few enough of them (one reduction level less)
             // (every rank must use the same wire format - option "p2p_rows" - but may be on either side of the group limit)
             const bool p2p_rows = p2p && r->p2p_rows == 1 && groups <= static_cast<size_t>(kP2pMaxGroups);  // (2: always the single row - tests)
             set_pose(sp, loop.T);
-            sp.pass = it, sp.mode = multi ? 3 : (p2p ? (p2p_rows ? 6 : (r->p2p_rows ? 7 : 5)) : (rows_mode ? 4 : 2));
+            sp.pass = it, sp.mode = multi ? 3 : (p2p ? (p2p_rows ? 6 : 7) : 4);
             if (p2p) {  // every rank issues the same sequence of exchanges: the step number doubles as tag and buffer parity
                 const unsigned long long step = r->p2p_step++;
                 sp.p2p_peers = r->d_p2p_table, sp.p2p_nranks = r->nranks, sp.p2p_rank = r->rank;
@@ -1043,11 +983,6 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
                 const unsigned long long step = r->shm_step++;
                 mine_host = r->shm + (step & 1) * r->nranks + r->rank;
                 sp.pub_value = shm_value = step + 1;
-                if (!rows_mode) {  // the GPU writes the slot itself
-                    if (!r->d_shm) return fail(KICP_ERR_HIP, "the shared segment has no device view (hipHostRegister failed): keep group_rows = 1");
-                    kicp_reg::ShmSlot *mine = r->d_shm + (step & 1) * r->nranks + r->rank;
-                    sp.pub_words = mine->words, sp.pub_seq = &mine->seq;
-                }
             } else {
                 sp.pub_words = r->d_rec->words, sp.pub_seq = &r->d_rec->seq;
                 sp.pub_value = (call_id << 16) | static_cast<unsigned long long>(it + 1);
@@ -1081,8 +1016,6 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
                     __atomic_store_n(&mine_host->seq, shm_value, __ATOMIC_RELEASE);
                     if (int rc = wait_shm(r, shm_value, words)) return rc;
                 }
-            } else if (shm) {
-                if (int rc = wait_shm(r, sp.pub_value, words)) return rc;
             } else {
                 if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
                 for (int i = 0; i < kReduceWords; ++i) words[i] = rec->words[i];
@@ -1109,56 +1042,6 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
         if (loop.nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
         return loop.nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
     }
-    if (r->loop_mode == 0) {
-        for (int it = 0; it < max_it; ++it)
-            if (int rc = enqueue_iteration(it)) return rc;
-        HIP_TRY(hipGetLastError());
-        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
-        if (int rc = wait_record(r, call_id, 0, true, &seq)) return rc;
-    } else {
-        // stepped: the host polls the stop flag after every iteration.  When the previous scan needed more than one
-        // iteration, iteration it+1 is queued before the flag of iteration it is known, so the GPU never idles on the
-        // host (at most one queued iteration turns out to be unnecessary and exits at once); when scans converge in
-        // one iteration - the usual case with good wheel odometry - nothing is queued speculatively.
-        int queued = 0;
-        if (int rc = enqueue_iteration(queued++)) return rc;
-        for (int it = 0;; ++it) {
-            if (r->speculate && queued < max_it && queued == it + 1)
-                if (int rc = enqueue_iteration(queued++)) return rc;
-            if (int rc = wait_record(r, call_id, static_cast<unsigned>(it + 1), false, &seq)) return rc;
-            if (seq & 0x8000ull) break;
-            if (queued == it + 1)
-                if (int rc = enqueue_iteration(queued++)) return rc;
-        }
-        r->speculate = (seq & 0x7FFFull) > 1 ? 1 : 0;
-        HIP_TRY(hipGetLastError());
-        if (r->timing) HIP_TRY(hipEventRecord(r->ev1, r->stream));
-    }
-    const HostRecord *rec = r->rec;  // stable: after `done` no kernel writes the record again
-    pose_to(rec->T, out_pose_qt);
-    if (stats) {
-        // (a NaN pose: the reference runs on to max_num_iterations with empty associations - accounted for, not run)
-        stats->iterations = rec->nan_flag ? max_it : rec->iter, stats->converged = rec->converged, stats->beta = rec->beta;
-        for (int j = rec->iter; rec->nan_flag && j < max_it && j < KICP_MAX_LOG_PASSES; ++j) stats->dx[j][0] = stats->dx[j][1] = std::nan("");
-        const int k = rec->iter < KICP_MAX_LOG_PASSES ? rec->iter : KICP_MAX_LOG_PASSES;
-        for (int i = 0; i < k; ++i) {
-            stats->n_corr[i] = rec->log_ncorr[i];
-            for (int j = 0; j < 6; ++j) stats->sums[i][j] = rec->log_sums[i][j];
-            stats->dx[i][0] = rec->log_dx[i][0], stats->dx[i][1] = rec->log_dx[i][1];
-        }
-        if (r->timing) {
-            float ms = 0.f;
-            HIP_TRY(hipEventSynchronize(r->ev1));
-            HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
-            stats->gpu_ms = ms;
-            for (int i = 0; pass_events && i < k; ++i) {
-                HIP_TRY(hipEventElapsedTime(&ms, r->evp[2 * i], r->evp[2 * i + 1]));
-                stats->pass_ms[i] = ms;
-            }
-        }
-    }
-    if (rec->nan_flag == 2) return fail(KICP_ERR_CAPACITY, "a per-point term exceeded the exact-accumulation range (|x| >= 2^43)");
-    return rec->nan_flag ? KICP_WARN_NO_CORRESPONDENCES : KICP_OK;
 }
 
 // Peer-mailbox mode: the ranks stay in step only while every exchange completes on every rank (tags and buffer parity are
@@ -1184,14 +1067,6 @@ int run_registration(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n
 // completed from the front.  On a give-up of the kernel (a workgroup that saw no command in time) the scans in hand and the rest
 // are left to the plain loop, too.
 constexpr uint32_t kBatchMaxPasses = 1024;  // passes (= tags) one launch may serve
-// A SHARDED batch on resident kernels (run_batch_resident_threads with the shared segment attached): the kernel of part t registers
-// this rank's shards of the part's scans, and every pass's rows are completed by the other ranks' through lane t of the owner's
-// segment before the solve - every rank runs the same parts in the same order, so lane t's hand-offs line up.
-struct ShardCtx {
-    kicp_reg *owner;      // the handle the segment is attached to (the batch call's)
-    int lane;             // its area of the segment, and its hand-off counter
-    size_t n_max;         // the largest shard of any scan of the batch on ANY rank (agreed through the segment: the launch's shape)
-};
 // one hand-off on lane `lane` of o's segment: this rank's words go out, every rank's come back - summed into `sum`, and (per_rank != nullptr)
 // one by one; blocking, bounded by KICP_WAIT_TIMEOUT_S
 int shm_lane_exchange(kicp_reg *o, int lane, const long long *mine, long long *sum, long long *per_rank = nullptr) {  // per_rank: [nranks][kReduceWords]
@@ -1214,30 +1089,24 @@ int shm_lane_exchange(kicp_reg *o, int lane, const long long *mine, long long *s
 }
 int depth_of(const kicp_reg *r) { return std::min<int>(std::max(r->batch_depth, 1), static_cast<int>(kPipeSlots)); }
 int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
-                       const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst, const ShardCtx *shard = nullptr) {
+                       const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, size_t *done, int *worst) {
     *done = 0;
     const int max_it = r->cfg.max_num_iterations;
     // (a batch call in this mode costs ~8 us of its own - the table, the kernel's leaving, the queue drained before the next call -
     //  against ~2.2 us saved per scan: from eight scans on it pays; measured in-process, cfg2 and cfg4, batches of 2 / 4 / 16 / 256)
     constexpr size_t kBatchResidentMinScans = 8;
     if (!r->batch_resident || !r->resident_generic || count < kBatchResidentMinScans || count > kCmdMaxScans || max_it <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->use_small && r->pass_kernel == 3 && r->host_solve && r->group_rows && (!r->shm || shard) && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
+    if (!(r->use_small && !r->shm && !r->comm && !r->allreduce_fn && !r->d_p2p_table &&
           r->timing == 0 && r->wait_mode == 0 && (r->dbg == 0 || (r->dbg >= 2 && r->dbg <= 5) || r->dbg == 9 || r->dbg == 14) && r->small_resident != 0))
         return 1;
     // one kind of kernel serves the whole batch: the generic one (scans beyond the small-scan kernels, up to what the device holds at
     // once) or one wave per query (scans of up to kWaveMaxPoints points); anything else - or a mix - takes the plain loop
     size_t n_max = 0, n_min = ~size_t(0);
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
-    SmallPlan pl;
-    if (shard) {  // shards: the generic kernel whatever their size (empty ones included), one launch shape on every rank
-        n_max = std::max<size_t>(shard->n_max, 1);
-        pl.generic = true;
-    } else {
-        if (n_min == 0) return 1;
-        pl = small_plan(r, n_max);
-        const SmallPlan pl_min = small_plan(r, n_min);
-        if (!(pl.generic && pl_min.generic) && !(pl.wave && pl_min.wave && pl.grid)) return 1;
-    }
+    if (n_min == 0) return 1;
+    SmallPlan pl = small_plan(r, n_max);
+    const SmallPlan pl_min = small_plan(r, n_min);
+    if (!(pl.generic && pl_min.generic) && !(pl.wave && pl_min.wave && pl.grid)) return 1;
     if (int rc = set_device(r->device)) return rc;
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
@@ -1282,7 +1151,7 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         HIP_TRY(hipStreamSynchronize(r->stream));  // (`table` is pageable and about to go out of scope)
         r->stream_dirty = false;
     }
-    if (!wave) pl.generic = true, pl.lat = !r->resident_four, pl.g = 1, pl.block = 256, pl.grid = grid;
+    if (!wave) pl.generic = true, pl.lat = true, pl.g = 1, pl.block = 256, pl.grid = grid;
     SmallParams sp{};
     PassParams &pp = sp.p;
     pp.src = n[0] ? d_frames[0] : reinterpret_cast<const double *>(r->d_state), pp.n = static_cast<uint32_t>(n[0]), pp.map = map->mirror.view, pp.tau = tau, pp.st = r->d_state;
@@ -1292,8 +1161,6 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
     pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     sp.cmd = r->d_cmd, sp.rows = r->d_rows, sp.cmd_dev = r->d_cmd_copies, sp.relay = (r->small_cmd == 1 && r->cmd_bar) ? 0 : 1;
     sp.timeout_ticks = static_cast<long long>(std::max(50.0, r->small_timeout_us) * 100.0);
-    // (sharded: a command may wait for the slowest PEER's rows - a workgroup that gave up would take this rank out of step with the others)
-    if (shard) sp.timeout_ticks = std::max<long long>(sp.timeout_ticks, 200000000ll);
     sp.scans = r->d_scans;
     sp.group_rows = grouped ? 1 : 0;
     // (the workgroups' shares of a scan move on by about 0.38 of the grid per pass - far from where they were, and back only after many passes)
@@ -1400,16 +1267,9 @@ int run_batch_resident(kicp_reg *r, kicp_map *map, size_t count, const double *c
         if (grouped) gave_up = (static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull, words[kNumLimbs] &= 0xFFll;
         if (gave_up) {  // (part of) the kernel has left: the scans in hand and the rest go through the plain loop
             ++r->small_relaunches;
-            if (shard) return leave(fail(KICP_ERR_COMM, "a resident kernel of a sharded batch gave up waiting for its command: the ranks are out of step"));
             return leave(KICP_OK);
         }
         ++r->batch_resident_passes;
-        if (shard) {  // this rank's sums of the pass + every other rank's = the scan's
-            long long total[kReduceWords];
-            if (int rc = shm_lane_exchange(shard->owner, shard->lane, words, total)) return leave(rc);
-            for (int i = 0; i < kReduceWords; ++i) words[i] = total[i];
-            words[kNumLimbs] = words[kNumLimbs] != 0 ? 1 : 0;
-        }
         if (!f.loop.step(r, words, &f.st)) continue;
         pose_to(f.loop.T, out_poses_qt + 7 * f.k);
         if (out_iterations) out_iterations[f.k] = f.loop.iter;
@@ -1570,7 +1430,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     // none of them looks at the shard sizes, which differ.
     const bool sharded = r->shm != nullptr;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
+    if (!(r->use_aql && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
           r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12 || r->dbg == 14)))
         return 1;
     if (sharded && r->shm_poisoned)
@@ -1599,7 +1459,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     BatchFlight flights[kMaxBatchQueues];
     for (int j = 0; j < queues; ++j) {
         kicp_reg *h = r->batch_lanes[j];
-        h->cfg = r->cfg, h->block = r->block, h->lanes_per_query = r->lanes_per_query, h->occupancy = r->occupancy, h->split_buckets = r->split_buckets;
+        h->cfg = r->cfg, h->lanes_per_query = r->lanes_per_query;
         h->query_every = r->query_every, h->dbg = r->dbg, h->latency_kernel = 0, h->small_resident = 0, h->batch_queues = 0;
         h->small_group_rows = r->small_group_rows;
         h->use_small = sharded ? 0 : r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
@@ -1809,76 +1669,30 @@ constexpr size_t kThreadsMaxGenericPoints = 24576;  // (five and more such kerne
 int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
                                const double *rel_odoms_qt, double tau, double *out_poses_qt, int *out_iterations, int *worst) {
     constexpr size_t kMinScansPerThread = 16;
-    // (every part's host thread spins on its kernel's rows: no more parts than CPUs this process may keep busy, one left for the rest;
-    //  a sharded batch applies that cap only once the ranks have exchanged theirs: until then every decision must be the same everywhere)
-    const int cpu_cap = std::max(1, host_cpu_budget() - 1);
-    int threads = std::min(r->batch_threads, kMaxBatchQueues + 1);
-    if (!r->shm) threads = std::min(threads, cpu_cap);
+    // (sharded batches - the shared segment attached - go through the queues: resident kernels that wait for their PEERS' rows as well as
+    //  for their host stalled intermittently with several ranks on one device; the option that enabled them is gone, round 6)
+    if (r->shm) return 1;
+    // every part's host thread spins on its kernel's rows: no more parts than CPUs this process may keep busy, one left for the rest
+    const int threads_cap = std::max(1, host_cpu_budget() - 1);
+    int threads = std::min({r->batch_threads, kMaxBatchQueues + 1, threads_cap});
     if (threads < 2 || count < 2 * kMinScansPerThread || r->cfg.max_num_iterations <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->pass_kernel == 3 && r->host_solve && r->group_rows && r->use_aql &&
+    if (!(r->batch_resident && r->resident_generic && r->use_small && r->small_wave && r->use_aql &&
           !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 && r->wait_mode == 0 && r->dbg == 0 && r->small_resident != 0 && r->debug_stall_us == 0.0))
         return 1;
-    // SHARDED (the shared segment attached): every rank is here with ITS shards of the same `count` scans, and every decision from
-    // here on must be the same on every rank - so the ranks first agree, through lane 0 of the segment, on the largest shard any of
-    // them holds (shards of one scan differ by a point between ranks: a size threshold could fall between them)
-    const bool sharded = r->shm != nullptr;
-    size_t sharers_max = 1;  // the most ranks any one device carries
     size_t n_max = 0, n_min = ~size_t(0);
     for (size_t k = 0; k < count; ++k) n_max = std::max(n_max, n[k]), n_min = std::min(n_min, n[k]);
-    if (sharded) {
-        // opt-in (option "shard_threads", the same on every rank): a part's kernel waits for its peers' as well as for its host, so a kernel
-        // that is not running - no room on a device that ranks share, no hardware queue slot among too many queues - stalls every rank
-        // until the exchange times out (seen with two ranks of bench.py on ONE GPU from eight resident kernels on), and every part
-        // costs its rank a spinning host thread; the queues (one thread per rank, nothing resident) stay the default for shards
-        if (r->shard_threads < 2) return 1;
-        if (r->shm_poisoned)
-            return fail(KICP_ERR_COMM, "the shared-segment exchange is out of step after a sharded batch that failed: kicp_reg_shm_destroy and _init again on every rank");
-        threads = std::min({threads, r->shard_threads, kicp_reg::kShmLanes});  // (may differ between ranks - their CPU budgets do: the smallest counts, below)
-        long long mine[kReduceWords] = {}, sum[kReduceWords];
-        std::vector<long long> every(static_cast<size_t>(r->nranks) * kReduceWords);
-        mine[0] = static_cast<long long>(n_max), mine[1] = static_cast<long long>(count), mine[3] = std::min(threads, cpu_cap);
-        {   // which physical device this rank sits on: ranks that share one (a test box with one GPU) must share its room, too
-            char bus[64] = {};
-            unsigned long long hsh = 1469598103934665603ull;
-            if (hipDeviceGetPCIBusId(bus, sizeof bus, r->device) == hipSuccess)
-                for (const char *c = bus; *c; ++c) hsh = (hsh ^ static_cast<unsigned char>(*c)) * 1099511628211ull;
-            mine[2] = static_cast<long long>(hsh >> 1);
-        }
-        if (int rc = shm_lane_exchange(r, 0, mine, sum, every.data())) {
-            r->shm_poisoned = true;
-            return rc;
-        }
-        for (int k = 0; k < r->nranks; ++k) {
-            if (every[static_cast<size_t>(k) * kReduceWords + 1] != static_cast<long long>(count)) {
-                r->shm_poisoned = true;
-                return fail(KICP_ERR_ARG, "the ranks of a sharded batch call disagree on the number of scans");
-            }
-            n_max = std::max(n_max, static_cast<size_t>(every[static_cast<size_t>(k) * kReduceWords]));
-            threads = static_cast<int>(std::min<long long>(threads, every[static_cast<size_t>(k) * kReduceWords + 3]));
-        }
-        for (int k = 0; k < r->nranks; ++k) {  // (the ranks of the fullest device set the number of parts for everybody)
-            size_t same = 0;
-            for (int j = 0; j < r->nranks; ++j) same += every[static_cast<size_t>(j) * kReduceWords + 2] == every[static_cast<size_t>(k) * kReduceWords + 2] ? 1 : 0;
-            sharers_max = std::max(sharers_max, same);
-        }
-    } else if (n_min == 0) {
-        return 1;
-    }
-    const SmallPlan pl = sharded ? SmallPlan() : small_plan(r, n_max), pl_min = sharded ? SmallPlan() : small_plan(r, n_min);
-    const bool wave = !sharded && pl.wave && pl_min.wave && pl.grid, generic = sharded || (pl.generic && pl_min.generic);  // (shards: the generic kernel whatever their size)
+    if (n_min == 0) return 1;
+    const SmallPlan pl = small_plan(r, n_max), pl_min = small_plan(r, n_min);
+    const bool wave = pl.wave && pl_min.wave && pl.grid, generic = pl.generic && pl_min.generic;
     if (!wave && !generic) return 1;
     // kernels that fit the device side by side; generic scans: the latency build (two workgroups per CU) where three and more of its
     // kernels fit, else the four-waves build (four per CU) where two and more do - 131 072-point scans: two kernels of 512 workgroups
     const size_t grid_g = std::max<size_t>(1, (n_max + 255) / 256);
-    // (sharded: a part's kernel also waits for its PEERS' - a kernel that finds no room would stall every rank until the exchange
-    //  times out, so a quarter of the device stays free and ranks that share a device share its room)
-    const size_t fit_lat = n_max > kThreadsMaxGenericPoints ? 0 : (sharded ? static_cast<size_t>(r->num_cus) * 3 / 2 / grid_g / sharers_max : static_cast<size_t>(r->num_cus) * 2 / grid_g);
-    const size_t fit_four = static_cast<size_t>(r->num_cus) * 4 / grid_g;
-    const bool four = generic && fit_lat < 3 && r->batch_threads_large != 0 && !sharded;
-    if (generic && fit_lat < 3 && !four) return 1;
-    const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64)) : (four ? fit_four : fit_lat);
+    const size_t fit_lat = n_max > kThreadsMaxGenericPoints ? 0 : static_cast<size_t>(r->num_cus) * 2 / grid_g;
+    if (generic && fit_lat < 3) return 1;  // (two kernels of the latency build would not beat the queues)
+    const size_t fit = wave ? static_cast<size_t>(r->num_cus) * 16 / std::max<size_t>(1, static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.block / 64)) : fit_lat;
     threads = static_cast<int>(std::min<size_t>({static_cast<size_t>(threads), count / kMinScansPerThread, fit}));
-    if (threads < ((wave || four) ? 2 : 3)) return 1;
+    if (threads < (wave ? 2 : 3)) return 1;
     if (int rc = set_device(r->device)) return rc;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;  // (once, here: the lanes then only read the copy)
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1897,8 +1711,6 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         h->batch_resident = 1, h->resident_generic = 1, h->small_cmd = r->cmd_bar ? 1 : r->small_cmd;
         handles.push_back(h);
     }
-    const int four_before = r->resident_four;
-    for (kicp_reg *h : handles) h->resident_four = four ? 1 : 0;
     for (kicp_reg *h : handles) passes_before.push_back(h->batch_resident_passes), relaunches_before.push_back(h->small_relaunches);
     std::vector<int> rcs(static_cast<size_t>(threads), KICP_OK), worsts(static_cast<size_t>(threads), KICP_OK);
     std::vector<std::string> messages(static_cast<size_t>(threads));
@@ -1906,11 +1718,8 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         kicp_reg *h = handles[t];
         const size_t lo = count * t / static_cast<size_t>(threads), hi = count * (t + 1) / static_cast<size_t>(threads);
         size_t done = 0;
-        const ShardCtx shard{r, static_cast<int>(t), n_max};
         int rc = run_batch_resident(h, map, hi - lo, d_frames + lo, n + lo, last_poses_qt + 7 * lo, rel_odoms_qt + 7 * lo, tau, out_poses_qt + 7 * lo,
-                                    out_iterations ? out_iterations + lo : nullptr, &done, &worsts[t], sharded ? &shard : nullptr);
-        if (sharded && rc >= 0 && done != hi - lo)  // (one call per scan would leave the peers' lane without its partner)
-            rc = fail(KICP_ERR_COMM, "a part of a sharded batch was not served by its resident kernel: the ranks are out of step");
+                                    out_iterations ? out_iterations + lo : nullptr, &done, &worsts[t]);
         kicp_stats st;
         for (size_t k = lo + done; rc >= 0 && k < hi; ++k) {  // (not a batch for the resident kernel after all, or its kernel gave up: one call per scan)
             rc = run_registration(h, map, d_frames[k], n[k], last_poses_qt + 7 * k, rel_odoms_qt + 7 * k, tau, out_poses_qt + 7 * k, out_iterations ? &st : nullptr);
@@ -1921,7 +1730,6 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
         if (rc < 0) messages[t] = kicp_last_error();  // (the message is per thread: carry it over)
     };
     lane_pool().run(static_cast<size_t>(threads), lane);
-    r->resident_four = four_before;
     r->last_batch_threads = threads;
     for (int t = 1; t < threads; ++t) {  // (the caller reads the counters on its own handle)
         r->batch_resident_passes += handles[t]->batch_resident_passes - passes_before[t];
@@ -1929,7 +1737,6 @@ int run_batch_resident_threads(kicp_reg *r, kicp_map *map, size_t count, const d
     }
     for (int t = 0; t < threads; ++t) {
         if (rcs[t] < 0) {
-            if (sharded) r->shm_poisoned = true;  // (the ranks' lane counters can no longer be assumed equal)
             return fail(rcs[t], messages[t]);
         }
         *worst = std::max(*worst, worsts[t]);
@@ -1966,15 +1773,12 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
         kicp_reg_destroy(r);
         return fail(KICP_ERR_HIP, std::string("kicp_reg_create: ") + hipGetErrorString(e));
     }
-    if (const char *env = std::getenv("KICP_PASS_KERNEL")) r->pass_kernel = std::atoi(env) == 0 ? 0 : 3;
-    if (const char *env = std::getenv("KICP_BLOCK")) r->block = normalized_block(std::atoi(env));
-    if (const char *env = std::getenv("KICP_LOOP")) r->loop_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_WAIT")) r->wait_mode = std::atoi(env);
     if (const char *env = std::getenv("KICP_QUERY_EVERY")) r->query_every = std::atoi(env);
     if (const char *env = std::getenv("KICP_SMALL")) r->use_small = std::atoi(env) != 0;
     if (const char *env = std::getenv("KICP_SMALL_RESIDENT")) r->small_resident = std::atoi(env) != 0;
     if (const char *env = std::getenv("KICP_SMALL_CMD")) r->small_cmd = std::atoi(env) != 0;
-    if (const char *env = std::getenv("KICP_P2P_ROWS")) r->p2p_rows = std::atoi(env) == 2 ? 2 : (std::atoi(env) != 0 ? 1 : 0);
+    if (const char *env = std::getenv("KICP_P2P_ROWS")) r->p2p_rows = std::atoi(env) == 2 ? 2 : 1;  // (test hook: 2 = the one-row format launches of more than 32 groups use)
     *out = r;
     return KICP_OK;
 }
@@ -2024,38 +1828,25 @@ int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config) {
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
     if (!reg || !name) return fail(KICP_ERR_ARG, "null argument");
     const std::string k(name);
-    if (k == "pass_kernel") {
-        if (value != 0.0 && value != 3.0) return fail(KICP_ERR_ARG, "pass_kernel must be 3 (default) or 0");
-        reg->pass_kernel = static_cast<int>(value);
+    if (k == "timing") {
+        reg->timing = static_cast<int>(value);
     }
-    else if (k == "block") reg->block = normalized_block(static_cast<int>(value));
-    else if (k == "loop") reg->loop_mode = static_cast<int>(value);
     else if (k == "wait") reg->wait_mode = static_cast<int>(value);
-    else if (k == "host_solve") reg->host_solve = static_cast<int>(value);
-    else if (k == "group_rows") reg->group_rows = static_cast<int>(value);
+    else if (k == "debug_p2p_one_row") reg->p2p_rows = value != 0.0 ? 2 : 1;  // tests: this rank sends its total as ONE row, as launches of more than 32 groups do
     else if (k == "debug_tag") reg->tag = static_cast<uint32_t>(value) & 0xFFFFu;  // tests: jump next to the 16-bit tag's wrap-around
     else if (k == "lanes_per_query") reg->lanes_per_query = (value >= 4) ? 4 : (value >= 2 ? 2 : (value >= 1 ? 1 : 0));
-    else if (k == "occupancy") reg->occupancy = value == 3.0 ? 3 : 4;
     else if (k == "resident_generic") reg->resident_generic = value != 0.0;
     else if (k == "batch_resident") reg->batch_resident = value != 0.0;
     else if (k == "batch_queues") reg->batch_queues = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues);
     else if (k == "batch_rotate") reg->batch_rotate = value != 0.0;
-    else if (k == "batch_threads_large") reg->batch_threads_large = value != 0.0 ? 1 : 0;
-    else if (k == "shard_threads") reg->shard_threads = std::min<int>(std::max(static_cast<int>(value), 0), kicp_reg::kShmLanes);
-    else if (k == "resident_four_waves") reg->resident_four = value != 0.0 ? 1 : 0;
     else if (k == "batch_threads") reg->batch_threads = std::min<int>(std::max(static_cast<int>(value), 0), kMaxBatchQueues + 1);
     else if (k == "batch_depth") reg->batch_depth = std::min<int>(std::max(static_cast<int>(value), 1), kPipeSlots);
-    else if (k == "p2p_rows") reg->p2p_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
     else if (k == "latency_kernel") reg->latency_kernel = value == 2.0 ? 2 : (value == 1.0 ? 1 : 0);
-    else if (k == "split_buckets") reg->split_buckets = value != 0.0 ? 1 : 0;
-    else if (k == "timing") reg->timing = static_cast<int>(value);
     else if (k == "aql") reg->use_aql = value != 0.0 ? 1 : 0;
     else if (k == "bar_frame") reg->use_bar_frame = value != 0.0 ? 1 : 0;
     else if (k == "fetch_upload") reg->fetch_frames = value != 0.0 ? 1 : 0;
     else if (k == "small") reg->use_small = value != 0.0 ? 1 : 0;
     else if (k == "small_resident") reg->small_resident = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);  // 1 adaptive (default), 2 always, 0 never
-    else if (k == "small_group_rows") reg->small_group_rows = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
-    else if (k == "small_block") reg->small_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : 256);
     else if (k == "small_wave") reg->small_wave = value != 0.0 ? 1 : 0;
     else if (k == "small_trace") {  // debugging aid: per-pass wall-clock stamps of workgroup 0 + host-side phase times
         if (value != 0.0 && !reg->d_trace) {
@@ -2069,32 +1860,27 @@ int kicp_reg_set_option(kicp_reg *reg, const char *name, double value) {
         if (reg->cmd_bar || (value != 0.0) == (reg->small_cmd != 0)) return KICP_OK;  // (once the copies live in the BAR they stay there)
         reg->small_cmd = value != 0.0 ? 1 : 0;
     }
-    else if (k == "wave_block") reg->wave_block = value == 1024.0 ? 1024 : (value == 512.0 ? 512 : (value == 256.0 ? 256 : 0));
     else if (k == "small_timeout_us") reg->small_timeout_us = value;
     else if (k == "debug_stall_us") reg->debug_stall_us = value;
-    else if (k == "dbg") reg->dbg = static_cast<int>(value);
-    else if (k == "query_every") reg->query_every = static_cast<int>(value);
+    else if (k == "dbg") {
+#ifdef KICP_DBG_BUILD
+        reg->dbg = static_cast<int>(value);
+#else
+        if (value != 0.0) return fail(KICP_ERR_ARG, "this library is built without the pass kernels' ablation switches: load libkicp_amd_dbg.so (make dbg) for option dbg");
+#endif
+    }
     else return fail(KICP_ERR_ARG, "unknown option " + k);
     return KICP_OK;
 }
 double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (!reg || !name) return -1.0;
     const std::string k(name);
-    if (k == "pass_kernel") return reg->pass_kernel;
-    if (k == "block") return reg->block;
-    if (k == "loop") return reg->loop_mode;
     if (k == "wait") return reg->wait_mode;
-    if (k == "host_solve") return reg->host_solve;
-    if (k == "group_rows") return reg->group_rows;
     if (k == "debug_tag") return reg->tag;
     if (k == "lanes_per_query") return reg->lanes_per_query;
-    if (k == "occupancy") return reg->occupancy;
     if (k == "resident_generic") return reg->resident_generic;
     if (k == "resident_passes") return reg->last_resident_passes;
     if (k == "batch_resident") return reg->batch_resident;
-    if (k == "batch_threads_large") return reg->batch_threads_large;
-    if (k == "shard_threads") return reg->shard_threads;
-    if (k == "resident_four_waves") return reg->resident_four;
     if (k == "batch_threads") return reg->batch_threads;
     if (k == "batch_threads_active") return reg->last_batch_threads;
     if (k == "batch_depth") return reg->batch_depth;
@@ -2102,9 +1888,7 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "batch_queues") return reg->batch_queues;
     if (k == "batch_queue_passes") return static_cast<double>(reg->batch_queue_passes);
     if (k == "batch_resident_passes") return static_cast<double>(reg->batch_resident_passes);
-    if (k == "p2p_rows") return reg->p2p_rows;
     if (k == "latency_kernel") return reg->latency_kernel;
-    if (k == "split_buckets") return reg->split_buckets;
     if (k == "timing") return reg->timing;
     if (k == "aql") return reg->use_aql;
     if (k == "aql_kernarg") return !reg->aql.ready ? -1.0 : (std::strcmp(reg->aql.kernarg_place(), "host memory") == 0 ? 0.0 : (std::strcmp(reg->aql.kernarg_place(), "device memory") == 0 ? 1.0 : 2.0));
@@ -2117,8 +1901,6 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
     if (k == "fetch_upload") return reg->fetch_frames;
     if (k == "small") return reg->use_small;
     if (k == "small_resident") return reg->small_resident;
-    if (k == "small_group_rows") return reg->small_group_rows;
-    if (k == "small_block") return reg->small_block;
     if (k == "small_wave") return reg->small_wave;
     if (k == "trace_host_us") return reg->trace_n ? reg->trace_host_us / static_cast<double>(reg->trace_n) : 0.0;
     if (k == "trace_device_us") return reg->trace_n ? reg->trace_dev_us / static_cast<double>(reg->trace_n) : 0.0;
@@ -2131,7 +1913,6 @@ double kicp_reg_get_option(const kicp_reg *reg, const char *name) {
         return (i >= 0 && i < 4096) ? static_cast<double>(v[i]) : -1.0;
     }
     if (k == "small_cmd") return (reg->small_cmd == 1 && reg->cmd_bar) ? 1.0 : (reg->small_cmd ? 0.5 : 0.0);  // 1: BAR copies in use; 0.5: requested, not yet set up
-    if (k == "wave_block") return reg->wave_block;
     if (k == "small_timeout_us") return reg->small_timeout_us;
     if (k == "small_active") return reg->last_small;  // path of the last registration: 0 generic, 1 small (sub-lanes per query), 2 small (wave per query)
     if (k == "small_relaunches") return static_cast<double>(reg->small_relaunches);
@@ -2309,13 +2090,13 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     if (!reg || !out) return fail(KICP_ERR_ARG, "null argument");
     kicp_reg *c = nullptr;
     if (int rc = kicp_reg_create(&reg->cfg, reg->device, &c)) return rc;
-    c->group_rows = reg->group_rows, c->use_bar_frame = reg->use_bar_frame, c->fetch_frames = reg->fetch_frames;
-    c->pass_kernel = reg->pass_kernel, c->block = reg->block, c->loop_mode = reg->loop_mode, c->wait_mode = reg->wait_mode, c->timing = reg->timing;
-    c->query_every = reg->query_every, c->lanes_per_query = reg->lanes_per_query, c->occupancy = reg->occupancy, c->latency_kernel = reg->latency_kernel;
-    c->split_buckets = reg->split_buckets, c->host_solve = reg->host_solve, c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
+    c->use_bar_frame = reg->use_bar_frame, c->fetch_frames = reg->fetch_frames;
+    c->wait_mode = reg->wait_mode, c->timing = reg->timing;
+    c->query_every = reg->query_every, c->lanes_per_query = reg->lanes_per_query, c->latency_kernel = reg->latency_kernel;
+    c->p2p_rows = reg->p2p_rows, c->use_aql = reg->use_aql;
     c->small_cmd = reg->cmd_bar ? 1 : reg->small_cmd, c->use_small = reg->use_small, c->small_block = reg->small_block, c->small_wave = reg->small_wave;
     c->wave_block = reg->wave_block, c->small_resident = reg->small_resident, c->small_timeout_us = reg->small_timeout_us, c->small_group_rows = reg->small_group_rows;
-    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads, c->batch_threads_large = reg->batch_threads_large, c->shard_threads = reg->shard_threads;
+    c->resident_generic = reg->resident_generic, c->batch_resident = reg->batch_resident, c->batch_depth = reg->batch_depth, c->batch_rotate = reg->batch_rotate, c->batch_queues = reg->batch_queues, c->batch_threads = reg->batch_threads ;
     *out = c;
     return KICP_OK;
 }
@@ -2566,19 +2347,10 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
     // aql_kernel_for / aql_small_kernel_for look it up
     std::string all;
     char name[128];
-    for (int b : {64, 128, 256}) {
-        for (int occ : {4, 3}) {
-            for (int g : {1, 2, 4}) {
-                std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, false, false>(\n", b, g, occ);
-                all += name;
-            }
-            std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 2, %d, true, false>(\n", b, occ);
-            all += name;
-        }
-        std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, 1, 2, false, true>(\n", b);
-        all += name;
-    }
-    all += "void kicp::k_pass_gather32<512, 1, 4, false, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 1, 2, false, true>(\n";
+    all += "void kicp::k_pass_gather32<256, 1, 4, false, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 2, 4, true, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 4, 4, false, false>(\n";
     for (int b : {256, 512, 1024})
         for (int g : {1, 2, 4}) {
             std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(\n", b, g);
@@ -2589,7 +2361,6 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
         all += name;
     }
     all += "void kicp::k_pass_resident<256, 2, true>(\n";
-    all += "void kicp::k_pass_resident<256, 4, false>(\n";
     if (out && cap) {
         const size_t n = std::min(cap - 1, all.size());
         std::memcpy(out, all.data(), n);

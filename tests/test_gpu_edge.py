@@ -28,15 +28,13 @@ KERNELS = [
     ("default", {}),                                                        # <= 4 096 points: one wave per query, resident
     ("sub_lanes", {"small_wave": 0}),                                       # k_pass_small
     ("small_one_launch_per_pass", {"small_resident": 0}),
-    ("small_row_per_workgroup", {"small_group_rows": 0}),                   # round 3's hand-over everywhere
-    ("small_row_per_group", {"small_group_rows": 2, "small_wave": 0}),      # round 5's (counting accumulators), also where the default does not take it
     ("generic_auto_lanes", {"small": 0}),                                   # k_pass_gather32, 4 / 2 / 1 sub-lanes by scan size
     ("generic_latency_build", {"small": 0, "lanes_per_query": 1}),          # <.., LAT>
     ("generic_four_waves", {"small": 0, "lanes_per_query": 1, "latency_kernel": 0}),
-    ("generic_two_lanes_dealt", {"small": 0, "lanes_per_query": 2, "split_buckets": 0}),
-    ("generic_fp64_gather", {"small": 0, "pass_kernel": 0}),
+    ("generic_two_lanes", {"small": 0, "lanes_per_query": 2}),
+    ("generic_four_lanes", {"small": 0, "lanes_per_query": 4}),
     ("generic_hip_launch", {"small": 0, "aql": 0}),
-    ("generic_device_solve", {"small": 0, "host_solve": 0}),
+    ("generic_stream_sync", {"small": 0, "wait": 1}),
 ]
 
 
@@ -117,8 +115,6 @@ def world():
 @pytest.mark.parametrize("via", ["host", "f32", "device", "batch"])
 def test_known_answers_through_the_hip_path(world, name, options, via):
     maps1, maps2 = world
-    if via == "batch" and options.get("host_solve", 1) == 0:
-        pytest.skip("(the batch entry point is exercised with the host-side solve)")
     last, rel = syn.planar_pose(1, 2, 0.3), syn.planar_pose(0.5, 0, 0.1)
     # KAT-0: empty map -> prediction, whatever the frame
     reg = _reg(options, **CFG)
@@ -418,45 +414,8 @@ def test_batch_of_small_scans_on_several_resident_kernels_side_by_side(kind, thr
         before = two.get_option("batch_queue_passes")
         assert np.array_equal(two.ComputeRobotMotionBatch(b3, g, 0.5), want, equal_nan=True)
         assert two.get_option("batch_threads_active") == 0.0 and two.get_option("batch_queue_passes") > before
-        # the resident kernel's four-waves-per-SIMD build (selectable; measured no faster than the queues on 131 072-point scans, where
-        # two of them fill the device): one such kernel across the batch's scans (two side by side: the next test)
-        four = _reg({"batch_threads": 0, "batch_queues": 0, "resident_four_waves": 1}, **CFG)
-        b4 = four.prepare_batch(dev, lasts, rels)
-        before = four.get_option("batch_resident_passes"), four.get_option("batch_queue_passes")
-        assert np.array_equal(four.ComputeRobotMotionBatch(b4, g, 0.5), want, equal_nan=True) and list(b4.iterations) == list(b0.iterations)
-        assert four.get_option("batch_threads_active") == 0.0
-        assert four.get_option("batch_resident_passes") > before[0] and four.get_option("batch_queue_passes") == before[1]
     # too few scans per thread: one kernel, the caller's thread
     short = reg.prepare_batch(dev[:20], lasts[:20], rels[:20])
     assert np.array_equal(reg.ComputeRobotMotionBatch(short, g, 0.5), want[:20], equal_nan=True) and reg.get_option("batch_threads_active") == 0.0
 
 
-def test_batch_of_large_scans_on_resident_kernels_of_the_four_waves_build():
-    """option "batch_threads_large" (off by default: on cfg2 two such kernels measured 6.9 us per scan against the queues' 6.5): scans too
-    large for three kernels of the resident latency build - 45 000 .. 60 000 points, 176 .. 235 workgroups - take the four-waves build,
-    as many kernels as fit at four workgroups per CU, each with a part of the batch; bit-equal to one call per scan."""
-    maps, _ = _big_world(n_map=90000, n_src=10, seed=37)
-    g = maps[0]
-    count = 35
-    rng = np.random.default_rng(5)
-    src = np.concatenate([rng.uniform(-39, 39, (60000, 2)), rng.uniform(0, 0.05, (60000, 1))], 1)  # (points of the same noisy plane, not the map's own)
-    sizes = [int(rng.integers(45000, len(src) + 1)) for _ in range(count)]
-    frames = [src[(97 * i) % (len(src) - k + 1):][:k] - np.array([float(rng.uniform(-0.06, 0.08)), 0.0, 0.0]) for i, k in enumerate(sizes)]
-    frames[7] = np.full((50000, 3), 400.0)  # no correspondence at all
-    lasts = [syn.planar_pose(0.002 * i, 0.0, 0.0005 * i) for i in range(count)]
-    rels = [syn.planar_pose(-0.001 * i, 0.0, 0.0005) for i in range(count)]
-    dev = [K.DeviceFrame(f, device=0) for f in frames]
-    plain = _reg({"batch_resident": 0, "batch_queues": 0, "batch_threads": 0}, **CFG)
-    b0 = plain.prepare_batch(dev, lasts, rels)
-    want = plain.ComputeRobotMotionBatch(b0, g, 0.5).copy()
-    reg = _reg({"batch_threads_large": 1}, **CFG)
-    b1 = reg.prepare_batch(dev, lasts, rels)
-    for _ in range(2):
-        before = reg.get_option("batch_resident_passes")
-        assert np.array_equal(reg.ComputeRobotMotionBatch(b1, g, 0.5), want, equal_nan=True) and list(b1.iterations) == list(b0.iterations)
-        assert reg.get_option("batch_threads_active") == 2.0 and reg.get_option("batch_resident_passes") > before
-    default = _reg({}, **CFG)  # (the default: four queues)
-    b2 = default.prepare_batch(dev, lasts, rels)
-    before = default.get_option("batch_queue_passes")
-    assert np.array_equal(default.ComputeRobotMotionBatch(b2, g, 0.5), want, equal_nan=True)
-    assert default.get_option("batch_threads_active") == 0.0 and default.get_option("batch_queue_passes") > before

@@ -13,8 +13,8 @@ from checkers import okicp
 
 pytestmark = pytest.mark.gpu
 VARIANTS = [dict(), dict(small=0), dict(small=0, lanes_per_query=1), dict(small=0, lanes_per_query=1, latency_kernel=0), dict(small=0, lanes_per_query=4),
-            dict(small=0, pass_kernel=0), dict(small_wave=0)]
-PASS_VARIANTS = [(3, 256), (3, 256, 1), (3, 256, 1, None, 0), (3, 64, 4), (3, 256, 2, 1), (3, 256, 2, 0), (0, 128)]
+            dict(small=0, lanes_per_query=2), dict(small_wave=0)]
+PASS_VARIANTS = [(None, None), (1, 2), (1, 0), (4, None), (2, None)]  # (sub-lanes per query, latency_kernel): tests/test_gpu_parity.py VARIANTS
 
 
 @st.composite

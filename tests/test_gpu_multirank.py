@@ -53,7 +53,7 @@ def _run_cases(reg, world, rank):
     return out
 
 
-def _callback_worker(rank, world, port, host_solve, q):
+def _callback_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     try:
         import torch
@@ -63,7 +63,6 @@ def _callback_worker(rank, world, port, host_solve, q):
         dist.init_process_group(backend="gloo")
         torch.cuda.set_device(0)
         reg = K.KinematicRegistration(device=0)
-        reg.set_option("host_solve", host_solve)
         calls = []
 
         def allreduce(ptr, count, stream):
@@ -113,17 +112,14 @@ def _spawn(target, world, extra):
     return results
 
 
-@pytest.mark.parametrize("world,host_solve", [(2, 1), (3, 1), (2, 0)])
-def test_callback_allreduce_across_processes(world, host_solve):
-    results = _spawn(_callback_worker, world, (_free_port(), host_solve))
+@pytest.mark.parametrize("world", [2, 3])
+def test_callback_allreduce_across_processes(world):
+    results = _spawn(_callback_worker, world, (_free_port(),))
     ref = _single_process_results()
     for r in range(world):
         for (pose, iters), (pose1, iters1) in zip(results[r], ref):
             assert iters == iters1
-            if host_solve:
-                assert np.array_equal(pose, pose1)  # exact integer sums, the same host-side solve: the same bits
-            else:                                   # device-side solve: libm vs device sin / cos in the last place
-                np.testing.assert_allclose(pose, pose1, rtol=0, atol=1e-13)
+            assert np.array_equal(pose, pose1)  # exact integer sums, the same host-side solve: the same bits
 
 
 def _rccl_worker(rank, world, uid, q):
@@ -190,16 +186,16 @@ def _p2p_worker(rank, world, barrier, handles, q):
         out = _run_cases(reg, world, rank)  # default wire format: every first-level group's row goes to every rank
         # a second round on the same mailboxes (tags and buffer parity keep advancing), then the plain path after a detach
         out2 = _run_cases(reg, world, rank)
-        # more, smaller workgroups = more group rows per rank; a rank that sends its total as one row (what a launch beyond the
-        # mailbox's row limit does) pairs up with ranks that send group rows; round 2's totals-as-halves format
-        reg.set_option("block", 64), reg.set_option("lanes_per_query", 4)
+        # more sub-lanes per query = more workgroups = more group rows per rank; a rank that sends its total as one row (what a launch
+        # beyond the mailbox's row limit does) pairs up with ranks that send group rows
+        reg.set_option("small", 0), reg.set_option("lanes_per_query", 4)
         out3 = _run_cases(reg, world, rank)
-        reg.set_option("block", 256), reg.set_option("lanes_per_query", 0)
+        reg.set_option("lanes_per_query", 0)
         if rank == 0:
-            reg.set_option("p2p_rows", 2)
+            reg.set_option("debug_p2p_one_row", 1)
         out4 = _run_cases(reg, world, rank)
         barrier.wait()
-        reg.set_option("p2p_rows", 0)
+        reg.set_option("debug_p2p_one_row", 0)
         out5 = _run_cases(reg, world, rank)
         barrier.wait()
         reg.p2p_destroy()

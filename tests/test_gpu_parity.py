@@ -16,13 +16,11 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-9
 SUM_RTOL = 1e-10
-# (pass kernel, workgroup size[, lanes per query]): variant 0 = plain fp64 gather; variant 3 = 16-bit mirror pre-selection
-# with the scan-size default (2 sub-lanes per query on this 16k scan), with one lane per query (what large scans run) and
-# with four (what very small scans run)
-# (pass kernel, workgroup size[, sub-lanes per query[, bucket sharing]])
-VARIANTS = [(0, 64), (0, 128), (0, 256), (3, 64), (3, 128), (3, 256), (3, 64, 1), (3, 128, 1), (3, 256, 1), (3, 64, 4), (3, 256, 4),
-            (3, 64, 2, 1), (3, 128, 2, 1), (3, 256, 2, 1), (3, 64, 2, 0), (3, 256, 2, 0),
-            (3, 64, 1, None, 2), (3, 128, 1, None, 2), (3, 256, 1, None, 2)]  # (.., 2): the two-voxels-per-round build
+# The builds of the generic pass kernel (kicp_reg.hip launch_pass; all of 256-thread workgroups since round 6) as
+# (sub-lanes per query, latency_kernel): the scan-size default (two sub-lanes sharing every bucket on this 16k scan), one lane per query
+# at four waves per SIMD (what large scans and batches in flight run), the same as the two-voxels-per-round build (what scans of up
+# to 131 072 points run one call at a time), and four sub-lanes per query (what very small scans run); None = the library's choice
+VARIANTS = [(None, None), (1, 0), (1, 2), (2, None), (4, None)]
 
 
 @pytest.fixture(scope="module")
@@ -46,14 +44,11 @@ def test_reference_build_is_present():
     ref()
 
 
-def _reg(kernel, block, lanes=None, split=None, latency=None, **kw):
+def _reg(lanes=None, latency=None, **kw):
     reg = K.KinematicRegistration(**kw)
-    reg.set_option("pass_kernel", kernel)
-    reg.set_option("block", block)
+    reg.set_option("small", 0)  # (the generic pass kernel: the small-scan kernels have tests/test_gpu_small.py)
     if lanes is not None:
         reg.set_option("lanes_per_query", lanes)
-    if split is not None:
-        reg.set_option("split_buckets", split)
     if latency is not None:
         reg.set_option("latency_kernel", latency)
     return reg
@@ -88,12 +83,11 @@ def test_pass_sums_match_oracle(case1, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("loop", [0, 1, 2])
-def test_registration_matches_oracle(case1, case1_ref, variant, loop):
+@pytest.mark.parametrize("wait", [0, 1])
+def test_registration_matches_oracle(case1, case1_ref, variant, wait):
     cfg, scans, gmap, omap = case1
     reg = _reg(*variant)
-    reg.set_option("host_solve", 1 if loop == 2 else 0)  # 2 = default mode: host-side solve
-    reg.set_option("loop", min(loop, 1))
+    reg.set_option("wait", wait)  # 0 (default): poll the tagged rows in host memory; 1: hipStreamSynchronize
     oreg = okicp.KinematicRegistration()
     for s in scans:
         # make the initial guess bad enough to need several iterations
@@ -158,27 +152,28 @@ def test_device_frame_equals_host_frame(case1):
 
 
 def test_all_variants_bit_identical(case1):
-    """Exact (integer) accumulation: every kernel variant, block size and loop mode gives the same bits."""
+    """Exact (integer) accumulation: every build of the pass kernel - generic and small-scan -, either way of waiting and either
+    launch path give the same bits."""
     cfg, scans, gmap, omap = case1
     s = scans[2]
     rel = syn.pose_mul(s["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(0.8)))
-    by_mode = {}
-    for host_solve in (1, 0):
-        poses = []
-        for variant in VARIANTS:
-            for loop in (0, 1):
-                for wait in (0, 1):
-                    reg = _reg(*variant)
-                    reg.set_option("host_solve", host_solve)
-                    reg.set_option("loop", loop)
-                    reg.set_option("wait", wait)
-                    poses.append(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, cfg.first_frame_tau()))
-                    assert reg.last_stats.iterations > 1
-        for p in poses[1:]:
-            assert np.array_equal(p, poses[0])
-        by_mode[host_solve] = poses[0]
-    # host-side and device-side solves run the same formulas on the same exact sums; only libm vs device sin/cos differ
-    np.testing.assert_allclose(by_mode[0], by_mode[1], rtol=0, atol=1e-13)
+    poses = []
+    for variant in VARIANTS:
+        for wait in (0, 1):
+            for aql in (1, 0):
+                reg = _reg(*variant)
+                reg.set_option("wait", wait), reg.set_option("aql", aql)
+                poses.append(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, cfg.first_frame_tau()))
+                assert reg.last_stats.iterations > 1
+    small = K.KinematicRegistration()  # (this 16k scan does not take the small-scan path by default: a 4 096-point part of it does)
+    part = s["frame"][:4096]
+    a = small.ComputeRobotMotion(part, gmap, s["last_pose"], rel, cfg.first_frame_tau())
+    assert small.get_option("small_active") != 0.0
+    poses_part = [_reg(*v).ComputeRobotMotion(part, gmap, s["last_pose"], rel, cfg.first_frame_tau()) for v in VARIANTS]
+    for p in poses[1:]:
+        assert np.array_equal(p, poses[0])
+    for p in poses_part:
+        assert np.array_equal(p, a)
 
 
 def test_random_order_input(case1):
@@ -216,13 +211,13 @@ def test_frozen_outputs_of_the_reference_build(name):
 
 
 @pytest.mark.parametrize("name", ["a", "b", "c"])
-@pytest.mark.parametrize("kernel", [0, 3])
+@pytest.mark.parametrize("kernel", [(None, None), (1, 0)])
 def test_golden_vectors(name, kernel):
     """The committed fixtures (multi-iteration small cases, incl. two that exhaust max_num_iterations)."""
     g = np.load(GOLD)
     m = K.VoxelHashMap(float(g[name + "_voxel"]), float(g[name + "_maxrange"]), 20)
     m.AddPoints(g[name + "_map"])
-    reg = _reg(kernel, 128)
+    reg = _reg(*kernel) if kernel[0] is not None else K.KinematicRegistration()  # the library's own choice (small-scan kernels) / the generic kernel
     p = reg.ComputeRobotMotion(g[name + "_frame"], m, g[name + "_last"], g[name + "_rel"], float(g[name + "_tau"]))
     st = reg.last_stats
     assert st.iterations == int(g[name + "_iters"]) and st.converged == int(g[name + "_converged"])
@@ -234,7 +229,7 @@ def test_golden_vectors(name, kernel):
     np.testing.assert_allclose(s0, g[name + "_sums0"], rtol=SUM_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("kernel", [0, 3])
+@pytest.mark.parametrize("kernel", [(None, None), (1, 0)])
 def test_shard_words_add_up_exactly(case1, kernel):
     """G-GPU emulation on one device: the limb words of disjoint shards sum to the words' value of the whole scan,
     bit for bit, for G in {2,4,8} -- the property that makes the multi-GPU pose independent of G."""
@@ -242,7 +237,7 @@ def test_shard_words_add_up_exactly(case1, kernel):
     cfg, scans, gmap, omap = case1
     s = scans[0]
     guess = syn.pose_mul(s["last_pose"], s["rel_odom"])
-    reg = _reg(kernel, 128)
+    reg = _reg(*kernel)
     tau = cfg.first_frame_tau()
     full = reg.pass_words(s["frame"], gmap, guess, tau)
     total = [sh.from_limbs(full[3 * i:3 * i + 3]) for i in range(7)]
@@ -274,7 +269,7 @@ def test_single_rank_communicator_and_callback(case1):
     assert calls and all(ok and c == 24 for ok, c in calls) and len(calls) >= reg2.last_stats.iterations
 
 
-@pytest.mark.parametrize("kernel", [0, 3])
+@pytest.mark.parametrize("kernel", [(None, None), (1, 2)])
 def test_registration_after_updates_with_pruning(kernel):
     """Map built by a sequence of Update(points, pose) calls that also prune (RemovePointsFarFromLocation), re-using freed
     buckets: the HBM mirror, its halo entries and neighbour-occupancy masks must track every change."""
@@ -284,7 +279,7 @@ def test_registration_after_updates_with_pruning(kernel):
     vs, max_range = 0.5, 12.0  # small range: voxels leave the map as the robot drives
     gmap, omap = K.VoxelHashMap(vs, max_range, 20), okicp.VoxelHashMap(vs, max_range, 20)
     rmap = ref().VoxelHashMap(vs, max_range, 20) if ref_available() else None
-    reg, oreg = _reg(kernel, 128), okicp.KinematicRegistration()
+    reg, oreg = _reg(*kernel), okicp.KinematicRegistration()
     pose = syn.planar_pose(-18.0, -15.0, 0.6)
     removed_any = False
     uploads = []
@@ -324,20 +319,18 @@ def test_registration_after_updates_with_pruning(kernel):
 
 
 def test_hand_off_modes_and_tag_wraparound(case1):
-    """The tagged-row hand-off (default), the single-record hand-off and the stream-sync wait give the same bits, also across
-    the 16-bit pass tag's wrap-around (where every buffer holding tagged words is cleared) and for scans of changing size."""
+    """The tagged-row hand-off polled in host memory (default) and the stream-sync wait give the same bits, also across the 16-bit
+    pass tag's wrap-around (where every buffer holding tagged words is cleared) and for scans of changing size."""
     cfg, scans, gmap, omap = case1
     tau = cfg.first_frame_tau()
     rel = [syn.pose_mul(s["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(0.8))) for s in scans]
     ref = K.KinematicRegistration()
-    ref.set_option("group_rows", 0)
     sizes = [len(scans[0]["frame"]), 5000, 64, 12345, 1]
     expected = [ref.ComputeRobotMotion(scans[i % 3]["frame"][:n], gmap, scans[i % 3]["last_pose"], rel[i % 3], tau) for i, n in enumerate(sizes)]
     assert ref.last_stats.iterations >= 1
     for wait in (0, 1):
         reg = K.KinematicRegistration()
         reg.set_option("wait", wait)
-        assert reg.get_option("group_rows") == 1
         reg.set_option("debug_tag", 65535 - 7)  # a few passes before the wrap
         assert reg.get_option("debug_tag") == 65528
         for rounds in range(4):
@@ -473,7 +466,7 @@ def test_aql_dispatch_equals_hip_launch(case1):
     far = syn.pose_mul(scans[1]["rel_odom"], syn.planar_pose(0.1, 0.0, np.deg2rad(1.0)))
     frames = [K.DeviceFrame(s["frame"]) for s in scans]
     for lanes in (None, 1, 2, 4):
-        a, b = _reg(3, 256, lanes), _reg(3, 256, lanes)
+        a, b = _reg(lanes), _reg(lanes)
         b.set_option("aql", 0)
         for k, (fr, s) in enumerate(zip(frames, scans)):
             rel = far if k == 1 else s["rel_odom"]

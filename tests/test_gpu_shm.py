@@ -172,95 +172,3 @@ def test_sharded_batch_with_scans_in_flight(world, queues):
         else:
             assert out[-1][2] == 0
         assert np.array_equal(one, want[0])
-
-
-# ---- sharded batches on RESIDENT KERNELS SIDE BY SIDE (round 5: what a rank's shards - 16 384 points of a 131 072-point scan on eight GPUs -
-#      are served by once ordinary launches of small kernels have hit their ceiling; tests/test_gpu_edge.py has the single-GPU twin) ------
-def _threads_worker(rank, world, name, threads, count, barrier, q):
-    sys.path.insert(0, ROOT)
-    import kinematic_icp_amd as K
-    from kinematic_icp_amd import sharding as sh
-    try:
-        g, frames, lasts, rels = _batch_case()
-        frames, lasts, rels = [frames[i % 12] for i in range(count)], [lasts[i % 12] for i in range(count)], [rels[i % 12] for i in range(count)]
-        reg = K.KinematicRegistration()
-        reg.set_option("shard_threads", threads)  # (opt-in: a sharded batch takes the queues by default)
-        if rank == 0:
-            reg.shm_init(world, 0, name)
-        barrier.wait()
-        if rank != 0:
-            reg.shm_init(world, rank, name)
-        barrier.wait()
-        m = K.VoxelHashMap(float(g["b_voxel"]), float(g["b_maxrange"]), 20)
-        m.AddPoints(g["b_map"])
-        shards = []
-        for f in frames:
-            lo, hi = sh.shard_bounds(len(f), world, rank)
-            shards.append(K.DeviceFrame(f[lo:hi] if hi > lo else np.zeros((0, 3)), device=0))
-        batch = reg.prepare_batch(shards, lasts, rels)
-        out = []
-        for _ in range(3):  # (the lanes' hand-off counters go on from call to call)
-            poses = reg.ComputeRobotMotionBatch(batch, m, float(g["b_tau"])).copy()
-            out.append((poses, np.array(batch.iterations).copy(), reg.get_option("batch_threads_active"), reg.get_option("batch_queue_passes")))
-        # a batch too short for the resident kernels takes the queues - on every rank alike - and the lanes stay in step
-        short = reg.prepare_batch(shards[:12], lasts[:12], rels[:12])
-        poses = reg.ComputeRobotMotionBatch(short, m, float(g["b_tau"])).copy()
-        out.append((poses, np.array(short.iterations).copy(), reg.get_option("batch_threads_active"), reg.get_option("batch_queue_passes")))
-        poses = reg.ComputeRobotMotionBatch(batch, m, float(g["b_tau"])).copy()
-        out.append((poses, np.array(batch.iterations).copy(), reg.get_option("batch_threads_active"), reg.get_option("batch_queue_passes")))
-        barrier.wait()
-        reg.shm_destroy()
-        q.put((rank, out, None))
-    except Exception as e:  # noqa: BLE001
-        q.put((rank, None, repr(e)))
-        try:
-            barrier.abort()
-        except Exception:  # noqa: BLE001
-            pass
-
-
-# (three kernels per rank: what the option is documented for.  With four and more per rank and two ranks SHARING one GPU a kernel's rows
-#  now and then never arrive - not a late start: setting the handles up before the ranks meet and a command timeout beyond the exchange's
-#  own turned the stall into that plain time-out, every time from five kernels per rank on; three ranks x three kernels and one process
-#  with eight run clean, so it is not the number of resident kernels on the device but how many never-ending ones each of SEVERAL
-#  processes keeps on it.  One reason the option is off by default; a rank with a GPU of its own is the single process of
-#  tests/test_gpu_edge.py)
-@pytest.mark.parametrize("world,threads", [(2, 3), (3, 3)])
-def test_sharded_batch_on_resident_kernels_side_by_side(world, threads):
-    """Two / three ranks sharing the box's GPU, each with ITS shards of 16 x threads + 5 scans: the ranks agree on the launch shape
-    through the segment, every rank serves the same contiguous parts of the batch from `threads` resident kernels, a host thread each,
-    and part t's passes are completed by the peers' through lane t of the segment: the bits of the single-GPU batch on the whole
-    scans, iteration counts included (empty shards, a scan without correspondences, 1 .. 10 iterations)."""
-    import kinematic_icp_amd as K
-    count = 16 * threads + 5
-    ctx = mp.get_context("spawn")
-    barrier, q = ctx.Barrier(world), ctx.Queue()
-    name = "kicp_threads_%d_%d_%d" % (os.getpid(), world, threads)
-    procs = [ctx.Process(target=_threads_worker, args=(r, world, name, threads, count, barrier, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = {}
-    for _ in range(world):
-        rank, out, err = q.get(timeout=300)
-        assert err is None, "rank %d: %s" % (rank, err)
-        results[rank] = out
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    g, frames, lasts, rels = _batch_case()
-    frames, lasts, rels = [frames[i % 12] for i in range(count)], [lasts[i % 12] for i in range(count)], [rels[i % 12] for i in range(count)]
-    m = K.VoxelHashMap(float(g["b_voxel"]), float(g["b_maxrange"]), 20)
-    m.AddPoints(g["b_map"])
-    single = K.KinematicRegistration()
-    single.set_option("batch_threads", 0)
-    whole = single.prepare_batch([K.DeviceFrame(f, device=0) for f in frames], lasts, rels)
-    want = single.ComputeRobotMotionBatch(whole, m, float(g["b_tau"])).copy()
-    want_it = np.array(whole.iterations).copy()
-    assert want_it.min() == 1 and want_it.max() >= 3 and np.isnan(want[9]).any()
-    for r in range(world):
-        out = results[r]
-        for i, (poses, iters, active, queue_passes) in enumerate(out):
-            if i == 3:  # the short batch: the queues
-                assert np.array_equal(poses, want[:12], equal_nan=True) and np.array_equal(iters, want_it[:12]) and active == 0.0 and queue_passes > 0
-            else:
-                assert np.array_equal(poses, want, equal_nan=True) and np.array_equal(iters, want_it) and active == float(threads)

@@ -92,16 +92,14 @@ def _run(reg, w, name, cfg, via):
 @pytest.mark.parametrize("name,options", KERNELS, ids=[k for k, _ in KERNELS])
 @pytest.mark.parametrize("via", ["host", "device", "batch"])
 def test_ties_through_every_pass_kernel(small, name, options, via):
-    if via == "batch" and options.get("host_solve", 1) == 0:
-        pytest.skip("(the batch entry point is exercised with the host-side solve)")
     for pose in POSES:
         for cfg in (CFG1, FIXED1, CFG10):
             _run(_reg(options, **cfg), small, pose, cfg, via)
 
 
 @pytest.mark.parametrize("options", [{}, {"small": 0}, {"small": 0, "lanes_per_query": 1}, {"small": 0, "lanes_per_query": 1, "latency_kernel": 0},
-                                     {"small": 0, "lanes_per_query": 4}, {"small_resident": 2}, {"small": 0, "pass_kernel": 0}],
-                         ids=["default", "generic", "latency_build", "four_waves_lending", "four_lanes", "resident", "fp64_gather"])
+                                     {"small": 0, "lanes_per_query": 4}, {"small_resident": 2}, {"small": 0, "lanes_per_query": 2}],
+                         ids=["default", "generic", "latency_build", "four_waves_lending", "four_lanes", "resident", "two_lanes"])
 def test_ties_on_scans_of_many_workgroups(medium, large, options):
     """the same cells sixty and a hundred-and-ten times over: every wave holds ties AND padding (the four-waves build lends idle lanes
     the tie queries' voxels), several groups of workgroups, k_pass_small and the resident generic kernel on their own turf"""

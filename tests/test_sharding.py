@@ -257,130 +257,6 @@ def test_sharded_batch_with_scans_in_flight_over_the_segment_lanes(tmp_path, wor
     assert sh.lane_scans(1, 4, 11) == [1, 5, 9] and sorted(sum((sh.lane_scans(j, lanes, 11) for j in range(lanes)), [])) == list(range(11))
 
 
-def _parts_worker(rank, world, wish, depth, shm_name, out_dir, seed):
-    """one rank of a sharded batch on RESIDENT KERNELS SIDE BY SIDE (run_batch_resident_threads with the segment attached, option
-    "shard_threads"): the ranks agree through lane 0 on the launch shape and on the number of parts (the smallest any rank can afford),
-    every rank cuts the batch into the same contiguous parts, and part t is served by a thread of its own - `depth` scans in flight,
-    the passes in the order their commands went out, every pass's sums completed by the peers' through a BLOCKING hand-off on lane t;
-    the oracle stands in for the GPU's pass, random pauses so that the parts advance at a different pace on every rank"""
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import threading
-    import time
-    from multiprocessing import shared_memory
-    seg = shared_memory.SharedMemory(name=shm_name)
-    cfg, omap, frame, last, rel = _world()
-    tau = cfg.first_frame_tau()
-    scans = _batch_of_scans(frame, last, rel)
-    ex = sh.SegmentLanes(seg.buf, world, rank, 8)
-    deadline = time.time() + 200
-
-    def wait(lane, value, each=False):
-        while True:
-            got = ex.collect_each(lane, value) if each else ex.collect(lane, value)
-            if got is not None:
-                return got
-            assert time.time() < deadline, "a lane never got its peers' hand-off"
-            time.sleep(0)
-
-    # the agreement: largest shard anywhere, the scan count, how many parts this rank could serve
-    mine = np.zeros(sh.REDUCE_WORDS, dtype=np.int64)
-    mine[0] = max(sh.shard_bounds(len(f), world, rank)[1] - sh.shard_bounds(len(f), world, rank)[0] for f, _, _ in scans)
-    mine[1], mine[3] = len(scans), wish[rank]
-    every = wait(0, ex.publish(0, mine), each=True)
-    assert np.all(every[:, 1] == len(scans))
-    n_max, parts = int(every[:, 0].max()), int(every[:, 3].min())
-    poses = [None] * len(scans)
-    errors = []
-
-    def serve(t):
-        try:
-            rng = np.random.default_rng(seed + 17 * rank + t)
-            lo, hi = sh.part_bounds(t, parts, len(scans))
-            nxt, slots, order = lo, [None] * depth, []  # order: slots whose passes are out, oldest first
-            while True:
-                while len(order) < depth:  # send out what can go out: a scan in hand first, else the part's next scan
-                    s = next((j for j in range(depth) if slots[j] is not None and j not in order), None)
-                    if s is None and nxt < hi:
-                        s = next(j for j in range(depth) if slots[j] is None)
-                        fr, la, re = scans[nxt]
-                        a, b = sh.shard_bounds(len(fr), world, rank)
-                        slots[s] = dict(k=nxt, shard=fr[a:b], T=okicp.se3_mul(la, re), it=0, beta=None)
-                        nxt += 1
-                    if s is None:
-                        break
-                    order.append(s)
-                if not order:
-                    return
-                st = slots[order.pop(0)]
-                if rng.random() < 0.3:
-                    time.sleep(rng.random() * 2e-3)  # this rank's kernel is late with the pass's rows
-                sums = sh.unpack(wait(t, ex.publish(t, sh.pack(shard_pass_fixed(omap, st["shard"], st["T"], tau)))))
-                if st["it"] == 0:
-                    st["beta"] = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
-                dx = okicp.solve(sums[:5], sums[6], st["beta"])
-                st["T"] = okicp.se3_mul(st["T"], okicp.motion_model(dx))
-                st["it"] += 1
-                if np.hypot(dx[0], dx[1]) < 1e-3 or st["it"] >= 10:
-                    poses[st["k"]] = np.concatenate([st["T"], [st["it"]]])
-                    slots[slots.index(st)] = None
-        except BaseException as e:  # noqa: BLE001
-            errors.append(repr(e))
-
-    threads = [threading.Thread(target=serve, args=(t,)) for t in range(parts)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    assert not errors, errors
-    np.save(os.path.join(out_dir, "parts_%d.npy" % rank), np.array([np.concatenate([p, [parts, n_max]]) for p in poses]))
-    del ex
-    seg.close()
-
-
-@pytest.mark.parametrize("world,depth", [(8, 3), (3, 1)])
-def test_sharded_batch_on_parts_with_a_lane_each(tmp_path, world, depth):
-    """the protocol of a sharded batch on resident kernels side by side, eight ranks (the node size the north star names) and three: the
-    agreement on lane 0, then every part on its own lane with a blocking hand-off per pass - every rank ends with the bits of the lock-step
-    registration of the whole scans, whatever pace its parts went at; the ranks' wishes for the number of parts differ, the smallest counts"""
-    import multiprocessing as mp
-    from multiprocessing import shared_memory
-    wish = [4, 3, 5, 3, 8, 4, 3, 6][:world]
-    seg = shared_memory.SharedMemory(create=True, size=sh.SegmentLanes.nbytes(world, 8))
-    try:
-        np.ndarray((seg.size // 8,), dtype=np.int64, buffer=seg.buf)[:] = 0
-        ctx = mp.get_context("spawn")
-        procs = [ctx.Process(target=_parts_worker, args=(r, world, wish, depth, seg.name, str(tmp_path), 4321)) for r in range(world)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(timeout=300)
-            assert p.exitcode == 0
-    finally:
-        seg.close()
-        seg.unlink()
-    got = [np.load(tmp_path / ("parts_%d.npy" % r)) for r in range(world)]
-    assert all(np.array_equal(g, got[0], equal_nan=True) for g in got[1:])
-    assert int(got[0][0][8]) == 3  # (the smallest wish)
-    cfg, omap, frame, last, rel = _world()
-    tau = cfg.first_frame_tau()
-    scans = _batch_of_scans(frame, last, rel)
-    assert int(got[0][0][9]) == max(-(-len(f) // world) for f, _, _ in scans)  # (the largest shard anywhere)
-    for k, (fr, la, re) in enumerate(scans):
-        T, beta, its = okicp.se3_mul(la, re), None, 0
-        for it in range(10):
-            words = np.sum([sh.pack(shard_pass_fixed(omap, fr[slice(*sh.shard_bounds(len(fr), world, r))], T, tau)) for r in range(world)], 0)
-            sums = sh.unpack(words)
-            if it == 0:
-                beta = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
-            dx = okicp.solve(sums[:5], sums[6], beta)
-            T, its = okicp.se3_mul(T, okicp.motion_model(dx)), it + 1
-            if np.hypot(dx[0], dx[1]) < 1e-3:
-                break
-        assert np.array_equal(got[0][k][:7], T, equal_nan=True) and int(got[0][k][7]) == its, k
-    assert [sh.part_bounds(t, 3, 11) for t in range(3)] == [(0, 3), (3, 7), (7, 11)]
-
-
 def test_small_scan_rows_add_up_exactly():
     """The small-scan kernels' row format (two 48-bit halves per 128-bit sum, kicp_small.hpp) against the limb payload: totals of
     either sign up to the accumulation range (|term| < 2^43, 1024 terms per workgroup), 272 rows, stale and marked rows."""

@@ -18,7 +18,7 @@ tau = cfg.first_frame_tau()
 frames = [K.DeviceFrame(s["frame"]) for s in scans]
 rels = [syn.pose_mul(s["rel_odom"], syn.planar_pose(0.05, 0.0, np.deg2rad(0.5))) for s in scans]
 n = len(scans[0]["frame"])
-for opts in (dict(), dict(wave_block=256), dict(wave_block=1024), dict(small_cmd=0)):
+for opts in (dict(), dict(small_cmd=0)):
     os.environ["KICP_KERNARG"] = "dev"
     reg = K.KinematicRegistration()
     for k, v in opts.items():
