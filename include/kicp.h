@@ -118,8 +118,9 @@ size_t kicp_map_num_points(const kicp_map *map);
 size_t kicp_map_num_voxels(const kicp_map *map);
 /* Pointcloud() -- KinematicICP.hpp:92.  Writes min(cap_points, total) points, returns total. */
 size_t kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap_points);
-/* GetClosestNeighbor(query) for n queries -- Registration.cpp:74.  Host arrays in/out; runs the DEVICE
- * search (the same 27-voxel 1-NN code path the fused registration kernel uses) on `device`.
+/* GetClosestNeighbor(query) for n queries -- Registration.cpp:74.  Host arrays in/out; runs on `device` the plain fp64 search
+ * over the 27 neighbour voxels (kicp_kernels.hpp search_global: the reference's loop, and the exact fallback of the fused pass
+ * kernels - NOT their mirror pre-selection: what the shipped pass kernels pick per query is what kicp_pass_correspondences returns).
  * No candidate -> nn = (0,0,0), dist = DBL_MAX, exactly like the reference. */
 int kicp_map_closest(kicp_map *map, int device, const double *queries_xyz, size_t n, double *out_nn_xyz, double *out_dist);
 /* Debug aid: verifies the table invariants the kernels rely on (neighbour masks, bucket records, halo entries, fp32
@@ -293,6 +294,17 @@ int kicp_register_device_concurrent(kicp_reg *const *regs, size_t lanes, kicp_ma
  * out_sums = {JTJ00, JTJ01, JTJ11, JTr0, JTr1, sum||r||^2, N_corr}, un-normalised.  Host frame pointer. */
 int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                    double max_correspondence_distance, double out_sums[7]);
+
+/* The correspondences of that pass themselves - what DataAssociation appends (Registration.cpp:73-77) -, one entry per source point,
+ * written by the SAME pass kernel build the handle registers a scan of this size with (its EXPORT instantiation: the search, the exact
+ * resolution, the tie rule and the acceptance test are the shipped code, with the decision also stored per query):
+ *   out_index[i]   index of the chosen map point in the device pool (bucket * max_points_per_voxel + position), -1: no correspondence
+ *                  (nothing within max_correspondence_distance)
+ *   out_d2[i]      its squared distance to pose * frame[i] (fp64, the reference's operation order); DBL_MAX without a correspondence
+ *   out_nn_xyz     its coordinates (3 doubles per point; zeros without a correspondence)
+ * Kernel-shape options ("small", "small_wave", "lanes_per_query", "latency_kernel") steer it as they steer kicp_register. */
+int kicp_pass_correspondences(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
+                              double max_correspondence_distance, int32_t *out_index, double *out_d2, double *out_nn_xyz);
 
 /* Same pass, but returns the raw all-reduce payload: KICP_REDUCE_WORDS int64 words = 3 limbs per sum (value * 2^40 =
  * l0 + l1*2^40 + l2*2^80) + range flag + padding.  Summing the words of disjoint shards element-wise gives exactly the

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "kicp_register_device_concurrent": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                                   _dp, _dp, C.c_double, _dp, C.POINTER(C.c_int)]),
     "kicp_pass_sums": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, _dp]),
+    "kicp_pass_correspondences": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_int32), _dp, _dp]),
     "kicp_pass_words": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_longlong)]),
     "kicp_pre_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "kicp_pre_destroy": (None, [C.c_void_p]),
@@ -443,6 +444,19 @@ class KinematicRegistration:
         out = np.zeros(7, dtype=np.float64)
         _check(lib().kicp_pass_sums(self._h, voxel_map._h, p, a.size // 3, q, max_correspondence_distance, out.ctypes.data_as(_dp)))
         return out
+
+    def pass_correspondences(self, frame, voxel_map, pose, max_correspondence_distance):
+        """kicp_pass_correspondences: DataAssociation's output per source point from the pass kernel this handle registers a scan of this
+        size with -> (index[n] int32, -1 = none; d2[n]; nn[n, 3])."""
+        a, p = _d(frame)
+        _, q = _d(pose)
+        n = a.size // 3
+        idx = np.empty(n, dtype=np.int32)
+        d2 = np.empty(n, dtype=np.float64)
+        nn = np.empty((n, 3), dtype=np.float64)
+        _check(lib().kicp_pass_correspondences(self._h, voxel_map._h, p, n, q, max_correspondence_distance, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               d2.ctypes.data_as(_dp), nn.ctypes.data_as(_dp)))
+        return idx, d2, nn
 
     def pass_words(self, frame, voxel_map, pose, max_correspondence_distance):
         """The same pass as raw int64[24] limb words (the multi-GPU all-reduce payload; see sharding.py)."""

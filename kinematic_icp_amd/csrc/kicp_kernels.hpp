@@ -158,7 +158,12 @@ struct PassParams {
     unsigned int *tickets;         // first-level arrival counters, one per group, 128 B apart, zero between launches
     unsigned long long *group_acc; // resident kernels: the groups' counting accumulators (finish_pass, ROWS_ONLY), zero between passes
     SolveParams sol;
-    int32_t dbg;          // ablation switches for tools/gpu_dbg.py (0 = normal operation); read by the DBG build only (dbg_is)
+    int32_t dbg;          // ablation switches for tools/dbg_census.py (0 = normal operation); read by the DBG build only (dbg_is)
+    // kicp_pass_correspondences (the EXPORT instantiations of the pass kernels only; nullptr otherwise): what DataAssociation appends
+    // for query i (Registration.cpp:73-77) - the chosen map point's index in the pool (-1: no correspondence), its squared distance
+    // to T * source[i] and its coordinates
+    int32_t *corr_index;
+    double *corr_d2, *corr_nn;
 };
 // The ablation / attribution switches (`dbg`, tools/gpu_dbg.py, tools/ab_option.py, bench.py's floor and rounds census) exist in
 // libkicp_amd_dbg.so only (make dbg: -DKICP_DBG_BUILD).  In the production library every test below is a compile-time constant:
@@ -1194,8 +1199,16 @@ __device__ __forceinline__ const PassParams &args_at_point_of_use() {
 // exact resolution of a finished search: the winner (and whatever lies within the margin of it) re-evaluated in fp64, the
 // reference's tie rule, the acceptance test and the per-correspondence terms (Registration.cpp:74-77, 86-93)
 // `host_pose`: T is the host's pose (the kernel arguments carry its basis); otherwise the basis is formed here, from T
+// EXPORT (kicp_pass_correspondences): the decision is also written out per query - index, squared distance, coordinates
+__device__ __forceinline__ void export_correspondence(const PassParams &p, uint32_t i, uint32_t idx, double d2, double x, double y, double z) {
+    p.corr_index[i] = idx == kNoIndex32 ? -1 : static_cast<int32_t>(idx);
+    p.corr_d2[i] = idx == kNoIndex32 ? DBL_MAX : d2;
+    p.corr_nn[3 * i] = x, p.corr_nn[3 * i + 1] = y, p.corr_nn[3 * i + 2] = z;
+}
+template <bool EXPORT = false>
 __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParams &p, bool host_pose, const double *__restrict__ src, const Pose &T, uint32_t i,
                                                        const Best3 &t, const KeptQuery *kept = nullptr) {
+    if (EXPORT && i != kNoIndex32) export_correspondence(p, i, kNoIndex32, 0.0, 0.0, 0.0, 0.0);  // (overwritten below when the query has a correspondence)
     if (i == kNoIndex32 || t.i1 == kNoIndex32 || (kDbgBuild && p.dbg != 0 && p.dbg != 9 && p.dbg != 11 && p.dbg != 12 && p.dbg != 13 && p.dbg != 14)) return;
     const MapView &m = p.map;
     const float margin = p.search.margin_u;
@@ -1237,6 +1250,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
             const double *tp = m.pool + static_cast<size_t>(best_idx) * 3;
             wx = tp[0], wy = tp[1], wz = tp[2];
         }
+        if (EXPORT) export_correspondence(p, i, best_idx, best, wx, wy, wz);
         // The basis is taken up HERE - behind an opaque copy of the flag, so that the compiler cannot merge its two sources ahead of
         // the exact phase and carry sixteen registers through it (the four-waves build spilled them) - and, where it is the host's,
         // read from the kernarg segment here rather than at the kernel's start (args_at_point_of_use).
@@ -1268,7 +1282,7 @@ __device__ __forceinline__ void resolve_and_accumulate(Acc &acc, const PassParam
 constexpr int kParkWords = 5;
 // `host_pose`: T is the host's pose (kernel arguments) and p.sol.basis its basis; where the kernel got T from the device the basis
 // is formed right before the exact phase, not kept through the search.
-template <int BLOCK, int G, bool SPLIT, bool LAT, bool PARK = false>
+template <int BLOCK, int G, bool SPLIT, bool LAT, bool PARK = false, bool EXPORT = false>
 __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T, bool host_pose, uint32_t tid, Acc &acc, const double *__restrict__ src, uint32_t n,
                                               uint32_t block, int *lend = nullptr, double *park = nullptr) {
     const MapView &m = p.map;
@@ -1401,13 +1415,13 @@ __device__ __forceinline__ void gather32_pass(const PassParams &p, const Pose &T
         kept.sx = park[3 * BLOCK + tid], kept.sy = park[4 * BLOCK + tid], kept.voxel = false;
     }
     if (sub == 0) {
-        resolve_and_accumulate(acc, p, host_pose, src, T, L.i, L.t, (LAT || PARK) ? &kept : nullptr);
+        resolve_and_accumulate<EXPORT>(acc, p, host_pose, src, T, L.i, L.t, (LAT || PARK) ? &kept : nullptr);
     }
     // dbg 10 (bench.py's latency model): no correspondences are formed; the "count" sum carries the number of visiting rounds
     // this WAVE ran - its chain of dependent bucket visits - from lane 0 (as rounds x 2^40: limb 1 holds bits 21..41, limb 2 the rest)
     if (dbg_is(p, 10) && (tid & 63u) == 0u) acc.limb[6 * kTermLimbs + 1] = static_cast<int>(rounds & 3u) << 19, acc.limb[6 * kTermLimbs + 2] = static_cast<int>(rounds >> 2);
 }
-template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false>
+template <int BLOCK, int G, int OCC, bool SPLIT, bool LAT = false, bool EXPORT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p) {
     static_assert(!SPLIT || G == 2, "bucket sharing is written for pairs of lanes");
     static_assert(!LAT || G == 1, "the latency-oriented build serves one lane per query");
@@ -1418,7 +1432,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_pass_gather32(const PassParams p
     const Pose T = load_pose(p);
     const bool host_pose = p.sol.pass == 0 || p.sol.mode >= 2;  // (load_pose)
     Acc acc{};
-    gather32_pass<BLOCK, G, SPLIT, LAT, kLends>(p, T, host_pose, threadIdx.x, acc, p.src, p.n, blockIdx.x, kLends ? &s_lend[kLends ? threadIdx.x / 64 : 0][0] : nullptr,
+    gather32_pass<BLOCK, G, SPLIT, LAT, kLends, EXPORT>(p, T, host_pose, threadIdx.x, acc, p.src, p.n, blockIdx.x, kLends ? &s_lend[kLends ? threadIdx.x / 64 : 0][0] : nullptr,
                                                 s_park);
     if (BLOCK > 64) __syncthreads();
     finish_pass<BLOCK>(acc, p, s_red, &s_flag, p.sol.tag);

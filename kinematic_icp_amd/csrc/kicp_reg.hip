@@ -107,6 +107,10 @@ struct kicp_reg {
     int wait_mode = 0;    // 0 poll the host-mapped record; 1 hipStreamSynchronize
     int timing = 0;       // record HIP events around the call -> stats.gpu_ms
     int dbg = 0;
+    // kicp_pass_correspondences: device buffers the EXPORT instantiations of the pass kernels write the per-query decisions to (set for
+    // the duration of that call only)
+    int32_t *corr_index = nullptr;
+    double *corr_d2 = nullptr, *corr_nn = nullptr;
     int query_every = 512; // polls between hipStreamQuery calls while waiting (a call costs ~1 us of host time)
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
     int latency_kernel = 1;   // variant 3, one lane per query: the two-voxels-per-round build (0 never | 1 scans <= kLatencyMaxPoints | 2 always)
@@ -246,7 +250,7 @@ const AqlKernel *aql_lookup(kicp_reg *r, int key, const char *demangled_prefix) 
 // the names below must agree with tools/aql_kernel_names.py (tests/test_host.py checks them against build/kicp_reg.hsaco)
 const AqlKernel *aql_kernel_for(kicp_reg *r, int b, int g, int occ, bool split, bool lat) {
     char name[128];
-    std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s, %s>(", b, g, occ, split ? "true" : "false", lat ? "true" : "false");
+    std::snprintf(name, sizeof name, "void kicp::k_pass_gather32<%d, %d, %d, %s, %s, false>(", b, g, occ, split ? "true" : "false", lat ? "true" : "false");
     return aql_lookup(r, b * 1000 + g * 100 + occ * 10 + (split ? 1 : 0) + (lat ? 2 : 0), name);
 }
 const AqlKernel *aql_resident_kernel_for(kicp_reg *r, bool lat) {
@@ -254,8 +258,8 @@ const AqlKernel *aql_resident_kernel_for(kicp_reg *r, bool lat) {
 }
 const AqlKernel *aql_small_kernel_for(kicp_reg *r, int block, int g, bool wave) {
     char name[128];
-    if (wave) std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(", block);
-    else std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(", block, g);
+    if (wave) std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d, false>(", block);
+    else std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d, false>(", block, g);
     return aql_lookup(r, -(block * 10 + (wave ? 9 : g)), name);
 }
 // Before HIP work follows kernels that went through the handle's AQL queue: wait for them.  A time-out is an error (a kernel
@@ -286,6 +290,15 @@ int launch_pass(kicp_reg *r, const PassParams &p, bool allow_aql = false) {
     const bool split = g == 2;
     // While HIP work may be pending on the handle's stream (a frame upload, a mirror refresh, a clear) the kernel goes
     // through the stream, ordered behind it; once the host has that pass's result the stream is known to be idle.
+    if (p.corr_index) {  // kicp_pass_correspondences: the same build with the per-query decisions written out, through the HIP stream
+        if (int rc = aql_quiesce(r)) return rc;
+        r->last_via_aql = false;
+        if (lat) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 1, 2, false, true, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+        else if (g == 1) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 1, 4, false, false, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+        else if (g == 2) hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 2, 4, true, false, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+        else hipLaunchKernelGGL((k_pass_gather32<kPassBlock, 4, 4, false, false, true>), dim3(grid), dim3(kPassBlock), 0, r->stream, p);
+        return KICP_OK;
+    }
     if (allow_aql && r->use_aql && !r->stream_dirty) {
         if (const AqlKernel *k = aql_kernel_for(r, kPassBlock, g, occ, split, lat)) {
             // Fences of the packet.  Acquire: agent scope - the kernel start invalidates the vector / scalar L1s and the
@@ -641,6 +654,19 @@ void send_command(kicp_reg *r, unsigned long long seq, uint32_t op, const Pose &
 int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
     const int b = pl.block, g = pl.g;
     const uint32_t grid = pl.grid;
+    if (sp.p.corr_index) {  // kicp_pass_correspondences: the same kernels with the per-query decisions written out, through the HIP stream
+        if (pl.generic) return fail(KICP_ERR_ARG, "correspondences are exported by one-pass launches");
+        if (int rc = aql_quiesce(r)) return rc;
+        r->last_via_aql = false, r->stream_dirty = false;
+        if (pl.wave && b == 1024) hipLaunchKernelGGL((k_pass_wave<1024, true>), dim3(grid), dim3(1024), 0, r->stream, sp);
+        else if (pl.wave && b == 512) hipLaunchKernelGGL((k_pass_wave<512, true>), dim3(grid), dim3(512), 0, r->stream, sp);
+        else if (pl.wave) hipLaunchKernelGGL((k_pass_wave<256, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+        else if (g == 1) hipLaunchKernelGGL((k_pass_small<256, 1, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+        else if (g == 2) hipLaunchKernelGGL((k_pass_small<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+        else hipLaunchKernelGGL((k_pass_small<256, 4, true>), dim3(grid), dim3(256), 0, r->stream, sp);
+        HIP_TRY(hipGetLastError());
+        return KICP_OK;
+    }
     if (r->use_aql && !r->stream_dirty) {
         if (const AqlKernel *k = pl.generic ? aql_resident_kernel_for(r, pl.lat) : aql_small_kernel_for(r, b, g, pl.wave)) {
             if (r->aql.dispatch(*k, grid, static_cast<uint32_t>(b), &sp, sizeof sp, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT)) {
@@ -652,19 +678,14 @@ int launch_small(kicp_reg *r, const SmallParams &sp, const SmallPlan &pl) {
     r->stream_dirty = false;  // the host waits for this kernel's rows: by then everything queued before it is done
     if (int rc = aql_quiesce(r)) return rc;
     r->last_via_aql = false;
-#define KICP_SMALL(B)                                                                                     \
-    do {                                                                                                  \
-        if (pl.wave) hipLaunchKernelGGL((k_pass_wave<B>), dim3(grid), dim3(B), 0, r->stream, sp);         \
-        else if (g == 1) hipLaunchKernelGGL((k_pass_small<B, 1>), dim3(grid), dim3(B), 0, r->stream, sp); \
-        else if (g == 2) hipLaunchKernelGGL((k_pass_small<B, 2>), dim3(grid), dim3(B), 0, r->stream, sp); \
-        else hipLaunchKernelGGL((k_pass_small<B, 4>), dim3(grid), dim3(B), 0, r->stream, sp);             \
-    } while (0)
     if (pl.generic && pl.lat) hipLaunchKernelGGL((k_pass_resident<256, 2, true>), dim3(grid), dim3(256), 0, r->stream, sp);
     else if (pl.generic) return fail(KICP_ERR_ARG, "the resident generic kernel exists as the latency-oriented build only");
-    else if (b == 1024) KICP_SMALL(1024);
-    else if (b == 512) KICP_SMALL(512);
-    else KICP_SMALL(256);
-#undef KICP_SMALL
+    else if (pl.wave && b == 1024) hipLaunchKernelGGL((k_pass_wave<1024>), dim3(grid), dim3(1024), 0, r->stream, sp);
+    else if (pl.wave && b == 512) hipLaunchKernelGGL((k_pass_wave<512>), dim3(grid), dim3(512), 0, r->stream, sp);
+    else if (pl.wave) hipLaunchKernelGGL((k_pass_wave<256>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else if (g == 1) hipLaunchKernelGGL((k_pass_small<256, 1>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else if (g == 2) hipLaunchKernelGGL((k_pass_small<256, 2>), dim3(grid), dim3(256), 0, r->stream, sp);
+    else hipLaunchKernelGGL((k_pass_small<256, 4>), dim3(grid), dim3(256), 0, r->stream, sp);
     HIP_TRY(hipGetLastError());
     return KICP_OK;
 }
@@ -799,6 +820,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.sol.max_iterations = max_it, pp.sol.convergence_criterion = r->cfg.convergence_criterion, pp.sol.mode = 4;
     pp.dbg = r->dbg;  // (0, or 14: the in-process A/B switch of the plain launch's hand-over)
+    pp.corr_index = r->corr_index, pp.corr_d2 = r->corr_d2, pp.corr_nn = r->corr_nn;  // (kicp_pass_correspondences; nullptr otherwise)
     if (grouped) pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc, pp.sol.pub_rows = r->d_rows, pp.sol.call_id = ++r->call_id, pp.sol.rec = r->d_rec;
     if (grouped)
         if (int rc = clear_stale_tickets(r)) return rc;
@@ -942,6 +964,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     pp.search = search_params(tau, map->mirror.view.voxel_size);
     pp.partials = r->d_partials, pp.tickets = r->d_tickets, pp.group_acc = r->d_group_acc;
     pp.dbg = r->dbg;
+    pp.corr_index = r->corr_index, pp.corr_d2 = r->corr_d2, pp.corr_nn = r->corr_nn;  // (kicp_pass_correspondences; nullptr otherwise)
     SolveParams &sp = pp.sol;
     set_pose(sp, T0), sp.max_iterations = max_it, sp.convergence_criterion = r->cfg.convergence_criterion;
     sp.adaptive = r->cfg.use_adaptive_odometry_regularization, sp.fixed_regularization = r->cfg.fixed_regularization;
@@ -2100,6 +2123,43 @@ int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out) {
     *out = c;
     return KICP_OK;
 }
+// DataAssociation's output for one pose (Registration.cpp:62-81), from the very kernel the handle would register this scan with: a
+// registration of ONE iteration at `pose` (last pose = pose, odometry = identity) whose pass kernel is the EXPORT instantiation of the
+// build that scan size and the handle's options select (launch_pass / launch_small).
+int kicp_pass_correspondences(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7], double max_correspondence_distance,
+                              int32_t *out_index, double *out_d2, double *out_nn_xyz) {
+    KICP_TRACE_CALL();
+    if (!reg || !map || (!frame_xyz && n) || !pose_qt || (n && (!out_index || !out_d2 || !out_nn_xyz))) return fail(KICP_ERR_ARG, "null argument");
+    if (n == 0) return KICP_OK;
+    if (n > 0x7FFFFFF0ull / 3) return fail(KICP_ERR_CAPACITY, "frame too large");
+    if (reg->comm || reg->allreduce_fn || reg->shm || reg->d_p2p_table) return fail(KICP_ERR_ARG, "detach the multi-GPU exchange first: correspondences are exported per device");
+    if (int rc = set_device(reg->device)) return rc;
+    if (int rc = ensure_frame(reg, n)) return rc;
+    if (int rc = staged_upload(reg->stage, 0, reg->d_frame, frame_xyz, n * 24, reg->stream)) return rc;
+    reg->stream_dirty = true;
+    unsigned char *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, n * 36));
+    reg->corr_nn = reinterpret_cast<double *>(buf), reg->corr_d2 = reg->corr_nn + 3 * n, reg->corr_index = reinterpret_cast<int32_t *>(reg->corr_d2 + n);
+    hipError_t e = hipMemsetAsync(buf, 0, n * 32, reg->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(reg->corr_index, 0xFF, n * 4, reg->stream);  // (-1: an empty map returns before any kernel runs)
+    const int max_it = reg->cfg.max_num_iterations;
+    reg->cfg.max_num_iterations = 1;
+    const double identity[7] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
+    double pose_out[7];
+    int rc = e == hipSuccess ? run_registration(reg, map, reg->d_frame, n, pose_qt, identity, max_correspondence_distance, pose_out, nullptr) : KICP_ERR_HIP;
+    reg->cfg.max_num_iterations = max_it;
+    reg->corr_index = nullptr, reg->corr_d2 = reg->corr_nn = nullptr;
+    if (e == hipSuccess && rc >= 0) e = hipStreamSynchronize(reg->stream);
+    if (e == hipSuccess && rc >= 0) e = hipMemcpy(out_nn_xyz, buf, n * 24, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc >= 0) e = hipMemcpy(out_d2, buf + n * 24, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc >= 0) e = hipMemcpy(out_index, buf + n * 32, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(KICP_ERR_HIP, std::string("kicp_pass_correspondences: ") + hipGetErrorString(e));
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < n; ++i)
+        if (out_index[i] < 0) out_d2[i] = DBL_MAX;
+    return KICP_OK;  // (a pass without correspondences is a result here, not a warning)
+}
 static int pass_once(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
                      double max_correspondence_distance, double out_sums[7], long long out_words[24]);
 int kicp_pass_sums(kicp_reg *reg, kicp_map *map, const double *frame_xyz, size_t n, const double pose_qt[7],
@@ -2347,17 +2407,16 @@ size_t kicp_aql_kernel_names(char *out, size_t cap) {
     // aql_kernel_for / aql_small_kernel_for look it up
     std::string all;
     char name[128];
-    all += "void kicp::k_pass_gather32<256, 1, 2, false, true>(\n";
-    all += "void kicp::k_pass_gather32<256, 1, 4, false, false>(\n";
-    all += "void kicp::k_pass_gather32<256, 2, 4, true, false>(\n";
-    all += "void kicp::k_pass_gather32<256, 4, 4, false, false>(\n";
-    for (int b : {256, 512, 1024})
-        for (int g : {1, 2, 4}) {
-            std::snprintf(name, sizeof name, "void kicp::k_pass_small<%d, %d>(\n", b, g);
-            all += name;
-        }
+    all += "void kicp::k_pass_gather32<256, 1, 2, false, true, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 1, 4, false, false, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 2, 4, true, false, false>(\n";
+    all += "void kicp::k_pass_gather32<256, 4, 4, false, false, false>(\n";
+    for (int g : {1, 2, 4}) {
+        std::snprintf(name, sizeof name, "void kicp::k_pass_small<256, %d, false>(\n", g);
+        all += name;
+    }
     for (int b : {256, 512, 1024}) {
-        std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d>(\n", b);
+        std::snprintf(name, sizeof name, "void kicp::k_pass_wave<%d, false>(\n", b);
         all += name;
     }
     all += "void kicp::k_pass_resident<256, 2, true>(\n";

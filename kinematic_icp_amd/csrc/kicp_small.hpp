@@ -190,7 +190,7 @@ __device__ __forceinline__ void small_publish(const Acc &a, const SmallParams &s
 // G sub-lanes per query as in k_pass_gather32 (the neighbour voxels of a query are dealt round-robin to its sub-lanes).
 // BLOCK = 256 (default): one wave per SIMD on as many CUs as the scan has workgroups - the search is a chain of dependent
 // loads, and waves that share a SIMD and a CU's L1 path only lengthen it; 1024: a quarter of the rows for the host to add.
-template <int BLOCK, int G>
+template <int BLOCK, int G, bool EXPORT = false>
 __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read through fresh_args() */) {
     __shared__ int s_red[BLOCK / 64][kWaveLimbs];
     __shared__ int s_flag;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_small(const SmallParams /* read 
                 o.i1 = __shfl_xor(L.t.i1, off, 64), o.i2 = __shfl_xor(L.t.i2, off, 64), o.o1 = __shfl_xor(L.t.o1, off, 64), o.o2 = __shfl_xor(L.t.o2, off, 64);
                 best3_merge(L.t, o);
             }
-            if (sub == 0) resolve_and_accumulate(acc, p, false, p.src, T, L.i, L.t);
+            if (sub == 0) resolve_and_accumulate<EXPORT>(acc, p, false, p.src, T, L.i, L.t);
         }
         __syncthreads();  // s_flag is reset; (s_red of the previous pass has long been read)
         tid = fresh_tid();
@@ -402,7 +402,7 @@ __device__ __forceinline__ bool better_candidate(double cd, uint32_t co, const W
     return co < b.ord ? !closer_by_norm(b.d2, cd) : closer_by_norm(cd, b.d2);
 }
 
-template <int BLOCK>
+template <int BLOCK, bool EXPORT = false>
 __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read through fresh_args() */) {
     constexpr int kWaves = BLOCK / 64;
     constexpr int kTripPoints = static_cast<int>(kMirrorTrip);  // 20 lanes per bucket: three buckets side by side, two such sets per lane
@@ -566,7 +566,9 @@ __global__ __launch_bounds__(BLOCK) void k_pass_wave(const SmallParams /* read t
                     more = __ballot((active[0] && kk == kTripPoints - 1 && (mp[0].y >> 16) == 0u) || (active[1] && kk == kTripPoints - 1 && (mp[1].y >> 16) == 0u)) != 0ull;
                 }
             }
-            if (best.idx != kNoIndex32 && sqrt(best.d2) < p.tau) {  // `distance < max_correspondance_distance`, Registration.cpp:75
+            const bool take = best.idx != kNoIndex32 && sqrt(best.d2) < p.tau;  // `distance < max_correspondance_distance`, Registration.cpp:75
+            if (EXPORT && lane == 0) export_correspondence(p, qi, take ? best.idx : kNoIndex32, best.d2, take ? best.x : 0.0, take ? best.y : 0.0, take ? best.z : 0.0);
+            if (take) {
                 accepted = true;
                 // the terms of kicp_kernels.hpp::correspondence_terms (one function for every pass kernel: the same doubles), lane k < 6
                 // taking term k to convert and park; JTJ(0,0) is the expression basis_of converts

@@ -762,6 +762,22 @@ void okicp_pass(void *m, const double *frame_xyz, size_t n, const double pose_qt
     if (out_counters) out_counters[0] = qc.probes, out_counters[1] = qc.occupied, out_counters[2] = qc.points_scanned;
 }
 
+// DataAssociation per query (Registration.cpp:73-77, serial): accepted[i] = 1 and nn / dist = GetClosestNeighbor(T * frame[i]) when
+// `distance < max_correspondance_distance`, else accepted[i] = 0 (nn / dist still what GetClosestNeighbor returned).  The checker of
+// kicp_pass_correspondences (tests/test_gpu_correspondences.py).
+void okicp_associate(void *m, const double *frame_xyz, size_t n, const double pose_qt[7], double tau, int32_t *accepted, double *out_nn,
+                     double *out_dist) {
+    const auto *map = static_cast<VoxelMap *>(m);
+    const SE3 T = se3_from_qt(pose_qt);
+    const V3 *points = reinterpret_cast<const V3 *>(frame_xyz);
+    for (size_t i = 0; i < n; ++i) {
+        const auto [closest_neighbor, distance] = map->GetClosestNeighbor(se3_act(T, points[i]), nullptr);
+        accepted[i] = distance < tau ? 1 : 0;
+        out_nn[3 * i] = closest_neighbor.x, out_nn[3 * i + 1] = closest_neighbor.y, out_nn[3 * i + 2] = closest_neighbor.z;
+        out_dist[i] = distance;
+    }
+}
+
 // KinematicRegistration::ComputeRobotMotion.  count_work!=0 also fills the probe/scan counters
 // (slower; leave 0 when timing).  Returns 0, or 1 if the result contains NaN (zero correspondences).
 int okicp_register(void *m, const double *frame_xyz, size_t n, const double last_pose_qt[7], const double rel_odom_qt[7],

@@ -77,6 +77,7 @@ def lib():
         L.okicp_map_pointcloud.argtypes = [C.c_void_p, _dp, C.c_size_t]
         L.okicp_map_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp]
         L.okicp_pass.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.c_int, _dp, C.POINTER(C.c_uint64)]
+        L.okicp_associate.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.c_double, C.POINTER(C.c_int32), _dp, _dp]
         L.okicp_register.restype = C.c_int
         L.okicp_register.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_double, C.c_int, C.c_double, C.c_int,
                                      C.c_int, C.c_double, C.c_int, _dp, C.POINTER(Stats)]
@@ -174,6 +175,19 @@ def icp_pass(vmap, frame, pose_qt, tau, num_threads=1):
     cnt = (C.c_uint64 * 3)()
     lib().okicp_pass(vmap._h, p, a.size // 3, q, tau, num_threads, sums.ctypes.data_as(_dp), cnt)
     return sums, np.array(list(cnt), dtype=np.uint64)
+
+
+def associate(vmap, frame, pose_qt, tau):
+    """DataAssociation per query (Registration.cpp:73-77): (accepted[n] bool, nn[n, 3], distance[n]) - nn / distance are
+    GetClosestNeighbor(pose * frame[i]); accepted = distance < tau."""
+    a, p = _d(frame)
+    _, q = _d(pose_qt)
+    n = a.size // 3
+    acc = np.zeros(n, dtype=np.int32)
+    nn = np.empty((n, 3), dtype=np.float64)
+    d = np.empty(n, dtype=np.float64)
+    lib().okicp_associate(vmap._h, p, n, q, tau, acc.ctypes.data_as(C.POINTER(C.c_int32)), nn.ctypes.data_as(_dp), d.ctypes.data_as(_dp))
+    return acc.astype(bool), nn, d
 
 
 class KinematicRegistration:

@@ -341,3 +341,21 @@ def test_golden_case_a_matches_numpy_restatement():
     p, it = rn.compute_robot_motion(g["a_frame"], r, g["a_last"], g["a_rel"], float(g["a_tau"]))
     assert it == int(g["a_iters"])
     np.testing.assert_allclose(p, g["a_pose"], atol=1e-9)
+
+
+def test_association_per_query_is_the_pass_the_sums_come_from():
+    """okicp.associate (DataAssociation per query, Registration.cpp:73-77) - the checker of kicp_pass_correspondences: its accepted set is
+    the correspondence count of the fused pass, its neighbours and distances are GetClosestNeighbor's, acceptance is strict."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-6, 6, (3000, 3))
+    m = okicp.VoxelHashMap(1.0, 100.0, 20)
+    m.AddPoints(pts)
+    frame = rng.uniform(-6, 6, (500, 3))
+    pose = np.array([0.0, 0.0, np.sin(0.05), np.cos(0.05), 0.1, -0.2, 0.0])
+    acc, nn, d = okicp.associate(m, frame, pose, 0.4)
+    sums, _ = okicp.icp_pass(m, frame, pose, 0.4)
+    assert acc.sum() == sums[6] and 0 < acc.sum() < len(frame)
+    nn2, d2 = m.GetClosestNeighbor(okicp.se3_act(pose, frame))
+    assert np.array_equal(nn, nn2) and np.array_equal(d, d2) and np.array_equal(acc, d < 0.4)
+    k = int(np.argmax(acc))
+    assert not okicp.associate(m, frame[k:k + 1], pose, d[k])[0][0] and okicp.associate(m, frame[k:k + 1], pose, np.nextafter(d[k], 1.0))[0][0]
