@@ -20,22 +20,22 @@ ms per ICP iteration.
 
 N > 1: the scan's points are sharded contiguously across the N ranks, the map is replicated, and every ICP iteration
 sums 24 int64 words per rank (the exact limb sums of the 2x2 normal equations), so every rank returns the bit-identical
-pose.  --comm selects the exchange: "rccl" (default, the north star: ncclAllReduce over xGMI on the registration's
-stream), "shm" (every rank's host adds its GPU's rows and the ranks meet in a node-wide host shared segment: no device
-collective), "p2p" (one-shot exchange: every pass kernel writes its totals into all ranks' HBM mailboxes over xGMI peer
-mappings and adds the node's totals itself - no collective library), "torch" (torch.distributed all-reduce callback).  With
---comm rccl the shm and p2p figures are measured too and reported in `config`.  Total work is fixed -> "scaling": "strong".  (--mode replicas, not the default: every rank
-registers whole scans on its own - one robot per GPU - no exchange, "scaling": "weak".)
+pose.  --comm selects the exchange behind `value` (also printed as "comm"): "rccl" (default, the north star: ncclAllReduce
+over xGMI; a batch call keeps several sharded scans in flight, each lane on a sub-communicator and stream of its own),
+"shm" (every rank's host adds its GPU's rows and the ranks meet in a node-wide host shared segment: no device collective),
+"p2p" (one-shot exchange over xGMI peer mappings - no collective library), "torch" (torch.distributed all-reduce callback).
+Every exchange is measured in the same run (value_rccl, value_shm, value_p2p).  Total work is fixed -> "scaling": "strong";
+"scaling_bound" says what sharding one scan can reach at best (Amdahl from the single-GPU floor), "value_replicas" what the same
+GPUs deliver as independent replicas (--mode replicas makes that the headline: every rank registers whole scans, "scaling": "weak").
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
-  "roofline"     the dominant kernel (fused association+accumulation pass).  `achieved` follows the contract (SURVEY.md
-                 section 8d algorithmic bytes per launch / live HIP-event duration on the kernel's own stream, vs the
-                 8 TB/s HBM peak) and may exceed the peak: the algorithmic count is what the REFERENCE touches (27 probes
-                 + every scanned bucket point per query) while this kernel skips provably irrelevant voxels and is served
-                 by L1/L2 - the kernel is latency bound, not HBM bound.  Next to it: `b_min` (compulsory bytes, a true
-                 lower bound), `time_split_us` (fixed launch+reduction floor measured live vs query work), and - when a
-                 rocprofv3 profile of THIS workload is committed under profiles/ - measured HBM traffic, L2 / L1 request
-                 traffic against their peaks, VALU busy and occupancy.
+  "roofline"     the dominant kernel (fused association+accumulation pass).  `achieved` / `frac` = HBM bytes per launch MEASURED
+                 in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same registrations) / the kernel's live
+                 HIP-event duration, against the 8 TB/s peak.  The kernel is not HBM bound: `frac_latency` (the chain of dependent
+                 accesses a wave must walk, on top of the fixed floor) and `valu_issue` (VALU issue slots per pass) are the bounds
+                 it is held to.  SURVEY.md section 8d's algorithmic bytes - what the REFERENCE touches - are kept under
+                 `algorithmic` for the record; this kernel skips most of them, so that ratio may exceed 1.  `b_min`: compulsory
+                 bytes; `time_split_us`: floor vs query work; `counters`: the committed rocprofv3 profile of this workload.
   "cpu_baseline" the reference's own Registration.cpp (oracle/_ref, kind "reference") timed on this box's host cores
                  at 1 thread (the reference's default) and at the best of several thread counts, on a bounded sample of
                  the same scans; the oracle port's figures beside it.
@@ -112,11 +112,11 @@ def main():
     ap.add_argument("--pipeline-frames", type=int, default=24,
                     help="frames of the `pipeline` block (the whole drop-in KinematicICP::RegisterFrame - ingest, pre-steps, registration, map update - on a "
                          "synthetic drive of 131 072-point PointCloud2 messages, with the reference's own RegisterFrame timed beside it); 0: skip")
-    ap.add_argument("--comm", default="shm", choices=["rccl", "shm", "p2p", "torch"],
-                    help="N>1 exchange of the per-iteration sums behind `value`: host shared segment (default since round 5: no device collective, "
-                         "and the only exchange whose steps a batch call can interleave - several sharded scans in flight per rank, option "
-                         "batch_queues), built-in RCCL all-reduce (the north star's form; measured beside it in the same run: value_rccl, "
-                         "rccl_ranks), one-shot peer-mailbox exchange over xGMI mappings (value_p2p), or a torch.distributed all-reduce callback")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "p2p", "torch"],
+                    help="N>1 exchange of the per-iteration sums behind `value`: the built-in RCCL all-reduce (default, the north star's form; since "
+                         "round 6 a batch call keeps several sharded scans in flight over it, a sub-communicator per lane), the host shared segment "
+                         "(no device collective; measured beside it in the same run: value_shm), the one-shot peer-mailbox exchange over xGMI "
+                         "mappings (value_p2p), or a torch.distributed all-reduce callback.  Ranks that share one GPU (tests) fall back to shm")
     ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for barriers/timing")
     ap.add_argument("--mode", default="shard", choices=["shard", "replicas"],
                     help="N>1: 'shard' (default, the north star) splits every scan's points across the ranks and exchanges the sums each "
@@ -325,6 +325,9 @@ def main():
 
     comm = args.comm if exchange else None
     comm_note = None
+    if comm == "rccl" and (torch.cuda.device_count() < world or "KICP_BENCH_DEVICE" in os.environ):
+        comm_note = "RCCL needs one GPU per rank (this run's ranks share a device): the host shared segment carries the exchange instead"
+        comm = args.comm = "shm"
     try:
         reg, keep = make_reg(comm)
     except K.KicpError as e:  # e.g. RCCL cannot be initialised on this box: the scaling run still gets a number
@@ -784,6 +787,7 @@ def main():
         **({} if elapsed_serial is None else {"value_one_scan_in_flight": round(serial_steps * B / elapsed_serial, 2)}),
         "unit": "scans/s",
         "n_gpus": world,
+        **({"comm": comm, "scaling_bound": _scaling_bound(world)} if exchange and world > 1 else {}),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 5),
@@ -858,6 +862,24 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+
+
+def _scaling_bound(world):
+    """What sharding ONE scan's points over N GPUs can reach at best: a pass is a fixed floor (dispatch, wave launch, reduction,
+    hand-off) plus query work that divides by N, so the speed-up is bounded by pass / (floor + (pass - floor) / N) even with a free
+    exchange (Amdahl).  Floor and pass time are the single-GPU run's own (the newest committed profiles/r*_bench_n1.json:
+    roofline.time_split_us); beyond that bound only independent replicas scale (value_replicas)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            ts = d["roofline"]["time_split_us"]
+            floor, work = float(ts["fixed_floor_launch_reduction_handoff"]), float(ts["query_work"])
+            return {"speedup_bound_sharded": round((floor + work) / (floor + work / world), 2), "floor_us": floor, "query_work_us": work,
+                    "from": os.path.basename(f), "what": "(floor + work) / (floor + work / N): one scan's pass sharded over N GPUs with a free exchange"}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
 
 
 def _dbg_census(workload, latency_kernel):

@@ -142,90 +142,44 @@ void kicp_reg_destroy(kicp_reg *reg);
 int kicp_reg_clone(const kicp_reg *reg, kicp_reg **out);
 int kicp_reg_get_config(const kicp_reg *reg, kicp_reg_config *out);
 int kicp_reg_set_config(kicp_reg *reg, const kicp_reg_config *config); /* the reference's fields are public & mutable */
-/* Backend tuning knobs (not part of the reference API):
- *   "pass_kernel"  3 (default) thread-per-query gather over the 16-bit mirror with exact fp64 resolution; 0 plain fp64
- *                  gather (baseline of the ablation)
- *   "block"        workgroup size of the generic pass kernel (64|128|256; default 256; 512 is accepted for the one-lane-per-query
- *                  variant only - an experiment that measured no faster)
- *   "lanes_per_query" sub-lanes sharing one query (1|2|4; 0 = chosen from the scan size, default)
- *   "split_buckets" two sub-lanes per query: the pair shares every bucket (ten points each) instead of dealing the neighbour
- *                  voxels between them (1 default | 0)
- *   "occupancy"    waves per SIMD the generic kernel's register allocation aims for (4 default | 3)
+/* Backend tuning knobs (not part of the reference API).  Seventeen settable options; everything that lost its A/B over five rounds
+ * (other workgroup sizes and register budgets, the plain fp64 gather, the device-side solve, single-record hand-offs, ...) was deleted
+ * in round 6, and the pass kernels' ablation switches ("dbg") exist in libkicp_amd_dbg.so only (make -C kinematic_icp_amd/csrc dbg).
+ * Which kernel runs:
+ *   "lanes_per_query"  sub-lanes sharing one query of the generic pass kernel (1 | 2 | 4; 0 = by scan size, default: 4 up to 4 096 points,
+ *                  2 up to 32 768, else 1)
  *   "latency_kernel" one lane per query: 1 (default) scans of at most 131 072 points - which leave the device two waves per SIMD
- *                  anyway - run the build that has TWO neighbour voxels in flight per round (k_pass_gather32<.., LAT>, 185
- *                  VGPRs); 2: every such scan; 0: never
- *   "small"        1 (default): scans of at most 16 384 lanes (points x sub-lanes: up to 4 096 points by default) take the
- *                  small-scan path - every workgroup's exact sums go straight to the host (no reduction tree) and the kernel
- *                  stays resident for the iterations of the call, polling a command line in host-mapped memory for the next
- *                  pose; 0: always the generic pass kernel.  "small_active" (read only): which path the last call took
- *   "small_resident" 1 (default): resident unless the previous call converged in one iteration (a call that needs more gets a
- *                  resident launch from its second pass on); 2: always resident; 0: one launch per iteration.  Set 0 on
- *                  handles that register small scans from several threads at once on one device (a resident kernel holds its
- *                  CUs until its host answers; kicp_register_device_concurrent does this for its lanes)
- *   "resident_generic" 1 (default): scans beyond the small-scan kernels and up to 131 072 points (256 CUs) keep the generic
- *                  kernel's latency-oriented build resident for the later iterations of a call too (k_pass_resident; same commands,
- *                  time-out and "small_resident" policy); 0: one launch per iteration.  "resident_passes" (read only): passes of
- *                  the last call that a resident launch of the generic kernel served
- *   "batch_queues" (default 4, 0 .. 8): kicp_register_device_batch keeps this many scans in flight at a time, each on a handle and HSA
- *                  queue of its own, when the batch holds scans for the generic pass kernel; < 2: off.  "batch_queue_passes" (read only): passes
- *                  served that way so far
- *   "batch_resident" 1 (default): kicp_register_device_batch - for batches of eight scans and more that "batch_queues" does not
- *                  take - keeps ONE resident kernel on the device ACROSS the scans of a batch (what starts a pass is a polled
- *                  command naming its scan instead of a dispatch; the batch's scan table travels with the launch); 0: every scan
- *                  of such a batch is a call of its own.  "batch_resident_passes" (read only): passes served that way so far
- *   "batch_depth"  (default 3, 1 .. 4): scans of the batch that kernel has in flight - the host answers the rows of pass k while the
- *                  workgroups search passes k + 1 .. k + depth - 1, which belong to other scans; 1: one scan at a time
- *   "batch_threads" (default 8, 0 .. 9): batches of scans that leave most of the device empty - every scan at most 4 096 points, or every
- *                  scan one for the generic kernel with at most 24 576 points; at least 16 scans per thread -: up to this many
- *                  resident kernels side by side, each serving a contiguous part of the batch from a host thread of the library's lane pool
- *                  (as many as fit the device at once: three for 1 080-point scans, eight for 16 384-point scans; generic scans only
- *                  if three fit - two would not beat the queues); < 2: one kernel, the caller's thread, or the queues.
- *                  "batch_threads_active" (read only): how many the last batch call used (0: another path)
- *   "shard_threads" (default 0, 0 .. 8; the same on every rank): SHARDED batches (shared segment attached) of at least 32 scans whose
- *                  largest shard on any rank has at most 24 576 points: up to this many resident kernels side by side per rank, part t of
- *                  the batch on kernel t, its passes completed by the peers' through lane t of the segment (the ranks agree on the
- *                  launch shape through lane 0 first); three-quarters of the device at most, shared among the ranks that sit on one
- *                  device.  EXPERIMENTAL and off by default: a part's kernel waits for its peers' as well as for its host, and every
- *                  part costs its rank a spinning host thread - with two ranks on ONE GPU, 3 per rank measured 2.4 x the queues on
- *                  8 192-point shards, 4 and more per rank stalled intermittently (a stall ends in KICP_ERR_COMM after KICP_WAIT_TIMEOUT_S; one process
- *                  alone runs eight: it is several processes with many never-ending kernels each on ONE device that do not get on)
- *   "batch_threads_large" 0 (default) | 1: generic scans too large for three resident kernels of the latency build (up to 131 072 points)
- *                  take resident kernels of the FOUR-WAVES build side by side (four workgroups per CU: two kernels of 512 workgroups
- *                  fill the device) instead of the queues - measured 5 % slower than the queues on 131 072-point scans, kept for
- *                  experiments; "resident_four_waves" 1: that build for the ONE resident kernel of a batch ("batch_queues" 0)
- *   "batch_rotate" 1 (default): with depth > 1 the workgroups of that kernel take turns at the parts of a scan (a workgroup that
- *                  had a heavy share catches up on the lighter ones that follow); 0: workgroup b always searches points
- *                  256 b .. 256 b + 255
- *   "small_group_rows" the workgroups of the small-scan kernels hand their exact sums over through their groups' counting accumulators in
- *                  HBM - ONE row per 32 workgroups crosses PCIe (5 rows instead of 135 for a 1 080-point scan): 2 always; 0 never (every
- *                  workgroup sends a row of its own straight to the host, round 3); 1 (default) where it measured faster - the
- *                  wave-per-query kernel while one pass is out at a time
- *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query only
- *   "wave_block" / "small_block" workgroup size of the wave-per-query / sub-lanes-per-query kernel (256 | 512 | 1024;
- *                  wave_block 0 = by scan size, default)
- *   "small_cmd"    1 (default): the host writes the resident kernel's command copies straight into HBM through the PCIe BAR;
- *                  0: workgroup 0 polls a line of host memory and relays it
- *   "small_timeout_us" how long a resident workgroup waits for the next command before it leaves on its own (default 20 000;
- *                  the host then launches afresh - "small_relaunches" counts those)
+ *                  anyway - run the build that has TWO neighbour voxels in flight per round; 2: every such scan; 0: never (the
+ *                  four-waves-per-SIMD build)
+ *   "small"        1 (default): scans of at most 16 384 lanes (points x sub-lanes) take the small-scan path - the kernel stays resident for
+ *                  the iterations of a call, polling for the next pose; 0: always the generic pass kernel
+ *   "small_wave"   1 (default): scans of at most 4 096 points run ONE WAVE PER QUERY (k_pass_wave); 0: sub-lanes per query (k_pass_small)
+ *   "small_resident" 1 (default): resident unless the previous call converged in one iteration; 2: always; 0: one launch per iteration.
+ *                  A resident kernel holds the CUs it runs on until its host answers (at most "small_timeout_us"): set 0 where several
+ *                  threads or processes register small scans on one device
+ *   "small_timeout_us" how long a resident workgroup waits for the next command before it leaves on its own (default 20 000; the host
+ *                  then launches afresh)
+ *   "resident_generic" 1 (default): scans beyond the small-scan kernels and up to 131 072 points keep the generic kernel's latency build
+ *                  resident for the later iterations of a call too; 0: one launch per iteration
+ * Batches of independent scans (kicp_register_device_batch):
+ *   "batch_queues"   (default 4, 0 .. 8) scans in flight at a time, each on a handle and HSA queue of its own; < 2: off
+ *   "batch_resident" 1 (default): batches "batch_queues" does not take keep ONE resident kernel across the batch's scans; 0: scan by scan
+ *   "batch_depth"    (default 3, 1 .. 4) scans that kernel has in flight
+ *   "batch_threads"  (default 8, 0 .. 9) batches of scans that leave most of the device empty: up to this many resident kernels side by
+ *                  side, a host thread of the library's pool each (capped by the CPUs this process may use: cpuset and cgroup quota)
+ *   "batch_rotate"   1 (default): the workgroups of a resident kernel take turns at the parts of a scan; 0: fixed shares
+ * Transfers and launches:
  *   "bar_frame"    1 (default): kicp_register writes host frames of up to 8 192 points straight into HBM through the PCIe BAR
- *                  instead of staging them for the DMA engine; 0: always stage
- *   "fetch_upload" 1 (default): larger host frames are copied into the pinned staging buffer in 384 KB pieces and PULLED by a small
- *                  kernel per piece (which also widens float32 frames) while the CPU copies the next piece; 0: one DMA per 1 MB piece
- *   "p2p_rows"     peer-mailbox exchange, wire format (the same value on every rank): 1 (default) the first-level group rows
- *                  themselves; 0 the ranks' totals (round 2); 2 always one row per rank (what launches of more than 32 groups send)
- *   "host_solve"   1 (default) the pass kernel publishes the exact sums and the host solves the 2x2 system and updates the
- *                  pose (one launch per iteration, pose passed by value); 0 the last workgroup solves on the device
- *   "group_rows"   host-side solve: 1 (default) the device reduction stops at groups of 32 workgroups, whose tagged rows the
- *                  host adds as they arrive (two dependent device-scope round trips); 0 the device folds everything into
- *                  one record first (six)
- *   "loop"         device-side solve only: 1 stepped (host polls the stop flag), 0 all iterations queued up front
- *   "wait"         0 (default) poll the host-mapped result record; 1 hipStreamSynchronize
- *   "timing"       1 -> kicp_stats.gpu_ms from HIP events on the handle's stream; 2 -> also kicp_stats.pass_ms[]
- *   "aql"          1 (default) dispatch the pass kernels with hand-written AQL packets on the handle's own HSA queue wherever the
- *                  host polls for the result and nothing on the HIP stream must follow the kernel; 0 always launch through the
- *                  HIP stream (also: KICP_AQL=0 in the environment).  "aql_active" (read only): how the last pass was launched;
- *                  "aql_kernarg" (read only): 0 kernel arguments in host memory, 1 in device memory (KICP_KERNARG=dev), 2 + HDP
- *                  flush (KICP_KERNARG=devhdp) */
+ *   "fetch_upload" 1 (default): larger host frames are pulled out of the pinned staging buffer by a small kernel per piece; 0: DMA engine
+ *   "aql"          1 (default): pass kernels are dispatched with hand-written AQL packets on the handle's own HSA queue; 0: HIP launches
+ *   "wait"         0 (default): poll the tagged rows in host memory; 1: hipStreamSynchronize
+ *   "timing"       1: kicp_stats.gpu_ms from HIP events; 2: also kicp_stats.pass_ms[]
+ * Read only: "small_active" (path of the last call: 0 generic, 1 sub-lanes, 2 wave per query), "resident_passes", "batch_queue_passes",
+ *   "batch_resident_passes", "batch_threads_active", "small_relaunches", "aql_active", "aql_kernarg", "comm_ranks".
+ * Test hooks (exercise fall-backs that this hardware does not reach by itself): "small_cmd" 0 - workgroup 0 relays the resident kernels'
+ *   commands (platforms without a CPU-writable BAR); "debug_tag" - jump next to the 16-bit pass tag's wrap-around; "debug_stall_us" -
+ *   be late with one command; "debug_p2p_one_row" - send this rank's total as one mailbox row, as launches of more than 32 groups
+ *   do; "small_trace" - in-kernel time stamps (tools/trace_small.py). */
 int kicp_reg_set_option(kicp_reg *reg, const char *name, double value);
 double kicp_reg_get_option(const kicp_reg *reg, const char *name);
 
@@ -268,7 +222,8 @@ int kicp_register_device(kicp_reg *reg, kicp_map *map, const double *d_frame_xyz
  * lanes' exchanges interleave freely while every lane's sequence of exchanges is the same on every rank.  Poses and iteration counts
  * are bit-equal to the single-GPU batch on the whole scans, on every rank.  A sharded batch that fails half-way leaves the ranks'
  * lane counters in doubt: later sharded batches return KICP_ERR_COMM until kicp_reg_shm_destroy / _init have been redone on every
- * rank.  (RCCL / callback / peer-mailbox exchanges: a batch call registers the scans one after the other, an exchange per pass.)
+ * rank.  The same with the RCCL communicator attached (round 6): lane j issues its all-reduces on a sub-communicator of its own
+ * (ncclCommSplit on first use) and on its own stream.  (Callback / peer-mailbox exchanges: the scans one after the other.)
  * Poses: count x 7 doubles.  `out_iterations` (nullable): ICP iterations each scan ran.  Returns the first error (< 0) - scans
  * after the first one that failed are then unspecified (some of them may have completed), nothing of the call is still running
  * on the device - otherwise the largest warning code seen (KICP_OK if none). */
@@ -448,8 +403,7 @@ int kicp_reg_comm_destroy(kicp_reg *reg);
 /* Single-node alternative without any device collective: all ranks map one POSIX shared-memory segment (`name`, created
  * by rank 0 - call it there first, e.g. before a barrier).  Each rank's 24 limb totals + a sequence word go into its own slot
  * of the segment - written by its host, which has just added its GPU's tagged group rows exactly as in the single-GPU
- * hand-off (default), or by the pass kernel itself ("group_rows" = 0) -; every rank's host polls all slots, adds the integers
- * and solves.  The "all-reduce" thus costs no more than the single-GPU hand-off (a 192-byte RCCL all-reduce
+ * hand-off -; every rank's host polls all slots, adds the integers and solves.  The "all-reduce" thus costs no more than the single-GPU hand-off (a 192-byte RCCL all-reduce
  * costs tens of microseconds per ICP iteration, as long as the kernel itself).  Every rank must issue the same sequence
  * of kicp_register* calls. */
 int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name);
@@ -460,8 +414,7 @@ int kicp_reg_shm_destroy(kicp_reg *reg);
  * mailboxes (the peers' through IPC mappings: stores over xGMI), and the last workgroup of group 0 adds the rows of all
  * ranks' groups as they arrive in its own mailbox (integers, fixed order: bit-identical on every rank) and hands the totals
  * to its host, which solves - no second reduction level, no collective.  (A launch of more than 32 groups - 262 144 lanes
- * per rank - reduces on two levels and sends one row.  Option "p2p_rows" = 0, on EVERY rank, selects round 2's format: the
- * launch's last workgroup exchanges the rank's totals.)  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
+ * per rank - reduces on two levels and sends one row.)  Usage: every rank calls kicp_reg_p2p_export, the caller all-gathers the handles (any
  * transport), every rank calls kicp_reg_p2p_connect with the nranks handles in rank order; a barrier between connect and
  * the first registration, and before kicp_reg_p2p_destroy, is the caller's.  nranks <= KICP_P2P_MAX_RANKS.
  * Recovery contract: the ranks stay in step only while every exchange completes on every rank.  When a registration fails

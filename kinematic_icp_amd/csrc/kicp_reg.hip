@@ -45,6 +45,8 @@ struct CommApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // (optional: diagnostics only)
+    // (optional: one sub-communicator per lane of a sharded batch call - run_batch_queues; without it such a batch registers scan after scan)
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;
     bool load(std::string &err) {
         if (handle) return true;
         // prefer an RCCL that is already in the process (e.g. the one torch.distributed loaded)
@@ -64,6 +66,7 @@ struct CommApi {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
         CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(handle, "ncclCommCount"));
+        CommSplit = reinterpret_cast<decltype(CommSplit)>(dlsym(handle, "ncclCommSplit"));
         if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
             err = "librccl lacks an expected symbol";
             return false;
@@ -115,6 +118,11 @@ struct kicp_reg {
     int lanes_per_query = 0;  // variant 3: sub-lanes sharing one query (1, 2 or 4); 0 = by scan size
     int latency_kernel = 1;   // variant 3, one lane per query: the two-voxels-per-round build (0 never | 1 scans <= kLatencyMaxPoints | 2 always)
     // multi-GPU
+    // RCCL: the communicator of single calls; a sharded batch call (run_batch_queues) gives every lane a communicator of its own, split off
+    // this one on first use, so that each lane issues ITS collectives in its own fixed order on its own stream (lane_comms: owned here,
+    // lent to the lanes' handles for the duration of a call)
+    ncclComm_t lane_comms[8] = {};
+    bool lane_comms_failed = false;
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     kicp_allreduce_fn allreduce_fn = nullptr;
@@ -1341,10 +1349,27 @@ struct BatchFlight {
     size_t next = 0;
     bool at_peers = false;
     unsigned long long shm_value = 0;
+    // sharded over RCCL: the pass ends in the device-side tree + ncclAllReduce + k_publish_words on the lane's stream; the record's
+    // sequence word the host polls for
+    bool via_comm = false;
+    unsigned long long comm_seq = 0;
 };
 // the rows of a flight's pass that have arrived since the last look: 1 all in (sums in out_words), 0 not yet, < 0 error
 int flight_rows(BatchFlight &f, long long out_words[kReduceWords]) {
     kicp_reg *h = f.h;
+    if (f.via_comm) {  // the all-reduced totals arrive as ONE record behind the collective (k_publish_words)
+        if (__atomic_load_n(&h->rec->seq, __ATOMIC_ACQUIRE) != f.comm_seq) {
+            if (++f.polls % 256u == 0u) {
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(KICP_ERR_HIP, std::string("stream fault: ") + hipGetErrorString(q));
+                if (f.since.passed()) return fail(KICP_ERR_COMM, "timed out waiting for a lane's all-reduce (KICP_WAIT_TIMEOUT_S)");
+            }
+            return 0;
+        }
+        for (int i = 0; i < kReduceWords; ++i) out_words[i] = h->rec->words[i];
+        out_words[kNumLimbs] = out_words[kNumLimbs] != 0 ? 1 : 0;
+        return 1;
+    }
     const uint32_t tag = f.tag;
     const int row_words = f.own_rows ? kSmallRowWords : kReduceWords;
     for (; f.row_next < f.rows; ++f.row_next) {
@@ -1441,6 +1466,15 @@ int flight_launch(BatchFlight &f, const kicp_map *map, const double *d_frame, si
     if (int rc = next_tag(h, &sol.tag)) return rc;
     f.tag = sol.tag;
     f.since = Deadline();
+    if (f.via_comm) {  // device-side tree -> all-reduce on the lane's communicator -> the totals to the host, all on the lane's stream
+        sol.mode = 3;
+        f.comm_seq = (sol.call_id << 16) | static_cast<unsigned long long>(f.loop.iter + 1);
+        if (int rc = launch_pass(h, pp, false)) return rc;
+        if (int rc = enqueue_allreduce(h)) return rc;
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rec, sol.call_id, f.loop.iter);
+        HIP_TRY(hipGetLastError());
+        return KICP_OK;
+    }
     return launch_pass(h, pp, true);
 }
 int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *const *d_frames, const size_t *n, const double *last_poses_qt,
@@ -1451,12 +1485,17 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
     // SHARDED batches (the shared segment attached, kicp_reg_shm_init): every rank calls with ITS shard of every scan, the lanes'
     // exchanges go through the segment (below).  Every decision up to here and in the loop must then be the same on every rank - so
     // none of them looks at the shard sizes, which differ.
-    const bool sharded = r->shm != nullptr;
+    // ... or through RCCL: lane j owns a sub-communicator of the handle's (ncclCommSplit on first use: every rank comes here with the
+    // same arguments, so the splits line up), its collectives go out in the lane's own fixed order - scans j, j + lanes, ..., pass by
+    // pass - on the lane's own stream, and the lanes' collectives interleave freely (round 6: until then an RCCL batch registered scan
+    // after scan while the shared segment kept four in flight)
+    const bool over_rccl = r->comm != nullptr && !r->shm && g_comm.CommSplit != nullptr && !r->lane_comms_failed;
+    const bool sharded = r->shm != nullptr || over_rccl;
     if (queues < 2 || count < 2u * static_cast<size_t>(queues) || max_it <= 0 || kicp_map_empty(map)) return 1;
-    if (!(r->use_aql && !r->comm && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
+    if (!(r->use_aql && (!r->comm || over_rccl) && !r->allreduce_fn && !r->d_p2p_table && r->timing == 0 &&
           r->wait_mode == 0 && (r->dbg == 0 || r->dbg == 11 || r->dbg == 12 || r->dbg == 14)))
         return 1;
-    if (sharded && r->shm_poisoned)
+    if (r->shm && r->shm_poisoned)
         return fail(KICP_ERR_COMM, "the shared-segment exchange is out of step after a sharded batch that failed: kicp_reg_shm_destroy and _init again on every rank");
     // a batch of small scans only (kicp_small.hpp) is better off with ONE resident kernel and several scans in flight inside it
     // (run_batch_resident): a launch and a sweep over every workgroup's row per pass is more than one host thread can turn round in
@@ -1488,6 +1527,18 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
         h->use_small = sharded ? 0 : r->use_small, h->small_block = r->small_block, h->small_wave = r->small_wave, h->wave_block = r->wave_block;
         flights[j].h = h;
         flights[j].next = static_cast<size_t>(j);  // (sharded: lane j's first scan)
+        flights[j].via_comm = over_rccl;
+        if (over_rccl) {
+            if (!r->lane_comms[j]) {
+                const ncclResult_t rc = g_comm.CommSplit(r->comm, 0, r->rank, &r->lane_comms[j], nullptr);
+                if (rc != ncclSuccess || !r->lane_comms[j]) {  // (every rank fails alike: the same library, the same arguments)
+                    r->lane_comms[j] = nullptr, r->lane_comms_failed = true;
+                    for (int i = 0; i < j; ++i) flights[i].h->comm = nullptr;
+                    return 1;  // this and later batches go scan after scan over the handle's own communicator
+                }
+            }
+            h->comm = r->lane_comms[j], h->nranks = r->nranks, h->rank = r->rank;
+        }
     }
     r->last_small = 0, r->last_resident_passes = 0;
     {
@@ -1502,7 +1553,8 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
             (void)hipStreamSynchronize(flights[j].h->stream);
             if (rc < 0 && flights[j].active) flights[j].h->acc_dirty = true;  // (a pass that was not collected: its accumulators may be part full)
         }
-        if (rc < 0 && sharded) r->shm_poisoned = true;  // (the ranks' lane counters can no longer be assumed equal)
+        if (rc < 0 && r->shm) r->shm_poisoned = true;  // (the ranks' lane counters can no longer be assumed equal)
+        for (int j = 0; j < queues && over_rccl; ++j) flights[j].h->comm = nullptr;  // (the communicators stay this handle's)
         while (front < count && complete[front]) ++front;
         *done = front;
         return rc;
@@ -1533,7 +1585,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
                 if (ready == 0) continue;
                 if ((static_cast<unsigned long long>(words[kNumLimbs]) >> 8) != 0ull)
                     return leave(fail(KICP_ERR_HIP, "a workgroup's row did not reach its group's reader in time (kRowWaitTicks)"));
-                if (sharded) {  // this rank's totals of the pass go into its slot of the lane's area; then the lane waits for every rank's
+                if (r->shm) {  // this rank's totals of the pass go into its slot of the lane's area; then the lane waits for every rank's
                     const unsigned long long step = r->shm_lane_step[j]++;
                     kicp_reg::ShmSlot *mine = lane_slots(j, step) + r->rank;
                     for (int i = 0; i < kReduceWords; ++i) mine->words[i] = words[i];
@@ -1541,7 +1593,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
                     f.at_peers = true, f.shm_value = step + 1, f.since = Deadline(), f.polls = 0;
                 }
             }
-            if (sharded) {  // (a non-blocking look: the other lanes' rows and hand-offs are served meanwhile)
+            if (r->shm) {  // (a non-blocking look: the other lanes' rows and hand-offs are served meanwhile)
                 const kicp_reg::ShmSlot *slots = lane_slots(j, f.shm_value - 1);
                 bool all_in = true;
                 for (int k = 0; k < r->nranks && all_in; ++k) all_in = __atomic_load_n(&slots[k].seq, __ATOMIC_ACQUIRE) == f.shm_value;
@@ -1567,6 +1619,7 @@ int run_batch_queues(kicp_reg *r, kicp_map *map, size_t count, const double *con
             if (f.loop.nan_flag) *worst = std::max(*worst, static_cast<int>(KICP_WARN_NO_CORRESPONDENCES));
         }
     }
+    for (int j = 0; j < queues && over_rccl; ++j) flights[j].h->comm = nullptr;
     *done = count;
     return KICP_OK;
 }
@@ -1810,7 +1863,11 @@ void kicp_reg_destroy(kicp_reg *reg) {
     for (kicp_reg *lane : reg->batch_lanes) kicp_reg_destroy(lane);
     reg->batch_lanes.clear();
     hipSetDevice(reg->device);
-    if (reg->comm) g_comm.CommDestroy(reg->comm);
+    if (reg->comm) {
+        for (ncclComm_t &c : reg->lane_comms)
+            if (c) g_comm.CommDestroy(c), c = nullptr;
+        g_comm.CommDestroy(reg->comm);
+    }
     (void)reg->aql.drain(5.0);
     if (reg->stream) hipStreamSynchronize(reg->stream);
     if (reg->shm) kicp_reg_shm_destroy(reg);
@@ -2215,12 +2272,21 @@ int kicp_comm_unique_id(char id[KICP_COMM_ID_BYTES]) {
     std::memcpy(id, uid.internal, KICP_COMM_ID_BYTES);
     return KICP_OK;
 }
+static void destroy_lane_comms(kicp_reg *reg) {  // the lanes' sub-communicators go before the communicator they were split off
+    for (kicp_reg *lane : reg->batch_lanes)
+        if (lane->stream) hipStreamSynchronize(lane->stream), lane->comm = nullptr;
+    for (ncclComm_t &c : reg->lane_comms) {
+        if (c) g_comm.CommDestroy(c);
+        c = nullptr;
+    }
+    reg->lane_comms_failed = false;
+}
 int kicp_reg_comm_init(kicp_reg *reg, int nranks, int rank, const char id[KICP_COMM_ID_BYTES]) {
     if (!reg || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(KICP_ERR_ARG, "bad communicator arguments");
     std::string err;
     if (!g_comm.load(err)) return fail(KICP_ERR_COMM, err);
     if (int rc = set_device(reg->device)) return rc;
-    if (reg->comm) g_comm.CommDestroy(reg->comm), reg->comm = nullptr;
+    if (reg->comm) destroy_lane_comms(reg), g_comm.CommDestroy(reg->comm), reg->comm = nullptr;
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, KICP_COMM_ID_BYTES);
     const ncclResult_t rc = g_comm.CommInitRank(&reg->comm, nranks, uid, rank);
@@ -2236,6 +2302,7 @@ int kicp_reg_comm_destroy(kicp_reg *reg) {
     if (reg->comm) {
         hipSetDevice(reg->device);
         hipStreamSynchronize(reg->stream);
+        destroy_lane_comms(reg);
         g_comm.CommDestroy(reg->comm);
         reg->comm = nullptr;
     }

@@ -259,8 +259,24 @@ def test_single_rank_communicator_and_callback(case1):
     reg = K.KinematicRegistration()
     reg.comm_init(1, 0, K.comm_unique_id())
     a = reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau)
-    reg.comm_destroy()
     assert np.array_equal(a, base)
+    # a BATCH over the communicator: four scans in flight, lane j's all-reduces on a sub-communicator of its own (ncclCommSplit on first
+    # use), every pass = device-side tree -> all-reduce -> totals to the host on the lane's stream; the bits of the single-GPU batch
+    frames = [K.DeviceFrame(x["frame"]) for x in scans]
+    rels = [syn.pose_mul(x["rel_odom"], syn.planar_pose(0.02 * k, 0.0, np.deg2rad(0.2 * k))) for k, x in enumerate(scans)]
+    order = [k % len(scans) for k in range(13)]
+    plain = K.KinematicRegistration()
+    want_batch = plain.prepare_batch([frames[k] for k in order], [scans[k]["last_pose"] for k in order], [rels[k] for k in order])
+    want = plain.ComputeRobotMotionBatch(want_batch, gmap, tau).copy()
+    batch = reg.prepare_batch([frames[k] for k in order], [scans[k]["last_pose"] for k in order], [rels[k] for k in order])
+    for _ in range(2):
+        before = reg.get_option("batch_queue_passes")
+        got = reg.ComputeRobotMotionBatch(batch, gmap, tau).copy()
+        assert np.array_equal(got, want) and list(batch.iterations) == list(want_batch.iterations)
+        assert reg.get_option("batch_queue_passes") >= before + sum(want_batch.iterations)  # (the lanes served every pass)
+    assert np.array_equal(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau), base)  # single calls go on over the handle's own communicator
+    reg.comm_destroy()
+    assert np.array_equal(reg.ComputeRobotMotion(s["frame"], gmap, s["last_pose"], rel, tau), base)
     calls = []
     reg2 = K.KinematicRegistration()
     reg2.set_allreduce(lambda ptr, count, stream: calls.append((ptr != 0, count)))  # world size 1: in-place sum is a no-op

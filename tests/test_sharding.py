@@ -257,6 +257,89 @@ def test_sharded_batch_with_scans_in_flight_over_the_segment_lanes(tmp_path, wor
     assert sh.lane_scans(1, 4, 11) == [1, 5, 9] and sorted(sum((sh.lane_scans(j, lanes, 11) for j in range(lanes)), [])) == list(range(11))
 
 
+def _group_lane_worker(rank, world, lanes, port, out_dir, seed):
+    """one rank of a sharded batch whose lanes exchange through COLLECTIVES (kicp_reg.hip run_batch_queues, `over_rccl`): lane j owns a
+    sub-group of its own (ncclCommSplit there, dist.new_group here), its all-reduces go out asynchronously in the lane's own fixed order
+    - scans j, j + lanes, ..., pass by pass - and are polled for, so the lanes' collectives interleave in a different order on every
+    rank (random pauses) while every group sees the same sequence everywhere; the oracle stands in for the GPU's pass"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = [dist.new_group(list(range(world))) for _ in range(lanes)]  # (created in the same order on every rank, like the splits)
+    cfg, omap, frame, last, rel = _world()
+    tau = cfg.first_frame_tau()
+    scans = _batch_of_scans(frame, last, rel)
+    rng = np.random.default_rng(seed + rank)
+    state = [dict(todo=sh.lane_scans(j, lanes, len(scans)), k=None, work=None, buf=None) for j in range(lanes)]
+    poses = [None] * len(scans)
+    deadline = time.time() + 200
+    while any(st["todo"] or st["k"] is not None for st in state):
+        assert time.time() < deadline, "a lane's collective never completed"
+        for j, st in enumerate(state):
+            if st["k"] is None:
+                if not st["todo"]:
+                    continue
+                st["k"] = st["todo"].pop(0)
+                fr, la, re = scans[st["k"]]
+                lo, hi = sh.shard_bounds(len(fr), world, rank)
+                st.update(shard=fr[lo:hi], T=okicp.se3_mul(la, re), it=0, beta=None)
+            if st["work"] is None:
+                if rng.random() < 0.3:
+                    time.sleep(rng.random() * 2e-3)  # this rank's GPU is late with this lane's pass
+                    continue
+                st["buf"] = torch.from_numpy(sh.pack(shard_pass_fixed(omap, st["shard"], st["T"], tau)).copy())
+                st["work"] = dist.all_reduce(st["buf"], op=dist.ReduceOp.SUM, group=groups[j], async_op=True)
+            if not st["work"].is_completed():
+                continue
+            st["work"].wait()
+            st["work"] = None
+            sums = sh.unpack(st["buf"].numpy())
+            if st["it"] == 0:
+                st["beta"] = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+            dx = okicp.solve(sums[:5], sums[6], st["beta"])
+            st["T"] = okicp.se3_mul(st["T"], okicp.motion_model(dx))
+            st["it"] += 1
+            if np.hypot(dx[0], dx[1]) < 1e-3 or st["it"] >= 10:
+                poses[st["k"]] = np.concatenate([st["T"], [st["it"]]])
+                st["k"] = None
+    np.save(os.path.join(out_dir, "glanes_%d.npy" % rank), np.array(poses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lanes", [(2, 4), (8, 4)])
+def test_sharded_batch_with_a_collective_group_per_lane(tmp_path, world, lanes):
+    """What --comm rccl runs since round 6: four sharded scans in flight per rank, lane j's all-reduces on a communicator of its own.
+    World sizes 2 and 8 over gloo sub-groups: every rank ends with the same bits for every scan, equal to the lock-step sharded
+    registration (the segment-lanes test above computes the same reference) and to the unsharded oracle."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_group_lane_worker, args=(world, lanes, port, str(tmp_path), 4321), nprocs=world, join=True)
+    got = [np.load(tmp_path / ("glanes_%d.npy" % r)) for r in range(world)]
+    assert all(np.array_equal(g, got[0]) for g in got[1:])
+    cfg, omap, frame, last, rel = _world()
+    tau = cfg.first_frame_tau()
+    for k, (fr, la, re) in enumerate(_batch_of_scans(frame, last, rel)):
+        T, beta, its = okicp.se3_mul(la, re), None, 0
+        for it in range(10):
+            words = np.sum([sh.pack(shard_pass_fixed(omap, fr[slice(*sh.shard_bounds(len(fr), world, r))], T, tau)) for r in range(world)], 0)
+            sums = sh.unpack(words)
+            if it == 0:
+                beta = 1.0 / (sums[5] / sums[6] + np.finfo(np.float64).tiny)
+            dx = okicp.solve(sums[:5], sums[6], beta)
+            T, its = okicp.se3_mul(T, okicp.motion_model(dx)), it + 1
+            if np.hypot(dx[0], dx[1]) < 1e-3:
+                break
+        assert np.array_equal(got[0][k][:7], T, equal_nan=True) and int(got[0][k][7]) == its, k
+        if len(fr) > 100:
+            ref = okicp.KinematicRegistration()
+            np.testing.assert_allclose(T, ref.ComputeRobotMotion(fr, omap, la, re, tau), atol=1e-9)
+
+
 def test_small_scan_rows_add_up_exactly():
     """The small-scan kernels' row format (two 48-bit halves per 128-bit sum, kicp_small.hpp) against the limb payload: totals of
     either sign up to the accumulation range (|term| < 2^43, 1024 terms per workgroup), 272 rows, stale and marked rows."""
