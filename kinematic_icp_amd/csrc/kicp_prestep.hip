@@ -152,6 +152,10 @@ struct kicp_pre {
         Pose pose{};
         int state = 0;  // 0 none | 1 announced | 2 in the second slot
         double lo = 0.0, hi = 0.0;
+        // what the first and the last 64 bytes of the message were when it was uploaded: a caller that reuses one receive buffer and hands
+        // over ANOTHER message of the same size at the same address (against the contract) is caught instead of served the stale cloud
+        unsigned char edge[128] = {};
+        size_t edge_bytes = 0;
     } ahead;
     unsigned long long ahead_hits = 0;  // kicp_pre_ingest calls that found their message decoded ahead (kicp_pre_ahead_hits)
     JobThread ahead_thread;             // queues the look-ahead upload beside the calling thread's own kernels
@@ -418,6 +422,10 @@ int ahead_run(kicp_pre *p) {
     if (a.state != 1 || a.n == 0 || a.n > p->cap_n) return KICP_OK;  // (a cloud that does not fit the buffers is left to its kicp_pre_ingest call)
     if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
     if (int rc = ingest_run(p, a.data, a.n, a.layout, a.has_pose ? &a.pose : nullptr, p->ahead_stream, p->d_in2, p->d_ts2, p->stage_ahead, 1, &a.lo, &a.hi)) return rc;
+    const size_t bytes = a.n * static_cast<size_t>(a.layout.point_step);
+    a.edge_bytes = std::min<size_t>(64, bytes);
+    std::memcpy(a.edge, a.data, a.edge_bytes);
+    std::memcpy(a.edge + 64, static_cast<const unsigned char *>(a.data) + bytes - a.edge_bytes, a.edge_bytes);
     a.state = 2;
     return KICP_OK;
 }
@@ -440,7 +448,13 @@ int kicp_pre_ingest(kicp_pre *p, const void *data, size_t n_points, const kicp_c
     if (int rc = ahead_join(p)) return rc;  // (the announced message's upload has had the registration and the map update to finish behind)
     kicp_pre::Ahead &a = p->ahead;
     const bool pose_matches = sensor_pose_qt ? (a.has_pose && std::memcmp(&a.pose, sensor_pose_qt, 7 * sizeof(double)) == 0) : !a.has_pose;
+    bool same_bytes = false;
     if (a.state == 2 && a.data == data && a.n == n_points && same_layout(a.layout, L) && pose_matches) {
+        const size_t bytes = n_points * static_cast<size_t>(L.point_step);
+        same_bytes = std::memcmp(a.edge, data, a.edge_bytes) == 0 &&
+                     std::memcmp(a.edge + 64, static_cast<const unsigned char *>(data) + bytes - a.edge_bytes, a.edge_bytes) == 0;
+    }
+    if (same_bytes) {
         // the message was uploaded and decoded ahead (kicp_pre_ingest_ahead + the previous frame's chained pre-steps): take the slot
         std::swap(p->d_in, p->d_in2), std::swap(p->d_ts, p->d_ts2);
         a.state = 0, ++p->ahead_hits;

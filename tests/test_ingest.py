@@ -203,6 +203,16 @@ def test_gpu_look_ahead_ingest_equals_the_plain_ingest(stamp, layout):
     assert ahead.Ingest(*args(msgs[2])) == want[2][0]
     np.testing.assert_array_equal(ahead.ingested()[0], want[2][1][0])
     assert chain(ahead)[0] == want[2][2][0] and ahead.ahead_hits() == 3
+    # a receive buffer that is REUSED against the contract: message 0 announced and decoded ahead, then ANOTHER message of the same size
+    # written over it at the same address - the first and last bytes no longer match what was uploaded: ingested afresh, no stale cloud
+    buf = msgs[0][0].copy()
+    reused = (buf,) + tuple(args(msgs[0])[1:])
+    ahead.Ingest(*args(msgs[1]))
+    ahead.IngestAhead(*reused)
+    chain(ahead)
+    buf[:] = msgs[3][0]  # (message 3 has message 0's size and layout, other points)
+    assert ahead.Ingest(*reused) == want[3][0] and ahead.ahead_hits() == 3
+    np.testing.assert_array_equal(ahead.ingested()[0], want[3][1][0])
 
 
 def test_ordered_integer_keys_of_doubles_are_monotone():
