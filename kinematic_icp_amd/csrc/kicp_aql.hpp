@@ -4,7 +4,7 @@
 // every iteration.  hipLaunchKernelGGL costs ~3 us of host time per call on this runtime (argument marshalling, stream
 // bookkeeping, packet, doorbell: tools/micro/handoff.hip measures 2.97 us); writing the 64-byte AQL packet and ringing the
 // doorbell ourselves costs a few hundred nanoseconds.  Nothing else changes: same code object (the gfx950 image of
-// kicp_reg.hip, embedded in the library by kicp_hsaco.S), same kernel, same arguments, results still handed to the host
+// kicp_reg_launch.hip, embedded in the library by kicp_hsaco.S), same kernel, same arguments, results still handed to the host
 // through tagged rows in host-mapped memory.
 //
 // What this file does (host code, ROCr / HSA runtime API - the layer HIP itself sits on):
@@ -15,7 +15,7 @@
 //     writes the packet (barrier bit, system-scope acquire + release like HIP's own packets), publishes the header with a
 //     release store and rings the doorbell.
 // The queue is independent of the handle's HIP stream: the caller dispatches here only when nothing is pending on that
-// stream and nothing must be ordered behind the kernel on it (kicp_reg.hip: can_use_aql()).  Kernels that need scratch
+// stream and nothing must be ordered behind the kernel on it (kicp_reg_launch.hip: launch_pass).  Kernels that need scratch
 // memory are refused (the pass kernels need none); any failure at set-up leaves `ready` false and the handle keeps
 // launching through HIP.  KICP_AQL=0 in the environment disables this path.
 #pragma once

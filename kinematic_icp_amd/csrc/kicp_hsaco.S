@@ -1,4 +1,4 @@
-// kicp_hsaco.S -- embeds the gfx950 code object of kicp_reg.hip (build/kicp_reg.hsaco: the same translation unit compiled
+// kicp_hsaco.S -- embeds the gfx950 code object of kicp_reg_launch.hip (build/kicp_reg.hsaco: the same translation unit compiled
 // device-only) into libkicp_amd.so, so that kicp_aql.hpp can hand it to the HSA loader and dispatch the pass kernels with
 // hand-written AQL packets.  Read-only data, 4 KiB aligned.
     .section .rodata.kicp_hsaco, "a", @progbits

@@ -448,7 +448,7 @@ __device__ __forceinline__ void accumulate(Acc &a, const PassBasis &B, double sx
     a.limb[6 * kTermLimbs + 1] = 1 << 19;  // the count: 1.0 = 2^40 = 2^19 * 2^21 (the other limbs stay 0)
 }
 
-// (The solve + pose update - Registration.cpp:119-125, 159-167, 181-184 - is the host's: kicp_reg.hip HostLoop::step.  The device-side
+// (The solve + pose update - Registration.cpp:119-125, 159-167, 181-184 - is the host's: kicp_reg_internal.hpp HostLoop::step.  The device-side
 //  twin that round 1 to 5 carried - the launch's last workgroup solving on one lane - lost every A/B and went in round 6.)
 // Workgroup epilogue of every pass kernel: exact workgroup sum, then a last-arriver tree.  Default (mode 4): ONE level -
 // the last workgroup of every group of kGroup sends the group's row, tagged, to the host.  Other modes: two levels, the

@@ -47,7 +47,7 @@ def unpack(words):
     return np.array([from_limbs(words[3 * i:3 * i + 3]) / float(1 << FIX_BITS) for i in range(NUM_SUMS)], dtype=np.float64)
 
 
-# ---- tagged rows of the hand-off (kicp_kernels.hpp finish_pass, mode 4; kicp_reg.hip wait_rows) ----------------------
+# ---- tagged rows of the hand-off (kicp_kernels.hpp finish_pass, mode 4; kicp_reg_launch.hip wait_rows) ----------------------
 # Every word of a workgroup's / group's row carries the 16-bit tag of its pass in the low bits: word = value << 16 | tag.
 # A reader knows a row has landed when all its words carry the current tag - no store acknowledgement, no fence.
 TAG_BITS = 16
@@ -72,7 +72,7 @@ def untag_row(row, tag):
     return np.array(vals, dtype=np.int64), ok
 
 
-# ---- rows of the small-scan path (kicp_small.hpp small_publish / k_pass_wave; kicp_reg.hip wait_rows_small) -----------------
+# ---- rows of the small-scan path (kicp_small.hpp small_publish / k_pass_wave; kicp_reg_launch.hip wait_rows_small) -----------------
 # A workgroup's row is 16 tagged words = two 64-byte lines: per sum the low 48 bits and bits 48..95 of its 128-bit total (the
 # upper half carries the sign), then the flag word (bit 0 range error, bit 1 "gave up"), then one spare word.
 SMALL_ROW_WORDS = 16
@@ -106,7 +106,7 @@ def add_small_rows(rows, tag):
     return pack(totals), flags, ok
 
 
-# ---- several SHARDED scans in flight: the lanes of the shared segment (kicp_reg.hip run_batch_queues, `sharded`) ---------------
+# ---- several SHARDED scans in flight: the lanes of the shared segment (kicp_reg_queues.hip run_batch_queues, `sharded`) ---------------
 # A sharded batch call keeps `lanes` scans in flight on every rank.  Lane j registers scans j, j + lanes, j + 2 lanes, ... - the
 # same deal on every rank, so lane j issues the same sequence of exchanges everywhere, whatever order the lanes' passes complete
 # in on each rank.  Each lane owns an area [2 buffers][nranks] of slots (sequence word + 24 limb words) and counts its own

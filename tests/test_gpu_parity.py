@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-9
 SUM_RTOL = 1e-10
-# The builds of the generic pass kernel (kicp_reg.hip launch_pass; all of 256-thread workgroups since round 6) as
+# The builds of the generic pass kernel (kicp_reg_launch.hip launch_pass; all of 256-thread workgroups since round 6) as
 # (sub-lanes per query, latency_kernel): the scan-size default (two sub-lanes sharing every bucket on this 16k scan), one lane per query
 # at four waves per SIMD (what large scans and batches in flight run), the same as the two-voxels-per-round build (what scans of up
 # to 131 072 points run one call at a time), and four sub-lanes per query (what very small scans run); None = the library's choice

@@ -214,7 +214,7 @@ def _batch_of_scans(frame, last, rel):
 
 @pytest.mark.parametrize("world,lanes", [(8, 4), (3, 2)])
 def test_sharded_batch_with_scans_in_flight_over_the_segment_lanes(tmp_path, world, lanes):
-    """The interleaved protocol of sharded batches (kinematic_icp_amd/sharding.py::SegmentLanes = kicp_reg.hip run_batch_queues,
+    """The interleaved protocol of sharded batches (kinematic_icp_amd/sharding.py::SegmentLanes = kicp_reg_queues.hip run_batch_queues,
     `sharded`): eight ranks (the node size the north star names), four scans in flight on each, the lanes' hand-offs completing in a
     different order on every rank - every rank ends with the same bits for every scan, equal to registering the scan sharded in
     lock step (one scan at a time), and to the unsharded oracle to 1e-9."""
@@ -258,7 +258,7 @@ def test_sharded_batch_with_scans_in_flight_over_the_segment_lanes(tmp_path, wor
 
 
 def _group_lane_worker(rank, world, lanes, port, out_dir, seed):
-    """one rank of a sharded batch whose lanes exchange through COLLECTIVES (kicp_reg.hip run_batch_queues, `over_rccl`): lane j owns a
+    """one rank of a sharded batch whose lanes exchange through COLLECTIVES (kicp_reg_queues.hip run_batch_queues, `over_rccl`): lane j owns a
     sub-group of its own (ncclCommSplit there, dist.new_group here), its all-reduces go out asynchronously in the lane's own fixed order
     - scans j, j + lanes, ..., pass by pass - and are polled for, so the lanes' collectives interleave in a different order on every
     rank (random pauses) while every group sees the same sequence everywhere; the oracle stands in for the GPU's pass"""
