@@ -109,7 +109,7 @@ def main():
                                                           "of scans + the map exceed what the caches hold)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline-frames", type=int, default=24,
+    ap.add_argument("--pipeline-frames", type=int, default=40,
                     help="frames of the `pipeline` block (the whole drop-in KinematicICP::RegisterFrame - ingest, pre-steps, registration, map update - on a "
                          "synthetic drive of 131 072-point PointCloud2 messages, with the reference's own RegisterFrame timed beside it); 0: skip")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "shm", "p2p", "torch"],

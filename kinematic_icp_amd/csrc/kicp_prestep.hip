@@ -393,7 +393,10 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     ip.ticket_done = p->ticket_drawn[slot];
     unsigned long long *rec = p->h_rec + 8 + 4 * slot;
     ip.host_rec = rec, ip.seq = ++p->ingest_seq;
-    const size_t piece_records = std::max<size_t>(256, kIngestPiece / L.point_step / 256 * 256);
+    // this call's message: pieces, so that the GPU decodes piece k while the CPU copies piece k + 1; a look-ahead message (slot 1) is off
+    // the frame's critical path and goes up as ONE launch - the device starts a kernel every ~4.5 us whatever the number of queues,
+    // and a frame is ~20 launches as it is
+    const size_t piece_records = slot == 1 ? std::max<size_t>(n_points, 256) : std::max<size_t>(256, kIngestPiece / L.point_step / 256 * 256);
     for (size_t first = 0; first < n_points; first += piece_records) {
         const size_t count = std::min(piece_records, n_points - first), off = first * L.point_step, len = count * L.point_step;
         std::memcpy(stage.p + off, static_cast<const unsigned char *>(data) + off, len);
