@@ -743,7 +743,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     if (g_trace) {
-        std::fprintf(stderr, "[kicp]   chained pre-steps: %s, results at the host %.3f ms after the first launch; look-ahead upload: %s\n",
+        std::fprintf(stderr, "[kicp]   chained pre-steps: %zu -> %u -> %u -> %u points; %s, results at the host %.3f ms after the first launch; look-ahead upload: %s\n", n_in, misc[4], misc[5], misc[6],
                      !p->fused || grid > kFusedScanBlocks ? "unfused" : (unfused_tail ? "fused, table size guessed wrong: unfused downsamples" : "five launches"),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
                      ahead_out ? "on its own thread, collected by the message's kicp_pre_ingest" : "none");

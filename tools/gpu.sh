@@ -41,6 +41,8 @@ pipetrace)
   for m in raw raw_ahead; do
     timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_pipe_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/kt_pipe_$m.err
     python tools/prof_summary.py $(find $O/kt_pipe_$m -name "*.db" | head -1) > $O/pipeline_kernel_trace_$m.txt 2>&1; echo "== $m"; head -16 $O/pipeline_kernel_trace_$m.txt | cut -c1-160
+    counts=$(KICP_TRACE=1 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "chained pre-steps" | tail -1 | sed "s/.*steps: \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) points.*/\1 \2 \3 \4/")
+    python tools/pipeline_table.py $O/pipeline_kernel_trace_$m.txt $counts > $O/pipeline_kernel_table_$m.txt 2>&1; cat $O/pipeline_kernel_table_$m.txt | cut -c1-200
     rm -rf $O/kt_pipe_$m
   done ;;
 pipeab)   # A/B of the frame download: KICP_PRE_PUSH_WGS = workgroups of the push kernel (0: the DMA engine in pieces)
