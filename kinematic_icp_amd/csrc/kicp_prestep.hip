@@ -612,9 +612,14 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         ahead_out = p->ahead_job_out = true;  // (collected by the kicp_pre_ingest call of that message - or whoever needs its buffers first: ahead_join)
     }
     // buffer 0 is complete behind the event: its download overlaps the downsamples (n_in points: an upper bound)
+    // (two halves: the event goes into the stream right behind the launch that completes buffer 0; everything else - a dozen API calls,
+    //  ~15 us of this thread - waits until the chain's remaining launches are queued, so the device never idles on it)
+    auto mark_frame_ready = [&]() -> int {
+        if (out_frame_xyz) HIP_TRY(hipEventRecord(p->chain_ready, p->stream));
+        return KICP_OK;
+    };
     auto start_download = [&]() -> int {
         if (!out_frame_xyz) return KICP_OK;
-        HIP_TRY(hipEventRecord(p->chain_ready, p->stream));
         if (int rc = download_settle(p)) return rc;  // (an earlier download nobody collected)
         if (!p->copy_thread.joinable()) p->copy_thread = std::thread(copy_worker, p);
         if (int rc = download_reserve(p, n_in * 24)) return rc;
@@ -694,11 +699,12 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         const uint32_t grid_b = p->spec_tiles_b ? std::min(sgrid, std::max(32u, 2u * p->spec_tiles_b)) : std::min(sgrid, 1024u);
         hipLaunchKernelGGL(k_frame_pre, dim3(grid), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l1_replay, dim3(std::max(grid, f.tiles_spec)), dim3(256), 0, p->stream, f);
-        if (int rc = start_download()) return rc;
+        if (int rc = mark_frame_ready()) return rc;
         hipLaunchKernelGGL(k_frame_l1_gather, dim3(f.tiles_spec), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_replay, dim3(grid_b), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_gather, dim3(grid_b), dim3(256), 0, p->stream, f);
         HIP_TRY(hipGetLastError());
+        if (int rc = start_download()) return rc;
         const unsigned long long tag = static_cast<unsigned long long>(f.seq) << 32, hi = 0xFFFFFFFF00000000ull;
         for (int w = 4; w >= 0; --w)
             if (int rc = wait_word(p->h_rec + w, tag, hi, p->stream)) return rc;
@@ -720,6 +726,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         if (!raw_c) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, p->stream, p->d_block_counts, grid, cnt + 0);
         hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, p->stream, static_cast<const double *>(p->d_staged), static_cast<const uint32_t *>(p->d_flags),
                            static_cast<const uint32_t *>(p->d_block_counts), raw_c, cnt + 0, static_cast<uint32_t>(n_in), p->buf[0]);
+        if (int rc = mark_frame_ready()) return rc;
         if (int rc = start_download()) return rc;
     }
     if (unfused_tail) {
