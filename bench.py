@@ -870,7 +870,7 @@ def _scaling_bound(world):
     exchange (Amdahl).  Floor and pass time are the single-GPU run's own (the newest committed profiles/r*_bench_n1.json:
     roofline.time_split_us); beyond that bound only independent replicas scale (value_replicas)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")), reverse=True) + sorted(glob.glob(os.path.join(ROOT, "profiles", "history", "r05_final_bench_n1.json"))):
         try:
             d = json.load(open(f))
             ts = d["roofline"]["time_split_us"]
@@ -1093,9 +1093,9 @@ def _profile_counters(workload, world):
     not been profiled: nothing is borrowed from another configuration."""
     if world != 1:
         return None
-    for rnd in ("r05", "r04b", "r04", "r03", "r02"):
+    for rnd, sub in (("r06", ""), ("r05", "history"), ("r04b", "history"), ("r04", "history"), ("r03", "history"), ("r02", "history")):
         try:
-            with open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (rnd, workload))) as f:
+            with open(os.path.join(ROOT, "profiles", sub, "%s_counters_%s.json" % (rnd, workload))) as f:
                 d = json.load(f)
             d["source"] = ("profiles/%s_counters_%s.json (offline rocprofv3 --pmc passes of this workload, NOT this run; taken at commit %s)"
                            % (rnd, workload, d.get("git_sha", "of round " + rnd[1:])))

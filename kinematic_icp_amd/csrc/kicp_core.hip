@@ -14,6 +14,7 @@ bool env_flag(const char *name) {
     return e && *e && *e != '0';
 }
 const bool g_trace = env_flag("KICP_TRACE");
+thread_local std::chrono::steady_clock::time_point g_trace_t0;
 
 // roctx ranges (SURVEY.md section 5 "tracing"): libroctx64 is bound with dlopen the first time a range is opened, so that nothing
 // links against the profiler's library; a process without it simply gets no ranges

@@ -9,10 +9,14 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kicp.h"
@@ -31,11 +35,12 @@ extern const bool g_trace;
 extern const bool g_roctx;
 void roctx_push(const char *name);
 void roctx_pop();
+extern thread_local std::chrono::steady_clock::time_point g_trace_t0;
 struct TraceScope {
     const char *name;
     std::chrono::steady_clock::time_point t0;
     explicit TraceScope(const char *n) : name(n) {
-        if (g_trace) t0 = std::chrono::steady_clock::now();
+        if (g_trace) t0 = g_trace_t0 = std::chrono::steady_clock::now();
         if (g_roctx) roctx_push(n);
     }
     ~TraceScope() {
@@ -43,6 +48,11 @@ struct TraceScope {
         if (g_trace) std::fprintf(stderr, "[kicp] %-32s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
+// a point inside a traced call: microseconds since the innermost traced call of this thread began
+extern thread_local std::chrono::steady_clock::time_point g_trace_t0;
+inline void trace_lap(const char *what) {
+    if (g_trace) std::fprintf(stderr, "[kicp]     +%7.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_trace_t0).count(), what);
+}
 #define KICP_TRACE_CALL() ::kicp::host::TraceScope trace_scope_(__func__)
 struct RoctxScope {  // a named span inside a call (one ICP pass: dispatch -> rows -> solve)
     explicit RoctxScope(const char *n) {
@@ -56,6 +66,58 @@ struct RoctxScope {  // a named span inside a call (one ICP pass: dispatch -> ro
 // last error message of the calling thread (kicp_last_error) and the one way to report a failure
 std::string &last_error();
 int fail(int code, const std::string &msg);
+// One job at a time on a thread of its own (the pre-steps' look-ahead upload, the map update's launches): e.g. the look-ahead upload's host work (a 2 MB copy into the staging buffer and a dozen API
+// calls, ~85 us) runs beside the calling thread's own queueing of the frame's kernels (~100 us of API calls) instead of after it.
+struct JobThread {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    int state = 0;  // 0 idle | 1 posted | 2 done | -1 leaving
+    int result = 0;
+    std::string message;  // the job's error text (kicp_last_error is per thread: the waiting thread takes it over)
+    int device = 0;
+    void run() {
+        hipSetDevice(device);
+        std::unique_lock<std::mutex> lock(m);
+        for (;;) {
+            cv.wait(lock, [this] { return state == 1 || state == -1; });
+            if (state == -1) return;
+            lock.unlock();
+            const int rc = job();
+            lock.lock();
+            result = rc, state = 2;
+            if (rc < 0) message = last_error();
+            cv.notify_all();
+        }
+    }
+    void post(int dev, std::function<int()> fn) {
+        device = dev;
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = std::move(fn), state = 1;
+        }
+        cv.notify_all();
+    }
+    int wait() {  // (only after post)
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [this] { return state == 2; });
+        state = 0;
+        if (result < 0) last_error() = message;
+        return result;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        {
+            std::unique_lock<std::mutex> lock(m);
+            cv.wait(lock, [this] { return state != 1; });
+            state = -1;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
 #define HIP_TRY(expr)                                                                                                        \
     do {                                                                                                                     \
         hipError_t e_ = (expr);                                                                                              \
@@ -111,7 +173,9 @@ struct DeviceMirror {
     uint32_t *d_cnt = nullptr, *d_seg_start = nullptr, *d_free_list = nullptr;
     DevMapCounters *d_ctr = nullptr;
     size_t aux_slots = 0, free_cap = 0;
-    DevMapCounters *h_ctr = nullptr;  // pinned landing area of the counters (an update whose end the caller collects later)
+    unsigned long long *h_ctr = nullptr;  // pinned, host-coherent: [0..4] the counters of an update whose end the caller collects later, [7] its sequence number (k_up_publish)
+    unsigned long long *h_ctr_dev = nullptr, ctr_seq = 0;
+    bool ctr_clean = false;  // the per-update counters in d_ctr are zero (left so by k_up_publish): the next frame-sized update skips its memset
     double *d_world = nullptr;
     uint32_t *d_slot_of = nullptr, *d_order = nullptr, *d_touched = nullptr;
     size_t upd_cap = 0;

@@ -242,6 +242,7 @@ int device_rehash(kicp_map *map, size_t extra_entries) {
     hipStream_t st = nullptr;
     const size_t old_slots = mr.live_slots;
     HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 8, st));  // touched (borrowed as the live counter) + error
+    mr.ctr_clean = false;
     const uint32_t grid_old = static_cast<uint32_t>(std::min<size_t>((old_slots + 255) / 256, 8192));
     hipLaunchKernelGGL(k_rehash_count, dim3(grid_old), dim3(256), 0, st, mr.d_table, static_cast<uint32_t>(old_slots), map->host.count_bits(), &mr.d_ctr->touched);
     uint32_t live = 0;
@@ -342,7 +343,8 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
     // one synchronisation; a claim step that gives up (voxel coordinate out of range) turns the later steps into no-ops.
     if (n <= 16384 && (map->dev.n_entries + 27ull * n) * 4 <= mr.live_slots * 3ull) {
         bind();
-        HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
+        if (!mr.ctr_clean) HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy (k_up_publish left them at zero otherwise)
+        mr.ctr_clean = false;
         hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
         hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, st, up);
         enqueue_apply(n);
@@ -350,8 +352,14 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
         if (defer) {
             // the caller collects the end of this update later (kicp_map_update_finish, or whatever it calls on the map next):
             // the counters land in pinned memory, nothing is waited for here
-            if (!mr.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&mr.h_ctr), sizeof(DevMapCounters), hipHostMallocDefault));
-            HIP_TRY(hipMemcpyAsync(mr.h_ctr, mr.d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+            if (!mr.h_ctr) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&mr.h_ctr), 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+                std::memset(mr.h_ctr, 0, 8 * sizeof(unsigned long long));
+                HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&mr.h_ctr_dev), mr.h_ctr, 0));
+            }
+            hipLaunchKernelGGL(k_up_publish, dim3(1), dim3(64), 0, st, mr.d_ctr, mr.h_ctr_dev, ++mr.ctr_seq);
+            HIP_TRY(hipGetLastError());
+            mr.ctr_clean = true;
             map->device_ahead = true;
             map->pending_update = true, map->pending_points = d_points, map->pending_n = n, map->pending_pose = pose;
             map->pending_has_origin = remove_origin != nullptr;
@@ -377,6 +385,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
             if (int rc = device_rehash(map, 32 * n + 1024)) return rc;
         bind();
         HIP_TRY(hipMemsetAsync(&mr.d_ctr->touched, 0, 12, st));  // touched + error + may_occupy
+        mr.ctr_clean = false;
         hipLaunchKernelGGL(k_up_claim, dim3(grid), dim3(256), 0, st, up);
         if (n > 16384) {  // bulk: the scan over many workgroups (the number of touched voxels is only known on the device: <= n)
             const uint32_t spans = static_cast<uint32_t>((n + kScanSpan - 1) / kScanSpan);
@@ -425,8 +434,21 @@ int map_finish_pending(kicp_map *map) {
     map->pending_update = false;
     DeviceMirror &mr = map->mirror;
     if (int rc = set_device(mr.device)) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    const DevMapCounters c = *mr.h_ctr;
+    // the update's last launch said so in host memory (k_up_publish); a word that is not there after 2 ms: synchronise, look again
+    const volatile unsigned long long *words = mr.h_ctr;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; words[7] != mr.ctr_seq; ++spins) {
+        if ((spins & 255u) == 255u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            HIP_TRY(hipStreamSynchronize(nullptr));
+            if (words[7] != mr.ctr_seq) return fail(KICP_ERR_HIP, "the map update finished without handing its counters over");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    DevMapCounters c;
+    unsigned long long raw[5];
+    for (int w = 0; w < 5; ++w) raw[w] = words[w];
+    std::memcpy(&c, raw, sizeof c);
     map->dev = c;
     if (c.error == 3) return fail(KICP_ERR_CAPACITY, "device-side map update: voxel table full");
     if (c.error == 1) {
@@ -568,6 +590,8 @@ int kicp_map_update_pose_device_begin(kicp_map *map, int device, const double *d
     KICP_TRACE_CALL();
     if (!map || (!d_points_xyz && n) || !pose_qt) return fail(KICP_ERR_ARG, "null argument");
     const Pose pose = pose_from(pose_qt);
+    // (queuing the update's six launches from a thread of the map's own - ~20 us of API time off the caller's thread - was measured:
+    //  the frame then waits that much longer for its way back; no gain)
     const double origin[3] = {pose.tx, pose.ty, pose.tz};
     return map_update_device(map, device, d_points_xyz, n, pose, origin, true);
 }
@@ -576,7 +600,10 @@ int kicp_map_update_finish(kicp_map *map) {
     if (!map) return fail(KICP_ERR_ARG, "null map");
     return map_finish_pending(map);
 }
-unsigned long long kicp_map_device_updates(const kicp_map *map) { return map ? map->device_updates : 0ull; }
+unsigned long long kicp_map_device_updates(const kicp_map *map) {
+    if (map) (void)map_finish_pending(const_cast<kicp_map *>(map));
+    return map ? map->device_updates : 0ull;
+}
 int kicp_map_last_update_on_device(const kicp_map *map) {
     if (map) (void)map_finish_pending(const_cast<kicp_map *>(map));
     return map ? map->last_update_on_device : 0;

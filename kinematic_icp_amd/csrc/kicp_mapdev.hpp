@@ -468,6 +468,21 @@ static __global__ __launch_bounds__(256) void k_up_remove(const DevMap m, double
 // All points, voxel by voxel in table order - the order HostMap::Pointcloud emits - without bringing the table and the
 // pools back to the host: count per 256-slot block, scan the block totals, then every slot copies its bucket's points.
 // (Free slots are recognised in the packed-key side array, 8 B per slot: the 128-byte slots of a mostly empty table are never read.)
+// The end of an update whose caller collects it later (kicp_map_update_pose_device_begin): the counters go into host memory as
+// this one-wave launch's stores, the sequence number behind them - the host polls that word (map_finish_pending) instead of
+// synchronising the stream, which took ~55 us of a 200 us frame while other streams of the process were busy.
+// It also leaves the per-update counters (touched, error, may_occupy) at zero for the next update: two fill launches less per frame.
+static __global__ __launch_bounds__(64) void k_up_publish(DevMapCounters *ctr, unsigned long long *host_words, unsigned long long seq) {
+    static_assert(sizeof(DevMapCounters) == 40, "five words");
+    if (threadIdx.x < 5u) __hip_atomic_store(host_words + threadIdx.x, reinterpret_cast<const unsigned long long *>(ctr)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0u) ctr->touched = 0u, ctr->error = 0u, ctr->may_occupy = 0u;
+    if (threadIdx.x == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(host_words + 7, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 static __global__ __launch_bounds__(256) void k_pc_count(const Slot *table, const unsigned long long *keys64, uint32_t slots, uint32_t cbits, uint32_t *block_counts) {
     __shared__ uint32_t s_sum[4];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;

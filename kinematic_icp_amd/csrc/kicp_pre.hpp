@@ -489,6 +489,10 @@ static __global__ __launch_bounds__(256) void k_frame_l2_gather(const FrameParam
     }
 }
 
+// (round 6 tried the second level in ONE workgroup - replay, ballot bitmap + scan in LDS, gather, as a fourth and last launch: its chains
+//  of dependent loads - cluster walk, order -> point -> store - take as long on one CU as the two launches do on thirty, 100 vs 140 us
+//  per frame with a contiguous bucket range per thread, no gain with coalesced rows; removed.)
+
 // ---- the preprocessed frame on its way back to the caller (pipeline/KinematicICP.cpp:84 returns it) ------------------------
 // 3 MB that nothing on the device waits for.  A kernel on a stream of its own PUSHES buffer 0 into host-mapped pinned memory, 16 bytes
 // per lane (PCIe writes: ~46 GB/s with 64 workgroups, tools/micro/d2h.hip; the DMA engine reaches that only in ONE piece, and every
@@ -585,61 +589,69 @@ __device__ __forceinline__ T load_field(const unsigned char *p, bool aligned) {
 static __global__ __launch_bounds__(256) void k_ingest(const IngestParams p) {
     __shared__ unsigned long long s_min[4], s_max[4];
     __shared__ uint32_t s_last;
-    const uint32_t local = blockIdx.x * 256 + threadIdx.x, i = p.first + local;
     unsigned long long kmin = ~0ull, kmax = 0ull;
     const bool al = p.aligned != 0;  // (wave-uniform: the usual PointCloud2 layouts are naturally aligned)
-    // The workgroup's 256 records are contiguous bytes: they cross PCIe as full 16-byte loads per lane (one request per 64 bytes
+    // A workgroup's 256 records are contiguous bytes: they cross PCIe as full 16-byte loads per lane (one request per 64 bytes
     // whatever the field layout is; four 4-byte field loads per record were four times the requests and 17 GB/s) into LDS and are
     // picked apart there.  Records longer than kLdsStep bytes are read field by field from where they are.
+    // The launch's workgroups go round its tiles of 256 records: this call's message has one workgroup per tile; a look-ahead message
+    // gets a few dozen (kicp_prestep.hip ingest_run) - with all of its 2 MB requested at once, every kernel the frame dispatched in
+    // the meantime waited ~50 us for ITS packet and arguments to cross the same PCIe read queue.
     constexpr uint32_t kLdsStep = 128;
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[256 * kLdsStep];
     const bool via_lds = p.point_step <= kLdsStep;
-    if (via_lds) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const uint32_t first_local = blockIdx.x * 256u;
-        const uint32_t wg_bytes = (p.n - first_local < 256u ? p.n - first_local : 256u) * p.point_step;
-        const unsigned char *src = p.raw + static_cast<size_t>(first_local) * p.point_step;
-        for (uint32_t o = threadIdx.x * 16u; o < wg_bytes; o += 4096u) {
-            if (o + 16u <= wg_bytes) *reinterpret_cast<u32x4 *>(s_rec + o) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + o));
-            else
-                for (uint32_t k = o; k < wg_bytes; ++k) s_rec[k] = src[k];
+    const uint32_t tiles = (p.n + 255u) / 256u;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t first_local = tile * 256u, local = first_local + threadIdx.x, i = p.first + local;
+        if (via_lds) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const uint32_t wg_bytes = (p.n - first_local < 256u ? p.n - first_local : 256u) * p.point_step;
+            const unsigned char *src = p.raw + static_cast<size_t>(first_local) * p.point_step;
+            if (tile != blockIdx.x) __syncthreads();  // (the previous tile's records have been picked apart)
+            for (uint32_t o = threadIdx.x * 16u; o < wg_bytes; o += 4096u) {
+                if (o + 16u <= wg_bytes) *reinterpret_cast<u32x4 *>(s_rec + o) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + o));
+                else
+                    for (uint32_t k = o; k < wg_bytes; ++k) s_rec[k] = src[k];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (local < p.n) {
-        const unsigned char *rec = via_lds ? s_rec + threadIdx.x * p.point_step : p.raw + static_cast<size_t>(local) * p.point_step;
-        double x = static_cast<double>(load_field<float>(rec + p.off_x, al));
-        double y = static_cast<double>(load_field<float>(rec + p.off_y, al));
-        double z = static_cast<double>(load_field<float>(rec + p.off_z, al));
-        if (p.transform) {
-            double rx, ry, rz;
-            quat_rotate(p.T, x, y, z, rx, ry, rz);
-            x = rx + p.T.tx, y = ry + p.T.ty, z = rz + p.T.tz;
+        kmin = ~0ull, kmax = 0ull;
+        if (local < p.n) {
+            const unsigned char *rec = via_lds ? s_rec + threadIdx.x * p.point_step : p.raw + static_cast<size_t>(local) * p.point_step;
+            double x = static_cast<double>(load_field<float>(rec + p.off_x, al));
+            double y = static_cast<double>(load_field<float>(rec + p.off_y, al));
+            double z = static_cast<double>(load_field<float>(rec + p.off_z, al));
+            if (p.transform) {
+                double rx, ry, rz;
+                quat_rotate(p.T, x, y, z, rx, ry, rz);
+                x = rx + p.T.tx, y = ry + p.T.ty, z = rz + p.T.tz;
+            }
+            store_through(p.out_xyz + 3 * i, x), store_through(p.out_xyz + 3 * i + 1, y), store_through(p.out_xyz + 3 * i + 2, z);
+            if (p.stamp_type) {
+                double stamp;
+                if (p.stamp_type == 6) stamp = static_cast<double>(load_field<uint32_t>(rec + p.off_t, al));
+                else if (p.stamp_type == 7) stamp = static_cast<double>(load_field<float>(rec + p.off_t, al));
+                else stamp = load_field<double>(rec + p.off_t, al);
+                // TimeStampHandler.cpp:60-63,73-78: floor(log10(uint64(round(stamp))) + 1) > 10  <=>  round(stamp) >= 1e10
+                if (round(stamp) >= 1e10) stamp *= 1e-9;
+                store_through(p.out_stamps + i, stamp);
+                kmin = kmax = ordered_key(stamp);
+            }
         }
-        store_through(p.out_xyz + 3 * i, x), store_through(p.out_xyz + 3 * i + 1, y), store_through(p.out_xyz + 3 * i + 2, z);
         if (p.stamp_type) {
-            double stamp;
-            if (p.stamp_type == 6) stamp = static_cast<double>(load_field<uint32_t>(rec + p.off_t, al));
-            else if (p.stamp_type == 7) stamp = static_cast<double>(load_field<float>(rec + p.off_t, al));
-            else stamp = load_field<double>(rec + p.off_t, al);
-            // TimeStampHandler.cpp:60-63,73-78: floor(log10(uint64(round(stamp))) + 1) > 10  <=>  round(stamp) >= 1e10
-            if (round(stamp) >= 1e10) stamp *= 1e-9;
-            store_through(p.out_stamps + i, stamp);
-            kmin = kmax = ordered_key(stamp);
-        }
-    }
-    if (p.stamp_type) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
-            kmin = a < kmin ? a : kmin, kmax = b > kmax ? b : kmax;
-        }
-        if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = kmin, s_max[threadIdx.x >> 6] = kmax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) kmin = s_min[w] < kmin ? s_min[w] : kmin, kmax = s_max[w] > kmax ? s_max[w] : kmax;
-            const uint32_t gb = p.first / 256u + blockIdx.x;
-            store_through(p.block_minmax + 2 * gb, kmin), store_through(p.block_minmax + 2 * gb + 1, kmax);
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+                kmin = a < kmin ? a : kmin, kmax = b > kmax ? b : kmax;
+            }
+            if (tile != blockIdx.x) __syncthreads();  // (the previous tile's extrema have been folded)
+            if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = kmin, s_max[threadIdx.x >> 6] = kmax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < 4; ++w) kmin = s_min[w] < kmin ? s_min[w] : kmin, kmax = s_max[w] > kmax ? s_max[w] : kmax;
+                const uint32_t gb = p.first / 256u + tile;
+                store_through(p.block_minmax + 2 * gb, kmin), store_through(p.block_minmax + 2 * gb + 1, kmax);
+            }
         }
     }
     // The decoded cloud is read by kernels of other launches (and, after a look-ahead upload, of another stream) once the host has

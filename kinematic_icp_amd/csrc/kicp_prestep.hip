@@ -1,70 +1,11 @@
 // kicp_prestep.hip -- the pipeline's pre-steps behind include/kicp.h (kicp_pre_*): wire-format ingest, deskew + crop +
 // transform, voxel downsample (kernels: kicp_pre.hpp).
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
-
 #include "kicp_internal.hpp"
 #include "kicp_pre.hpp"
 
 using namespace kicp;
 using namespace kicp::host;
 
-namespace {
-// One job at a time on a thread of its own: the look-ahead upload's host work (a 2 MB copy into the staging buffer and a dozen API
-// calls, ~85 us) runs beside the calling thread's own queueing of the frame's kernels (~100 us of API calls) instead of after it.
-struct JobThread {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<int()> job;
-    int state = 0;  // 0 idle | 1 posted | 2 done | -1 leaving
-    int result = 0;
-    std::string message;  // the job's error text (kicp_last_error is per thread: the waiting thread takes it over)
-    int device = 0;
-    void run() {
-        hipSetDevice(device);
-        std::unique_lock<std::mutex> lock(m);
-        for (;;) {
-            cv.wait(lock, [this] { return state == 1 || state == -1; });
-            if (state == -1) return;
-            lock.unlock();
-            const int rc = job();
-            lock.lock();
-            result = rc, state = 2;
-            if (rc < 0) message = last_error();
-            cv.notify_all();
-        }
-    }
-    void post(int dev, std::function<int()> fn) {
-        device = dev;
-        if (!th.joinable()) th = std::thread([this] { run(); });
-        {
-            std::lock_guard<std::mutex> lock(m);
-            job = std::move(fn), state = 1;
-        }
-        cv.notify_all();
-    }
-    int wait() {  // (only after post)
-        std::unique_lock<std::mutex> lock(m);
-        cv.wait(lock, [this] { return state == 2; });
-        state = 0;
-        if (result < 0) last_error() = message;
-        return result;
-    }
-    void stop() {
-        if (!th.joinable()) return;
-        {
-            std::unique_lock<std::mutex> lock(m);
-            cv.wait(lock, [this] { return state != 1; });
-            state = -1;
-        }
-        cv.notify_all();
-        th.join();
-    }
-};
-}  // namespace
 struct kicp_pre {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -389,7 +330,10 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     ip.out_xyz = out_xyz, ip.out_stamps = out_ts, ip.block_minmax = p->d_block_minmax;
     ip.total_blocks = static_cast<uint32_t>((n_points + 255) / 256);
     ip.ticket = p->d_ticket + slot;
-    p->ticket_drawn[slot] += ip.total_blocks;
+    // a look-ahead message: few workgroups going round its tiles, so that at most ~100 KB of it are on request at any time (k_ingest)
+    static const uint32_t ahead_wgs = [] { const char *e = std::getenv("KICP_PRE_AHEAD_WGS"); return e && *e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 24u; }();
+    const uint32_t stride_wgs = slot == 1 ? std::min(ip.total_blocks, ahead_wgs) : 0u;
+    p->ticket_drawn[slot] += stride_wgs ? stride_wgs : ip.total_blocks;  // (one ticket per workgroup)
     ip.ticket_done = p->ticket_drawn[slot];
     unsigned long long *rec = p->h_rec + 8 + 4 * slot;
     ip.host_rec = rec, ip.seq = ++p->ingest_seq;
@@ -407,7 +351,7 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
             ip.raw = p->d_raw + off;
         }
         ip.first = static_cast<uint32_t>(first), ip.n = static_cast<uint32_t>(count);
-        hipLaunchKernelGGL(k_ingest, dim3(static_cast<uint32_t>((count + 255) / 256)), dim3(256), 0, stream, ip);
+        hipLaunchKernelGGL(k_ingest, dim3(stride_wgs ? stride_wgs : static_cast<uint32_t>((count + 255) / 256)), dim3(256), 0, stream, ip);
     }
     HIP_TRY(hipGetLastError());
     if (int rc = wait_word(rec + 2, ip.seq, ~0ull, stream)) return rc;  // (`data` and the staging buffer are free again behind this)
@@ -423,7 +367,18 @@ bool same_layout(const kicp_cloud_layout &a, const kicp_cloud_layout &b) {
 int ahead_run(kicp_pre *p) {
     kicp_pre::Ahead &a = p->ahead;
     if (a.state != 1 || a.n == 0 || a.n > p->cap_n) return KICP_OK;  // (a cloud that does not fit the buffers is left to its kicp_pre_ingest call)
-    if (!p->ahead_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
+    if (!p->ahead_stream) {
+        // lowest priority: background work - and the runtime keeps a pool of hardware queues per priority, so that this stream does
+        // not share a queue with the frame's way back (same pool: the look-ahead's kernel waited for the push kernel's 60 us)
+        int least = 0, greatest = 0;
+        static const bool low = [] { const char *e = std::getenv("KICP_PRE_AHEAD_PRIORITY"); return !(e && *e == '0'); }();
+        if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            HIP_TRY(hipStreamCreateWithPriority(&p->ahead_stream, hipStreamNonBlocking, least));
+        } else {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
+        }
+    }
     if (int rc = ingest_run(p, a.data, a.n, a.layout, a.has_pose ? &a.pose : nullptr, p->ahead_stream, p->d_in2, p->d_ts2, p->stage_ahead, 1, &a.lo, &a.hi)) return rc;
     const size_t bytes = a.n * static_cast<size_t>(a.layout.point_step);
     a.edge_bytes = std::min<size_t>(64, bytes);
@@ -699,16 +654,21 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         const uint32_t grid_b = p->spec_tiles_b ? std::min(sgrid, std::max(32u, 2u * p->spec_tiles_b)) : std::min(sgrid, 1024u);
         hipLaunchKernelGGL(k_frame_pre, dim3(grid), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l1_replay, dim3(std::max(grid, f.tiles_spec)), dim3(256), 0, p->stream, f);
-        if (int rc = mark_frame_ready()) return rc;
+        if (int rc = mark_frame_ready()) return rc;  // (buffer 0 is complete: its way back starts beside the downsamples' remaining launches)
         hipLaunchKernelGGL(k_frame_l1_gather, dim3(f.tiles_spec), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_replay, dim3(grid_b), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_gather, dim3(grid_b), dim3(256), 0, p->stream, f);
+        // (starting the frame's way back behind the WHOLE chain instead - the push's 3 MB of PCIe writes make the launches beside it
+        //  2-3 x as long - was measured: no faster with the look-ahead, 4 % slower without it)
         HIP_TRY(hipGetLastError());
+        trace_lap("the frame's launches queued");
         if (int rc = start_download()) return rc;
+        trace_lap("its way back queued");
         const unsigned long long tag = static_cast<unsigned long long>(f.seq) << 32, hi = 0xFFFFFFFF00000000ull;
         for (int w = 4; w >= 0; --w)
             if (int rc = wait_word(p->h_rec + w, tag, hi, p->stream)) return rc;
         const volatile unsigned long long *rec = p->h_rec;
+        trace_lap("the chain's record at the host");
         ++p->fused_frames;
         misc[4] = static_cast<uint32_t>(rec[0]), misc[5] = static_cast<uint32_t>(rec[1]), misc[6] = static_cast<uint32_t>(rec[2]);
         misc[2] = static_cast<uint32_t>(rec[3]), misc[1] = static_cast<uint32_t>(rec[4]) & 1u;
@@ -716,9 +676,10 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         p->spec_n0 = misc[4], p->spec_n_in = static_cast<uint32_t>(n_in);
         p->src_on_host = !unfused_tail && f.host_buf2 != nullptr;
         p->spec_tiles_b = misc[5] ? static_cast<uint32_t>(reference_bucket_count(misc[5]) + 255) / 256u : 1u;
-        if (unfused_tail) {  // the guess was wrong: table A holds claims made under the wrong size; buffer 0 and its count are in place
+        if (unfused_tail) {  // a guess was wrong: the tables hold claims made under the wrong size; buffer 0 and its count are in place
             ++p->spec_misses;
             HIP_TRY(hipMemsetAsync(p->d_table, 0xFF, p->table_slots * 20, p->stream));
+            HIP_TRY(hipMemsetAsync(p->d_table2, 0xFF, p->table_slots * 20, p->stream));
         }
     } else {
         hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, p->stream, pp);

@@ -87,6 +87,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
         } else if (int rc = launch_small(r, sp, pl)) {
             return rc;
         }
+        trace_lap("pass kernel dispatched");
         for (uint32_t k = 0; k < cnt; ++k) {
             const RoctxScope pass_span("icp pass: rows -> solve -> command");
             long long words[kReduceWords];
@@ -102,6 +103,7 @@ int run_small(kicp_reg *r, kicp_map *map, const double *d_frame, size_t n, const
                 rc_rows = wait_rows_small(r, grid, sp.tag0 + k, k % kPipeSlots, words, &gave_up);
             }
             const auto t_rows = std::chrono::steady_clock::now();
+            trace_lap("rows of a pass at the host");
             if (r->d_trace) {
                 const double us = std::chrono::duration<double, std::micro>(t_rows - t_sent).count();
                 if (k == 0) r->trace_first_us += us, ++r->trace_first_n;
@@ -165,6 +167,7 @@ int run_registration_impl(kicp_reg *r, kicp_map *map, const double *d_frame, siz
     const uint64_t epoch_before = map->mirror.synced_epoch;
     if (int rc = map_sync(map, r->device, r->stream)) return rc;
     if (map->mirror.synced_epoch != epoch_before) r->stream_dirty = true;  // the mirror was (re)uploaded through the HIP stream
+    trace_lap("map in step with its pending update");
     const bool shm = r->shm != nullptr;
     const bool multi = r->comm != nullptr || r->allreduce_fn != nullptr;
     const bool p2p = r->d_p2p_table != nullptr;

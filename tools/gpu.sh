@@ -4,6 +4,8 @@
 #   pretests   the pre-step / ingest / facade / golden-pipeline GPU tests
 #   tests      the whole GPU suite
 #   pipeline   the drop-in RegisterFrame on 40 frames of 131 072 points, raw and raw_ahead, 3 runs each + the C-ABI calls' wall times
+#   timeline   one frame's kernels, start offsets and queues, from a kernel trace of the drive
+#   pipeab     the same drive under sets of environment switches (AB_SETS), with the calls' wall times and their laps
 #   pipetrace  rocprofv3 kernel trace of the raw_ahead drive (pre-step / map kernels per frame)
 #   bench      bench.py at the default workload (cfg2), the driver's command
 #   benchall   bench.py for cfg1, cfg4, cfg5 as well
@@ -45,15 +47,25 @@ pipetrace)
     python tools/pipeline_table.py $O/pipeline_kernel_trace_$m.txt $counts > $O/pipeline_kernel_table_$m.txt 2>&1; cat $O/pipeline_kernel_table_$m.txt | cut -c1-200
     rm -rf $O/kt_pipe_$m
   done ;;
-pipeab)   # A/B of the frame download: KICP_PRE_PUSH_WGS = workgroups of the push kernel (0: the DMA engine in pieces)
+timeline)  # one frame's kernels with start offsets and queues (tools/pipeline_timeline.py), raw and raw_ahead
   pipe_dump
-  for wgs in 0 4 8 16 64; do
-    for m in raw raw_ahead; do
-      KICP_PRE_PUSH_WGS=$wgs timeout 300 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /tmp/pipe_ab.txt
-      echo "push_wgs=$wgs $m: $(timeout 300 python tools/bench_pipeline.py --frames 40 --mode $m --check /tmp/pipe_ab.txt --oracle-frames 0 --ref-frames 0 2>&1 | grep 'GPU RegisterFrame\|^drive' | cut -c1-100 | tr '\n' ' ')"
-      KICP_PRE_PUSH_WGS=$wgs KICP_TRACE=1 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | tail -78 | head -17 | grep "pre_frame_ingested\|register_device \|collect\|wait\|update_pose" | tr '\n' ';' | sed 's/  */ /g'; echo
+  for m in raw raw_ahead; do
+    timeout 300 rocprofv3 --kernel-trace -d $O/tl_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/tl_$m.err
+    python tools/pipeline_timeline.py $(find $O/tl_$m -name "*.db" | head -1) 2>&1 | grep -v "^tables\|^rocpd\|copies; sample" > $O/pipeline_timeline_$m.txt; cat $O/pipeline_timeline_$m.txt | cut -c1-150
+    rm -rf $O/tl_$m
+  done ;;
+pipeab)   # A/B of environment switches on the drop-in frame: AB_SETS="A=1,B=2 A=0 ..." ("-" = the defaults); the sets take turns, AB_REPS rounds
+  pipe_dump
+  for rep in $(seq 1 ${AB_REPS:-3}); do
+    for set in ${AB_SETS:-- KICP_PRE_PUSH_WGS=0}; do
+      envs=$(echo $set | tr ',' ' '); [ "$set" = "-" ] && envs="KICP_AB_DEFAULTS=1"
+      for m in raw raw_ahead; do
+        env $envs timeout 300 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /tmp/pipe_ab.txt
+        echo "$set $m: $(timeout 300 python tools/bench_pipeline.py --frames 40 --mode $m --check /tmp/pipe_ab.txt --oracle-frames 0 --ref-frames 0 2>&1 | grep 'GPU RegisterFrame\|^drive' | sed 's/the last 20 frames in //; s/wall clock.*//; s/(second half.*p10/p10/; s/first.*//' | tr '\n' ' ')"
+        [ $rep = 1 ] && env $envs KICP_TRACE=1 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "^\[kicp" | tail -120 | head -40 > $O/pipeline_ab_calls_${set//[^A-Za-z0-9]/_}_$m.txt
+      done
     done
-  done 2>&1 | tee $O/pipeline_ab.txt ;;
+  done 2>&1 | sort -s -k1,2 | tee $O/pipeline_ab.txt ;;
 bench)
   timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 600 $O/bench_n1.json; echo ;;
 benchall)
