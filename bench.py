@@ -155,6 +155,18 @@ def main():
     if "KICP_BENCH_DEVICE" in os.environ:  # testing aid: several ranks on one GPU (works with --comm shm --pg-backend gloo)
         device = int(os.environ["KICP_BENCH_DEVICE"])
     torch.cuda.set_device(device)
+    # the process runs on the NUMA node its GPU is attached to, as a deployment would start it (numactl --cpunodebind; INTEGRATION.md
+    # section 6): the host side of a registration is polls of, and copies through, pinned memory the GPU writes over PCIe.  The CPU
+    # baseline's threads inherit the binding (one socket's CPUs - more than the box's quota).  KICP_BENCH_PLACEMENT=0: left alone.
+    host_placement = "not bound"
+    if os.environ.get("KICP_BENCH_PLACEMENT", "1") != "0":
+        try:
+            near = K.cpus_near_gpu(device, one_l3_domain=False)
+            if near:
+                os.sched_setaffinity(0, near)
+                host_placement = "process bound to the %d CPUs of the GPU's NUMA node (%d)" % (len(near), K.device_locality(device)[0])
+        except Exception as e:  # noqa: BLE001 - placement is an extra
+            host_placement = "not bound (%s)" % e
     replicas = args.mode == "replicas" and world > 1
     use_comm = world > 1 or args.force_comm      # a process group exists (barriers, timing)
     exchange = use_comm and not replicas          # the registration itself exchanges sums
@@ -813,7 +825,7 @@ def main():
                    "parallelism": ("%d independent replicas (one robot per GPU), no exchange" % world) if replicas else
                                   (("points sharded x%d, map replicated, %s exchange of the 24 limb words per ICP pass, %d sharded scan(s) in flight per rank"
                                     % (world, args.comm, in_flight)) if use_comm else "single GPU"),
-                   "pass_kernel": pass_kernel, "launch_path": launch_path, "max_pose_abs_diff_vs_oracle": max_pose_err,
+                   "pass_kernel": pass_kernel, "launch_path": launch_path, "host_placement": host_placement, "max_pose_abs_diff_vs_oracle": max_pose_err,
                    "poses_checked_against_the_oracle": len(iters_ref_multi) + len(iters_ref),
                    "poses_of_the_timed_region_checked": timed_checked + timed_checked_multi,
                    "poses_of_the_timed_region_check": "every pose the timed batch calls returned (headline %d, multi-iteration %d; the batches as their last step left "

@@ -76,6 +76,11 @@ typedef struct kicp_stats {
 const char *kicp_last_error(void); /* thread-local, valid until the next failing call on this thread */
 int kicp_version(void);
 int kicp_device_count(void); /* number of visible HIP devices, <0 on runtime failure */
+/* Where the host should run the thread that calls this library for `device`: the NUMA node the GPU is attached to (-1: unknown) and
+ * its CPUs as the kernel prints them ("0-63,128-191"; empty: unknown), from /sys/bus/pci/devices/<bdf>/{numa_node,local_cpulist}.
+ * The library places its own helper threads and pinned buffers there (KICP_NUMA=0: not); the caller's thread is the caller's to
+ * place - a frame is ~5 % faster from that node and ~10 % from inside one L3 domain of it. */
+int kicp_device_locality(int device, int *out_numa_node, char *out_cpulist, size_t cap);
 
 /* ---- kiss_icp::VoxelHashMap (kiss-icp v1.2.0 core/VoxelHashMap.hpp) ------------------ */
 /* VoxelHashMap(voxel_size, max_distance, max_points_per_voxel)   -- pipeline/KinematicICP.hpp:79 */

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "kicp_last_error": (C.c_char_p, []),
     "kicp_version": (C.c_int, []),
     "kicp_device_count": (C.c_int, []),
+    "kicp_device_locality": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "kicp_map_create": (C.c_int, [C.c_double, C.c_double, C.c_uint, C.POINTER(C.c_void_p)]),
     "kicp_map_destroy": (None, [C.c_void_p]),
     "kicp_map_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -194,6 +195,37 @@ def probe_dependent_load(working_set_bytes, workgroups=512, block=256, steps=64,
 
 def device_count():
     return lib().kicp_device_count()
+
+
+def device_locality(device=0):
+    """(NUMA node the GPU is attached to | -1, its CPUs as a set | empty) - kicp_device_locality"""
+    node, buf = C.c_int(-1), C.create_string_buffer(4096)
+    _check(lib().kicp_device_locality(device, C.byref(node), buf, len(buf)))
+    cpus = set()
+    for part in buf.value.decode().split(","):
+        if part.strip():
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return node.value, cpus
+
+
+def cpus_near_gpu(device=0, one_l3_domain=True):
+    """CPUs to bind a process that drives `device` to: the GPU's NUMA node, narrowed to what the process may use and (by default) to
+    ONE L3 domain of it - the calling thread and the library's helper threads then share a last-level cache.  Empty: unknown."""
+    import os
+    _, cpus = device_locality(device)
+    cpus &= os.sched_getaffinity(0)
+    if not cpus or not one_l3_domain:
+        return cpus
+    try:
+        with open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % min(cpus)) as f:
+            l3 = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                l3.update(range(int(lo), int(hi or lo) + 1))
+        return (cpus & l3) or cpus
+    except OSError:
+        return cpus
 
 
 class VoxelHashMap:

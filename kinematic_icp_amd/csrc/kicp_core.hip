@@ -2,6 +2,12 @@
 // memory, version / device queries and the raw device-memory helpers of include/kicp.h.
 #include <dlfcn.h>
 
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <cctype>
+
 #include "kicp_internal.hpp"
 
 namespace kicp {
@@ -65,6 +71,94 @@ int fail(int code, const std::string &msg) {
 // DMA for callers that pass pinned (hipHostMalloc / hipHostRegister) memory.  An event recorded behind the last copy of an
 // upload guards the buffer: the next transfer through it waits for that event first, so an entry point that returns early
 // (error, max_num_iterations <= 0) cannot have its copy overtaken by the next call's CPU writes.
+// ---- NUMA locality of the GPU (kicp_internal.hpp) ---------------------------------------------------------------------------------
+namespace {
+struct GpuLocality {
+    int node = -1;
+    cpu_set_t cpus;
+    bool have_cpus = false;
+    std::string cpulist;
+};
+const bool g_numa = [] { const char *e = std::getenv("KICP_NUMA"); return !(e && *e == '0'); }();
+std::string read_line(const std::string &path) {
+    std::string out;
+    if (FILE *f = std::fopen(path.c_str(), "r")) {
+        char buf[4096];
+        if (std::fgets(buf, sizeof buf, f)) out = buf;
+        std::fclose(f);
+    }
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+    return out;
+}
+const GpuLocality &gpu_locality(int device) {
+    static std::mutex mutex;
+    static GpuLocality known[64];
+    static bool looked[64] = {};
+    static const GpuLocality none{};
+    if (device < 0 || device >= 64 || !g_numa) return none;
+    std::lock_guard<std::mutex> lock(mutex);
+    GpuLocality &g = known[device];
+    if (looked[device]) return g;
+    looked[device] = true;
+    CPU_ZERO(&g.cpus);
+    char bdf[64] = {};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return g;
+    }
+    for (char *c = bdf; *c; ++c) *c = static_cast<char>(std::tolower(*c));
+    const std::string base = std::string("/sys/bus/pci/devices/") + bdf + "/";
+    const std::string node = read_line(base + "numa_node");
+    if (!node.empty()) g.node = std::atoi(node.c_str());
+    // "0-63,128-191"
+    const std::string list = read_line(base + "local_cpulist");
+    g.cpulist = list;
+    for (size_t i = 0; i < list.size();) {
+        char *end = nullptr;
+        const long lo = std::strtol(list.c_str() + i, &end, 10);
+        long hi = lo;
+        if (end == list.c_str() + i) break;
+        i = static_cast<size_t>(end - list.c_str());
+        if (i < list.size() && list[i] == '-') {
+            hi = std::strtol(list.c_str() + i + 1, &end, 10);
+            i = static_cast<size_t>(end - list.c_str());
+        }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET(static_cast<int>(c), &g.cpus), g.have_cpus = true;
+        if (i < list.size() && list[i] == ',') ++i;
+    }
+    return g;
+}
+}  // namespace
+hipError_t pinned_alloc(void **ptr, size_t bytes, unsigned int flags) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError(), device = -1;
+    const int node = gpu_locality(device).node;
+    bool policy_set = false;
+    if (node >= 0 && node < 1024) {  // MPOL_PREFERRED (1): pages come from `node` while it has any, from anywhere else after that
+        unsigned long mask[16] = {};
+        mask[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
+        policy_set = syscall(SYS_set_mempolicy, 1, mask, 8 * sizeof mask + 1) == 0;
+    }
+    const hipError_t e = hipHostMalloc(ptr, bytes, flags);
+    if (policy_set) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0);  // MPOL_DEFAULT
+    return e;
+}
+int device_locality(int device, int *node, char *cpulist, size_t cap) {
+    const GpuLocality &g = gpu_locality(device);
+    if (node) *node = g.node;
+    if (cpulist && cap) std::snprintf(cpulist, cap, "%s", g.cpulist.c_str());
+    return KICP_OK;
+}
+void bind_thread_near_gpu(int device) {
+    const GpuLocality &g = gpu_locality(device);
+    if (!g.have_cpus) return;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    CPU_AND(&want, &allowed, &g.cpus);
+    if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &allowed)) return;
+    (void)sched_setaffinity(0, sizeof want, &want);
+}
+
 const bool g_direct_upload = env_flag("KICP_DIRECT_UPLOAD");
 static int stage_wait(HostStage &hs) {
     if (hs.pending) {
@@ -78,7 +172,7 @@ int stage_reserve(HostStage &hs, size_t bytes, hipStream_t stream) {
     HIP_TRY(hipStreamSynchronize(stream));
     hs.release();
     const size_t want = bytes + bytes / 2 + (1u << 20);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hs.p), want, hipHostMallocDefault));
+    HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hs.p), want, hipHostMallocDefault));
     hs.cap = want;
     hs.dev = nullptr;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&hs.dev), hs.p, 0) != hipSuccess) hs.dev = nullptr, (void)hipGetLastError();
@@ -223,6 +317,11 @@ int kicp_probe_dependent_load(int device, size_t working_set_bytes, int workgrou
 
 const char *kicp_last_error(void) { return last_error().c_str(); }
 int kicp_version(void) { return KICP_VERSION; }
+int kicp_device_locality(int device, int *out_numa_node, char *out_cpulist, size_t cap) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(KICP_ERR_ARG, "no such device");
+    return device_locality(device, out_numa_node, out_cpulist, cap);
+}
 int kicp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;

@@ -66,6 +66,16 @@ struct RoctxScope {  // a named span inside a call (one ICP pass: dispatch -> ro
 // last error message of the calling thread (kicp_last_error) and the one way to report a failure
 std::string &last_error();
 int fail(int code, const std::string &msg);
+// The host side of a frame is a few dozen polls of, and copies through, pinned host memory the GPU writes over PCIe: on a two-socket
+// host all of it is ~20 % slower (and bimodal from run to run) when the memory or the library's helper threads sit on the socket the
+// GPU is NOT attached to.  pinned_alloc is hipHostMalloc with the calling thread's memory policy set to the GPU's NUMA node for the
+// duration of the call (sysfs: /sys/bus/pci/devices/<bdf>/numa_node; nothing happens where that is unknown or there is one node);
+// bind_thread_near_gpu moves the CALLING thread - only ever a thread the library created - onto that node's CPUs (local_cpulist,
+// intersected with what the process may use).  KICP_NUMA=0 turns both off.  The caller's own threads are the caller's to place
+// (numactl --cpunodebind).
+hipError_t pinned_alloc(void **ptr, size_t bytes, unsigned int flags);
+void bind_thread_near_gpu(int device);
+int device_locality(int device, int *node, char *cpulist, size_t cap);
 // One job at a time on a thread of its own (the pre-steps' look-ahead upload, the map update's launches): e.g. the look-ahead upload's host work (a 2 MB copy into the staging buffer and a dozen API
 // calls, ~85 us) runs beside the calling thread's own queueing of the frame's kernels (~100 us of API calls) instead of after it.
 struct JobThread {
@@ -79,6 +89,7 @@ struct JobThread {
     int device = 0;
     void run() {
         hipSetDevice(device);
+        bind_thread_near_gpu(device);
         std::unique_lock<std::mutex> lock(m);
         for (;;) {
             cv.wait(lock, [this] { return state == 1 || state == -1; });

@@ -353,7 +353,7 @@ int map_update_device(kicp_map *map, int device, const double *d_points, size_t 
             // the caller collects the end of this update later (kicp_map_update_finish, or whatever it calls on the map next):
             // the counters land in pinned memory, nothing is waited for here
             if (!mr.h_ctr) {
-                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&mr.h_ctr), 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&mr.h_ctr), 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
                 std::memset(mr.h_ctr, 0, 8 * sizeof(unsigned long long));
                 HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&mr.h_ctr_dev), mr.h_ctr, 0));
             }

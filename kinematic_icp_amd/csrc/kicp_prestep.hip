@@ -204,7 +204,7 @@ int kicp_pre_create(int device, kicp_pre **out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_misc, 64);  // [0] total [1] error [2] longest probe [3] ticket [4..6] the chained pre-steps' three counts [7], [8]: kicp_pre.hpp
     if (e == hipSuccess) e = hipMemset(p->d_misc, 0, 64);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->chain_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_rec), 32 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = pinned_alloc(reinterpret_cast<void **>(&p->h_rec), 32 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) std::memset(p->h_rec, 0, 32 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&p->d_ticket, 16);
     if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 16);
@@ -330,17 +330,19 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     ip.out_xyz = out_xyz, ip.out_stamps = out_ts, ip.block_minmax = p->d_block_minmax;
     ip.total_blocks = static_cast<uint32_t>((n_points + 255) / 256);
     ip.ticket = p->d_ticket + slot;
-    // a look-ahead message: few workgroups going round its tiles, so that at most ~100 KB of it are on request at any time (k_ingest)
-    static const uint32_t ahead_wgs = [] { const char *e = std::getenv("KICP_PRE_AHEAD_WGS"); return e && *e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 24u; }();
-    const uint32_t stride_wgs = slot == 1 ? std::min(ip.total_blocks, ahead_wgs) : 0u;
-    p->ticket_drawn[slot] += stride_wgs ? stride_wgs : ip.total_blocks;  // (one ticket per workgroup)
-    ip.ticket_done = p->ticket_drawn[slot];
+    // a look-ahead message: few workgroups going round its tiles, so that at most ~200 KB of it are on request at any time (k_ingest;
+    // 24 / 48 / 64 workgroups and 0.5 / 1 / 4 MB pieces measured within the boxes' noise of each other, 8 and 512 clearly worse)
+    static const uint32_t ahead_wgs = [] { const char *e = std::getenv("KICP_PRE_AHEAD_WGS"); return e && *e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 48u; }();
+    static const size_t ahead_piece = [] { const char *e = std::getenv("KICP_PRE_AHEAD_PIECE_KB"); return (e && *e ? static_cast<size_t>(std::max(64, std::atoi(e))) : 512u) << 10; }();
+    const uint32_t wgs_cap = slot == 1 ? ahead_wgs : 0xFFFFFFFFu;
     unsigned long long *rec = p->h_rec + 8 + 4 * slot;
     ip.host_rec = rec, ip.seq = ++p->ingest_seq;
-    // this call's message: pieces, so that the GPU decodes piece k while the CPU copies piece k + 1; a look-ahead message (slot 1) is off
-    // the frame's critical path and goes up as ONE launch - the device starts a kernel every ~4.5 us whatever the number of queues,
-    // and a frame is ~20 launches as it is
-    const size_t piece_records = slot == 1 ? std::max<size_t>(n_points, 256) : std::max<size_t>(256, kIngestPiece / L.point_step / 256 * 256);
+    // pieces, so that the GPU decodes piece k while the CPU copies piece k + 1 (a look-ahead message too: as ONE launch behind the
+    // whole 2 MB copy it was not there when the next frame asked for it)
+    const size_t piece_records = std::max<size_t>(256, (slot == 1 ? ahead_piece : kIngestPiece) / L.point_step / 256 * 256);
+    for (size_t first = 0; first < n_points; first += piece_records)  // (one ticket per workgroup of every launch)
+        p->ticket_drawn[slot] += std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((std::min(piece_records, n_points - first) + 255) / 256));
+    ip.ticket_done = p->ticket_drawn[slot];
     for (size_t first = 0; first < n_points; first += piece_records) {
         const size_t count = std::min(piece_records, n_points - first), off = first * L.point_step, len = count * L.point_step;
         std::memcpy(stage.p + off, static_cast<const unsigned char *>(data) + off, len);
@@ -351,7 +353,7 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
             ip.raw = p->d_raw + off;
         }
         ip.first = static_cast<uint32_t>(first), ip.n = static_cast<uint32_t>(count);
-        hipLaunchKernelGGL(k_ingest, dim3(stride_wgs ? stride_wgs : static_cast<uint32_t>((count + 255) / 256)), dim3(256), 0, stream, ip);
+        hipLaunchKernelGGL(k_ingest, dim3(std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((count + 255) / 256))), dim3(256), 0, stream, ip);
     }
     HIP_TRY(hipGetLastError());
     if (int rc = wait_word(rec + 2, ip.seq, ~0ull, stream)) return rc;  // (`data` and the staging buffer are free again behind this)
@@ -641,7 +643,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
             if (p->h_src) HIP_TRY(hipHostFree(p->h_src));
             p->h_src = p->h_src_dev = nullptr, p->h_src_cap = 0;
             const size_t want = n_in * 24 + n_in * 6 + 4096;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_src), want, hipHostMallocDefault));
+            HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&p->h_src), want, hipHostMallocDefault));
             p->h_src_cap = want;
             if (hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_src_dev), p->h_src, 0) != hipSuccess) p->h_src_dev = nullptr, (void)hipGetLastError();
         }
@@ -658,8 +660,8 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         hipLaunchKernelGGL(k_frame_l1_gather, dim3(f.tiles_spec), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_replay, dim3(grid_b), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_gather, dim3(grid_b), dim3(256), 0, p->stream, f);
-        // (starting the frame's way back behind the WHOLE chain instead - the push's 3 MB of PCIe writes make the launches beside it
-        //  2-3 x as long - was measured: no faster with the look-ahead, 4 % slower without it)
+        // (starting the frame's way back one, two or three launches later instead - the push's 3 MB of PCIe writes make the launches
+        //  beside it 2-3 x as long, and the event costs the device 6 us between two launches - was measured: 1-4 % slower each)
         HIP_TRY(hipGetLastError());
         trace_lap("the frame's launches queued");
         if (int rc = start_download()) return rc;
@@ -845,7 +847,7 @@ static int download_reserve(kicp_pre *p, size_t bytes) {
     if (bytes > p->copy_cap) {
         if (p->copy_host) HIP_TRY(hipHostFree(p->copy_host));
         p->copy_host = nullptr, p->copy_host_dev = nullptr, p->copy_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->copy_host), bytes + bytes / 2 + (1u << 20), hipHostMallocDefault));
+        HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&p->copy_host), bytes + bytes / 2 + (1u << 20), hipHostMallocDefault));
         p->copy_cap = bytes + bytes / 2 + (1u << 20);
         if (hipHostGetDevicePointer(reinterpret_cast<void **>(&p->copy_host_dev), p->copy_host, 0) != hipSuccess) p->copy_host_dev = nullptr, (void)hipGetLastError();
     }
@@ -886,6 +888,7 @@ static hipError_t spin_on_event(hipEvent_t ev) {
 }
 static void copy_worker(kicp_pre *p) {
     hipSetDevice(p->device);
+    bind_thread_near_gpu(p->device);
     std::unique_lock<std::mutex> lock(p->copy_mutex);
     for (;;) {
         p->copy_cv.wait(lock, [p] { return p->copy_state == 1 || p->copy_state == -1; });
@@ -903,6 +906,8 @@ static void copy_worker(kicp_pre *p) {
             const volatile unsigned long long *flags = p->h_rec + 16;
             const unsigned long long tag = static_cast<unsigned long long>(p->copy_push_seq) << 32;
             const auto t0 = std::chrono::steady_clock::now();
+            double landed_us[kPushPieces] = {}, copied_us[kPushPieces] = {};
+            int pieces_seen = 0;
             for (int i = 0; i < kPushPieces && e == hipSuccess; ++i) {
                 unsigned long long f = 0;
                 for (unsigned spins = 0;; ++spins) {
@@ -918,8 +923,16 @@ static void copy_worker(kicp_pre *p) {
                 }
                 if (e != hipSuccess) break;
                 const size_t len = static_cast<size_t>(f & 0xFFFFFFFFull), off = static_cast<size_t>(p->copy_push_piece) * i;
+                if (g_trace) landed_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
                 if (len && p->copy_dst && off < want) std::memcpy(reinterpret_cast<unsigned char *>(p->copy_dst) + off, p->copy_host + off, std::min(len, want - off));
+                if (g_trace) copied_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), pieces_seen = i + 1;
                 if (len < p->copy_push_piece) break;
+            }
+            if (g_trace) {  // (since this thread took the job: when each piece's flag was seen, when its copy into the caller's memory was over)
+                std::string line = "[kicp]     the frame's way back, us (landed/copied):";
+                char buf[48];
+                for (int i = 0; i < pieces_seen; ++i) std::snprintf(buf, sizeof buf, " %.0f/%.0f", landed_us[i], copied_us[i]), line += buf;
+                std::fprintf(stderr, "%s\n", line.c_str());
             }
         } else if (p->copy_piece_bytes && p->copy_dst) {
             for (int i = 0; i < kicp_pre::kCopyPieces && e == hipSuccess; ++i) {

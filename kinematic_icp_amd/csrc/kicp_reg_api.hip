@@ -83,7 +83,7 @@ int kicp_reg_create(const kicp_reg_config *config, int device, kicp_reg **out) {
     if (e == hipSuccess) e = hipEventCreate(&r->ev1);
     if (e == hipSuccess) e = hipMalloc(&r->d_state, sizeof(IcpState));
     if (e == hipSuccess) e = hipMemset(r->d_state, 0, sizeof(IcpState));
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&r->rec), sizeof(HostRecord), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = pinned_alloc(reinterpret_cast<void **>(&r->rec), sizeof(HostRecord), hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) std::memset(r->rec, 0, sizeof(HostRecord));
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rec), r->rec, 0);
     if (e == hipSuccess) {

@@ -65,12 +65,31 @@ int kicp_reg_comm_destroy(kicp_reg *reg) {
 // Shared segment layout: one header slot (magic word written LAST by rank 0, then the rank count) followed by the
 // [2 buffers][nranks] hand-off slots of single calls and, behind them, one such area per lane of a sharded batch call.
 constexpr unsigned long long kShmMagic = 0x4B49435053484D31ull;  // "KICPSHM1"
+// Rank 0 writes this over the magic word before it unlinks a segment (its own at destroy, a left-over of that name at init): a
+// rank that opened the OLD segment in the window before the unlink sees it, lets go and opens the name again.  A rank
+// that had already passed the check exchanges on the dead segment and runs into the exchange's time-out - an error, never a hang
+// or a mixed-up sum; callers that re-initialise should put a barrier between kicp_reg_shm_destroy and kicp_reg_shm_init.
+constexpr unsigned long long kShmRetired = 0x4B49435044454144ull;  // "KICPDEAD"
+static void shm_retire_by_name(const std::string &nm) {
+    const int fd = shm_open(nm.c_str(), O_RDWR, 0600);
+    if (fd < 0) return;
+    struct stat st {};
+    if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= sizeof(kicp_reg::ShmSlot)) {
+        void *ptr = mmap(nullptr, sizeof(kicp_reg::ShmSlot), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (ptr != MAP_FAILED) {
+            __atomic_store_n(&static_cast<kicp_reg::ShmSlot *>(ptr)->seq, kShmRetired, __ATOMIC_RELEASE);
+            munmap(ptr, sizeof(kicp_reg::ShmSlot));
+        }
+    }
+    close(fd);
+}
 int kicp_reg_shm_destroy(kicp_reg *reg) {
     if (!reg) return fail(KICP_ERR_ARG, "null argument");
     if (reg->shm) {
         hipSetDevice(reg->device);
         hipStreamSynchronize(reg->stream);
         if (reg->d_shm) (void)hipHostUnregister(reg->shm_base);
+        if (reg->rank == 0) __atomic_store_n(&static_cast<kicp_reg::ShmSlot *>(reg->shm_base)->seq, kShmRetired, __ATOMIC_RELEASE);
         munmap(reg->shm_base, reg->shm_bytes);
         if (reg->rank == 0) shm_unlink(reg->shm_name.c_str());
         reg->shm = nullptr, reg->d_shm = nullptr, reg->shm_base = nullptr, reg->shm_bytes = 0;
@@ -87,7 +106,8 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
     const std::string nm = std::string(name[0] == '/' ? "" : "/") + name;
     void *ptr = MAP_FAILED;
     if (rank == 0) {
-        // a segment of this name left behind by a crashed run must not be adopted: remove it, then create exclusively
+        // a segment of this name left behind by a crashed run must not be adopted: mark it dead, remove it, then create exclusively
+        shm_retire_by_name(nm);
         shm_unlink(nm.c_str());
         const int fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) return fail(KICP_ERR_COMM, "shm_open(" + nm + ", O_CREAT | O_EXCL) failed");
@@ -115,12 +135,20 @@ int kicp_reg_shm_init(kicp_reg *reg, int nranks, int rank, const char *name) {
                     close(fd);
                     if (ptr == MAP_FAILED) return fail(KICP_ERR_COMM, "mmap of the shared segment failed");
                     auto *hdr = static_cast<kicp_reg::ShmSlot *>(ptr);
-                    while (__atomic_load_n(&hdr->seq, __ATOMIC_ACQUIRE) != kShmMagic) {
+                    unsigned long long word;
+                    while ((word = __atomic_load_n(&hdr->seq, __ATOMIC_ACQUIRE)) != kShmMagic && word != kShmRetired) {
                         if (deadline.passed()) {
                             munmap(ptr, bytes);
                             return fail(KICP_ERR_COMM, "timed out waiting for rank 0 to publish the shared segment");
                         }
                         usleep(50);
+                    }
+                    if (word == kShmRetired) {  // the previous incarnation's segment: rank 0 is about to replace it
+                        munmap(ptr, bytes);
+                        ptr = MAP_FAILED;
+                        if (deadline.passed()) return fail(KICP_ERR_COMM, "timed out waiting for rank 0 to replace the retired shared segment " + nm);
+                        usleep(200);
+                        continue;
                     }
                     if (hdr->words[0] != nranks) {
                         munmap(ptr, bytes);

@@ -164,7 +164,7 @@ int ensure_rows(kicp_reg *r, size_t groups) {
     if (r->rows) HIP_TRY(hipHostFree(r->rows));
     r->rows = nullptr, r->d_rows = nullptr, r->rows_groups = 0;
     const size_t want = groups + groups / 2 + 64;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->rows), want * kReduceWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&r->rows), want * kReduceWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(r->rows, 0, want * kReduceWords * sizeof(unsigned long long));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_rows), r->rows, 0));
     r->rows_groups = want;
@@ -349,7 +349,7 @@ SmallPlan small_plan(const kicp_reg *r, size_t n) {
 }
 int ensure_cmd(kicp_reg *r) {
     if (!r->cmd) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r->cmd), kPipeSlots * kCmdWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&r->cmd), kPipeSlots * kCmdWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(r->cmd, 0, kPipeSlots * kCmdWords * sizeof(unsigned long long));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&r->d_cmd), r->cmd, 0));
     }

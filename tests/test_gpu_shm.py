@@ -172,3 +172,43 @@ def test_sharded_batch_with_scans_in_flight(world, queues):
         else:
             assert out[-1][2] == 0
         assert np.array_equal(one, want[0])
+
+
+def test_a_segment_is_retired_before_it_is_replaced():
+    """kicp_reg_shm_destroy by rank 0 marks the segment dead before unlinking it, kicp_reg_shm_init waits for the NEW one:
+    rank 1 re-initialises while rank 0 has not recreated the segment yet, then both exchange on the new segment - twice over, so the
+    second round runs against a name that has just been retired.  Two handles in one process, one thread per rank."""
+    import threading
+    import kinematic_icp_amd as K
+    from kinematic_icp_amd import sharding as sh
+    g = np.load(GOLD)
+    m = K.VoxelHashMap(float(g["a_voxel"]), float(g["a_maxrange"]), 20)
+    m.AddPoints(g["a_map"])
+    frame = g["a_frame"]
+    ref = K.KinematicRegistration().ComputeRobotMotion(frame, m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+    regs = [K.KinematicRegistration(), K.KinematicRegistration()]
+    name = "kicp_test_retire_%d" % os.getpid()
+    for _ in range(2):
+        out, errs = {}, []
+
+        def late_rank(rank=1):
+            try:
+                regs[rank].shm_init(2, rank, name)  # (starts before rank 0 has created the segment: waits for it)
+                lo, hi = sh.shard_bounds(len(frame), 2, rank)
+                out[rank] = regs[rank].ComputeRobotMotion(frame[lo:hi], m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        t = threading.Thread(target=late_rank)
+        t.start()
+        import time
+        time.sleep(0.2)
+        regs[0].shm_init(2, 0, name)
+        lo, hi = sh.shard_bounds(len(frame), 2, 0)
+        out[0] = regs[0].ComputeRobotMotion(frame[lo:hi], m, g["a_last"], g["a_rel"], float(g["a_tau"]))
+        t.join(timeout=120)
+        assert not t.is_alive() and not errs, errs
+        assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+        regs[1].shm_destroy()
+        regs[0].shm_destroy()  # (rank 0: marks the segment dead, then unlinks it)
+        assert not os.path.exists("/dev/shm/" + name)

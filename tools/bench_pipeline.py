@@ -29,6 +29,21 @@ MODE_WHAT = {"raw": "IngestCloud + RegisterIngestedFrame on 16-byte FLOAT32 Poin
              "vectors": "RegisterFrame on std::vector<Eigen::Vector3d> + std::vector<double>, the reference's own signature (4.2 MB over PCIe per frame)"}
 
 
+def placement():
+    """(preexec_fn, description): the caller process of the drop-in is bound to one L3 domain of the GPU's NUMA node, as a deployment
+    would bind the node that drives the GPU (numactl / taskset).  KICP_BENCH_PLACEMENT=0: left where it is."""
+    if os.environ.get("KICP_BENCH_PLACEMENT", "1") == "0":
+        return None, "not bound (KICP_BENCH_PLACEMENT=0)"
+    try:
+        import kinematic_icp_amd as K
+        cpus = K.cpus_near_gpu(0)
+    except Exception as e:  # noqa: BLE001
+        return None, "not bound (%s)" % e
+    if not cpus:
+        return None, "not bound (the GPU's NUMA node is unknown)"
+    return (lambda: os.sched_setaffinity(0, cpus)), "bound to CPUs %s: one L3 domain of the GPU's NUMA node" % ",".join(str(c) for c in sorted(cpus))
+
+
 def json_block(a, facade, f, frames, stamps, ext, deltas):
     """every mode on the same frames: per-frame wall time of the drop-in RegisterFrame (the clock around the call), the drive's steady
     frame rate (wall clock around the loop: deferred map updates cannot hide in it), wall time per C-ABI call (KICP_TRACE, a run of
@@ -37,13 +52,14 @@ def json_block(a, facade, f, frames, stamps, ext, deltas):
     from oracle import rkicp
     res = {"frames": len(frames), "points_per_frame": int(len(frames[0])), "deskew": bool(a.deskew), "voxel_size": a.voxel, "modes": {}}
     gpu_poses = None
+    bind, res["caller_process"] = placement()
     for m in [x for x in a.json.split(",") if x]:
-        out = subprocess.check_output([facade, FACADE_MODE[m], f], text=True).splitlines()
+        out = subprocess.check_output([facade, FACADE_MODE[m], f], text=True, preexec_fn=bind).splitlines()
         ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
         drive = [l.split() for l in out if l.startswith("drive")]
         steady = ms[len(ms) // 2:]
         gpu_poses = [np.array([float(x) for x in l.split()[1:]]) for l in out if l.startswith("pose")]
-        tr = subprocess.run([facade, FACADE_MODE[m], f], text=True, capture_output=True, env=dict(os.environ, KICP_TRACE="1")).stderr.splitlines()
+        tr = subprocess.run([facade, FACADE_MODE[m], f], text=True, capture_output=True, env=dict(os.environ, KICP_TRACE="1"), preexec_fn=bind).stderr.splitlines()
         calls = {}
         for l in tr:
             mt = re.match(r"\[kicp\] (kicp_\w+)\s+([0-9.]+) ms", l)
@@ -127,7 +143,9 @@ def main():
         if a.check:
             out = open(a.check).read().splitlines()
         else:
-            out = subprocess.check_output([test_facade.build_facade(), FACADE_MODE[a.mode], f], text=True).splitlines()
+            bind, where = placement()
+            print("caller process:", where)
+            out = subprocess.check_output([test_facade.build_facade(), FACADE_MODE[a.mode], f], text=True, preexec_fn=bind).splitlines()
     ms = np.array([float(l.split()[3]) for l in out if l.startswith("frame")])
     ondev = np.array([int(l.split()[-1]) for l in out if l.startswith("frame")])
     ms_free = np.array([float(l.split()[4].strip("(")) for l in out if l.startswith("frame")])

@@ -17,6 +17,8 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 quiet() { grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl"; }
+# the process that drives the GPU runs on one L3 domain of the GPU's NUMA node (tools/bench_pipeline.py placement(); NEAR="" where unknown)
+near_gpu() { [ -n "${NEAR_SET:-}" ] || { CPUS=$(python -c "import kinematic_icp_amd as K; print(','.join(map(str, sorted(K.cpus_near_gpu(0)))))" 2>/dev/null); NEAR=""; [ -n "$CPUS" ] && [ "${KICP_BENCH_PLACEMENT:-1}" != 0 ] && NEAR="taskset -c $CPUS"; NEAR_SET=1; echo "caller placement: ${NEAR:-none}"; }; }
 pipe_dump() { [ -f /tmp/pipe.bin ] || timeout 300 python tools/bench_pipeline.py --frames 40 --mode raw --dump /tmp/pipe.bin > /dev/null 2>&1; }
 for stage in "$@"; do
 case $stage in
@@ -27,42 +29,42 @@ tests)
   ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
   quiet < $O/pytest.log | tail -12 > $O/gpu_tests.txt; cat $O/gpu_tests.txt ;;
 pipeline)
-  pipe_dump
+  pipe_dump; near_gpu
   for m in raw raw_ahead; do
     mode=pipeline_timed_raw; [ $m = raw_ahead ] && mode=pipeline_timed_raw_ahead
     for rep in 1 2 3; do
-      timeout 300 tests/cpp/facade_test $mode /tmp/pipe.bin > /tmp/pipe_$m.txt
+      $NEAR timeout 300 tests/cpp/facade_test $mode /tmp/pipe.bin > /tmp/pipe_$m.txt
       timeout 900 python tools/bench_pipeline.py --frames 40 --mode $m --check /tmp/pipe_$m.txt --oracle-frames 0 --ref-frames 0 2>&1 | grep -v "^frame [0-9]* ms" > $O/pipeline_${m}_$rep.txt
       grep "GPU RegisterFrame\|^drive" $O/pipeline_${m}_$rep.txt | cut -c1-220
     done
-    KICP_TRACE=1 tests/cpp/facade_test $mode /tmp/pipe.bin 2>&1 >/dev/null | tail -78 | head -17 > $O/pipeline_calls_$m.txt
+    KICP_TRACE=1 $NEAR tests/cpp/facade_test $mode /tmp/pipe.bin 2>&1 >/dev/null | grep "^\[kicp" | tail -100 | head -24 > $O/pipeline_calls_$m.txt
     echo "== $m"; cat $O/pipeline_calls_$m.txt
   done ;;
 pipetrace)
-  pipe_dump
+  pipe_dump; near_gpu
   for m in raw raw_ahead; do
-    timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_pipe_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/kt_pipe_$m.err
+    $NEAR timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_pipe_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/kt_pipe_$m.err
     python tools/prof_summary.py $(find $O/kt_pipe_$m -name "*.db" | head -1) > $O/pipeline_kernel_trace_$m.txt 2>&1; echo "== $m"; head -16 $O/pipeline_kernel_trace_$m.txt | cut -c1-160
-    counts=$(KICP_TRACE=1 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "chained pre-steps" | tail -1 | sed "s/.*steps: \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) points.*/\1 \2 \3 \4/")
+    counts=$(KICP_TRACE=1 $NEAR tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "chained pre-steps" | tail -1 | sed "s/.*steps: \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) -> \([0-9]*\) points.*/\1 \2 \3 \4/")
     python tools/pipeline_table.py $O/pipeline_kernel_trace_$m.txt $counts > $O/pipeline_kernel_table_$m.txt 2>&1; cat $O/pipeline_kernel_table_$m.txt | cut -c1-200
     rm -rf $O/kt_pipe_$m
   done ;;
 timeline)  # one frame's kernels with start offsets and queues (tools/pipeline_timeline.py), raw and raw_ahead
-  pipe_dump
+  pipe_dump; near_gpu
   for m in raw raw_ahead; do
-    timeout 300 rocprofv3 --kernel-trace -d $O/tl_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/tl_$m.err
+    $NEAR timeout 300 rocprofv3 --kernel-trace -d $O/tl_$m -o kt -- tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /dev/null 2> $O/tl_$m.err
     python tools/pipeline_timeline.py $(find $O/tl_$m -name "*.db" | head -1) 2>&1 | grep -v "^tables\|^rocpd\|copies; sample" > $O/pipeline_timeline_$m.txt; cat $O/pipeline_timeline_$m.txt | cut -c1-150
     rm -rf $O/tl_$m
   done ;;
 pipeab)   # A/B of environment switches on the drop-in frame: AB_SETS="A=1,B=2 A=0 ..." ("-" = the defaults); the sets take turns, AB_REPS rounds
-  pipe_dump
+  pipe_dump; near_gpu
   for rep in $(seq 1 ${AB_REPS:-3}); do
     for set in ${AB_SETS:-- KICP_PRE_PUSH_WGS=0}; do
       envs=$(echo $set | tr ',' ' '); [ "$set" = "-" ] && envs="KICP_AB_DEFAULTS=1"
       for m in raw raw_ahead; do
-        env $envs timeout 300 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /tmp/pipe_ab.txt
+        env $envs $NEAR timeout 300 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin > /tmp/pipe_ab.txt
         echo "$set $m: $(timeout 300 python tools/bench_pipeline.py --frames 40 --mode $m --check /tmp/pipe_ab.txt --oracle-frames 0 --ref-frames 0 2>&1 | grep 'GPU RegisterFrame\|^drive' | sed 's/the last 20 frames in //; s/wall clock.*//; s/(second half.*p10/p10/; s/first.*//' | tr '\n' ' ')"
-        [ $rep = 1 ] && env $envs KICP_TRACE=1 tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "^\[kicp" | tail -120 | head -40 > $O/pipeline_ab_calls_${set//[^A-Za-z0-9]/_}_$m.txt
+        [ $rep = 1 ] && env $envs KICP_TRACE=1 $NEAR tests/cpp/facade_test pipeline_timed_$m /tmp/pipe.bin 2>&1 >/dev/null | grep "^\[kicp" | tail -120 | head -40 > $O/pipeline_ab_calls_${set//[^A-Za-z0-9]/_}_$m.txt
       done
     done
   done 2>&1 | sort -s -k1,2 | tee $O/pipeline_ab.txt ;;
