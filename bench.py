@@ -161,10 +161,16 @@ def main():
     host_placement = "not bound"
     if os.environ.get("KICP_BENCH_PLACEMENT", "1") != "0":
         try:
+            # (OMP_PROC_BIND above binds the process's initial thread to ONE core as soon as an OpenMP runtime starts - torch's - and
+            #  every child process inherited that: undo it before looking at what this process may use)
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
             near = K.cpus_near_gpu(device, one_l3_domain=False)
             if near:
                 os.sched_setaffinity(0, near)
                 host_placement = "process bound to the %d CPUs of the GPU's NUMA node (%d)" % (len(near), K.device_locality(device)[0])
+            else:
+                host_placement = "not bound (GPU on NUMA node %d with %d CPUs, none of them among the %d this process may use)" % (
+                    K.device_locality(device)[0], len(K.device_locality(device)[1]), len(os.sched_getaffinity(0)))
         except Exception as e:  # noqa: BLE001 - placement is an extra
             host_placement = "not bound (%s)" % e
     replicas = args.mode == "replicas" and world > 1

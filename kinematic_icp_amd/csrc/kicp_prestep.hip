@@ -100,6 +100,7 @@ struct kicp_pre {
     } ahead;
     unsigned long long ahead_hits = 0;  // kicp_pre_ingest calls that found their message decoded ahead (kicp_pre_ahead_hits)
     JobThread ahead_thread;             // queues the look-ahead upload beside the calling thread's own kernels
+    hipStream_t ingest_stream2 = nullptr;  // this call's message: its pieces' decodes alternate between the handle's stream and this one
     bool ahead_job_out = false;         // ... and is only waited for where its result (or a buffer it uses) is needed: ahead_join
     HostStage stage_ahead;              // its own pinned staging buffer (the calling thread goes on using `stage` meanwhile)
     // the chained pre-steps hand the WHOLE download of buffer 0 to the helper thread (its dozen API calls cost the calling thread ~40 us):
@@ -226,6 +227,7 @@ void kicp_pre_destroy(kicp_pre *p) {
     p->ahead_thread.stop();
     p->stage_ahead.release();
     if (p->ahead_stream) hipStreamSynchronize(p->ahead_stream), hipStreamDestroy(p->ahead_stream);
+    if (p->ingest_stream2) hipStreamSynchronize(p->ingest_stream2), hipStreamDestroy(p->ingest_stream2);
     if (p->h_rec) hipHostFree(p->h_rec);
     if (p->h_src) hipHostFree(p->h_src);
     hipFree(p->d_in), hipFree(p->d_ts), hipFree(p->d_in2), hipFree(p->d_ts2), hipFree(p->d_staged), hipFree(p->d_flags), hipFree(p->d_block_counts), hipFree(p->d_table);
@@ -340,6 +342,17 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     // pieces, so that the GPU decodes piece k while the CPU copies piece k + 1 (a look-ahead message too: as ONE launch behind the
     // whole 2 MB copy it was not there when the next frame asked for it)
     const size_t piece_records = std::max<size_t>(256, (slot == 1 ? ahead_piece : kIngestPiece) / L.point_step / 256 * 256);
+    // (sharing the copy into the staging buffer with a helper thread - 128 KB sub-pieces, one thread from the front, one from the
+    //  back - was measured: the call takes the same 85 us; the pieces' PCIe-latency-bound decodes are what it waits for)
+    // this call's message: consecutive pieces' decodes go to two streams in turn - on one stream each launch waits for the one before
+    // it to drain (4 x 17 us of PCIe-latency-bound kernel + 6 us between them); side by side they keep the link busy
+    static const bool two_streams = [] { const char *e = std::getenv("KICP_PRE_INGEST_STREAMS"); return !(e && *e == '1'); }();
+    hipStream_t lanes[2] = {stream, stream};
+    if (slot == 0 && two_streams) {
+        if (!p->ingest_stream2) HIP_TRY(hipStreamCreateWithFlags(&p->ingest_stream2, hipStreamNonBlocking));
+        lanes[1] = p->ingest_stream2;
+    }
+    unsigned piece_index = 0;
     for (size_t first = 0; first < n_points; first += piece_records)  // (one ticket per workgroup of every launch)
         p->ticket_drawn[slot] += std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((std::min(piece_records, n_points - first) + 255) / 256));
     ip.ticket_done = p->ticket_drawn[slot];
@@ -349,11 +362,12 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
         if (direct) {
             ip.raw = stage.dev + off;
         } else {
-            HIP_TRY(hipMemcpyAsync(p->d_raw + off, stage.p + off, len, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(p->d_raw + off, stage.p + off, len, hipMemcpyHostToDevice, lanes[piece_index & 1u]));
             ip.raw = p->d_raw + off;
         }
         ip.first = static_cast<uint32_t>(first), ip.n = static_cast<uint32_t>(count);
-        hipLaunchKernelGGL(k_ingest, dim3(std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((count + 255) / 256))), dim3(256), 0, stream, ip);
+        hipLaunchKernelGGL(k_ingest, dim3(std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((count + 255) / 256))), dim3(256), 0, lanes[piece_index & 1u], ip);
+        ++piece_index;
     }
     HIP_TRY(hipGetLastError());
     if (int rc = wait_word(rec + 2, ip.seq, ~0ull, stream)) return rc;  // (`data` and the staging buffer are free again behind this)

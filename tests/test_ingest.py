@@ -89,7 +89,7 @@ def test_gpu_ingest_equals_oracle(layout, stamp, scale, base):
     import kinematic_icp_amd as kicp
     rng = np.random.Generator(np.random.PCG64(12))
     pre = kicp.PreSteps()
-    for n in (1, 63, 257, 70_001):
+    for n in (1, 63, 257, 70_001, 200_003):  # (1 MB and more: a helper thread shares the copy into the staging buffer, in 128 KB sub-pieces)
         rec, step, off = make_cloud(rng, n, stamp, layout, scale, base)
         mm = pre.Ingest(rec.tobytes(), n, step, off["x"], off["y"], off["z"], stamp or 0, off.get("t", 0))
         exp_xyz, exp_st, exp_mm = okicp.ingest(rec.tobytes(), n, step, off["x"], off["y"], off["z"], stamp or 0, off.get("t", 0))

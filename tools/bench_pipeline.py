@@ -36,6 +36,7 @@ def placement():
         return None, "not bound (KICP_BENCH_PLACEMENT=0)"
     try:
         import kinematic_icp_amd as K
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))  # (a parent's OMP_PROC_BIND may have left this process on one core)
         cpus = K.cpus_near_gpu(0)
     except Exception as e:  # noqa: BLE001
         return None, "not bound (%s)" % e

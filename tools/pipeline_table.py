@@ -41,6 +41,7 @@ BYTES = {
     "k_up_scatter": ("points into their voxels' segments", a.n1 * (24 + 8)),
     "k_up_apply": ("per touched voxel: bucket in, accepted points out (fp64 pool + 16-bit mirror)", a.n1 * (24 + 20 * 24 // 4 + 32)),
     "k_up_remove": ("first point of every voxel against the origin", 0),
+    "k_up_publish": ("the update's counters + sequence number -> host memory (40 B), per-update counters reset", 48),
 }
 rows = {}
 for line in open(a.trace):
