@@ -356,7 +356,7 @@ __device__ __forceinline__ unsigned long long voxel_key_of(double x, double y, d
 static __global__ __launch_bounds__(256) void k_frame_pre(const FrameParams f) {
     const PreprocessParams &p = f.pre;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) f.misc[2] = 0u, f.misc[3] = 0u, f.misc[7] = 0u;  // (raised / drawn / set by the launches behind this one)
+    if (i == 0) f.misc[2] = 0u, f.misc[3] = 0u, f.misc[7] = 0u, f.misc[9] = 0u;  // (raised / drawn / set by the launches behind this one)
     bool keep = false;
     double bx = 0.0, by = 0.0, bz = 0.0;
     if (i < p.n) {
@@ -371,8 +371,98 @@ static __global__ __launch_bounds__(256) void k_frame_pre(const FrameParams f) {
     claim_voxel(f.A.keys, f.A.min_index, f.spec_mask, key, ok, vx, vy, vz, i, f.misc + 1, f.misc + 8, f.seq);
 }
 
+// One 256-bucket tile of a claimed table: every cluster whose HEAD lies in the tile is put into the reference's order (replay_cluster's
+// result, bit for bit) - with TWO round trips to memory instead of a chain of them.  The first version walked global memory: this
+// bucket's key, then the one before it, then the ones behind it one by one, then replay_cluster's O(len^2) reloads of min_index and
+// its read-modify-writes of order / home_at - 5 dependent accesses for a cluster of one, dozens for a cluster of four, each 2-4 us
+// while the frame's push and the look-ahead decode load the memory system (the second-level replay: 10 us alone, 44 us in the drive).
+// Here the tile's keys and input indices, kReplayHalo buckets behind it and the one before it are fetched at once into LDS; heads,
+// lengths and the robin-hood replay work there (a cluster's LDS positions are its head thread's alone); the order goes back with one
+// store per bucket.  home_at is not written (the gather resets it, nobody else reads it).  A cluster that leaves the window, and
+// tables smaller than the window, take the global path.  Returns whether this thread's bucket is occupied.
+constexpr uint32_t kReplayHalo = 32, kReplayWindow = 256 + kReplayHalo;
+struct ReplayTile {
+    unsigned long long key[kReplayWindow];
+    uint32_t min[kReplayWindow], ord[kReplayWindow], home[kReplayWindow];
+    uint32_t prev_occupied;
+};
+__device__ __forceinline__ bool replay_tile(const DsTable &T, uint32_t mask, uint32_t tile, ReplayTile &L, uint32_t *probe_max) {
+    const uint32_t base = tile * 256u, i = threadIdx.x, s = base + i;
+    if (mask + 1u < 2u * kReplayWindow) {  // (a small table: window positions would alias buckets)
+        bool occupied = false;
+        if (s <= mask) {
+            occupied = T.keys[s] != kEmptyVoxelKey;
+            if (occupied && T.keys[(s - 1u) & mask] == kEmptyVoxelKey) {
+                uint32_t len = 1u;
+                while (T.keys[(s + len) & mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
+                const uint32_t probe = replay_cluster(T.keys, T.min_index, T.order, T.home_at, mask, s, len);
+                if (probe >= 32u) atomicMax(probe_max, probe);
+            }
+        }
+        return occupied;
+    }
+    unsigned long long k = kEmptyVoxelKey, kh = kEmptyVoxelKey, kp = kEmptyVoxelKey;
+    uint32_t m = 0xFFFFFFFFu, mh = 0xFFFFFFFFu;
+    if (s <= mask) k = T.keys[s], m = T.min_index[s];
+    if (i < kReplayHalo) kh = T.keys[(base + 256u + i) & mask], mh = T.min_index[(base + 256u + i) & mask];
+    if (i == 255u) kp = T.keys[(base - 1u) & mask];
+    __syncthreads();  // (a caller that loops over tiles: the previous tile's clusters are done with the window)
+    L.key[i] = k, L.min[i] = m, L.ord[i] = kFreeBucket;
+    if (i < kReplayHalo) L.key[256u + i] = kh, L.min[256u + i] = mh, L.ord[256u + i] = kFreeBucket;
+    if (i == 255u) L.prev_occupied = kp != kEmptyVoxelKey ? 1u : 0u;
+    __syncthreads();
+    const bool occupied = k != kEmptyVoxelKey;
+    const bool head = occupied && !(i ? L.key[i - 1u] != kEmptyVoxelKey : L.prev_occupied != 0u);
+    if (!head) return occupied;
+    uint32_t end = i + 1u;
+    while (end < kReplayWindow && L.key[end] != kEmptyVoxelKey) ++end;
+    uint32_t len = end - i;
+    if (end == kReplayWindow) {  // the cluster leaves the window: the global walk (order / home_at of its buckets are still untouched)
+        while (T.keys[(s + len) & mask] != kEmptyVoxelKey) ++len;
+        const uint32_t probe = replay_cluster(T.keys, T.min_index, T.order, T.home_at, mask, s, len);
+        if (probe >= 32u) atomicMax(probe_max, probe);
+        return occupied;
+    }
+    if (len == 1u) {
+        T.order[s] = m;
+        return occupied;
+    }
+    // replay_cluster (kicp_table_order.hpp) on window positions: bucket (s + j) & mask <-> position i + j
+    uint32_t max_probe = 0u, last = 0u;
+    for (uint32_t t = 0; t < len; ++t) {
+        uint32_t best = kFreeBucket, best_at = i;
+        for (uint32_t j = i; j < end; ++j) {  // the cluster's key with the lowest input index not inserted yet
+            const uint32_t v = L.min[j];
+            if (v >= last && v < best) best = v, best_at = j;
+        }
+        last = best + 1u;
+        uint32_t carry = best, carry_home = i + ((reference_hash_of_packed(L.key[best_at]) - s) & mask);  // (its ideal bucket lies in the cluster)
+        for (uint32_t pos = carry_home;; ++pos) {
+            const uint32_t resident = L.ord[pos], dist = pos - carry_home;
+            max_probe = dist > max_probe ? dist : max_probe;
+            if (resident == kFreeBucket) {
+                L.ord[pos] = carry, L.home[pos] = carry_home;
+                break;
+            }
+            const uint32_t resident_home = L.home[pos];
+            if (pos - carry_home > pos - resident_home) {
+                L.ord[pos] = carry, L.home[pos] = carry_home;
+                carry = resident, carry_home = resident_home;
+            }
+        }
+    }
+    for (uint32_t j = i; j < end; ++j) T.order[(base + j) & mask] = L.ord[j];
+    if (max_probe >= 32u) atomicMax(probe_max, max_probe);
+    return occupied;
+}
+
 static __global__ __launch_bounds__(256) void k_frame_l1_replay(const FrameParams f) {
     const PreprocessParams &p = f.pre;
+    // (this thread's point and its crop flag: fetched before the tile counts, not behind them - one round trip less)
+    const uint32_t point = blockIdx.x * 256 + threadIdx.x;
+    uint32_t flag = 0u;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    if (blockIdx.x < f.tiles_pts && point < p.n) flag = p.flags[point], sx = p.staged[3 * point], sy = p.staged[3 * point + 1], sz = p.staged[3 * point + 2];
     uint32_t offset, n0;
     tile_offset_total(p.block_counts, blockIdx.x, f.tiles_pts, offset, n0);
     const bool spec_ok = n0 == 0u || (expected_mask(n0) == f.spec_mask && f.misc[8] != f.seq);
@@ -381,37 +471,32 @@ static __global__ __launch_bounds__(256) void k_frame_l1_replay(const FrameParam
         if (!spec_ok) f.misc[7] = 1u;
     }
     if (blockIdx.x < f.tiles_pts) {  // order-preserving compaction of this tile's survivors: buffer 0, the frame the pipeline returns
-        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-        const bool keep = i < p.n && p.flags[i] != 0u;
+        const bool keep = flag != 0u;
         const uint32_t pos = tile_position(keep, offset);
-        if (keep) f.buf0[3 * pos] = p.staged[3 * i], f.buf0[3 * pos + 1] = p.staged[3 * i + 1], f.buf0[3 * pos + 2] = p.staged[3 * i + 2];
+        if (keep) f.buf0[3 * pos] = sx, f.buf0[3 * pos + 1] = sy, f.buf0[3 * pos + 2] = sz;
     }
     if (!spec_ok || blockIdx.x >= f.tiles_spec) return;
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x, mask = f.spec_mask;
-    bool occupied = false;
-    if (n0 != 0u && s <= mask) {
-        occupied = f.A.keys[s] != kEmptyVoxelKey;
-        if (occupied && f.A.keys[(s - 1u) & mask] == kEmptyVoxelKey) {
-            uint32_t len = 1u;
-            while (f.A.keys[(s + len) & mask] != kEmptyVoxelKey) ++len;  // ends: at least half of the buckets are free
-            const uint32_t probe = replay_cluster(f.A.keys, f.A.min_index, f.A.order, f.A.home_at, mask, s, len);
-            if (probe >= 32u) atomicMax(f.misc + 2, probe);
-        }
-    }
+    __shared__ ReplayTile s_tile;
+    const bool occupied = n0 != 0u && replay_tile(f.A, f.spec_mask, blockIdx.x, s_tile, f.misc + 2);  // (n0: the same for every thread)
     block_count_store(occupied, f.counts1);
 }
 
 static __global__ __launch_bounds__(256) void k_frame_l1_gather(const FrameParams f) {
+    // (the bucket's key and its place in the reference's order are fetched BEFORE the tile counts, not behind them: one round trip to
+    //  memory less in a chain of five, each 2-8 us while the push and the look-ahead decode run)
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long bucket_key = kEmptyVoxelKey;
+    uint32_t bucket_order = kFreeBucket;
+    if (s <= f.spec_mask) bucket_key = f.A.keys[s], bucket_order = f.A.order[s];
     if (f.misc[7]) return;
     uint32_t offset, n1;
     tile_offset_total(f.counts1, blockIdx.x, f.tiles_spec, offset, n1);
     if (blockIdx.x == 0 && threadIdx.x == 0) f.misc[5] = n1;
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    const bool occupied = f.misc[4] != 0u && s <= f.spec_mask && f.A.keys[s] != kEmptyVoxelKey;
+    const bool occupied = f.misc[4] != 0u && bucket_key != kEmptyVoxelKey;
     const uint32_t pos = tile_position(occupied, offset);
     double x = 0.0, y = 0.0, z = 0.0;
     if (occupied) {
-        const uint32_t i = f.A.order[s];
+        const uint32_t i = bucket_order;
         x = f.pre.staged[3 * i], y = f.pre.staged[3 * i + 1], z = f.pre.staged[3 * i + 2];
         f.buf1[3 * pos] = x, f.buf1[3 * pos + 1] = y, f.buf1[3 * pos + 2] = z;
         // leave the bucket as the next frame must find it (free slots were never written)
@@ -427,18 +512,9 @@ static __global__ __launch_bounds__(256) void k_frame_l1_gather(const FrameParam
 static __global__ __launch_bounds__(256) void k_frame_l2_replay(const FrameParams f) {
     if (f.misc[7]) return;
     const uint32_t n1 = f.misc[5], mask = expected_mask(n1), tiles = n1 ? (mask >> 8) + 1u : 0u;
+    __shared__ ReplayTile s_tile;
     for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const uint32_t s = t * 256 + threadIdx.x;
-        bool occupied = false;
-        if (s <= mask) {
-            occupied = f.B.keys[s] != kEmptyVoxelKey;
-            if (occupied && f.B.keys[(s - 1u) & mask] == kEmptyVoxelKey) {
-                uint32_t len = 1u;
-                while (f.B.keys[(s + len) & mask] != kEmptyVoxelKey) ++len;
-                const uint32_t probe = replay_cluster(f.B.keys, f.B.min_index, f.B.order, f.B.home_at, mask, s, len);
-                if (probe >= 32u) atomicMax(f.misc + 2, probe);
-            }
-        }
+        const bool occupied = replay_tile(f.B, mask, t, s_tile, f.misc + 2);
         block_count_store_at(occupied, f.counts2 + t);
     }
 }
@@ -447,45 +523,69 @@ static __global__ __launch_bounds__(256) void k_frame_l2_gather(const FrameParam
     __shared__ uint32_t s_last;
     const unsigned long long tag = static_cast<unsigned long long>(f.seq) << 32;
     auto publish = [&](int word, uint32_t v) { __hip_atomic_store(f.host_rec + word, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    // (the first tile's bucket and its place in the order: fetched before anything that depends on the counts - k_frame_l1_gather;
+    //  table B is never larger than table A, whose size the launch knows)
+    unsigned long long first_key = kEmptyVoxelKey;
+    uint32_t first_order = kFreeBucket;
+    if (blockIdx.x * 256u + threadIdx.x <= f.spec_mask) first_key = f.B.keys[blockIdx.x * 256u + threadIdx.x], first_order = f.B.order[blockIdx.x * 256u + threadIdx.x];
     if (f.misc[7]) {  // the table-size guess was wrong: nothing behind buffer 0 was done; the host takes the unfused steps from there
         if (blockIdx.x == 0 && threadIdx.x == 0) publish(0, f.misc[4]), publish(1, 0u), publish(2, 0u), publish(3, 0u), publish(4, 2u | (f.misc[1] ? 1u : 0u));
         return;
     }
     const uint32_t n1 = f.misc[5], mask = expected_mask(n1), tiles = n1 ? (mask >> 8) + 1u : 0u;
+    uint32_t n2_seen = 0xFFFFFFFFu;
     for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         uint32_t offset, n2;
-        tile_offset_total(f.counts2, t, tiles, offset, n2);
         const uint32_t s = t * 256 + threadIdx.x;
-        const bool occupied = s <= mask && f.B.keys[s] != kEmptyVoxelKey;
+        const bool mine = t == blockIdx.x;  // (this workgroup's first tile: fetched at the top of the kernel)
+        const unsigned long long bucket_key = mine ? first_key : (s <= mask ? f.B.keys[s] : kEmptyVoxelKey);
+        const uint32_t bucket_order = mine ? first_order : (s <= mask ? f.B.order[s] : kFreeBucket);
+        tile_offset_total(f.counts2, t, tiles, offset, n2);
+        n2_seen = n2;
+        const bool occupied = s <= mask && bucket_key != kEmptyVoxelKey;
         const uint32_t pos = tile_position(occupied, offset);
         if (occupied) {
-            const uint32_t i = f.B.order[s];
+            const uint32_t i = bucket_order;
             const double x = f.buf1[3 * i], y = f.buf1[3 * i + 1], z = f.buf1[3 * i + 2];
             store_through(f.buf2 + 3 * pos, x), store_through(f.buf2 + 3 * pos + 1, y), store_through(f.buf2 + 3 * pos + 2, z);
-            if (f.host_buf2) f.host_buf2[3 * pos] = x, f.host_buf2[3 * pos + 1] = y, f.host_buf2[3 * pos + 2] = z;  // (host memory: uncached on the device)
             f.B.keys[s] = kEmptyVoxelKey, f.B.min_index[s] = 0xFFFFFFFFu, f.B.order[s] = kFreeBucket, f.B.home_at[s] = 0xFFFFFFFFu;
         }
     }
     // The workgroup that finishes LAST tells the host (which polls the record instead of synchronising the stream).  Buffer 2 goes
-    // to a kernel on another queue next: its stores went through to memory (store_through) and every wave waits for them; the
-    // copy in host memory needs a release at system scope by every workgroup that wrote some of it (a record written by ANOTHER
-    // workgroup may overtake this one's bytes otherwise), then the workgroup draws its ticket.
+    // to a kernel on another queue next: its stores went through to memory (store_through) and every wave waits for them, then the
+    // workgroup draws its ticket.  (The copy of buffer 2 in host memory is k_frame_src_host's: written here, its PCIe writes queued
+    // up behind the frame push's and a system-scope release held the record back by ~10 us.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (f.host_buf2 && blockIdx.x < tiles) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         s_last = __hip_atomic_fetch_add(f.misc + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
-    uint32_t offset, n2;
-    tile_offset_total(f.counts2, 0u, tiles, offset, n2);
+    uint32_t offset, n2 = n2_seen;
+    if (n2_seen == 0xFFFFFFFFu) tile_offset_total(f.counts2, 0u, tiles, offset, n2);  // (a workgroup without a tile of its own; n2_seen: the same for every thread)
     if (threadIdx.x == 0) {
         f.misc[6] = n2;
         publish(0, f.misc[4]), publish(1, n1), publish(2, n2), publish(3, f.misc[2]), publish(4, f.misc[1] ? 1u : 0u);
+    }
+}
+
+// Buffer 2 - the registration source, ~1 300 points, the second cloud RegisterFrame returns - into host memory: a launch of its own
+// behind the chain, announced by word 5 of the host record ((seq << 32) | points), which only kicp_pre_download(2) waits for.
+// misc[9]: its ticket (reset by k_frame_pre).
+static __global__ __launch_bounds__(256) void k_frame_src_host(const FrameParams f) {
+    __shared__ uint32_t s_last;
+    if (f.misc[7]) return;  // (the guess was wrong: the host takes the unfused steps and downloads buffer 2 itself)
+    const uint32_t n2 = f.misc[6];
+    for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < 3u * n2; o += gridDim.x * 256u) f.host_buf2[o] = f.buf2[o];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // system scope: this workgroup's bytes are in host memory before its ticket - and so before the flag, whoever writes it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(f.misc + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+        if (s_last) __hip_atomic_store(f.host_rec + 5, (static_cast<unsigned long long>(f.seq) << 32) | n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -509,6 +609,7 @@ struct PushParams {
     unsigned long long ticket_done; // their value once this launch's last workgroup has drawn
     unsigned long long *host_flags; // [kPushPieces] pinned
     uint32_t seq;
+    uint32_t experiment;            // (timing experiments only: 1 = no system-scope release before the ticket)
 };
 static __global__ __launch_bounds__(256) void k_push_frame(const PushParams q) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -527,8 +628,10 @@ static __global__ __launch_bounds__(256) void k_push_frame(const PushParams q) {
         if (threadIdx.x == 0) {
             // system scope: this workgroup's bytes are in host memory before its ticket - and so before the flag, whoever writes it
             // (without the fence the flag of another workgroup overtook the bytes: measured)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (q.experiment != 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             s_last = __hip_atomic_fetch_add(q.tickets + piece, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == q.ticket_done ? 1u : 0u;
             if (s_last) __hip_atomic_store(q.host_flags + piece, (static_cast<unsigned long long>(q.seq) << 32) | static_cast<unsigned long long>(len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

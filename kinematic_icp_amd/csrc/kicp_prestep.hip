@@ -37,7 +37,8 @@ struct kicp_pre {
     // returns it too (KinematicICP.cpp:84), and a copy + stream synchronisation for it cost the frame ~40 us
     unsigned char *h_src = nullptr, *h_src_dev = nullptr;
     size_t h_src_cap = 0;
-    bool src_on_host = false;  // h_src holds buffer 2's current contents
+    bool src_on_host = false;  // h_src holds buffer 2's current contents - once word 5 of h_rec carries src_seq (k_frame_src_host)
+    uint32_t src_seq = 0;
     unsigned char *copy_host_dev = nullptr;  // the landing area as the device sees it (nullptr: not mapped - the DMA engine moves the frame)
     unsigned long long *d_ticket = nullptr;  // [2] the ingest kernels' tickets (never reset), one per record
     unsigned long long ticket_drawn[2] = {0ull, 0ull};
@@ -313,6 +314,7 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     const uint32_t stamp_bytes = st == KICP_FIELD_FLOAT64 ? 8u : 4u;
     const size_t bytes = n_points * static_cast<size_t>(L.point_step);
     if (int rc = stage_begin(stage, bytes, stream)) return rc;
+    if (slot == 0) trace_lap("staging buffer free");
     const bool direct = stage.dev != nullptr;  // the device reads the staging buffer itself
     if (!direct && bytes > p->raw_cap) {
         HIP_TRY(hipDeviceSynchronize());  // (rare: the buffer grows; nothing may still be reading the old one)
@@ -342,10 +344,12 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
     // pieces, so that the GPU decodes piece k while the CPU copies piece k + 1 (a look-ahead message too: as ONE launch behind the
     // whole 2 MB copy it was not there when the next frame asked for it)
     const size_t piece_records = std::max<size_t>(256, (slot == 1 ? ahead_piece : kIngestPiece) / L.point_step / 256 * 256);
-    // (sharing the copy into the staging buffer with a helper thread - 128 KB sub-pieces, one thread from the front, one from the
-    //  back - was measured: the call takes the same 85 us; the pieces' PCIe-latency-bound decodes are what it waits for)
+    // What the call waits for is the link: a kernel's loads pull ~30 GB/s out of host memory (2 MB: ~65 us from the first launch to the
+    // record), whoever copies and however the launches are arranged.  Measured and not kept: a helper thread sharing the copy into the
+    // staging buffer (all four launches queued by 47 us instead of 66 - the record arrives at 87 us either way), the copy engine moving
+    // the pieces into HBM first (106 us).
     // this call's message: consecutive pieces' decodes go to two streams in turn - on one stream each launch waits for the one before
-    // it to drain (4 x 17 us of PCIe-latency-bound kernel + 6 us between them); side by side they keep the link busy
+    // it to drain; side by side they keep the link busy (2 % of the frame)
     static const bool two_streams = [] { const char *e = std::getenv("KICP_PRE_INGEST_STREAMS"); return !(e && *e == '1'); }();
     hipStream_t lanes[2] = {stream, stream};
     if (slot == 0 && two_streams) {
@@ -368,9 +372,11 @@ int ingest_run(kicp_pre *p, const void *data, size_t n_points, const kicp_cloud_
         ip.first = static_cast<uint32_t>(first), ip.n = static_cast<uint32_t>(count);
         hipLaunchKernelGGL(k_ingest, dim3(std::min<uint32_t>(wgs_cap, static_cast<uint32_t>((count + 255) / 256))), dim3(256), 0, lanes[piece_index & 1u], ip);
         ++piece_index;
+        if (slot == 0) trace_lap("piece copied, its decode launched");
     }
     HIP_TRY(hipGetLastError());
     if (int rc = wait_word(rec + 2, ip.seq, ~0ull, stream)) return rc;  // (`data` and the staging buffer are free again behind this)
+    if (slot == 0) trace_lap("the decoded cloud's record at the host");
     *out_lo = *out_hi = 0.0;
     if (st != 0) *out_lo = ordered_value(rec[0]), *out_hi = ordered_value(rec[1]);
     return KICP_OK;
@@ -608,6 +614,8 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
             p->push_drawn += push_grid;
             q.tickets = p->d_push_tickets, q.ticket_done = p->push_drawn, q.host_flags = p->h_rec + 16, q.seq = ++p->push_seq;
             if (q.seq == 0u) q.seq = ++p->push_seq;
+            static const uint32_t push_experiment = [] { const char *e = std::getenv("KICP_DBG_PUSH_EXPERIMENT"); return e && *e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
+            q.experiment = push_experiment;
             HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->chain_ready, 0));
             hipLaunchKernelGGL(k_push_frame, dim3(push_grid), dim3(256), 0, p->copy_stream, q);
             HIP_TRY(hipGetLastError());
@@ -674,6 +682,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         hipLaunchKernelGGL(k_frame_l1_gather, dim3(f.tiles_spec), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_replay, dim3(grid_b), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_gather, dim3(grid_b), dim3(256), 0, p->stream, f);
+        if (f.host_buf2) hipLaunchKernelGGL(k_frame_src_host, dim3(4), dim3(256), 0, p->stream, f);  // (nobody waits for it before kicp_pre_download(2))
         // (starting the frame's way back one, two or three launches later instead - the push's 3 MB of PCIe writes make the launches
         //  beside it 2-3 x as long, and the event costs the device 6 us between two launches - was measured: 1-4 % slower each)
         HIP_TRY(hipGetLastError());
@@ -691,6 +700,7 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         unfused_tail = (static_cast<uint32_t>(rec[4]) & 2u) != 0u;
         p->spec_n0 = misc[4], p->spec_n_in = static_cast<uint32_t>(n_in);
         p->src_on_host = !unfused_tail && f.host_buf2 != nullptr;
+        p->src_seq = f.seq;
         p->spec_tiles_b = misc[5] ? static_cast<uint32_t>(reference_bucket_count(misc[5]) + 255) / 256u : 1u;
         if (unfused_tail) {  // a guess was wrong: the tables hold claims made under the wrong size; buffer 0 and its count are in place
             ++p->spec_misses;
@@ -819,8 +829,10 @@ int kicp_pre_download(const kicp_pre *p, int buffer, double *out_xyz, size_t cap
     if (int rc = set_device(p->device)) return rc;
     const size_t n = p->buf_n[buffer], k = std::min(n, cap_points);
     if (k && out_xyz) {
-        if (buffer == 2 && p->src_on_host) std::memcpy(out_xyz, p->h_src, k * 24);  // (the fused chain left a copy in host memory)
-        else if (int rc = staged_download(p->stage, out_xyz, p->buf[buffer], k * 24, p->stream)) return rc;
+        if (buffer == 2 && p->src_on_host) {  // (the fused chain leaves a copy in host memory)
+            if (int rc = wait_word(p->h_rec + 5, static_cast<unsigned long long>(p->src_seq) << 32, 0xFFFFFFFF00000000ull, p->stream)) return rc;
+            std::memcpy(out_xyz, p->h_src, k * 24);
+        } else if (int rc = staged_download(p->stage, out_xyz, p->buf[buffer], k * 24, p->stream)) return rc;
     }
     if (out_n) *out_n = n;
     return KICP_OK;
