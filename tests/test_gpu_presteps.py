@@ -240,3 +240,46 @@ def test_the_fused_chain_equals_the_unfused_one_whatever_it_guesses(guess):
         np.testing.assert_array_equal(fused.download(2), ref)
     assert plain.get_option("fused_frames") == 0 and fused.get_option("fused_frames") == 3
     assert fused.get_option("guess_misses") >= (1 if guess == 100 else 0)
+
+
+def test_long_clusters_of_the_downsample_table():
+    """The chained pre-steps replay a table's clusters through an LDS window of 256 + 32 buckets per tile (kicp_pre.hpp replay_tile):
+    voxels whose reference hashes fall into a few consecutive buckets make clusters that (a) sit inside one window with long robin-hood
+    displacements, (b) start near a tile's end and leave the window (the global walk takes over), (c) wrap around the table's end.
+    6 000 points -> 16 384 buckets at the first level; everything equals the unfused chain and the oracle bit for bit."""
+    rng = np.random.default_rng(99)
+    n_total, mask = 6000, 16383
+
+    def voxels_hashing_into(lo, count, want):
+        """`want` distinct voxel x coordinates (y = z = 0) whose hash & mask lies in [lo, lo + count) cyclically"""
+        x = np.arange(-(1 << 19), 1 << 19, dtype=np.int64)
+        h = ((x * 73856093) & 0xFFFFFFFF) & mask
+        hit = x[((h - lo) & mask) < count]
+        assert len(hit) >= want
+        return rng.choice(hit, want, replace=False)
+
+    crafted = np.concatenate([voxels_hashing_into(5 * 256 + 100, 8, 24),     # (a) 24 keys for 8 home buckets, mid-tile
+                              voxels_hashing_into(9 * 256 + 236, 12, 70),    # (b) 70 keys from bucket 236 of a tile on: leaves the window
+                              voxels_hashing_into(mask - 6, 10, 30)])        # (c) across the table's end
+    pts = np.zeros((n_total, 3))
+    pts[:len(crafted), 0] = (crafted + 0.5) * 0.5
+    pts[:len(crafted), 1:] = 0.25
+    filler = rng.uniform(-400, 400, (n_total - len(crafted), 3))
+    filler[:, 2] = rng.uniform(5, 40, len(filler))  # (away from the crafted row)
+    pts[len(crafted):] = filler
+    pts = pts[rng.permutation(n_total)].astype(np.float32).astype(np.float64)
+    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    fused, plain = K.PreSteps(), K.PreSteps()
+    plain.set_option("fused", 0)
+    for _ in range(2):  # (the second frame finds the tables as the first one left them)
+        c1, f1 = fused.Frame(pts, np.zeros(n_total), ident, ident, 1e9, 0.0, 0, 0.5, 1.5)
+        c0, f0 = plain.Frame(pts, np.zeros(n_total), ident, ident, 1e9, 0.0, 0, 0.5, 1.5)
+        assert c1 == c0 and c1[0] == n_total and c1[1] > 5900  # (distinct voxels: the table has 16 384 buckets)
+        np.testing.assert_array_equal(f1, f0)
+        for b in (0, 1, 2):
+            np.testing.assert_array_equal(fused.download(b), plain.download(b))
+        first = okicp.voxel_downsample(f0, 0.5)
+        np.testing.assert_array_equal(fused.download(1), first)
+        np.testing.assert_array_equal(fused.download(2), okicp.voxel_downsample(first, 1.5))
+    assert fused.get_option("fused_frames") == 2 and fused.get_option("guess_misses") == 0
+    assert fused.last_max_probe() >= 32  # (the long clusters were there: 70 keys for 12 home buckets)
