@@ -164,10 +164,11 @@ def main():
             # (OMP_PROC_BIND above binds the process's initial thread to ONE core as soon as an OpenMP runtime starts - torch's - and
             #  every child process inherited that: undo it before looking at what this process may use)
             os.sched_setaffinity(0, range(os.cpu_count() or 1))
-            near = K.cpus_near_gpu(device, one_l3_domain=False)
+            l3_only = os.environ.get("KICP_BENCH_PLACEMENT", "1") == "l3"
+            near = K.cpus_near_gpu(device, one_l3_domain=l3_only)
             if near:
                 os.sched_setaffinity(0, near)
-                host_placement = "process bound to the %d CPUs of the GPU's NUMA node (%d)" % (len(near), K.device_locality(device)[0])
+                host_placement = "process bound to the %d CPUs of %sthe GPU's NUMA node (%d)" % (len(near), "one L3 domain of " if l3_only else "", K.device_locality(device)[0])
             else:
                 host_placement = "not bound (GPU on NUMA node %d with %d CPUs, none of them among the %d this process may use)" % (
                     K.device_locality(device)[0], len(K.device_locality(device)[1]), len(os.sched_getaffinity(0)))
