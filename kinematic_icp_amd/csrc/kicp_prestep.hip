@@ -1,5 +1,7 @@
 // kicp_prestep.hip -- the pipeline's pre-steps behind include/kicp.h (kicp_pre_*): wire-format ingest, deskew + crop +
 // transform, voxel downsample (kernels: kicp_pre.hpp).
+#include <hip/hip_ext.h>  // hipExtLaunchKernelGGL: a launch with its own stop event
+
 #include "kicp_internal.hpp"
 #include "kicp_pre.hpp"
 
@@ -677,8 +679,16 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
         // many as the previous frame's second table had tiles (twice that, for a frame that keeps more), sgrid at most
         const uint32_t grid_b = p->spec_tiles_b ? std::min(sgrid, std::max(32u, 2u * p->spec_tiles_b)) : std::min(sgrid, 1024u);
         hipLaunchKernelGGL(k_frame_pre, dim3(grid), dim3(256), 0, p->stream, f);
-        hipLaunchKernelGGL(k_frame_l1_replay, dim3(std::max(grid, f.tiles_spec)), dim3(256), 0, p->stream, f);
-        if (int rc = mark_frame_ready()) return rc;  // (buffer 0 is complete: its way back starts beside the downsamples' remaining launches)
+        // buffer 0 is complete behind this launch: its way back starts beside the downsamples' remaining launches.  The event rides on the
+        // launch's own completion signal (hipExtLaunchKernelGGL's stop event) where that is on - an event recorded behind the launch
+        // is a packet of its own, and cost the device ~7 us between this launch and the next
+        static const bool event_on_launch = [] { const char *e = std::getenv("KICP_PRE_EVENT_ON_LAUNCH"); return !(e && *e == '0'); }();
+        if (event_on_launch && out_frame_xyz) {
+            hipExtLaunchKernelGGL(k_frame_l1_replay, dim3(std::max(grid, f.tiles_spec)), dim3(256), 0, p->stream, nullptr, p->chain_ready, 0, f);
+        } else {
+            hipLaunchKernelGGL(k_frame_l1_replay, dim3(std::max(grid, f.tiles_spec)), dim3(256), 0, p->stream, f);
+            if (int rc = mark_frame_ready()) return rc;
+        }
         hipLaunchKernelGGL(k_frame_l1_gather, dim3(f.tiles_spec), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_replay, dim3(grid_b), dim3(256), 0, p->stream, f);
         hipLaunchKernelGGL(k_frame_l2_gather, dim3(grid_b), dim3(256), 0, p->stream, f);

@@ -87,3 +87,24 @@ def test_another_process_keeps_its_rate_beside_resident_registrations(kind):
     print("%s kernel loop: %.0f / s alone, %.0f / s beside %.0f registrations / s (%.0f %%)" % (kind, alone, beside, mine, 100.0 * beside / alone))
     assert mine > 1000.0
     assert beside >= 0.5 * alone, (alone, beside)
+
+
+def test_device_locality_names_cpus_this_process_could_use():
+    """kicp_device_locality: the GPU's NUMA node and CPU list from sysfs (what the library places its pinned buffers and helper threads
+    by, and what a deployment binds its caller with): consistent with each other and with the process's own affinity mask"""
+    import os
+    import kinematic_icp_amd as K
+    node, cpus = K.device_locality(0)
+    assert node >= -1 and all(0 <= c < 4096 for c in cpus)
+    if node >= 0 and os.path.isdir("/sys/devices/system/node/node%d" % node):
+        assert cpus  # (a GPU with a node has that node's CPUs)
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            listed = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                listed.update(range(int(lo), int(hi or lo) + 1))
+        assert cpus <= listed
+    near, near_l3 = K.cpus_near_gpu(0, one_l3_domain=False), K.cpus_near_gpu(0)
+    assert near <= os.sched_getaffinity(0) and near_l3 <= (near or near_l3)
+    with pytest.raises(K.KicpError):
+        K.device_locality(4096)
