@@ -1,3 +1,6 @@
+# Where the caller of the drop-in runs on a two-socket host: the look-ahead drive (tests/cpp/facade_test) six times each - unbound, bound to
+# eight CPUs of node 0, to every other CPU, to 32 CPUs - with the host's topology printed first.  The figures of INTEGRATION.md section 5
+# ("where the host side runs") come from this script:  gpurun -- 'bash tools/micro/modes.sh'
 cd $GRAFT_REPO_ROOT
 lscpu | grep -i "model name\|socket\|core(s)\|thread(s)\|numa\|^CPU(s)" 
 nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; taskset -p $$
