@@ -11,6 +11,7 @@
 #   benchall   bench.py for cfg1, cfg4, cfg5 as well
 #   trace      rocprofv3 --kernel-trace --stats of the bench command
 #   counters   PMC passes of the pass kernel (cfg2, cfg5)
+#   counters4  the same for cfg4's wave-per-query kernel (FETCH_SIZE / WRITE_SIZE / TCC), one launch per pass
 #   ranks2     two ranks on one GPU (shm and rccl exchanges)
 #   smoke      __graft_entry__.smoke()
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -93,6 +94,18 @@ counters)
     KICP_GIT_SHA=$(cat .git_sha 2>/dev/null) python tools/prof_counters_json.py $O/counters_$w.json $kern ${avg:-0} $(find $O/pmc_${w}_* -name "*.db") > $O/counters_$w.txt 2>&1; cut -c1-300 $O/counters_$w.txt
     rm -rf $O/kt_$w $O/pmc_${w}_*
   done ;;
+counters4)  # cfg4 (1 080-point scans, the wave-per-query kernel): HBM traffic per pass, one launch per pass so that dispatches = passes
+  kern=k_pass_wave
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_cfg4 -o kt -- python tools/prof_target.py --workload cfg4 --calls 600 --option small_resident=0 > $O/kt_cfg4.json 2> $O/kt_cfg4.err
+  python tools/prof_summary.py $(find $O/kt_cfg4 -name "*.db" | head -1) > $O/kernel_trace_cfg4.txt 2>&1; grep k_pass $O/kernel_trace_cfg4.txt | cut -c1-160
+  i=0
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+    i=$((i+1))
+    timeout 150 rocprofv3 --pmc $c -d $O/pmc_cfg4_$i -o pmc -- python tools/prof_target.py --workload cfg4 --calls 300 --option small_resident=0 > /dev/null 2> $O/pmc_cfg4_$i.err || echo "pmc pass $i ($c) failed for cfg4"
+  done
+  avg=$(grep $kern $O/kernel_trace_cfg4.txt | head -1 | awk '{print $(NF-3)}')
+  KICP_GIT_SHA=$(cat .git_sha 2>/dev/null) python tools/prof_counters_json.py $O/counters_cfg4.json $kern ${avg:-0} $(find $O/pmc_cfg4_* -name "*.db") > $O/counters_cfg4.txt 2>&1; cut -c1-300 $O/counters_cfg4.txt
+  rm -rf $O/kt_cfg4 $O/pmc_cfg4_* ;;
 ranks2)
   for comm in shm rccl; do
     KICP_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 bench.py --gpus 2 --comm $comm --pg-backend gloo --no-cpu-baseline --no-pmc --scans 16 > $O/bench_2ranks_1gpu_$comm.json 2> $O/bench_2ranks_1gpu_$comm.err
