@@ -355,6 +355,28 @@ def main():
         comm_note = "rccl set-up failed (%s): fell back to the host shared segment" % e
         comm = args.comm = "shm"
         reg, keep = make_reg(comm)
+    # RCCL with >= 2 ranks could never be tried on hardware in any round (no multi-GPU box): its first use here - a few single
+    # registrations, then one small batch, which brings up the lanes' sub-communicators - is a probe.  Should it fail on ANY rank
+    # (every wait inside is bounded by KICP_WAIT_TIMEOUT_S), all ranks move to the host shared segment together and say so; the
+    # failed handle is kept out of reach of its destructor (a communicator with collectives outstanding may never come back from it).
+    leaked = []
+    if comm == "rccl" and world > 1:
+        probe_err = None
+        try:
+            for i in range(4):
+                run_scan(reg, i, rel_single)
+            idx = [i % len(wl.scans) for i in range(8)]
+            reg.ComputeRobotMotionBatch(reg.prepare_batch([wl.frames[i] for i in idx], [wl.scans[i]["last_pose"] for i in idx], [rel_single[i] for i in idx]), wl.gmap, wl.tau)
+        except K.KicpError as e:
+            probe_err = e
+        try:
+            all_ranks_ok(probe_err)
+        except K.KicpError as e:
+            leaked.append((reg, keep))
+            state["rccl_failed"] = True
+            comm_note = "rccl failed on first use (%s): every rank fell back to the host shared segment" % str(e)[:200]
+            comm = args.comm = "shm"
+            reg, keep = make_reg(comm)
     rccl_ranks = int(reg.get_option("comm_ranks")) if comm == "rccl" else None
     # ---- one-time settling (setup, not measurement): the HIP runtime finishes its lazy initialisation (signal pools,
     #      code objects, clocks) during the first few hundred launches of a process; a ~30 ms hiccup there would
@@ -545,6 +567,9 @@ def main():
         for alt in ("rccl", "shm", "p2p"):
             if alt == "rccl" and (torch.cuda.device_count() < world or "KICP_BENCH_DEVICE" in os.environ):
                 exch[alt] = {"note": "skipped: RCCL needs one GPU per rank"}
+                continue
+            if alt == "rccl" and state.get("rccl_failed"):
+                exch[alt] = {"note": "skipped: RCCL failed on its first use in this run (config.comm_note)"}
                 continue
             try:
                 reg2, keep2 = make_reg(alt)
@@ -881,6 +906,8 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    if leaked:  # (see the probe above: no destructor for the failed RCCL handle)
+        os._exit(0)
 
 
 def _scaling_bound(world):
