@@ -249,6 +249,7 @@ def _p2p_timeout_worker(rank, world, barrier, handles, q):
     """rank 0 registers, rank 1 connects its mailbox but never shows up: rank 0's kernel must give up after its bounded
     wait and the call must come back with KICP_ERR_COMM (then work again, single GPU)."""
     sys.path.insert(0, ROOT)
+    os.environ["KICP_WAIT_TIMEOUT_S"] = "3"  # (the bound every wait inside the library shares; default 20 s - read once per process)
     try:
         import kinematic_icp_amd as K
         g = np.load(GOLD)
