@@ -16,7 +16,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from tools.sim_rounds import SHIFTS  # noqa: E402
+# the 27 neighbour shifts in the reference's visiting order (Registration.cpp:40-57 / kicp_common.hpp)
+SHIFTS = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [1, -1, 0], [-1, 1, 0], [-1, -1, 0],
+                   [1, 0, 1], [1, 0, -1], [-1, 0, 1], [-1, 0, -1], [0, 1, 1], [0, 1, -1], [0, -1, 1], [0, -1, -1], [1, 1, 1], [1, 1, -1],
+                   [1, -1, 1], [1, -1, -1], [-1, 1, 1], [-1, 1, -1], [-1, -1, 1], [-1, -1, -1]])
 
 
 def lines(byte_lo, byte_hi):
@@ -114,7 +117,32 @@ def main():
                           ("16-bit mirror buckets read (%d B each, not line aligned)" % stride16, mirror_lines, "%d buckets; SURVEY counts 12 B for each of %d touched points" % (b_read.size, touched_points)),
                           ("fp64 points of the winners (exact phase)", pool_lines, "not in SURVEY's count: it prices a point once, at 12 B")):
         print("  %-62s %9d lines = %6.1f MB   (%s)" % (name, k, k * 128 / 1e6, what))
-    print("  sum %.1f MB = %.2f x b_min (%.1f MB); measured traffic is this x the re-fetches across the eight XCDs' L2s" % (total / 1e6, total / b_min, b_min / 1e6))
+    print("  sum %.1f MB = %.2f x b_min (%.1f MB)" % (total / 1e6, total / b_min, b_min / 1e6))
+    # The device has EIGHT L2s (one per XCD) and workgroup w (queries 256 w .. 256 w + 255) runs on XCD w mod 8: a line that queries of
+    # several XCDs need is fetched from memory once per XCD.  The same count per (line, XCD):
+    xcd = (np.arange(n) // 256) % 8
+    per_xcd = src_lines
+    for x in range(8):
+        mine = xcd == x
+        per_xcd += np.unique(pack(qv[has_entry & mine])).size
+        bx = np.unique(vox[visited & mine[:, None]])
+        if bx.size:
+            per_xcd += lines(bx * stride16, bx * stride16 + stride16)
+        wx = win[(win >= 0) & mine]
+        if wx.size:
+            wbx = np.searchsorted(start, wx, side="right") - 1
+            offx = wbx * cap * 24 + (wx - start[wbx]) * 24
+            per_xcd += lines(offx, offx + 24)
+    predicted = 128 * per_xcd
+    line = "  with a fetch per (line, XCD): %.1f MB = %.2f x b_min" % (predicted / 1e6, predicted / b_min)
+    try:
+        import json
+        measured = json.load(open(os.path.join(ROOT, "profiles", "r06_counters_%s.json" % args.workload)))["hbm_bytes_per_launch"]
+        line += "; measured (profiles/r06_counters_%s.json, FETCH_SIZE x 2 + WRITE_SIZE) %.1f MB: the model is %+.0f %% off" % (
+            args.workload, measured / 1e6, 100.0 * (predicted - measured) / measured)
+    except (OSError, KeyError, ValueError):
+        pass
+    print(line)
 
 
 if __name__ == "__main__":
