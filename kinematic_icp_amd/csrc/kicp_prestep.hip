@@ -396,10 +396,10 @@ int ahead_run(kicp_pre *p) {
         // not share a queue with the frame's way back (same pool: the look-ahead's kernel waited for the push kernel's 60 us)
         int least = 0, greatest = 0;
         static const bool low = [] { const char *e = std::getenv("KICP_PRE_AHEAD_PRIORITY"); return !(e && *e == '0'); }();
-        if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-            HIP_TRY(hipStreamCreateWithPriority(&p->ahead_stream, hipStreamNonBlocking, least));
-        } else {
-            (void)hipGetLastError();
+        if (!(low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+              hipStreamCreateWithPriority(&p->ahead_stream, hipStreamNonBlocking, least) == hipSuccess)) {
+            (void)hipGetLastError();  // (no priorities on this platform: an ordinary stream)
+            p->ahead_stream = nullptr;
             HIP_TRY(hipStreamCreateWithFlags(&p->ahead_stream, hipStreamNonBlocking));
         }
     }
