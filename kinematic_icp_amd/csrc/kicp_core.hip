@@ -134,13 +134,17 @@ hipError_t pinned_alloc(void **ptr, size_t bytes, unsigned int flags) {
     if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError(), device = -1;
     const int node = gpu_locality(device).node;
     bool policy_set = false;
-    if (node >= 0 && node < 1024) {  // MPOL_PREFERRED (1): pages come from `node` while it has any, from anywhere else after that
+    int old_mode = 0;
+    unsigned long old_mask[16] = {};
+    if (node >= 0 && node < 1024 && syscall(SYS_get_mempolicy, &old_mode, old_mask, 8 * sizeof old_mask + 1, nullptr, 0ul) == 0) {
+        // MPOL_PREFERRED (1): pages come from `node` while it has any, from anywhere else after that; the thread's own policy (numactl
+        // --membind and the like) is put back behind the allocation
         unsigned long mask[16] = {};
         mask[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
         policy_set = syscall(SYS_set_mempolicy, 1, mask, 8 * sizeof mask + 1) == 0;
     }
     const hipError_t e = hipHostMalloc(ptr, bytes, flags);
-    if (policy_set) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0);  // MPOL_DEFAULT
+    if (policy_set) (void)syscall(SYS_set_mempolicy, old_mode, old_mode == 0 ? nullptr : old_mask, old_mode == 0 ? 0ul : 8 * sizeof old_mask + 1);
     return e;
 }
 int device_locality(int device, int *node, char *cpulist, size_t cap) {
