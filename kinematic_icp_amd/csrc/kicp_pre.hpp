@@ -609,7 +609,6 @@ struct PushParams {
     unsigned long long ticket_done; // their value once this launch's last workgroup has drawn
     unsigned long long *host_flags; // [kPushPieces] pinned
     uint32_t seq;
-    uint32_t experiment;            // (timing experiments only: 1 = no system-scope release before the ticket)
 };
 static __global__ __launch_bounds__(256) void k_push_frame(const PushParams q) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -628,10 +627,9 @@ static __global__ __launch_bounds__(256) void k_push_frame(const PushParams q) {
         if (threadIdx.x == 0) {
             // system scope: this workgroup's bytes are in host memory before its ticket - and so before the flag, whoever writes it
             // (without the fence the flag of another workgroup overtook the bytes: measured)
-            if (q.experiment != 1u) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // (a timing run WITHOUT this fence left the launches beside the push as slow as with it: the fence is not what they pay for)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_last = __hip_atomic_fetch_add(q.tickets + piece, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == q.ticket_done ? 1u : 0u;
             if (s_last) __hip_atomic_store(q.host_flags + piece, (static_cast<unsigned long long>(q.seq) << 32) | static_cast<unsigned long long>(len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

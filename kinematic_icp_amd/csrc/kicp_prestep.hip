@@ -616,8 +616,6 @@ static int pre_frame_chain(kicp_pre *p, size_t n_in, bool do_deskew, const doubl
             p->push_drawn += push_grid;
             q.tickets = p->d_push_tickets, q.ticket_done = p->push_drawn, q.host_flags = p->h_rec + 16, q.seq = ++p->push_seq;
             if (q.seq == 0u) q.seq = ++p->push_seq;
-            static const uint32_t push_experiment = [] { const char *e = std::getenv("KICP_DBG_PUSH_EXPERIMENT"); return e && *e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
-            q.experiment = push_experiment;
             HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->chain_ready, 0));
             hipLaunchKernelGGL(k_push_frame, dim3(push_grid), dim3(256), 0, p->copy_stream, q);
             HIP_TRY(hipGetLastError());
