@@ -427,30 +427,8 @@ __device__ __forceinline__ bool replay_tile(const DsTable &T, uint32_t mask, uin
         T.order[s] = m;
         return occupied;
     }
-    // replay_cluster (kicp_table_order.hpp) on window positions: bucket (s + j) & mask <-> position i + j
-    uint32_t max_probe = 0u, last = 0u;
-    for (uint32_t t = 0; t < len; ++t) {
-        uint32_t best = kFreeBucket, best_at = i;
-        for (uint32_t j = i; j < end; ++j) {  // the cluster's key with the lowest input index not inserted yet
-            const uint32_t v = L.min[j];
-            if (v >= last && v < best) best = v, best_at = j;
-        }
-        last = best + 1u;
-        uint32_t carry = best, carry_home = i + ((reference_hash_of_packed(L.key[best_at]) - s) & mask);  // (its ideal bucket lies in the cluster)
-        for (uint32_t pos = carry_home;; ++pos) {
-            const uint32_t resident = L.ord[pos], dist = pos - carry_home;
-            max_probe = dist > max_probe ? dist : max_probe;
-            if (resident == kFreeBucket) {
-                L.ord[pos] = carry, L.home[pos] = carry_home;
-                break;
-            }
-            const uint32_t resident_home = L.home[pos];
-            if (pos - carry_home > pos - resident_home) {
-                L.ord[pos] = carry, L.home[pos] = carry_home;
-                carry = resident, carry_home = resident_home;
-            }
-        }
-    }
+    // replay_cluster's result on window positions (kicp_table_order.hpp replay_window, CPU-tested against it): bucket (s + j) & mask <-> position i + j
+    const uint32_t max_probe = replay_window(L.key, L.min, L.ord, L.home, i, end, s, mask);
     for (uint32_t j = i; j < end; ++j) T.order[(base + j) & mask] = L.ord[j];
     if (max_probe >= 32u) atomicMax(probe_max, max_probe);
     return occupied;

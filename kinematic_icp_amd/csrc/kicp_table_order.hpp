@@ -89,4 +89,37 @@ KICP_HD uint32_t replay_cluster(const unsigned long long *keys, const uint32_t *
     return max_probe;
 }
 
+// The same replay on a WINDOW of the table held in arrays of its own (the kernels' LDS copy of a 256-bucket tile and the buckets behind
+// it: kicp_pre.hpp replay_tile): position j of the window is bucket (window_bucket0 + j) & mask; the cluster occupies positions
+// first .. end-1 and its head is bucket (window_bucket0 + first) & mask.  key / min_index: the window's copies (read); ord: kFreeBucket
+// on entry inside the cluster, the reference's arrangement on return; home: scratch.  Distances need no wrap here - a key's ideal
+// bucket lies inside its cluster, so every position involved is a plain offset.  Returns replay_cluster's figure.
+KICP_HD uint32_t replay_window(const unsigned long long *key, const uint32_t *min_index, uint32_t *ord, uint32_t *home, uint32_t first, uint32_t end,
+                               uint32_t head_bucket, uint32_t mask) {
+    uint32_t max_probe = 0u, last = 0u;
+    for (uint32_t t = first; t < end; ++t) {
+        uint32_t best = kFreeBucket, best_at = first;
+        for (uint32_t j = first; j < end; ++j) {  // the cluster's key with the lowest input index not inserted yet
+            const uint32_t v = min_index[j];
+            if (v >= last && v < best) best = v, best_at = j;
+        }
+        last = best + 1u;
+        uint32_t carry = best, carry_home = first + ((reference_hash_of_packed(key[best_at]) - head_bucket) & mask);
+        for (uint32_t pos = carry_home;; ++pos) {
+            const uint32_t resident = ord[pos], dist = pos - carry_home;
+            max_probe = dist > max_probe ? dist : max_probe;
+            if (resident == kFreeBucket) {
+                ord[pos] = carry, home[pos] = carry_home;
+                break;
+            }
+            const uint32_t resident_home = home[pos];
+            if (pos - carry_home > pos - resident_home) {
+                ord[pos] = carry, home[pos] = carry_home;
+                carry = resident, carry_home = resident_home;
+            }
+        }
+    }
+    return max_probe;
+}
+
 }  // namespace kicp

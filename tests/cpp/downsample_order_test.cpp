@@ -72,6 +72,18 @@ std::vector<uint32_t> claimed_and_replayed(const std::vector<Vox> &pts, size_t b
         while (keys[(s + len) & mask] != ~0ull) ++len;
         const uint32_t probe = kicp::replay_cluster(keys.data(), min_index.data(), order.data(), home_at.data(), mask, s, len);
         if (max_probe) *max_probe = std::max(*max_probe, probe);
+        // the kernels' LDS form of the same replay (replay_window): the cluster copied into a window that starts `lead` buckets before
+        // its head must come out in the same order with the same probe figure
+        const uint32_t lead = s % 7u;
+        std::vector<unsigned long long> wkey(lead + len, ~0ull);
+        std::vector<uint32_t> wmin(lead + len, 0xFFFFFFFFu), word(lead + len, kFreeBucket), whome(lead + len, 0xDEADBEEFu);
+        for (uint32_t j = 0; j < len; ++j) wkey[lead + j] = keys[(s + j) & mask], wmin[lead + j] = min_index[(s + j) & mask];
+        const uint32_t wprobe = kicp::replay_window(wkey.data(), wmin.data(), word.data(), whome.data(), lead, lead + len, s, mask);
+        for (uint32_t j = 0; j < len; ++j)
+            if (word[lead + j] != order[(s + j) & mask] || wprobe != probe) {
+                std::printf("WINDOW replay differs: cluster at %u len %u position %u: %u vs %u (probe %u vs %u)\n", s, len, j, word[lead + j], order[(s + j) & mask], wprobe, probe);
+                std::exit(1);
+            }
     }
     return order;
 }
